@@ -1,0 +1,119 @@
+/*
+ * ndt_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Single-threaded fp64 plain-C restatement of the NDT hot path that
+ * MalcolmMielle/ndt_feature_graph drives through perception_oru
+ * (ndt_map / ndt_registration, un-vendored, NO version pinned anywhere in the
+ * reference: ndt_feature/package.xml:34-45).
+ *
+ * PARITY UNPINNED: the reference holds no golden vector, known-answer test or
+ * fixture for this path and cannot be compiled here
+ * (needs Eigen, PCL, Boost, ROS, perception_oru).  The restatement is anchored
+ * on the in-repo verbatim-derived copy of the Newton loop and More-Thuente
+ * driver (ndt_feature/include/ndt_feature/ndt_matcher_d2d_fusion.h:390-793,
+ * 797-1155), the reference call sites, the published MINPACK-2 dcstep
+ * algorithm, and first-principles derivation of the D2D derivatives that is
+ * checked by finite differences in tests/.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * use this library, and only as the checker / the timed CPU baseline.
+ */
+#ifndef NDT_ORACLE_H
+#define NDT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_map oracle_map;
+
+/* lslgeneric::LazyGrid(res) + NDTMap::initialize / guessSize
+ * (ndt_feature_fuser_hmt.cpp:87-89, 195-196, 222). */
+oracle_map *oracle_map_create(double res, const double centre[3], const double size_m[3]);
+void oracle_map_destroy(oracle_map *m);
+
+/* LazyGrid::getIndexForPoint: idx = floor((p-c)/res + 0.5) + size/2.0 -> int.
+ * Returns 1 when inside the grid. */
+int oracle_map_index_for_point(const oracle_map *m, const double p[3], int idx[3]);
+
+/* NDTMap::loadPointCloud(pc, range_limit) (ndt_feature_fuser_hmt.cpp:225) and
+ * the point-binning half of loadPointCloudCentroid (:201,216) when
+ * range_origin != NULL (range measured from that origin).
+ * Replaces the map content.  stride in floats (3 = packed xyz, 4 = PointXYZ). */
+int oracle_map_load_points(oracle_map *m, const float *xyz, size_t n, size_t stride_floats,
+                           double range_limit, const double *range_origin);
+
+/* NDTMap::computeNDTCells(CELL_UPDATE_MODE_SAMPLE_VARIANCE) ->
+ * NDTCell::computeGaussian (first Gaussian) + rescaleCovariance
+ * (ndt_feature_fuser_hmt.cpp:227; ndt_odom_debug.cpp:179). */
+int oracle_map_compute_cells(oracle_map *m, int n_min, double eval_factor);
+
+/* number of cells with hasGaussian_, in slot order (x-major, then y, then z) */
+int oracle_map_num_cells(const oracle_map *m);
+/* export gaussian cells in slot order: mean3[3*i], cov9[9*i] (row-major), idx3, npts */
+int oracle_map_export_cells(const oracle_map *m, double *mean3, double *cov9, int32_t *idx3,
+                            int32_t *npts);
+/* install cells directly (CellVector::addNDTCell-like; used by KATs) */
+int oracle_map_set_cells(oracle_map *m, const double *mean3, const double *cov9, size_t ncells);
+
+typedef struct {
+    int n_neighbours;   /* matcher_d2d.n_neighbours (ndt_feature_graph.cpp:262) */
+    int itr_max;        /* ITR_MAX (ndt_feature_fuser_hmt.h:82) */
+    double delta_score; /* DELTA_SCORE */
+    int step_control;   /* More-Thuente on/off */
+    double lfd1, lfd2;  /* 1, 0.05 */
+    int dof_mask;       /* bit a set = pose dof a active; 0x3f = 6-DoF, 0x23 = {x,y,yaw} */
+    int use_initial_guess;
+} oracle_match_params;
+
+typedef struct {
+    int converged;   /* ret of match(): 0 when the iteration cap was hit */
+    int iterations;  /* itr_ctr at exit */
+    int fevals;      /* number of derivativesNDT evaluations */
+    double score;    /* final score (after best-score rollback: score at returned T is min(best,final)) */
+    int exit_code;   /* 0 step<delta, 1 gradient vanished, 2 wrong direction, 3 iteration cap */
+} oracle_match_result;
+
+/* NDTMatcherD2D::derivativesNDT (called at ndt_matcher_d2d_fusion.h:856,444,617,1085).
+ * src cells are already in the target frame.  g[6], H[36] row-major. */
+double oracle_derivatives(const oracle_map *target, const double *src_mean3, const double *src_cov9,
+                          size_t m, int n_neighbours, int compute_hessian, double lfd1, double lfd2,
+                          double g[6], double H[36]);
+
+/* D2D score only at pose increment p applied on the left of T (for FD tests):
+ * cells transformed by TR(p)*T then summed. */
+double oracle_score_at(const oracle_map *target, const oracle_map *source, const double T[16],
+                       const double p[6], int n_neighbours, double lfd1, double lfd2);
+
+/* NDTMatcherD2D::match(target, source, T, useInitialGuess) (ndt_feature_graph.cpp:273),
+ * loop restated from ndt_matcher_d2d_fusion.h:847-1121 with the NDT term only.
+ * T: 4x4 column-major (Eigen::Affine3d storage), in/out. */
+int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double T[16],
+                     const oracle_match_params *prm, oracle_match_result *res);
+
+/* MoreThuente::cstep (MINPACK-2 dcstep; called at ndt_matcher_d2d_fusion.h:756,775). */
+int oracle_mt_cstep(double *stx, double *fx, double *dx, double *sty, double *fy, double *dy,
+                    double *stp, double fp, double dp, int *brackt, double stmin, double stmax);
+
+/* The More-Thuente driver of ndt_matcher_d2d_fusion.h:390-793 on a scalar
+ * function phi(stp) -> (f, dg) supplied by the caller; finit/dginit are
+ * phi(0).  Returns the step (recovery step 0.1 on failure); *nfev_out =
+ * number of phi evaluations. */
+typedef double (*oracle_phi_fn)(void *ctx, double stp, double *dg);
+double oracle_mt_linesearch(oracle_phi_fn phi, void *ctx, double finit, double dginit,
+                            int *nfev_out, int *info_out);
+
+/* small algebra exported for KATs */
+void oracle_pose_to_T(const double p[6], double T[16]);          /* Trans*Rx*Ry*Rz (fusion.h:1036-1039) */
+int oracle_eig_sym(int n, const double *A, double *evals, double *evecs); /* n<=6, row-major */
+int oracle_ldlt_solve(int n, const double *A, const double *b, double *x);
+/* computeScore/Gradient/HessianMahalanobis (ndt_matcher_d2d_fusion.h:11-32) */
+double oracle_mahalanobis(const double x[6], const double Q[36], double g[6], double H[36]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
