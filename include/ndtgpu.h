@@ -1,0 +1,167 @@
+/*
+ * ndtgpu.h -- C-ABI of the MI355X-native NDT scan-matching front-end.
+ *
+ * Drop-in boundary for the lslgeneric:: classes that MalcolmMielle/ndt_feature_graph calls
+ * on its hot path (there is no FFI layer in the reference: the path sits behind the C++
+ * class API of perception_oru's ndt_map / ndt_registration).  Each
+ * entry point cites the reference interface it replaces (paths relative to the reference
+ * root).  Plain pointers and sizes only; handles are opaque; outputs are caller-owned.
+ *
+ * Conventions
+ *   - 4x4 poses are 16 doubles, COLUMN-major, exactly Eigen::Affine3d::data().
+ *   - points are float xyz records, `stride_bytes` apart (12 = packed, 16 = pcl::PointXYZ).
+ *   - a "mapset" is B NDT maps that share one grid geometry (cell size, extent in cells) and
+ *     live in one device arena; a single lslgeneric::NDTMap is a mapset with B = 1.
+ *   - every call returns ndtgpu_status; convergence is reported in the result struct, never
+ *     as an error (reference: match() returns bool, fusion.h:1075-1079).
+ *   - handles are not thread-safe; distinct handles may be used from distinct threads.
+ *   - the library never falls back to the CPU: without a HIP device every compute entry
+ *     point returns NDTGPU_ERR_NO_DEVICE.
+ */
+#ifndef NDTGPU_H
+#define NDTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int ndtgpu_status;
+enum {
+    NDTGPU_OK = 0,
+    NDTGPU_ERR_INVALID = -1,   /* bad argument */
+    NDTGPU_ERR_HIP = -2,       /* HIP runtime error (see ndtgpu_last_error) */
+    NDTGPU_ERR_NO_DEVICE = -3, /* no gfx950 device visible */
+    NDTGPU_ERR_CAPACITY = -4,  /* a map needed more cells than max_cells */
+    NDTGPU_ERR_ALLOC = -5
+};
+
+typedef struct ndtgpu_mapset ndtgpu_mapset;
+typedef void *ndtgpu_stream; /* hipStream_t; NULL = default stream */
+
+/* lslgeneric::LazyGrid(res) + NDTMap::initialize(cx,cy,cz,sx,sy,sz) / guessSize(...)
+ * (ndt_feature/src/ndt_feature_src/ndt_feature_fuser_hmt.cpp:87-89, 195-196, 222). */
+typedef struct {
+    double res;        /* cubic cell size [m] (params_.resolution) */
+    double centre[3];  /* grid centre [m]; per-map override: ndtgpu_mapset_set_centre */
+    double size[3];    /* extent [m]; cells per axis = |ceil(size/res)| (LazyGrid::initialize) */
+    uint32_t max_cells; /* capacity of occupied cells per map; 0 = min(slots, 16384) */
+} ndtgpu_grid_params;
+
+/* NDTCell::computeGaussian / rescaleCovariance knobs. */
+typedef struct {
+    int32_t n_min;       /* points needed for a first Gaussian (upstream: 3) */
+    double eval_factor;  /* EVAL_FACTOR, eigenvalue floor lambda_max/eval_factor (1000; utils.h:200) */
+} ndtgpu_cell_params;
+
+/* NDTMatcherD2D members set by the callers (ndt_feature_graph.cpp:261-262;
+ * ndt_feature_fuser_hmt.cpp:356-357; ndt_matcher_d2d_fusion.h:1170-1174). */
+typedef struct {
+    int32_t n_neighbours;      /* matcher.n_neighbours */
+    int32_t itr_max;           /* ITR_MAX */
+    double delta_score;        /* DELTA_SCORE */
+    int32_t step_control;      /* More-Thuente line search on/off */
+    double lfd1, lfd2;         /* 1.0, 0.05 */
+    int32_t dof_mask;          /* bit a = pose dof a active: 0x3f NDTMatcherD2D, 0x23 NDTMatcherD2D_2D */
+    int32_t use_initial_guess; /* match(..., useInitialGuess) */
+} ndtgpu_match_params;
+
+typedef struct {
+    int32_t converged;  /* return value of match(): 0 = iteration cap hit */
+    int32_t iterations; /* itr_ctr at exit */
+    int32_t fevals;     /* derivativesNDT evaluations */
+    int32_t exit_code;  /* 0 step<delta, 1 gradient vanished, 2 wrong direction, 3 iteration cap */
+    double score;       /* score at the returned pose */
+    int32_t n_source;   /* Gaussian cells in the source map */
+    int32_t n_target;
+} ndtgpu_match_result;
+
+/* ---- library ------------------------------------------------------------------------- */
+const char *ndtgpu_version(void);
+const char *ndtgpu_last_error(void);
+/* number of usable devices (0 on a box without a GPU; never an error) */
+int ndtgpu_device_count(void);
+void ndtgpu_default_cell_params(ndtgpu_cell_params *p);
+void ndtgpu_default_match_params(ndtgpu_match_params *p);
+
+/* ---- maps ---------------------------------------------------------------------------- */
+/* new NDTMap(new LazyGrid(res)) x n_maps + initialize()  (fuser_hmt.cpp:87-89, 195-196) */
+ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps, ndtgpu_mapset **out);
+/* NDTMap destructor (ndt_feature_graph.h:78-88 deletes node maps) */
+ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *set);
+/* LazyGrid::setCenter -- e.g. the snapped centroid of loadPointCloudCentroid
+ * (fuser_hmt.cpp:201-217; ndt_odom_debug.cpp:191) or the node pose (fuser_hmt.cpp:89) */
+ndtgpu_status ndtgpu_mapset_set_centre(ndtgpu_mapset *set, size_t map, const double centre[3]);
+ndtgpu_status ndtgpu_mapset_info(const ndtgpu_mapset *set, size_t *n_maps, int32_t cells_per_axis[3],
+                                 uint32_t *max_cells);
+
+/* NDTMap::loadPointCloud(cloud, range) + computeNDTCells(CELL_UPDATE_MODE_SAMPLE_VARIANCE)
+ * (fuser_hmt.cpp:225-227; ndt_odom_debug.cpp:178-179) for maps [first, first+count).
+ * xyz_dev: DEVICE pointer; map k reads n_points records from
+ *   (char*)xyz_dev + k*map_stride_bytes, records stride_bytes apart.
+ * range_limit <= 0 disables the range filter; range_origins (HOST, 3 doubles per map, may be
+ * NULL = sensor at the frame origin) gives the origin the range is measured from
+ * (loadPointCloudCentroid, fuser_hmt.cpp:201-202).  Replaces the maps' content.
+ * Asynchronous on `stream`. */
+ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *set, size_t first, size_t count, const void *xyz_dev,
+                                  size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                  double range_limit, const double *range_origins,
+                                  const ndtgpu_cell_params *cell, ndtgpu_stream stream);
+/* same, points in HOST memory (one H2D copy; the reference hands over host PointClouds) */
+ndtgpu_status ndtgpu_mapset_build_host(ndtgpu_mapset *set, size_t first, size_t count, const void *xyz_host,
+                                       size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                       double range_limit, const double *range_origins,
+                                       const ndtgpu_cell_params *cell);
+
+/* NDTMap::numberOfActiveCells / getAllCells (fuser_hmt.cpp:234; ndtgraph_conversion.h:34-43):
+ * Gaussian cells in slot order (x-major, y, z).  Synchronises the build stream.
+ * Any output pointer may be NULL.  cov9 row-major 3x3, idx3 = LazyGrid cell indices. */
+ndtgpu_status ndtgpu_mapset_num_cells(ndtgpu_mapset *set, size_t map, uint32_t *n);
+ndtgpu_status ndtgpu_mapset_export_cells(ndtgpu_mapset *set, size_t map, double *mean3, double *cov9,
+                                         int32_t *idx3, uint32_t *npts);
+/* installs ready-made Gaussians (CellVector::addNDTCell / a node map received from elsewhere;
+ * ndt_odom_debug.cpp:217-229); the cell index is LazyGrid::getIndexForPoint(mean). */
+ndtgpu_status ndtgpu_mapset_set_cells(ndtgpu_mapset *set, size_t map, const double *mean3, const double *cov9,
+                                      size_t n_cells);
+
+/* ---- matcher ---------------------------------------------------------------------------- */
+/* NDTMatcherD2D::derivativesNDT(sourceCells, targetMap, g, H, computeHessian)
+ * (ndt_matcher_d2d_fusion.h:80, 238, 444, 617, 856, 1085): lets the in-repo matchFusion host
+ * loop run unchanged.  src_* are HOST arrays of m cells already in the target frame.
+ * g[6]; H[36] row-major (untouched when compute_hessian == 0). */
+ndtgpu_status ndtgpu_derivatives(ndtgpu_mapset *target, size_t target_map, const double *src_mean3,
+                                 const double *src_cov9, size_t m, int n_neighbours, int compute_hessian,
+                                 double lfd1, double lfd2, double *score, double g[6], double H[36]);
+
+/* NDTMatcherD2D::match(target, source, T, useInitialGuess) (ndt_feature_graph.cpp:273) and
+ * NDTMatcherD2D_2D::match (ndt_matcher_d2d_fusion.h:1175) for n_pairs independent pairs --
+ * the loop of NDTFeatureGraph::updateLinksUsingNDTRegistration (ndt_feature_graph.cpp:347-353).
+ * Pair k matches target_set[target_idx[k]] (fixed) against source_set[source_idx[k]] (moving).
+ * T16: HOST, n_pairs x 16 doubles, in: initial guess, out: result.  results: HOST, n_pairs.
+ * One persistent workgroup per pair; the whole Newton / More-Thuente loop runs on the device.
+ * Synchronous (returns after the results are on the host). */
+ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx, ndtgpu_mapset *source_set,
+                                 const uint32_t *source_idx, double *T16, size_t n_pairs,
+                                 const ndtgpu_match_params *prm, ndtgpu_match_result *results,
+                                 ndtgpu_stream stream);
+/* device-resident variant for pipelines: T16_dev / results_dev are DEVICE buffers, idx arrays
+ * DEVICE uint32; asynchronous on `stream` (graph-capturable: no allocation, no sync). */
+ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *target_set, const uint32_t *target_idx_dev,
+                                        ndtgpu_mapset *source_set, const uint32_t *source_idx_dev,
+                                        double *T16_dev, size_t n_pairs, const ndtgpu_match_params *prm,
+                                        ndtgpu_match_result *results_dev, ndtgpu_stream stream);
+/* single pair convenience == graph.cpp:273 */
+ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *target_set, size_t target_map, ndtgpu_mapset *source_set,
+                               size_t source_map, double T16[16], const ndtgpu_match_params *prm,
+                               ndtgpu_match_result *result);
+
+/* ---- profiling hooks ------------------------------------------------------------------ */
+/* kernel names as they appear in rocprofv3 --kernel-trace, for bench.py / profiles/ */
+const char *ndtgpu_kernel_name(int which); /* 0 build, 1 match, 2 derivatives */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDTGPU_H */

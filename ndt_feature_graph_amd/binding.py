@@ -1,0 +1,271 @@
+"""ctypes host layer over libndtgpu.so (include/ndtgpu.h)."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SO = os.path.join(_HERE, "libndtgpu.so")
+_SOURCES = ["ndt_build.hip", "ndt_match.hip", "ndtgpu_api.hip"]
+
+STATUS = {0: "OK", -1: "ERR_INVALID", -2: "ERR_HIP", -3: "ERR_NO_DEVICE", -4: "ERR_CAPACITY", -5: "ERR_ALLOC"}
+
+
+class NdtGpuError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("ndtgpu %s (%d): %s" % (STATUS.get(status, "?"), status, msg))
+        self.status = status
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False, verbose=False):
+    """hipcc cross-compiles the kernels + C-ABI for gfx950 into the in-tree libndtgpu.so."""
+    csrc = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(csrc, s) for s in _SOURCES]
+    deps = srcs + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(_ROOT, "include", "ndtgpu.h")]
+    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps):
+        return _SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
+           "-Wno-unused-function", *srcs, "-o", _SO + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(_SO + ".tmp", _SO)
+    return _SO
+
+
+class GridParams(C.Structure):
+    _fields_ = [("res", C.c_double), ("centre", C.c_double * 3), ("size", C.c_double * 3), ("max_cells", C.c_uint32)]
+
+
+class CellParams(C.Structure):
+    _fields_ = [("n_min", C.c_int32), ("eval_factor", C.c_double)]
+
+
+class MatchParams(C.Structure):
+    _fields_ = [("n_neighbours", C.c_int32), ("itr_max", C.c_int32), ("delta_score", C.c_double),
+                ("step_control", C.c_int32), ("lfd1", C.c_double), ("lfd2", C.c_double), ("dof_mask", C.c_int32),
+                ("use_initial_guess", C.c_int32)]
+
+
+class MatchResult(C.Structure):
+    _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("fevals", C.c_int32), ("exit_code", C.c_int32),
+                ("score", C.c_double), ("n_source", C.c_int32), ("n_target", C.c_int32)]
+
+
+RESULT_DTYPE = np.dtype([("converged", "<i4"), ("iterations", "<i4"), ("fevals", "<i4"), ("exit_code", "<i4"),
+                         ("score", "<f8"), ("n_source", "<i4"), ("n_target", "<i4")])
+assert RESULT_DTYPE.itemsize == C.sizeof(MatchResult)
+
+# every symbol include/ndtgpu.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu_default_cell_params",
+           "ndtgpu_default_match_params", "ndtgpu_mapset_create", "ndtgpu_mapset_destroy", "ndtgpu_mapset_set_centre",
+           "ndtgpu_mapset_info", "ndtgpu_mapset_build", "ndtgpu_mapset_build_host", "ndtgpu_mapset_num_cells",
+           "ndtgpu_mapset_export_cells", "ndtgpu_mapset_set_cells", "ndtgpu_derivatives", "ndtgpu_match_batch",
+           "ndtgpu_match_batch_device", "ndtgpu_match_d2d", "ndtgpu_kernel_name"]
+
+_lib = None
+
+
+def lib():
+    """Loads libndtgpu.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise NdtGpuError(-2, "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % _SO)
+    L = C.CDLL(_SO)
+    vp, dp, u32p, i32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+    L.ndtgpu_version.restype = C.c_char_p
+    L.ndtgpu_last_error.restype = C.c_char_p
+    L.ndtgpu_kernel_name.restype = C.c_char_p
+    L.ndtgpu_kernel_name.argtypes = [C.c_int]
+    L.ndtgpu_device_count.restype = C.c_int
+    L.ndtgpu_default_cell_params.argtypes = [C.POINTER(CellParams)]
+    L.ndtgpu_default_match_params.argtypes = [C.POINTER(MatchParams)]
+    L.ndtgpu_mapset_create.argtypes = [C.POINTER(GridParams), C.c_size_t, C.POINTER(vp)]
+    L.ndtgpu_mapset_destroy.argtypes = [vp]
+    L.ndtgpu_mapset_set_centre.argtypes = [vp, C.c_size_t, dp]
+    L.ndtgpu_mapset_info.argtypes = [vp, C.POINTER(C.c_size_t), i32p, u32p]
+    L.ndtgpu_mapset_build.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double,
+                                      dp, C.POINTER(CellParams), vp]
+    L.ndtgpu_mapset_build_host.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t,
+                                           C.c_double, dp, C.POINTER(CellParams)]
+    L.ndtgpu_mapset_num_cells.argtypes = [vp, C.c_size_t, u32p]
+    L.ndtgpu_mapset_export_cells.argtypes = [vp, C.c_size_t, dp, dp, i32p, u32p]
+    L.ndtgpu_mapset_set_cells.argtypes = [vp, C.c_size_t, dp, dp, C.c_size_t]
+    L.ndtgpu_derivatives.argtypes = [vp, C.c_size_t, dp, dp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double,
+                                     dp, dp, dp]
+    L.ndtgpu_match_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, C.POINTER(MatchParams), vp, vp]
+    L.ndtgpu_match_batch_device.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(MatchParams), vp, vp]
+    L.ndtgpu_match_d2d.argtypes = [vp, C.c_size_t, vp, C.c_size_t, dp, C.POINTER(MatchParams), C.POINTER(MatchResult)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise NdtGpuError(rc, lib().ndtgpu_last_error().decode())
+
+
+def device_count():
+    return lib().ndtgpu_device_count()
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def match_params(**kw):
+    p = MatchParams()
+    lib().ndtgpu_default_match_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise TypeError("unknown match parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if hasattr(stream, "cuda_stream"):
+        return C.c_void_p(stream.cuda_stream)
+    return C.c_void_p(int(stream))
+
+
+class MapSet:
+    """B x lslgeneric::NDTMap(new LazyGrid(res)) with one grid geometry, resident in HBM."""
+
+    def __init__(self, res, centre, size_m, n_maps=1, max_cells=0):
+        L = lib()
+        gp = GridParams()
+        gp.res = float(res)
+        gp.centre[:] = [float(x) for x in centre]
+        gp.size[:] = [float(x) for x in size_m]
+        gp.max_cells = int(max_cells)
+        h = C.c_void_p()
+        _check(L.ndtgpu_mapset_create(C.byref(gp), int(n_maps), C.byref(h)))
+        self.h = h
+        self.n_maps = int(n_maps)
+        self.res = float(res)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ndtgpu_mapset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        n = C.c_size_t()
+        cells = (C.c_int32 * 3)()
+        cap = C.c_uint32()
+        _check(lib().ndtgpu_mapset_info(self.h, C.byref(n), cells, C.byref(cap)))
+        return dict(n_maps=n.value, cells_per_axis=list(cells), max_cells=cap.value)
+
+    def set_centre(self, i, centre):
+        c = _f64(centre)
+        _check(lib().ndtgpu_mapset_set_centre(self.h, int(i), _dp(c)))
+
+    def build(self, xyz, range_limit=-1.0, range_origins=None, first=0, n_min=3, eval_factor=1000.0, stream=None):
+        """loadPointCloud + computeNDTCells for maps [first, first+B).  xyz: [B,N,3|4] float32,
+        a torch CUDA tensor (device path, asynchronous) or a NumPy array (host path)."""
+        cp = CellParams(int(n_min), float(eval_factor))
+        ro = None
+        is_torch = hasattr(xyz, "data_ptr")
+        if xyz.ndim == 2:
+            xyz = xyz[None]
+        B, N, W = int(xyz.shape[0]), int(xyz.shape[1]), int(xyz.shape[2])
+        assert W in (3, 4)
+        if range_origins is not None:
+            ro = _f64(range_origins).reshape(B, 3)
+        rop = _dp(ro) if ro is not None else None
+        if is_torch:
+            import torch
+            assert xyz.dtype == torch.float32 and xyz.is_cuda and xyz.is_contiguous()
+            if stream is None:
+                stream = torch.cuda.current_stream()
+            _check(lib().ndtgpu_mapset_build(self.h, int(first), B, C.c_void_p(xyz.data_ptr()), N, 4 * W, 4 * W * N,
+                                             float(range_limit), rop, C.byref(cp), _stream_ptr(stream)))
+        else:
+            a = np.ascontiguousarray(xyz, dtype=np.float32)
+            _check(lib().ndtgpu_mapset_build_host(self.h, int(first), B, C.c_void_p(a.ctypes.data), N, 4 * W,
+                                                  4 * W * N, float(range_limit), rop, C.byref(cp)))
+
+    def num_cells(self, i=0):
+        n = C.c_uint32()
+        _check(lib().ndtgpu_mapset_num_cells(self.h, int(i), C.byref(n)))
+        return n.value
+
+    def export_cells(self, i=0):
+        n = self.num_cells(i)
+        mean = np.zeros((n, 3))
+        cov = np.zeros((n, 3, 3))
+        idx = np.zeros((n, 3), dtype=np.int32)
+        npts = np.zeros(n, dtype=np.uint32)
+        _check(lib().ndtgpu_mapset_export_cells(self.h, int(i), _dp(mean), _dp(cov),
+                                                idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                npts.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return mean, cov, idx, npts
+
+    def set_cells(self, i, mean, cov):
+        mean, cov = _f64(mean).reshape(-1, 3), _f64(cov).reshape(-1, 3, 3)
+        _check(lib().ndtgpu_mapset_set_cells(self.h, int(i), _dp(mean), _dp(cov), mean.shape[0]))
+
+
+def derivatives(target, tmap, src_mean, src_cov, n_neighbours=2, compute_hessian=True, lfd1=1.0, lfd2=0.05):
+    """NDTMatcherD2D::derivativesNDT on the device (source cells already in the target frame)."""
+    src_mean, src_cov = _f64(src_mean).reshape(-1, 3), _f64(src_cov).reshape(-1, 3, 3)
+    s = C.c_double()
+    g = np.zeros(6)
+    H = np.zeros((6, 6))
+    _check(lib().ndtgpu_derivatives(target.h, int(tmap), _dp(src_mean), _dp(src_cov), src_mean.shape[0],
+                                    int(n_neighbours), int(bool(compute_hessian)), lfd1, lfd2, C.byref(s), _dp(g), _dp(H)))
+    return s.value, g, H
+
+
+def match_batch(target_set, target_idx, source_set, source_idx, T, stream=None, **params):
+    """NDTFeatureGraph::updateLinksUsingNDTRegistration's loop: match(target, source, T, true) for every
+    pair.  T: [n,4,4] (math convention); returns (T_out [n,4,4], results structured array)."""
+    ti = np.ascontiguousarray(target_idx, dtype=np.uint32)
+    si = np.ascontiguousarray(source_idx, dtype=np.uint32)
+    n = ti.shape[0]
+    Tc = np.ascontiguousarray(np.transpose(np.asarray(T, dtype=np.float64).reshape(n, 4, 4), (0, 2, 1))).copy()
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    p = match_params(**params)
+    _check(lib().ndtgpu_match_batch(target_set.h, ti.ctypes.data_as(C.POINTER(C.c_uint32)), source_set.h,
+                                    si.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), n, C.byref(p),
+                                    C.c_void_p(res.ctypes.data), _stream_ptr(stream)))
+    return np.transpose(Tc, (0, 2, 1)).copy(), res
+
+
+def match_batch_device(target_set, tidx_dev, source_set, sidx_dev, T16_dev, results_dev, n_pairs, stream=None, **params):
+    """Asynchronous device-resident variant (torch CUDA tensors: uint32/int32 idx, float64 [n,16]
+    column-major poses, uint8 [n,32] results)."""
+    p = match_params(**params)
+    _check(lib().ndtgpu_match_batch_device(target_set.h, C.c_void_p(tidx_dev.data_ptr()), source_set.h,
+                                           C.c_void_p(sidx_dev.data_ptr()), C.c_void_p(T16_dev.data_ptr()), int(n_pairs),
+                                           C.byref(p), C.c_void_p(results_dev.data_ptr()), _stream_ptr(stream)))
+
+
+def match_d2d(target_set, tmap, source_set, smap, T, **params):
+    To, res = match_batch(target_set, [tmap], source_set, [smap], np.asarray(T)[None], **params)
+    return To[0], res[0]

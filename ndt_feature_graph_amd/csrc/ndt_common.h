@@ -1,0 +1,85 @@
+// ndt_common.h -- shared host/device types of the MI355X NDT front-end (product code).
+//
+// Data layout in HBM (DESIGN.md "Layout"):
+//   table  int32 [n_maps][slots]        dense LazyGrid slot -> cell rank (-1 = no Gaussian);
+//                                       slot = (ix*sy + iy)*sz + iz, like dataArray[x][y][z]
+//   cells  NdtCell [n_maps][max_cells]  80-byte records, Gaussian cells only, in slot order
+//   acc    NdtAcc  [n_maps][max_cells]  80-byte int64 fixed-point moment accumulators
+//                                       (build scratch; all-zero between builds)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NDT_HD __host__ __device__ __forceinline__
+#define NDT_D __device__ __forceinline__
+
+// lambda_min <= NDT_DEGENERATE_REL * lambda_max counts as "eigenvalue <= 0" in
+// NDTCell::rescaleCovariance (rank-deficient sample covariance; see DESIGN.md "Deviations").
+#define NDT_DEGENERATE_REL 1e-9
+// Eigen computeInverseAndDetWithCheck default threshold on |det(CSum)|
+#define NDT_DET_EPS 1e-12
+
+struct alignas(16) NdtCell {   // 80 B: the algorithmic per-cell record
+    double mean[3];
+    double cov[6];             // xx xy xz yy yz zz
+    uint32_t n;                // points that built the Gaussian
+    uint32_t slot;             // linear LazyGrid slot
+};
+static_assert(sizeof(NdtCell) == 80, "NdtCell must be 80 bytes");
+
+struct alignas(16) NdtAcc {    // 80 B fixed-point moments of u = (p - cell_centre)/res
+    unsigned long long n;
+    long long s1[3];           // sum round(u * 2^40)
+    long long s2[6];           // sum round(u_a u_b * 2^s2_shift)
+};
+static_assert(sizeof(NdtAcc) == 80, "NdtAcc must be 80 bytes");
+
+#define NDT_S1_SHIFT 40
+
+struct NdtGrid {               // geometry shared by all maps of a set
+    double res;
+    int size[3];               // cells per axis
+    int slots;                 // size[0]*size[1]*size[2]
+    uint32_t max_cells;
+};
+
+struct NdtMapCounters {        // per map, device resident
+    uint32_t n_alloc;          // ids handed out during accumulation (0 between builds)
+    uint32_t n_cells;          // Gaussian cells after finalize
+    uint32_t overflow;         // ids requested beyond max_cells
+    uint32_t n_dropped;        // points dropped (NaN / range / outside grid)
+};
+
+struct NdtSetView {            // what kernels see of a mapset
+    NdtGrid grid;
+    int32_t *table;            // [n_maps][slots]
+    NdtCell *cells;            // [n_maps][max_cells]
+    NdtAcc *acc;               // [n_maps][max_cells]
+    uint32_t *acc_slot;        // [n_maps][max_cells] slot of each accumulator id
+    NdtMapCounters *counters;  // [n_maps]
+    double *centres;           // [n_maps][3]
+};
+
+struct NdtMatchParamsDev {
+    int n_neighbours, itr_max, step_control, dof_mask, use_initial_guess;
+    double delta_score, lfd1, lfd2;
+};
+
+struct NdtMatchResultDev {     // mirrors ndtgpu_match_result
+    int32_t converged, iterations, fevals, exit_code;
+    double score;
+    int32_t n_source, n_target;
+};
+
+// host launchers (defined next to their kernels)
+hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                            size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                            const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream);
+hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const double *mean3_dev,
+                                    const double *cov9_dev, size_t n_cells, hipStream_t stream);
+hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
+                            const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
+                            NdtMatchResultDev *res_dev, hipStream_t stream);
+hipError_t ndt_launch_derivatives(const NdtSetView &tset, size_t tmap, const NdtCell *src_cells_dev, size_t m,
+                                  int n_neighbours, int compute_hessian, double lfd1, double lfd2, double *out28_dev,
+                                  hipStream_t stream);

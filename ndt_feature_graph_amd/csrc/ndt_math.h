@@ -1,0 +1,201 @@
+// ndt_math.h -- fixed-size fp64 algebra for the NDT kernels (host + device, no Eigen).
+#pragma once
+#include "ndt_common.h"
+#include <math.h>
+
+struct d3 { double x, y, z; };
+
+NDT_HD d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+NDT_HD d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+NDT_HD d3 operator*(double s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
+NDT_HD double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+NDT_HD d3 cross(d3 a, d3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+// e_k x v
+NDT_HD d3 ex_cross(d3 v) { return {0.0, -v.z, v.y}; }
+NDT_HD d3 ey_cross(d3 v) { return {v.z, 0.0, -v.x}; }
+NDT_HD d3 ez_cross(d3 v) { return {-v.y, v.x, 0.0}; }
+
+struct sym3 { double xx, xy, xz, yy, yz, zz; };
+NDT_HD sym3 operator+(sym3 a, sym3 b) { return {a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz}; }
+NDT_HD d3 mul(sym3 a, d3 v)
+{
+    return {a.xx * v.x + a.xy * v.y + a.xz * v.z, a.xy * v.x + a.yy * v.y + a.yz * v.z,
+            a.xz * v.x + a.yz * v.y + a.zz * v.z};
+}
+
+// (C_i + C_j)^-1 with Eigen's computeInverseAndDetWithCheck semantics (|det| > 1e-12)
+NDT_HD bool inverse_check(sym3 a, sym3 &inv)
+{
+    double c00 = a.yy * a.zz - a.yz * a.yz;
+    double c01 = a.yz * a.xz - a.xy * a.zz;
+    double c02 = a.xy * a.yz - a.yy * a.xz;
+    double det = a.xx * c00 + a.xy * c01 + a.xz * c02;
+    if (!(fabs(det) > NDT_DET_EPS)) return false;
+    double id = 1.0 / det;
+    inv.xx = c00 * id;
+    inv.xy = c01 * id;
+    inv.xz = c02 * id;
+    inv.yy = (a.xx * a.zz - a.xz * a.xz) * id;
+    inv.yz = (a.xy * a.xz - a.xx * a.yz) * id;
+    inv.zz = (a.xx * a.yy - a.xy * a.xy) * id;
+    return true;
+}
+
+struct rigid { double r[9]; double t[3]; };   // row-major rotation + translation
+
+NDT_HD d3 apply(const rigid &T, d3 p)
+{
+    return {T.r[0] * p.x + T.r[1] * p.y + T.r[2] * p.z + T.t[0], T.r[3] * p.x + T.r[4] * p.y + T.r[5] * p.z + T.t[1],
+            T.r[6] * p.x + T.r[7] * p.y + T.r[8] * p.z + T.t[2]};
+}
+
+// R C R^T for symmetric C
+NDT_HD sym3 rotate_cov(const double *R, sym3 c)
+{
+    double a[9]; // a = R C
+    for (int i = 0; i < 3; i++) {
+        a[i * 3 + 0] = R[i * 3] * c.xx + R[i * 3 + 1] * c.xy + R[i * 3 + 2] * c.xz;
+        a[i * 3 + 1] = R[i * 3] * c.xy + R[i * 3 + 1] * c.yy + R[i * 3 + 2] * c.yz;
+        a[i * 3 + 2] = R[i * 3] * c.xz + R[i * 3 + 1] * c.yz + R[i * 3 + 2] * c.zz;
+    }
+    sym3 o;
+    o.xx = a[0] * R[0] + a[1] * R[1] + a[2] * R[2];
+    o.xy = a[0] * R[3] + a[1] * R[4] + a[2] * R[5];
+    o.xz = a[0] * R[6] + a[1] * R[7] + a[2] * R[8];
+    o.yy = a[3] * R[3] + a[4] * R[4] + a[5] * R[5];
+    o.yz = a[3] * R[6] + a[4] * R[7] + a[5] * R[8];
+    o.zz = a[6] * R[6] + a[7] * R[7] + a[8] * R[8];
+    return o;
+}
+
+// TR = Translation(p0,p1,p2) * Rx(p3) * Ry(p4) * Rz(p5)   (ndt_matcher_d2d_fusion.h:1036-1039)
+NDT_HD void pose_to_rigid(const double *p, rigid &T)
+{
+    double cx = cos(p[3]), sx = sin(p[3]);
+    double cy = cos(p[4]), sy = sin(p[4]);
+    double cz = cos(p[5]), sz = sin(p[5]);
+    // Rx*Ry*Rz
+    T.r[0] = cy * cz;                  T.r[1] = -cy * sz;                 T.r[2] = sy;
+    T.r[3] = cx * sz + sx * sy * cz;   T.r[4] = cx * cz - sx * sy * sz;   T.r[5] = -sx * cy;
+    T.r[6] = sx * sz - cx * sy * cz;   T.r[7] = sx * cz + cx * sy * sz;   T.r[8] = cx * cy;
+    T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];
+}
+
+// C = A * B (apply B first)
+NDT_HD void rigid_mul(const rigid &A, const rigid &B, rigid &C)
+{
+    rigid o;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            o.r[i * 3 + j] = A.r[i * 3] * B.r[j] + A.r[i * 3 + 1] * B.r[3 + j] + A.r[i * 3 + 2] * B.r[6 + j];
+        o.t[i] = A.r[i * 3] * B.t[0] + A.r[i * 3 + 1] * B.t[1] + A.r[i * 3 + 2] * B.t[2] + A.t[i];
+    }
+    C = o;
+}
+
+// cyclic Jacobi eigensolver, symmetric n x n (n <= 6), row-major; evals ascending, evecs in columns.
+// Stands in for Eigen::SelfAdjointEigenSolver (fusion.h:922-928; NDTCell::rescaleCovariance).
+template <int NMAX>
+NDT_HD void jacobi_eig(int n, const double *A, double *evals, double *V)
+{
+    double a[NMAX * NMAX];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            a[i * NMAX + j] = 0.5 * (A[i * n + j] + A[j * n + i]);
+            V[i * n + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) {
+            diag += a[i * NMAX + i] * a[i * NMAX + i];
+            for (int j = i + 1; j < n; j++) off += a[i * NMAX + j] * a[i * NMAX + j];
+        }
+        if (off == 0.0 || off <= 1e-60 * diag) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = a[p * NMAX + q];
+                if (apq == 0.0) continue;
+                double theta = (a[q * NMAX + q] - a[p * NMAX + p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    double akp = a[k * NMAX + p], akq = a[k * NMAX + q];
+                    a[k * NMAX + p] = c * akp - s * akq;
+                    a[k * NMAX + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = a[p * NMAX + k], aqk = a[q * NMAX + k];
+                    a[p * NMAX + k] = c * apk - s * aqk;
+                    a[q * NMAX + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    // selection sort of (eval, column)
+    for (int i = 0; i < n; i++) evals[i] = a[i * NMAX + i];
+    for (int i = 0; i < n; i++) {
+        int m = i;
+        for (int j = i + 1; j < n; j++)
+            if (evals[j] < evals[m]) m = j;
+        if (m != i) {
+            double t = evals[i]; evals[i] = evals[m]; evals[m] = t;
+            for (int k = 0; k < n; k++) { double u = V[k * n + i]; V[k * n + i] = V[k * n + m]; V[k * n + m] = u; }
+        }
+    }
+}
+
+// x = A^-1 b by LDL^T with symmetric diagonal pivoting (Hessian.ldlt().solve, fusion.h:966);
+// zero pivots give a zero component like Eigen's LDLT::solve.
+template <int NMAX>
+NDT_HD void ldlt_solve(int n, const double *A, const double *b, double *x)
+{
+    double a[NMAX * NMAX], y[NMAX];
+    int perm[NMAX];
+    for (int i = 0; i < n; i++) {
+        perm[i] = i;
+        for (int j = 0; j < n; j++) a[i * NMAX + j] = 0.5 * (A[i * n + j] + A[j * n + i]);
+    }
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        double best = fabs(a[k * NMAX + k]);
+        for (int i = k + 1; i < n; i++)
+            if (fabs(a[i * NMAX + i]) > best) { best = fabs(a[i * NMAX + i]); piv = i; }
+        if (piv != k) {
+            for (int j = 0; j < n; j++) { double t = a[k * NMAX + j]; a[k * NMAX + j] = a[piv * NMAX + j]; a[piv * NMAX + j] = t; }
+            for (int i = 0; i < n; i++) { double t = a[i * NMAX + k]; a[i * NMAX + k] = a[i * NMAX + piv]; a[i * NMAX + piv] = t; }
+            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        }
+        double d = a[k * NMAX + k];
+        if (fabs(d) <= 2.2250738585072014e-308) continue;
+        for (int i = k + 1; i < n; i++) {
+            double l = a[i * NMAX + k] / d;
+            for (int j = k + 1; j < n; j++) a[i * NMAX + j] -= l * a[k * NMAX + j];
+            a[i * NMAX + k] = l;
+        }
+        for (int j = k + 1; j < n; j++) a[k * NMAX + j] = 0.0;
+    }
+    for (int i = 0; i < n; i++) y[i] = b[perm[i]];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++) y[i] -= a[i * NMAX + j] * y[j];
+    for (int i = 0; i < n; i++) {
+        double d = a[i * NMAX + i];
+        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;
+    }
+    for (int i = n - 1; i >= 0; i--)
+        for (int j = i + 1; j < n; j++) y[i] -= a[j * NMAX + i] * y[j];
+    for (int i = 0; i < n; i++) x[perm[i]] = y[i];
+}
+
+// LazyGrid::getIndexForPoint: idx = floor((p - centre)/res + 0.5) + size/2.0, double -> int.
+// Contraction is off so that the host oracle and the device agree bit-for-bit at cell faces.
+NDT_HD int lazygrid_index(double p, double centre, double res, int size)
+{
+#pragma clang fp contract(off)
+    double v = floor((p - centre) / res + 0.5) + size / 2.0;
+    if (!(v > -2.0e9 && v < 2.0e9)) return -1;   // NaN / far away: outside any grid
+    return (int)v;
+}

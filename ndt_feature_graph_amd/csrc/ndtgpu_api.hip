@@ -1,0 +1,446 @@
+// ndtgpu_api.hip -- C-ABI (include/ndtgpu.h) over the HIP kernels.  Host side only: handle and
+// arena management, argument checking, staging copies.  No CPU compute path exists here: without a
+// device every compute entry point fails with NDTGPU_ERR_NO_DEVICE.
+#include "../../include/ndtgpu.h"
+#include "ndt_math.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+ndtgpu_status fail(ndtgpu_status s, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return s;
+}
+
+#define HIP_TRY(expr)                                                       \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) return fail(NDTGPU_ERR_HIP, #expr, _e);       \
+    } while (0)
+
+bool have_device()
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+}  // namespace
+
+struct ndtgpu_mapset {
+    NdtSetView v{};
+    size_t n_maps = 0;
+    std::vector<double> centres_host;
+    hipStream_t last_stream = nullptr;
+    // staging buffers reused across calls
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    double *origins_dev = nullptr;
+    size_t origins_cap = 0;
+
+    ndtgpu_status ensure_stage(size_t bytes)
+    {
+        if (bytes <= stage_bytes) return NDTGPU_OK;
+        if (stage) (void)hipFree(stage);
+        stage = nullptr;
+        stage_bytes = 0;
+        HIP_TRY(hipMalloc(&stage, bytes));
+        stage_bytes = bytes;
+        return NDTGPU_OK;
+    }
+};
+
+extern "C" {
+
+const char *ndtgpu_version(void) { return "ndtgpu 0.1 (gfx950)"; }
+const char *ndtgpu_last_error(void) { return g_err.c_str(); }
+
+int ndtgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void ndtgpu_default_cell_params(ndtgpu_cell_params *p)
+{
+    p->n_min = 3;
+    p->eval_factor = 1000.0;
+}
+
+void ndtgpu_default_match_params(ndtgpu_match_params *p)
+{
+    // the fuser preset: ndt_feature_fuser_hmt.cpp:356-357 with the production launch values
+    p->n_neighbours = 2;
+    p->itr_max = 30;
+    p->delta_score = 1e-6;
+    p->step_control = 1;
+    p->lfd1 = 1.0;
+    p->lfd2 = 0.05;
+    p->dof_mask = 0x3f;
+    p->use_initial_guess = 1;
+}
+
+const char *ndtgpu_kernel_name(int which)
+{
+    switch (which) {
+    case 0: return "ndt_build_kernel";
+    case 1: return "ndt_match_kernel";
+    case 2: return "ndt_derivatives_kernel";
+    default: return "";
+    }
+}
+
+ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps, ndtgpu_mapset **out)
+{
+    if (!grid || !out || n_maps == 0 || !(grid->res > 0)) return fail(NDTGPU_ERR_INVALID, "mapset_create: bad argument");
+    if (!have_device()) return fail(NDTGPU_ERR_NO_DEVICE, "mapset_create: no HIP device");
+    ndtgpu_mapset *s = new (std::nothrow) ndtgpu_mapset();
+    if (!s) return fail(NDTGPU_ERR_ALLOC, "mapset_create: host alloc");
+    s->n_maps = n_maps;
+    NdtGrid &g = s->v.grid;
+    g.res = grid->res;
+    long long slots = 1;
+    for (int a = 0; a < 3; a++) {
+        // LazyGrid::initialize: sizeX = abs(ceil(sizeXmeters / cellSizeX))
+        g.size[a] = std::abs((int)std::ceil(grid->size[a] / grid->res));
+        if (g.size[a] <= 0) { delete s; return fail(NDTGPU_ERR_INVALID, "mapset_create: empty grid axis"); }
+        slots *= g.size[a];
+    }
+    if (slots > (1ll << 30)) { delete s; return fail(NDTGPU_ERR_INVALID, "mapset_create: grid too large"); }
+    g.slots = (int)slots;
+    uint32_t cap = grid->max_cells ? grid->max_cells : (uint32_t)std::min<long long>(slots, 16384);
+    if (cap > (1u << 24) - 1) cap = (1u << 24) - 1;
+    g.max_cells = cap;
+    s->centres_host.resize(n_maps * 3);
+    for (size_t m = 0; m < n_maps; m++)
+        for (int a = 0; a < 3; a++) s->centres_host[m * 3 + a] = grid->centre[a];
+
+    hipError_t e;
+#define ALLOC(ptr, bytes)                                                          \
+    if ((e = hipMalloc((void **)&(ptr), (bytes))) != hipSuccess) {                 \
+        ndtgpu_mapset_destroy(s);                                                  \
+        return fail(NDTGPU_ERR_ALLOC, "mapset_create: hipMalloc " #ptr, e);        \
+    }
+    ALLOC(s->v.table, n_maps * (size_t)g.slots * sizeof(int32_t));
+    ALLOC(s->v.cells, n_maps * (size_t)cap * sizeof(NdtCell));
+    ALLOC(s->v.acc, n_maps * (size_t)cap * sizeof(NdtAcc));
+    ALLOC(s->v.acc_slot, n_maps * (size_t)cap * sizeof(uint32_t));
+    ALLOC(s->v.counters, n_maps * sizeof(NdtMapCounters));
+    ALLOC(s->v.centres, n_maps * 3 * sizeof(double));
+#undef ALLOC
+    if ((e = hipMemset(s->v.table, 0xFF, n_maps * (size_t)g.slots * sizeof(int32_t))) != hipSuccess ||
+        (e = hipMemset(s->v.acc, 0, n_maps * (size_t)cap * sizeof(NdtAcc))) != hipSuccess ||
+        (e = hipMemset(s->v.counters, 0, n_maps * sizeof(NdtMapCounters))) != hipSuccess ||
+        (e = hipMemcpy(s->v.centres, s->centres_host.data(), n_maps * 3 * sizeof(double), hipMemcpyHostToDevice)) !=
+            hipSuccess) {
+        ndtgpu_mapset_destroy(s);
+        return fail(NDTGPU_ERR_HIP, "mapset_create: init", e);
+    }
+    *out = s;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
+{
+    if (!s) return NDTGPU_OK;
+    (void)hipDeviceSynchronize();
+    if (s->v.table) (void)hipFree(s->v.table);
+    if (s->v.cells) (void)hipFree(s->v.cells);
+    if (s->v.acc) (void)hipFree(s->v.acc);
+    if (s->v.acc_slot) (void)hipFree(s->v.acc_slot);
+    if (s->v.counters) (void)hipFree(s->v.counters);
+    if (s->v.centres) (void)hipFree(s->v.centres);
+    if (s->stage) (void)hipFree(s->stage);
+    if (s->origins_dev) (void)hipFree(s->origins_dev);
+    delete s;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_set_centre(ndtgpu_mapset *s, size_t map, const double centre[3])
+{
+    if (!s || !centre || map >= s->n_maps) return fail(NDTGPU_ERR_INVALID, "set_centre: bad argument");
+    for (int a = 0; a < 3; a++) s->centres_host[map * 3 + a] = centre[a];
+    HIP_TRY(hipMemcpy(s->v.centres + map * 3, centre, 3 * sizeof(double), hipMemcpyHostToDevice));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_info(const ndtgpu_mapset *s, size_t *n_maps, int32_t cells_per_axis[3], uint32_t *max_cells)
+{
+    if (!s) return fail(NDTGPU_ERR_INVALID, "mapset_info: null");
+    if (n_maps) *n_maps = s->n_maps;
+    if (cells_per_axis)
+        for (int a = 0; a < 3; a++) cells_per_axis[a] = s->v.grid.size[a];
+    if (max_cells) *max_cells = s->v.grid.max_cells;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                                  size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                  const double *range_origins, const ndtgpu_cell_params *cell, ndtgpu_stream stream)
+{
+    if (!s || first + count > s->n_maps || (!xyz_dev && n_points) || stride_bytes < 12 || (stride_bytes & 3) ||
+        n_points > 0xFFFFFFFFull)
+        return fail(NDTGPU_ERR_INVALID, "mapset_build: bad argument");
+    ndtgpu_cell_params cp;
+    ndtgpu_default_cell_params(&cp);
+    if (cell) cp = *cell;
+    hipStream_t st = (hipStream_t)stream;
+    const double *orig_dev = nullptr;
+    if (range_origins && count) {
+        if (s->origins_cap < count * 3) {
+            if (s->origins_dev) (void)hipFree(s->origins_dev);
+            s->origins_dev = nullptr;
+            s->origins_cap = 0;
+            HIP_TRY(hipMalloc((void **)&s->origins_dev, count * 3 * sizeof(double)));
+            s->origins_cap = count * 3;
+        }
+        HIP_TRY(hipMemcpyAsync(s->origins_dev, range_origins, count * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+        orig_dev = s->origins_dev;
+    }
+    s->last_stream = st;
+    hipError_t e = ndt_launch_build(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit,
+                                    orig_dev, cp.n_min, cp.eval_factor, st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: launch", e);
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_build_host(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,
+                                       size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                       double range_limit, const double *range_origins, const ndtgpu_cell_params *cell)
+{
+    if (!s || (!xyz_host && n_points) || count == 0) return fail(NDTGPU_ERR_INVALID, "mapset_build_host: bad argument");
+    size_t bytes = (count - 1) * map_stride_bytes + n_points * stride_bytes;
+    if (bytes == 0) bytes = 16;
+    ndtgpu_status rc = s->ensure_stage(bytes);
+    if (rc != NDTGPU_OK) return rc;
+    if (n_points) HIP_TRY(hipMemcpy(s->stage, xyz_host, bytes, hipMemcpyHostToDevice));
+    rc = ndtgpu_mapset_build(s, first, count, s->stage, n_points, stride_bytes, map_stride_bytes, range_limit,
+                             range_origins, cell, nullptr);
+    if (rc != NDTGPU_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NDTGPU_OK;
+}
+
+static ndtgpu_status read_counters(ndtgpu_mapset *s, size_t map, NdtMapCounters *c)
+{
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    HIP_TRY(hipMemcpy(c, s->v.counters + map, sizeof *c, hipMemcpyDeviceToHost));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_num_cells(ndtgpu_mapset *s, size_t map, uint32_t *n)
+{
+    if (!s || !n || map >= s->n_maps) return fail(NDTGPU_ERR_INVALID, "num_cells: bad argument");
+    NdtMapCounters c;
+    ndtgpu_status rc = read_counters(s, map, &c);
+    if (rc != NDTGPU_OK) return rc;
+    *n = c.n_cells;
+    if (c.overflow) return fail(NDTGPU_ERR_CAPACITY, "map needs more cells than max_cells");
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_export_cells(ndtgpu_mapset *s, size_t map, double *mean3, double *cov9, int32_t *idx3,
+                                         uint32_t *npts)
+{
+    if (!s || map >= s->n_maps) return fail(NDTGPU_ERR_INVALID, "export_cells: bad argument");
+    NdtMapCounters c;
+    ndtgpu_status rc = read_counters(s, map, &c);
+    if (rc != NDTGPU_OK) return rc;
+    std::vector<NdtCell> host(c.n_cells);
+    if (c.n_cells)
+        HIP_TRY(hipMemcpy(host.data(), s->v.cells + map * (size_t)s->v.grid.max_cells, c.n_cells * sizeof(NdtCell),
+                          hipMemcpyDeviceToHost));
+    const NdtGrid &g = s->v.grid;
+    for (uint32_t i = 0; i < c.n_cells; i++) {
+        const NdtCell &k = host[i];
+        if (mean3)
+            for (int a = 0; a < 3; a++) mean3[3 * i + a] = k.mean[a];
+        if (cov9) {
+            double *o = cov9 + 9 * i;
+            o[0] = k.cov[0]; o[1] = k.cov[1]; o[2] = k.cov[2];
+            o[3] = k.cov[1]; o[4] = k.cov[3]; o[5] = k.cov[4];
+            o[6] = k.cov[2]; o[7] = k.cov[4]; o[8] = k.cov[5];
+        }
+        if (idx3) {
+            idx3[3 * i + 2] = (int32_t)(k.slot % g.size[2]);
+            idx3[3 * i + 1] = (int32_t)((k.slot / g.size[2]) % g.size[1]);
+            idx3[3 * i + 0] = (int32_t)(k.slot / ((uint32_t)g.size[2] * g.size[1]));
+        }
+        if (npts) npts[i] = k.n;
+    }
+    if (c.overflow) return fail(NDTGPU_ERR_CAPACITY, "map needs more cells than max_cells");
+    return NDTGPU_OK;
+}
+
+// host-side packing of caller-provided Gaussians into NdtCell records keyed by LazyGrid slot
+static ndtgpu_status pack_cells(const NdtGrid &g, const double *centre, const double *mean3, const double *cov9,
+                                size_t n, bool need_slot, std::vector<NdtCell> &out)
+{
+    out.clear();
+    out.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        NdtCell c;
+        for (int a = 0; a < 3; a++) c.mean[a] = mean3[3 * i + a];
+        const double *v = cov9 + 9 * i;
+        c.cov[0] = v[0]; c.cov[1] = v[1]; c.cov[2] = v[2]; c.cov[3] = v[4]; c.cov[4] = v[5]; c.cov[5] = v[8];
+        c.n = 1;
+        c.slot = 0;
+        if (need_slot) {
+            int idx[3];
+            bool inside = true;
+            for (int a = 0; a < 3; a++) {
+                idx[a] = lazygrid_index(c.mean[a], centre[a], g.res, g.size[a]);
+                inside = inside && idx[a] >= 0 && idx[a] < g.size[a];
+            }
+            if (!inside) continue;   // LazyGrid::addPoint drops what falls outside the grid
+            c.slot = (uint32_t)((idx[0] * g.size[1] + idx[1]) * g.size[2] + idx[2]);
+        }
+        out.push_back(c);
+    }
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_set_cells(ndtgpu_mapset *s, size_t map, const double *mean3, const double *cov9,
+                                      size_t n_cells)
+{
+    if (!s || map >= s->n_maps || (n_cells && (!mean3 || !cov9)))
+        return fail(NDTGPU_ERR_INVALID, "set_cells: bad argument");
+    std::vector<NdtCell> cells;
+    pack_cells(s->v.grid, &s->centres_host[map * 3], mean3, cov9, n_cells, true, cells);
+    // one Gaussian per slot (a later cell replaces an earlier one, like setMean/setCov on the same
+    // NDTCell), sorted by slot = the canonical cell order of the build kernel
+    std::stable_sort(cells.begin(), cells.end(), [](const NdtCell &a, const NdtCell &b) { return a.slot < b.slot; });
+    std::vector<NdtCell> uniq;
+    for (size_t i = 0; i < cells.size(); i++) {
+        if (!uniq.empty() && uniq.back().slot == cells[i].slot) uniq.back() = cells[i];
+        else uniq.push_back(cells[i]);
+    }
+    if (uniq.size() > s->v.grid.max_cells) return fail(NDTGPU_ERR_CAPACITY, "set_cells: more cells than max_cells");
+    ndtgpu_status rc = s->ensure_stage(std::max<size_t>(uniq.size() * sizeof(NdtCell), 16));
+    if (rc != NDTGPU_OK) return rc;
+    if (!uniq.empty()) HIP_TRY(hipMemcpy(s->stage, uniq.data(), uniq.size() * sizeof(NdtCell), hipMemcpyHostToDevice));
+    s->last_stream = nullptr;
+    hipError_t e = ndt_launch_install_cells(s->v, map, (const double *)s->stage, nullptr, uniq.size(), nullptr);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "set_cells: launch", e);
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_derivatives(ndtgpu_mapset *t, size_t tmap, const double *src_mean3, const double *src_cov9,
+                                 size_t m, int n_neighbours, int compute_hessian, double lfd1, double lfd2,
+                                 double *score, double g[6], double H[36])
+{
+    if (!t || tmap >= t->n_maps || (m && (!src_mean3 || !src_cov9)) || !score || !g || n_neighbours < 0 ||
+        n_neighbours > 3)
+        return fail(NDTGPU_ERR_INVALID, "derivatives: bad argument");
+    std::vector<NdtCell> cells;
+    pack_cells(t->v.grid, nullptr, src_mean3, src_cov9, m, false, cells);
+    size_t bytes = cells.size() * sizeof(NdtCell) + 32 * sizeof(double);
+    ndtgpu_status rc = t->ensure_stage(bytes);
+    if (rc != NDTGPU_OK) return rc;
+    double *out_dev = (double *)t->stage;
+    NdtCell *src_dev = (NdtCell *)((char *)t->stage + 32 * sizeof(double));
+    HIP_TRY(hipStreamSynchronize(t->last_stream));
+    if (!cells.empty()) HIP_TRY(hipMemcpy(src_dev, cells.data(), cells.size() * sizeof(NdtCell), hipMemcpyHostToDevice));
+    hipError_t e = ndt_launch_derivatives(t->v, tmap, src_dev, cells.size(), n_neighbours, compute_hessian, lfd1, lfd2,
+                                          out_dev, nullptr);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "derivatives: launch", e);
+    double out[28];
+    HIP_TRY(hipMemcpy(out, out_dev, sizeof out, hipMemcpyDeviceToHost));
+    *score = out[0];
+    for (int a = 0; a < 6; a++) g[a] = out[1 + a];
+    if (compute_hessian && H) {
+        int o = 7;
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) { H[a * 6 + b] = out[o]; H[b * 6 + a] = out[o]; o++; }
+    }
+    return NDTGPU_OK;
+}
+
+static NdtMatchParamsDev to_dev(const ndtgpu_match_params *p)
+{
+    ndtgpu_match_params d;
+    ndtgpu_default_match_params(&d);
+    if (p) d = *p;
+    NdtMatchParamsDev o;
+    o.n_neighbours = d.n_neighbours;
+    o.itr_max = d.itr_max;
+    o.step_control = d.step_control;
+    o.dof_mask = d.dof_mask;
+    o.use_initial_guess = d.use_initial_guess;
+    o.delta_score = d.delta_score;
+    o.lfd1 = d.lfd1;
+    o.lfd2 = d.lfd2;
+    return o;
+}
+
+static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result layouts must agree");
+
+ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
+                                        const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
+                                        const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
+                                        ndtgpu_stream stream)
+{
+    if (!ts || !ss || (n_pairs && (!tidx_dev || !sidx_dev || !T16_dev || !results_dev)))
+        return fail(NDTGPU_ERR_INVALID, "match_batch_device: bad argument");
+    NdtMatchParamsDev p = to_dev(prm);
+    if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
+        return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
+    hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
+                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                 double *T16, size_t n_pairs, const ndtgpu_match_params *prm,
+                                 ndtgpu_match_result *results, ndtgpu_stream stream)
+{
+    if (!ts || !ss || (n_pairs && (!tidx || !sidx || !T16 || !results)))
+        return fail(NDTGPU_ERR_INVALID, "match_batch: bad argument");
+    if (n_pairs == 0) return NDTGPU_OK;
+    for (size_t k = 0; k < n_pairs; k++)
+        if (tidx[k] >= ts->n_maps || sidx[k] >= ss->n_maps) return fail(NDTGPU_ERR_INVALID, "match_batch: map index");
+    hipStream_t st = (hipStream_t)stream;
+    size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
+    size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
+           off_si = (off_ti + bI + 255) & ~(size_t)255, total = off_si + bI;
+    // builds on other streams must have finished before the maps are read
+    HIP_TRY(hipStreamSynchronize(ts->last_stream));
+    HIP_TRY(hipStreamSynchronize(ss->last_stream));
+    ndtgpu_status rc = ts->ensure_stage(total);
+    if (rc != NDTGPU_OK) return rc;
+    char *base = (char *)ts->stage;
+    HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
+    rc = ndtgpu_match_batch_device(ts, (const uint32_t *)(base + off_ti), ss, (const uint32_t *)(base + off_si),
+                                   (double *)base, n_pairs, prm, (ndtgpu_match_result *)(base + off_R), stream);
+    if (rc != NDTGPU_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *ts, size_t tmap, ndtgpu_mapset *ss, size_t smap, double T16[16],
+                               const ndtgpu_match_params *prm, ndtgpu_match_result *result)
+{
+    uint32_t ti = (uint32_t)tmap, si = (uint32_t)smap;
+    return ndtgpu_match_batch(ts, &ti, ss, &si, T16, 1, prm, result, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+"""HIP path vs CPU oracle through the C-ABI (include/ndtgpu.h).  Needs a real MI355X: -m gpu.
+
+Bars (BASELINE.json north_star): integer / index work bit-exact (cell set, point counts); cell
+statistics 1e-9 (fixed-point moments); derivatives 1e-9 relative; final pose within
+1e-4 m / 1e-4 rad of the CPU matcher on identical inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4
+POSE_TOL_RAD = 1e-4
+
+
+@pytest.fixture(scope="module")
+def N():
+    import ndt_feature_graph_amd as N
+    if N.device_count() < 1:
+        pytest.fail("no HIP device visible: the HIP path cannot run (there is no CPU fallback)")
+    return N
+
+
+@pytest.fixture(scope="module")
+def O():
+    import oracle
+    return oracle
+
+
+def rot_angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1.0) / 2.0
+    return float(np.arccos(np.clip(c, -1.0, 1.0)))
+
+
+def pose_close(Ta, Tb):
+    return np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]), rot_angle(Ta[:3, :3], Tb[:3, :3])
+
+
+def oracle_map(O, pts, res, size, centre=(0, 0, 0), rng=30.0, n_min=3):
+    m = O.OracleMap(res, centre, size)
+    m.load_points(pts, rng)
+    m.compute_cells(n_min=n_min)
+    return m
+
+
+def assert_cells_equal(gpu, cpu, res):
+    gm, gc, gi, gn = gpu
+    cm, cc, ci, cn = cpu
+    assert len(gn) == len(cn), "number of Gaussian cells differs: %d vs %d" % (len(gn), len(cn))
+    assert np.array_equal(gi, ci), "cell index sets differ"
+    assert np.array_equal(gn.astype(np.int64), cn.astype(np.int64)), "per-cell point counts differ"
+    assert np.max(np.abs(gm - cm)) < 1e-9 * max(1.0, res)
+    scale = np.max(np.abs(cc), axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(gc - cc) / scale) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_pts,res", [(10000, 1.0), (100000, 0.5)])
+def test_build_parity_scan(N, O, n_pts, res):
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_2d([11, 12], n_pts)
+    ms = N.MapSet(res, [0, 0, 0], [100, 100, 1], n_maps=4)
+    pts = np.concatenate([pr["fixed"].numpy(), pr["moving"].numpy()])        # 4 scans
+    ms.build(pts, range_limit=30.0)
+    for k in range(4):
+        cpu = oracle_map(O, pts[k], res, [100, 100, 1])
+        assert_cells_equal(ms.export_cells(k), cpu.export_cells(), res)
+
+
+def test_build_device_pointer_path_and_stride16(N, O):
+    import torch
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_2d([21], 30000)
+    p3 = pr["fixed"][0]
+    p4 = torch.cat([p3, torch.full((p3.shape[0], 1), 7.0)], dim=1).contiguous()   # pcl::PointXYZ padding
+    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2)
+    ms.build(p3[None].cuda().contiguous(), range_limit=30.0, first=0)
+    ms.build(p4[None].cuda().contiguous(), range_limit=30.0, first=1)
+    torch.cuda.synchronize()
+    cpu = oracle_map(O, p3.numpy(), 0.5, [100, 100, 1]).export_cells()
+    assert_cells_equal(ms.export_cells(0), cpu, 0.5)
+    assert_cells_equal(ms.export_cells(1), cpu, 0.5)
+
+
+def test_build_golden_cells(N, golden):
+    for k in range(6):
+        pts = golden["cell%d_pts" % k]
+        centre = np.round(pts.mean(axis=0).astype(float) * 2) / 2
+        ms = N.MapSet(0.5, centre, [0.5, 0.5, 0.5])
+        ms.build(pts[None])
+        if not bool(golden["cell%d_ok" % k]):
+            assert ms.num_cells() == 0
+            continue
+        mean, cov, idx, n = ms.export_cells()
+        assert len(n) == 1 and n[0] == len(pts)
+        np.testing.assert_allclose(mean[0], golden["cell%d_mean" % k], rtol=0, atol=1e-10)
+        want = golden["cell%d_cov" % k]
+        assert np.max(np.abs(cov[0] - want)) < 1e-8 * np.max(np.abs(want))
+
+
+def test_build_edge_cases(N, O):
+    ms = N.MapSet(1.0, [0, 0, 0], [10, 10, 2], n_maps=3)
+    base = np.array([[0.1, 0.1, 0.1], [0.2, 0.15, 0.05], [0.15, 0.3, 0.2], [0.3, 0.2, 0.15], [0.25, 0.1, 0.3]], np.float32)
+    junk = np.array([[np.nan, 0, 0], [0, np.nan, 0], [4.0, 0.2, 0.1], [100.0, 0, 0], [0, -5.6, 0]], np.float32)
+    allnan = np.full((10, 3), np.nan, np.float32)
+    ms.build(np.stack([np.concatenate([base, junk]), np.concatenate([junk, base]), allnan]), range_limit=3.0)
+    cpu = oracle_map(O, np.concatenate([base, junk]), 1.0, [10, 10, 2], rng=3.0)
+    assert_cells_equal(ms.export_cells(0), cpu.export_cells(), 1.0)
+    assert_cells_equal(ms.export_cells(1), cpu.export_cells(), 1.0)        # order of points is irrelevant
+    assert ms.num_cells(2) == 0                                           # empty scan
+    # rebuild in place replaces the content
+    ms.build(allnan[None], first=0)
+    assert ms.num_cells(0) == 0
+    # range measured from an origin (loadPointCloudCentroid)
+    ms.build(np.concatenate([base, junk])[None], range_limit=3.0, range_origins=[[3.0, 0, 0]], first=0)
+    m = O.OracleMap(1.0, [0, 0, 0], [10, 10, 2])
+    m.load_points(np.concatenate([base, junk]), 3.0, [3.0, 0, 0]); m.compute_cells()
+    assert_cells_equal(ms.export_cells(0), m.export_cells(), 1.0)
+
+
+def test_build_unordered_points_same_result(N):
+    from ndt_feature_graph_amd import synth
+    pts = synth.pair_2d([31], 50000)["fixed"][0].numpy()
+    perm = np.random.default_rng(0).permutation(len(pts))
+    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2)
+    ms.build(np.stack([pts, pts[perm]]), range_limit=30.0)
+    a, b = ms.export_cells(0), ms.export_cells(1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)          # integer moments: order-independent, bit-identical
+
+
+def test_capacity_overflow_is_reported(N):
+    from ndt_feature_graph_amd import synth
+    pts = synth.pair_2d([41], 20000)["fixed"][0].numpy()
+    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], max_cells=16)
+    ms.build(pts[None], range_limit=30.0)
+    with pytest.raises(N.NdtGpuError) as e:
+        ms.num_cells()
+    assert e.value.status == -4
+
+
+# ---------------------------------------------------------------------------------------------
+def test_derivatives_golden_and_oracle(N, O, golden):
+    res = float(golden["d2d_res"])
+    size = golden["d2d_size"] * res
+    tg = N.MapSet(res, golden["d2d_centre"], size)
+    tg.set_cells(0, golden["d2d_tgt_mean"], golden["d2d_tgt_cov"])
+    assert tg.num_cells() == len(golden["d2d_tgt_mean"])
+    ot = O.OracleMap(res, golden["d2d_centre"], size)
+    ot.set_cells(golden["d2d_tgt_mean"], golden["d2d_tgt_cov"])
+    for nn in (0, 1, 2):
+        s, g, H = N.derivatives(tg, 0, golden["d2d_src_mean"], golden["d2d_src_cov"], n_neighbours=nn)
+        so, go, Ho = O.derivatives(ot, golden["d2d_src_mean"], golden["d2d_src_cov"], n_neighbours=nn)
+        assert abs(s - so) < 1e-11 * abs(so)
+        assert np.max(np.abs(g - go)) < 1e-10 * np.max(np.abs(go))
+        assert np.max(np.abs(H - Ho)) < 1e-10 * np.max(np.abs(Ho))
+        s2, g2, _ = N.derivatives(tg, 0, golden["d2d_src_mean"], golden["d2d_src_cov"], n_neighbours=nn,
+                                  compute_hessian=False)
+        assert abs(s2 - s) < 1e-13 * abs(s) and np.max(np.abs(g2 - g)) < 1e-12 * np.max(np.abs(g))
+    s, g, H = N.derivatives(tg, 0, golden["d2d_src_mean"], golden["d2d_src_cov"], n_neighbours=2)
+    assert abs(s - float(golden["d2d_score"])) < 1e-11 * abs(s)                 # NumPy restatement
+    assert np.max(np.abs(g - golden["d2d_grad_fd"])) < 1e-6 * np.max(np.abs(g))  # vs NumPy finite differences
+    assert np.max(np.abs(H - golden["d2d_hess_fd"])) < 2e-5 * np.max(np.abs(H))
+
+
+def test_derivatives_on_scan_maps(N, O):
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_2d([5], 60000)
+    f, m = pr["fixed"][0].numpy(), pr["moving"][0].numpy()
+    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2)
+    ms.build(np.stack([f, m]), range_limit=30.0)
+    ot = oracle_map(O, f, 0.5, [100, 100, 1])
+    mean, cov, _, _ = ms.export_cells(1)
+    T = pr["T_init"][0].numpy()
+    mm, cc = mean @ T[:3, :3].T + T[:3, 3], T[:3, :3] @ cov @ T[:3, :3].T
+    s, g, H = N.derivatives(ms, 0, mm, cc)
+    so, go, Ho = O.derivatives(ot, mm, cc)
+    assert abs(s - so) < 1e-9 * abs(so)
+    assert np.max(np.abs(g - go)) < 1e-9 * np.max(np.abs(go))
+    assert np.max(np.abs(H - Ho)) < 1e-9 * np.max(np.abs(Ho))
+
+
+# ---------------------------------------------------------------------------------------------
+def _pair_maps(N, O, seeds, n_pts, res):
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_2d(seeds, n_pts)
+    B = len(seeds)
+    tg = N.MapSet(res, [0, 0, 0], [100, 100, 1], n_maps=B)
+    sr = N.MapSet(res, [0, 0, 0], [100, 100, 1], n_maps=B)
+    tg.build(pr["fixed"].numpy(), range_limit=30.0)
+    sr.build(pr["moving"].numpy(), range_limit=30.0)
+    om = [(oracle_map(O, pr["fixed"][b].numpy(), res, [100, 100, 1]),
+           oracle_map(O, pr["moving"][b].numpy(), res, [100, 100, 1])) for b in range(B)]
+    return pr, tg, sr, om
+
+
+@pytest.mark.parametrize("n_pts,res,seeds", [(10000, 1.0, [1, 2, 3, 4]), (100000, 0.5, [1, 2, 3, 4, 5, 6])])
+def test_match_parity_6dof(N, O, n_pts, res, seeds):
+    """configs[0] (10 k pts, 1.0 m) and configs[1] (100 k pts, 0.5 m): pose parity per pair."""
+    pr, tg, sr, om = _pair_maps(N, O, seeds, n_pts, res)
+    B = len(seeds)
+    T0 = pr["T_init"].numpy()
+    T, r = N.match_batch(tg, np.arange(B), sr, np.arange(B), T0)
+    for b in range(B):
+        To, ro = O.match_d2d(om[b][0], om[b][1], T0[b])
+        dt, dr = pose_close(T[b], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
+        assert bool(r["converged"][b]) == ro["converged"]
+        assert abs(r["score"][b] - ro["score"]) < 1e-6 * abs(ro["score"])
+        assert r["n_source"][b] == om[b][1].num_cells() and r["n_target"][b] == om[b][0].num_cells()
+        gt = pr["T_gt"][b].numpy()
+        assert pose_close(T[b], gt)[0] < 0.03          # and it is the right answer, not just the same one
+
+
+def test_match_parity_edge_preset_and_3dof(N, O):
+    pr, tg, sr, om = _pair_maps(N, O, [7, 8], 40000, 0.5)
+    T0 = pr["T_init"].numpy()
+    # "edge" preset: default-constructed NDTMatcherD2D, DELTA_SCORE 1e-3 (graph.cpp:261-262)
+    T, r = N.match_batch(tg, [0, 1], sr, [0, 1], T0, delta_score=1e-3)
+    for b in range(2):
+        To, ro = O.match_d2d(om[b][0], om[b][1], T0[b], delta_score=1e-3)
+        dt, dr = pose_close(T[b], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+        assert r["iterations"][b] == ro["iterations"]
+    # NDTMatcherD2D_2D: {x, y, yaw}; start near the optimum (the 3x3 regulariser is fragile far away)
+    Tn = pr["T_gt"].numpy().copy()
+    Tn[:, 0, 3] += 0.02
+    Tn[:, 1, 3] -= 0.01
+    T, r = N.match_batch(tg, [0, 1], sr, [0, 1], Tn, dof_mask=0x23)
+    for b in range(2):
+        To, ro = O.match_d2d(om[b][0], om[b][1], Tn[b], dof_mask=0x23)
+        dt, dr = pose_close(T[b], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+        assert abs(T[b][2, 3]) < 1e-15 and abs(T[b][2, 2] - 1) < 1e-15       # z, roll, pitch untouched
+    # no step control, iteration cap, no initial guess
+    T, r = N.match_batch(tg, [0], sr, [0], T0[:1], step_control=0)
+    To, ro = O.match_d2d(om[0][0], om[0][1], T0[0], step_control=0)
+    assert pose_close(T[0], To)[0] <= POSE_TOL_M
+    T, r = N.match_batch(tg, [0], sr, [0], T0[:1], itr_max=1)
+    To, ro = O.match_d2d(om[0][0], om[0][1], T0[0], itr_max=1)
+    assert (not r["converged"][0]) and r["iterations"][0] == ro["iterations"] == 3 and r["exit_code"][0] == 3
+    assert pose_close(T[0], To)[0] <= POSE_TOL_M
+    T, r = N.match_batch(tg, [0], sr, [0], T0[:1], use_initial_guess=0)
+    To, ro = O.match_d2d(om[0][0], om[0][1], T0[0], use_initial_guess=0)
+    dt, dr = pose_close(T[0], To)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_match_batch_is_deterministic_and_order_free(N, O):
+    pr, tg, sr, om = _pair_maps(N, O, [1, 2, 3, 4, 5], 20000, 0.5)
+    T0 = pr["T_init"].numpy()
+    idx = np.arange(5)
+    Ta, ra = N.match_batch(tg, idx, sr, idx, T0)
+    Tb, rb = N.match_batch(tg, idx, sr, idx, T0)
+    assert np.array_equal(Ta, Tb) and np.array_equal(ra, rb)                    # run-to-run identical
+    perm = np.array([3, 0, 4, 1, 2])
+    Tc, rc = N.match_batch(tg, idx[perm], sr, idx[perm], T0[perm])
+    assert np.array_equal(Tc, Ta[perm])                                        # a pair's result ignores its batch
+    T1, r1 = N.match_d2d(tg, 2, sr, 2, T0[2])
+    assert np.array_equal(T1, Ta[2])
+
+
+def test_self_match_and_empty_maps(N):
+    from ndt_feature_graph_amd import synth
+    pts = synth.pair_2d([9], 20000)["fixed"].numpy()
+    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2)
+    ms.build(np.concatenate([pts, np.full_like(pts, np.nan)]), range_limit=30.0)
+    T, r = N.match_d2d(ms, 0, ms, 0, np.eye(4))
+    assert r["converged"] and np.max(np.abs(T - np.eye(4))) < 1e-9
+    # empty source / empty target: zero gradient -> "gradient vanished" exit, pose untouched
+    T0 = np.eye(4); T0[0, 3] = 0.3
+    for a, b in ((0, 1), (1, 0), (1, 1)):
+        T, r = N.match_d2d(ms, a, ms, b, T0)
+        assert np.array_equal(T, T0) and r["exit_code"] == 1 and r["score"] == 0.0
+
+
+def test_config5_3d_small(N, O):
+    """configs[4] at reduced size: Velodyne-style cloud, 6-DoF, 0.5 m voxels."""
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_3d([1], rings=32, azimuths=1500)
+    size = [100, 100, 10]
+    ms = N.MapSet(0.5, [0, 0, 0], size, n_maps=2, max_cells=60000)
+    pts = np.concatenate([pr["fixed"].numpy(), pr["moving"].numpy()])
+    ms.build(pts, range_limit=70.0)
+    of = oracle_map(O, pts[0], 0.5, size, rng=70.0)
+    om = oracle_map(O, pts[1], 0.5, size, rng=70.0)
+    assert_cells_equal(ms.export_cells(0), of.export_cells(), 0.5)
+    T0 = pr["T_init"][0].numpy()
+    T, r = N.match_d2d(ms, 0, ms, 1, T0)
+    To, ro = O.match_d2d(of, om, T0)
+    dt, dr = pose_close(T, To)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+    assert pose_close(T, pr["T_gt"][0].numpy())[0] < 0.05
