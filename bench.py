@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- NDT scan-pair registrations/sec (100k pts, 0.5 m cells) on MI355X.
+
+One STEP = one pass of the hot path over one batch of synthetic scan pairs resident in HBM:
+    grid build (K1-K3) of the 2*B scans  +  D2D match (K4-K5) of the B pairs to convergence
+(+ the RCCL all-gather of the edge transforms when WORLD_SIZE > 1).  Workload = BASELINE.json
+configs[2] ("batch of 1024 independent scan pairs, 100k pts each, 1xMI355X"), the single-GPU
+configuration the throughput metric is quoted on; per rank the batch is fixed (weak scaling).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (largest share of the step),
+`kernels` lists both; `cpu_baseline` times the CPU oracle (single thread) on a bounded sample of
+the same pairs and `parity` compares the GPU poses of that sample with the oracle's.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
+    ap.add_argument("--points", type=int, default=100000)
+    ap.add_argument("--res", type=float, default=0.5)
+    ap.add_argument("--cpu-sample", type=int, default=128, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ndt_feature_graph_amd as N
+    from ndt_feature_graph_amd import binding, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available() or N.device_count() < 1:
+        raise RuntimeError("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B, NP, res = args.pairs, args.points, args.res
+    size_m = [100.0, 100.0, 1.0]           # gustav_laser_tf.launch:16-18
+    rng_lim = 30.0                          # sensor_range, launch:22
+
+    # ---- synthetic batch, generated on the GPU, resident in HBM before the timed region -----
+    seeds = torch.arange(1 + rank * B, 1 + (rank + 1) * B, dtype=torch.int64, device=dev)
+    pr = synth.pair_2d(seeds, NP, device=dev, chunk_bytes=2 << 30)
+    fixed, moving = pr["fixed"].contiguous(), pr["moving"].contiguous()
+    T_init_cm = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)     # column-major Affine3d
+    T16 = T_init_cm.clone()
+    results = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
+    idx = torch.arange(B, dtype=torch.int32, device=dev)
+
+    tset = N.MapSet(res, [0, 0, 0], size_m, n_maps=B, max_cells=4096)
+    sset = N.MapSet(res, [0, 0, 0], size_m, n_maps=B, max_cells=4096)
+    tset.profiling(True)
+    sset.profiling(True)
+    stream = torch.cuda.current_stream()
+    gathered = None
+    if world > 1:
+        gathered = [torch.empty((world * B, 16), dtype=torch.float64, device=dev),
+                    torch.empty((world * B, 32), dtype=torch.uint8, device=dev)]
+
+    def step():
+        tset.build(fixed, range_limit=rng_lim, stream=stream)
+        sset.build(moving, range_limit=rng_lim, stream=stream)
+        T16.copy_(T_init_cm)
+        binding.match_batch_device(tset, idx, sset, idx, T16, results, B, stream=stream)
+        if world > 1:   # final gather of the edge transforms (the only collective on the path)
+            dist.all_gather_into_tensor(gathered[0], T16)
+            dist.all_gather_into_tensor(gathered[1], results)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    k_build, k_match = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # per-kernel HIP-event durations (events recorded on the launch stream inside the library)
+        k_build.append((tset.last_kernel_ms(0), sset.last_kernel_ms(0)))
+        k_match.append(tset.last_kernel_ms(1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    # ---- bookkeeping outside the timed region -------------------------------------------------
+    res_np = results.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
+    T_out = T16.cpu().numpy().reshape(B, 4, 4).transpose(0, 2, 1)
+    m_t, m_s = res_np["n_target"].astype(np.int64), res_np["n_source"].astype(np.int64)
+    build_ms = float(np.mean([a + b for a, b in k_build])) / 2.0       # per launch (B scans)
+    match_ms = float(np.mean(k_match))
+    # algorithmic bytes: build 12*N + 80*M per scan; match 80*(M_src+M_tgt) per pair
+    build_bytes = 0.5 * (2 * B * 12.0 * NP + 80.0 * float(m_t.sum() + m_s.sum()))   # per launch
+    match_bytes = 80.0 * float(m_t.sum() + m_s.sum())
+    kern = {
+        "ndt_build_kernel": {"ms_per_launch": build_ms, "launches_per_step": 2, "algorithmic_bytes": build_bytes,
+                             "GBps": build_bytes / build_ms / 1e6},
+        "ndt_match_kernel": {"ms_per_launch": match_ms, "launches_per_step": 1, "algorithmic_bytes": match_bytes,
+                             "GBps": match_bytes / match_ms / 1e6,
+                             "mean_iterations": float(res_np["iterations"].mean()),
+                             "mean_fevals": float(res_np["fevals"].mean()),
+                             "converged_frac": float(res_np["converged"].mean())},
+    }
+    dominant = "ndt_build_kernel" if 2 * build_ms >= match_ms else "ndt_match_kernel"
+    dk = kern[dominant]
+    roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "note": "algorithmic bytes / HIP-event kernel duration; PMC traffic: profiles/ (rocprofv3 --pmc)"}
+
+    out = {
+        "metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)",
+        "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[2]: batch of %d independent 2D scan pairs per GPU, %d pts/scan, %.2f m cells, "
+                               "map 100x100x1 m, range 30 m, n_neighbours 2, ITR_MAX 30, DELTA_SCORE 1e-6, 6-DoF, "
+                               "grid build of both scans + D2D match per registration" % (B, NP, res),
+                   "pairs_per_gpu": B, "points_per_scan": NP, "cell_m": res,
+                   "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2)},
+        "roofline": roofline, "kernels": kern,
+    }
+
+    # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ---------------------------
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
+        import oracle as O
+        S = min(args.cpu_sample, B)
+        f_h, m_h = fixed[:S].cpu().numpy(), moving[:S].cpu().numpy()
+        Ti = pr["T_init"][:S].cpu().numpy()
+        t_cpu = 0.0
+        max_dt = max_dr = 0.0
+        for b in range(S):
+            c0 = time.perf_counter()
+            ot = O.OracleMap(res, [0, 0, 0], size_m); ot.load_points(f_h[b], rng_lim); ot.compute_cells()
+            os_ = O.OracleMap(res, [0, 0, 0], size_m); os_.load_points(m_h[b], rng_lim); os_.compute_cells()
+            To, ro = O.match_d2d(ot, os_, Ti[b])
+            t_cpu += time.perf_counter() - c0
+            dt = float(np.linalg.norm(T_out[b][:3, 3] - To[:3, 3]))
+            dr = float(np.arccos(np.clip((np.trace(T_out[b][:3, :3].T @ To[:3, :3]) - 1) / 2, -1, 1)))
+            max_dt, max_dr = max(max_dt, dt), max(max_dr, dr)
+        cpu_rate = S / t_cpu
+        out["cpu_baseline"] = {"value": cpu_rate, "unit": "registrations/s", "cores": 1, "kind": "port",
+                               "sample": "first %d of the %d pairs (same inputs, same parameters), oracle/ndt_oracle.c "
+                                         "single thread, %.1f s" % (S, B, t_cpu),
+                               "host_cpus": os.cpu_count()}
+        out["parity"] = {"pairs_checked": S, "max_dt_m": max_dt, "max_drot_rad": max_dr,
+                         "tolerance": "1e-4 m / 1e-4 rad", "ok": bool(max_dt <= 1e-4 and max_dr <= 1e-4)}
+        out["speedup_vs_cpu_1thread"] = value / cpu_rate
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

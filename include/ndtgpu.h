@@ -158,6 +158,12 @@ ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *target_set, size_t target_map, ndt
                                ndtgpu_match_result *result);
 
 /* ---- profiling hooks ------------------------------------------------------------------ */
+/* When enabled, every build launched on `set` and every match whose TARGET set is `set` is
+ * bracketed by HIP events recorded on the launch stream (kernel only: table reset and copies are
+ * outside the bracket).  ndtgpu_last_kernel_ms waits for the end event and returns the duration
+ * of the most recent launch of kernel `which` (0 build, 1 match). */
+ndtgpu_status ndtgpu_profiling_enable(ndtgpu_mapset *set, int on);
+ndtgpu_status ndtgpu_last_kernel_ms(ndtgpu_mapset *set, int which, float *ms);
 /* kernel names as they appear in rocprofv3 --kernel-trace, for bench.py / profiles/ */
 const char *ndtgpu_kernel_name(int which); /* 0 build, 1 match, 2 derivatives */
 

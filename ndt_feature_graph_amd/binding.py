@@ -71,7 +71,8 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_default_match_params", "ndtgpu_mapset_create", "ndtgpu_mapset_destroy", "ndtgpu_mapset_set_centre",
            "ndtgpu_mapset_info", "ndtgpu_mapset_build", "ndtgpu_mapset_build_host", "ndtgpu_mapset_num_cells",
            "ndtgpu_mapset_export_cells", "ndtgpu_mapset_set_cells", "ndtgpu_derivatives", "ndtgpu_match_batch",
-           "ndtgpu_match_batch_device", "ndtgpu_match_d2d", "ndtgpu_kernel_name"]
+           "ndtgpu_match_batch_device", "ndtgpu_match_d2d", "ndtgpu_kernel_name", "ndtgpu_profiling_enable",
+           "ndtgpu_last_kernel_ms"]
 
 _lib = None
 
@@ -81,6 +82,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch bundles its own libamdhip64.so.7; load it first so that ONE HIP runtime serves both
+        # torch (device memory, streams, torch.distributed) and libndtgpu.so (same soname -> shared).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(_SO):
         raise NdtGpuError(-2, "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % _SO)
     L = C.CDLL(_SO)
@@ -108,6 +115,8 @@ def lib():
     L.ndtgpu_match_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, C.POINTER(MatchParams), vp, vp]
     L.ndtgpu_match_batch_device.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(MatchParams), vp, vp]
     L.ndtgpu_match_d2d.argtypes = [vp, C.c_size_t, vp, C.c_size_t, dp, C.POINTER(MatchParams), C.POINTER(MatchResult)]
+    L.ndtgpu_profiling_enable.argtypes = [vp, C.c_int]
+    L.ndtgpu_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     _lib = L
     return L
 
@@ -209,6 +218,19 @@ class MapSet:
             a = np.ascontiguousarray(xyz, dtype=np.float32)
             _check(lib().ndtgpu_mapset_build_host(self.h, int(first), B, C.c_void_p(a.ctypes.data), N, 4 * W,
                                                   4 * W * N, float(range_limit), rop, C.byref(cp)))
+
+    def profiling(self, on=True):
+        _check(lib().ndtgpu_profiling_enable(self.h, int(bool(on))))
+
+    def last_kernel_ms(self, which):
+        """HIP-event duration of the most recent build (0) / match (1) kernel launched on this set."""
+        ms = C.c_float()
+        _check(lib().ndtgpu_last_kernel_ms(self.h, int(which), C.byref(ms)))
+        return ms.value
+
+    def num_cells_all(self):
+        """n_cells of every map (one D2H of the counters; synchronises)."""
+        return np.array([self.num_cells(i) for i in range(self.n_maps)], dtype=np.int64)
 
     def num_cells(self, i=0):
         n = C.c_uint32()

@@ -292,15 +292,19 @@ extern "C" __global__ void ndt_install_cells_kernel(NdtSetView set, unsigned map
     }
 }
 
+// reset the dense tables of the maps being rebuilt (-1 everywhere); must precede ndt_launch_build
+hipError_t ndt_launch_table_reset(const NdtSetView &set, size_t first, size_t count, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    return hipMemsetAsync(set.table + first * (size_t)set.grid.slots, 0xFF,
+                          count * (size_t)set.grid.slots * sizeof(int32_t), stream);
+}
+
 hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                             size_t stride_bytes, size_t map_stride_bytes, double range_limit,
                             const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream)
 {
     if (count == 0) return hipSuccess;
-    // reset the dense tables of the maps being rebuilt (-1 everywhere)
-    hipError_t e = hipMemsetAsync(set.table + first * (size_t)set.grid.slots, 0xFF,
-                                  count * (size_t)set.grid.slots * sizeof(int32_t), stream);
-    if (e != hipSuccess) return e;
     // second-moment scale: N * max|u_a u_b| * 2^shift < 2^63 with |u| < 2  ->  shift <= 61 - ceil(log2 N)
     int lg = 1;
     while ((1ull << lg) < (unsigned long long)(n_points ? n_points : 1)) lg++;

@@ -72,6 +72,7 @@ struct NdtMatchResultDev {     // mirrors ndtgpu_match_result
 };
 
 // host launchers (defined next to their kernels)
+hipError_t ndt_launch_table_reset(const NdtSetView &set, size_t first, size_t count, hipStream_t stream);
 hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                             size_t stride_bytes, size_t map_stride_bytes, double range_limit,
                             const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream);

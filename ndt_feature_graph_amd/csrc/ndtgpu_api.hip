@@ -49,6 +49,10 @@ struct ndtgpu_mapset {
     size_t stage_bytes = 0;
     double *origins_dev = nullptr;
     size_t origins_cap = 0;
+    // profiling hooks: [0,1] bracket the build kernel, [2,3] the match kernel
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid[2] = {false, false};
 
     ndtgpu_status ensure_stage(size_t bytes)
     {
@@ -165,6 +169,8 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (s->v.centres) (void)hipFree(s->v.centres);
     if (s->stage) (void)hipFree(s->stage);
     if (s->origins_dev) (void)hipFree(s->origins_dev);
+    for (int k = 0; k < 4; k++)
+        if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     delete s;
     return NDTGPU_OK;
 }
@@ -211,9 +217,32 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
         orig_dev = s->origins_dev;
     }
     s->last_stream = st;
-    hipError_t e = ndt_launch_build(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit,
-                                    orig_dev, cp.n_min, cp.eval_factor, st);
+    hipError_t e = ndt_launch_table_reset(s->v, first, count, st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: table reset", e);
+    if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
+    e = ndt_launch_build(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit,
+                         orig_dev, cp.n_min, cp.eval_factor, st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: launch", e);
+    if (s->profiling) { HIP_TRY(hipEventRecord(s->ev[1], st)); s->ev_valid[0] = true; }
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_profiling_enable(ndtgpu_mapset *s, int on)
+{
+    if (!s) return fail(NDTGPU_ERR_INVALID, "profiling_enable: null");
+    if (on)
+        for (int k = 0; k < 4; k++)
+            if (!s->ev[k]) HIP_TRY(hipEventCreate(&s->ev[k]));
+    s->profiling = on != 0;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_last_kernel_ms(ndtgpu_mapset *s, int which, float *ms)
+{
+    if (!s || !ms || which < 0 || which > 1 || !s->ev_valid[which])
+        return fail(NDTGPU_ERR_INVALID, "last_kernel_ms: nothing recorded");
+    HIP_TRY(hipEventSynchronize(s->ev[2 * which + 1]));
+    HIP_TRY(hipEventElapsedTime(ms, s->ev[2 * which], s->ev[2 * which + 1]));
     return NDTGPU_OK;
 }
 
@@ -399,9 +428,11 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
     NdtMatchParamsDev p = to_dev(prm);
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
+    if (ts->profiling) HIP_TRY(hipEventRecord(ts->ev[2], (hipStream_t)stream));
     hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
                                     reinterpret_cast<NdtMatchResultDev *>(results_dev), (hipStream_t)stream);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
+    if (ts->profiling) { HIP_TRY(hipEventRecord(ts->ev[3], (hipStream_t)stream)); ts->ev_valid[1] = true; }
     return NDTGPU_OK;
 }
 
