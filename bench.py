@@ -68,7 +68,7 @@ def main():
     fixed, moving = pr["fixed"].contiguous(), pr["moving"].contiguous()
     T_init_cm = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)     # column-major Affine3d
     T16 = T_init_cm.clone()
-    results = torch.zeros((B, 32), dtype=torch.uint8, device=dev)
+    results = torch.zeros((B, 48), dtype=torch.uint8, device=dev)
     idx = torch.arange(B, dtype=torch.int32, device=dev)
 
     tset = N.MapSet(res, [0, 0, 0], size_m, n_maps=B, max_cells=4096)
@@ -79,7 +79,7 @@ def main():
     gathered = None
     if world > 1:
         gathered = [torch.empty((world * B, 16), dtype=torch.float64, device=dev),
-                    torch.empty((world * B, 32), dtype=torch.uint8, device=dev)]
+                    torch.empty((world * B, 48), dtype=torch.uint8, device=dev)]
 
     def step():
         tset.build(fixed, range_limit=rng_lim, stream=stream)

@@ -76,6 +76,8 @@ typedef struct {
     double score;       /* score at the returned pose */
     int32_t n_source;   /* Gaussian cells in the source map */
     int32_t n_target;
+    int64_t cycles_eval;   /* shader clocks spent in derivative evaluations (profiling aid) */
+    int64_t cycles_solver; /* shader clocks spent in the serial Newton / line-search code */
 } ndtgpu_match_result;
 
 /* ---- library ------------------------------------------------------------------------- */

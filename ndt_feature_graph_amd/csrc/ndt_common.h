@@ -69,6 +69,7 @@ struct NdtMatchResultDev {     // mirrors ndtgpu_match_result
     int32_t converged, iterations, fevals, exit_code;
     double score;
     int32_t n_source, n_target;
+    int64_t cycles_eval, cycles_solver;
 };
 
 // host launchers (defined next to their kernels)

@@ -29,14 +29,7 @@
 
 #define NDT_MATCH_THREADS 256
 #define NDT_MATCH_WAVES (NDT_MATCH_THREADS / 64)
-#define NDT_QN 128
-
-extern "C" __global__ void ndt_match_kernel(NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset,
-                                            const uint32_t *__restrict__ sidx, double *__restrict__ T16,
-                                            NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res);
-extern "C" __global__ void ndt_derivatives_kernel(NdtSetView tset, unsigned tmap, const NdtCell *__restrict__ src,
-                                                  unsigned m, int nn, int with_h, double lfd1, double lfd2,
-                                                  double *__restrict__ out28);
+#define NDT_QN 512
 
 namespace {
 
@@ -142,6 +135,7 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
 {
     constexpr int NACC = WITH_H ? 28 : 7;
     constexpr int W = 2 * NN + 1;
+    static_assert(63 + W * 64 <= NDT_QN, "per-wave hit queue too small for this neighbourhood");
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; k++) acc[k] = 0.0;
@@ -151,20 +145,25 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
     unsigned qhead = 0, qcount = 0;   // wave-uniform
     const unsigned long long lt = lanemask_lt();
 
-    auto process = [&](unsigned n) {
-        if (lane < n) {
-            uint32_t e = myq[(qhead + lane) & (NDT_QN - 1)];
-            unsigned sl = e >> 24, id = e & 0xFFFFFFu;
-            d3 m = {mysrc[0 * 64 + sl], mysrc[1 * 64 + sl], mysrc[2 * 64 + sl]};
-            sym3 C = {mysrc[3 * 64 + sl], mysrc[4 * 64 + sl], mysrc[5 * 64 + sl],
-                      mysrc[6 * 64 + sl], mysrc[7 * 64 + sl], mysrc[8 * 64 + sl]};
-            const NdtCell *tc = tg.cells + id;
-            d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
-            sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
-            pair_term<WITH_H>(m, C, mu, Cj, lfd1, lfd2, acc);
+    // TERM stage: pops up to 64 (source lane, target cell) pairs; every lane does one dense pair term.
+    // `min_fill` = 64 while probing (only full batches), 1 for the final flush of a source tile.
+    auto drain = [&](unsigned min_fill) {
+        while (qcount >= min_fill && qcount > 0) {
+            unsigned n = qcount < 64u ? qcount : 64u;
+            if (lane < n) {
+                uint32_t e = myq[(qhead + lane) & (NDT_QN - 1)];
+                unsigned sl = e >> 24, id = e & 0xFFFFFFu;
+                d3 m = {mysrc[0 * 64 + sl], mysrc[1 * 64 + sl], mysrc[2 * 64 + sl]};
+                sym3 C = {mysrc[3 * 64 + sl], mysrc[4 * 64 + sl], mysrc[5 * 64 + sl],
+                          mysrc[6 * 64 + sl], mysrc[7 * 64 + sl], mysrc[8 * 64 + sl]};
+                const NdtCell *tc = tg.cells + id;
+                d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
+                sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
+                pair_term<WITH_H>(m, C, mu, Cj, lfd1, lfd2, acc);
+            }
+            qhead = (qhead + n) & (NDT_QN - 1);
+            qcount -= n;
         }
-        qhead = (qhead + n) & (NDT_QN - 1);
-        qcount -= n;
     };
 
     for (int base = (int)wave * 64; base < msrc; base += NDT_MATCH_THREADS) {
@@ -184,34 +183,35 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
             iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy);
             iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
         }
+        // PROBE stage: (2n+1)^3 dense-table slots around the lane's cell; one row of W loads in flight
         for (int dz = -NN; dz <= NN; dz++) {
             int zz = iz + dz;
             bool zok = vi && zz >= 0 && zz < tg.sz;
             if (!__ballot(zok)) continue;
-            int ids[W * W];
-#pragma unroll
-            for (int dx = 0; dx < W; dx++) {
+#pragma unroll 1
+            for (int dx = -NN; dx <= NN; dx++) {
+                int xx = ix + dx;
+                bool xok = zok && xx >= 0 && xx < tg.sx;
+                int ids[W];
 #pragma unroll
                 for (int dy = 0; dy < W; dy++) {
-                    int xx = ix + dx - NN, yy = iy + dy - NN;
-                    bool ok = zok && xx >= 0 && xx < tg.sx && yy >= 0 && yy < tg.sy;
-                    ids[dx * W + dy] = ok ? tg.table[((size_t)xx * tg.sy + yy) * tg.sz + zz] : -1;
+                    int yy = iy + dy - NN;
+                    bool ok = xok && yy >= 0 && yy < tg.sy;
+                    ids[dy] = ok ? tg.table[((size_t)xx * tg.sy + yy) * tg.sz + zz] : -1;
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < W * W; k++) {
-                bool hit = ids[k] >= 0;
-                unsigned long long mask = __ballot(hit);
-                if (mask) {
+                for (int k = 0; k < W; k++) {
+                    bool hit = ids[k] >= 0;
+                    unsigned long long mask = __ballot(hit);
                     if (hit)
                         myq[(qhead + qcount + (unsigned)__popcll(mask & lt)) & (NDT_QN - 1)] =
                             (lane << 24) | (uint32_t)ids[k];
                     qcount += (unsigned)__popcll(mask);
-                    if (qcount >= 64) process(64);
                 }
+                drain(64);
             }
         }
-        if (qcount) process(qcount);   // the per-wave source tile is overwritten by the next batch
+        drain(1);   // the per-wave source tile is overwritten by the next batch
     }
 
     // 28 (or 7) sums: wave tree, then fixed-order sum of the wave partials
@@ -229,19 +229,6 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
     __syncthreads();
 }
 
-template <bool WITH_H>
-NDT_D bool eval_dispatch(int nn, const MapView &tg, const NdtCell *src, int msrc, const rigid &T, double lfd1,
-                         double lfd2, double *s_src, uint32_t *s_queue, double *s_part, double *s_sums)
-{
-    switch (nn) {
-    case 0: eval_derivs<0, WITH_H>(tg, src, msrc, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums); return true;
-    case 1: eval_derivs<1, WITH_H>(tg, src, msrc, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums); return true;
-    case 2: eval_derivs<2, WITH_H>(tg, src, msrc, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums); return true;
-    case 3: eval_derivs<3, WITH_H>(tg, src, msrc, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums); return true;
-    default: return false;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // serial part (thread 0): Newton step + More-Thuente state machine
 // ------------------------------------------------------------------------------------------------
@@ -255,6 +242,9 @@ struct MatchState {
     double stp, finit, dginit, dgtest, width, width1, stx, fx, dgx, sty, fy, dgy, stmin, stmax;
     int brackt, stage1, nfev, infoc;
     int itr_ctr, fevals, ret, exit_code, phase, with_h, done;
+    // workspace of the pivoted LDL^T (dynamically indexed -> kept in LDS, not in scratch)
+    double ws_a[36], ws_y[6], ws_H[36], ws_g[6], ws_dx[6];
+    int ws_perm[6];
 };
 
 NDT_D double dmin(double a, double b) { return a < b ? a : b; }
@@ -407,44 +397,64 @@ __device__ __noinline__ void apply_step(MatchState &st, double step_size, const 
 
 __device__ __noinline__ void newton_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
 {
-    int dofs[6], nd = 0;
-    for (int a = 0; a < 6; a++)
-        if (prm.dof_mask & (1 << a)) dofs[nd++] = a;
     st.fevals++;
     st.score_here = sums[0];
-    // unpack gradient / upper-triangular Hessian, restricted to the active dofs
-    double H6[36];
-    {
-        int o = 7;
-        for (int a = 0; a < 6; a++)
-            for (int b = a; b < 6; b++) { H6[a * 6 + b] = sums[o]; H6[b * 6 + a] = sums[o]; o++; }
-    }
-    double g[6], H[36];
-    for (int i = 0; i < nd; i++) {
-        g[i] = sums[1 + dofs[i]];
-        for (int k = 0; k < nd; k++) H[i * nd + k] = H6[dofs[i] * 6 + dofs[k]];
-    }
     if (st.score_here < st.score_best) {   // fusion.h:914-920
         st.Tbest = st.T;
         st.score_best = st.score_here;
     }
+    // Hessian in registers (static indices).  Inactive dofs (NDTMatcherD2D_2D) are decoupled and given
+    // the diagonal value of the first active dof, which leaves lambda_min / lambda_max of the active
+    // block unchanged (a diagonal entry is a Rayleigh quotient) and yields a zero increment for them.
+    double H[6][6], g[6];
+    {
+        int o = 7;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) { H[a][b] = sums[o]; H[b][a] = sums[o]; o++; }
+    }
+    double pad = 0.0;
+    bool havepad = false;
     double gnorm = 0;
-    for (int i = 0; i < nd; i++) gnorm += g[i] * g[i];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        bool on = (prm.dof_mask >> a) & 1;
+        g[a] = on ? sums[1 + a] : 0.0;
+        if (on && !havepad) { pad = H[a][a]; havepad = true; }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        bool on_a = (prm.dof_mask >> a) & 1;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            bool on_b = (prm.dof_mask >> b) & 1;
+            if (!(on_a && on_b)) H[a][b] = (a == b) ? pad : 0.0;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) gnorm += g[a] * g[a];
     gnorm = sqrt(gnorm);
-    // fusion.h:922-940
-    double ev[6], V[36];
-    jacobi_eig<6>(nd, H, ev, V);
-    double minC = ev[0], maxC = ev[nd - 1];
-    if (minC < 0) {
-        double regularizer = gnorm;
-        regularizer = (regularizer + minC > 0) ? regularizer : 0.001 * maxC - minC;
-        for (int i = 0; i < nd; i++) ev[i] += regularizer;
-        for (int i = 0; i < nd; i++)
-            for (int k = 0; k < nd; k++) {
-                double s = 0;
-                for (int q = 0; q < nd; q++) s += V[i * nd + q] * ev[q] * V[k * nd + q];
-                H[i * nd + k] = s;
-            }
+    // fusion.h:922-940.  evals += regularizer with the same regularizer for every eigenvalue, then
+    // H = V diag(evals) V^T, i.e. H + regularizer*I: only lambda_min and lambda_max are needed.  A
+    // positive definite H (the usual case near the optimum) is certified by an unpivoted Cholesky
+    // and skips the eigen-decomposition altogether.
+    if (!chol_is_pd<6>(H)) {
+        double A[6][6], V[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b < 6; b++) A[a][b] = H[a][b];
+        jacobi_static<6, false>(A, V);
+        double minC = A[0][0], maxC = A[0][0];
+#pragma unroll
+        for (int a = 1; a < 6; a++) { minC = dmin(minC, A[a][a]); maxC = dmax(maxC, A[a][a]); }
+        if (minC < 0) {
+            double regularizer = gnorm;
+            regularizer = (regularizer + minC > 0) ? regularizer : 0.001 * maxC - minC;
+#pragma unroll
+            for (int a = 0; a < 6; a++) H[a][a] += regularizer;
+        }
     }
     if (gnorm <= prm.delta_score) {        // fusion.h:943-965
         if (st.score_here > st.score_best) st.T = st.Tbest;
@@ -452,13 +462,22 @@ __device__ __noinline__ void newton_step(MatchState &st, const double *sums, con
         st.done = 1;
         return;
     }
-    double dx[6];
-    ldlt_solve<6>(nd, H, g, dx);           // fusion.h:966
+    // fusion.h:966  pose_increment_v = -Hessian.ldlt().solve(score_gradient).  The padded 6x6 system
+    // performs exactly the arithmetic of the active block (the padding is decoupled, its solution 0).
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        st.ws_g[a] = g[a];
+#pragma unroll
+        for (int b = 0; b < 6; b++) st.ws_H[a * 6 + b] = H[a][b];
+    }
+    ldlt_solve_ws<6>(6, st.ws_H, st.ws_g, st.ws_dx, st.ws_a, st.ws_y, st.ws_perm);
     double dginit = 0;
-    for (int a = 0; a < 6; a++) st.incr[a] = 0;
-    for (int i = 0; i < nd; i++) {
-        st.incr[dofs[i]] = -dx[i];
-        dginit += -dx[i] * g[i];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        bool on = (prm.dof_mask >> a) & 1;
+        double d = on ? -st.ws_dx[a] : 0.0;
+        st.incr[a] = d;
+        dginit += d * g[a];
     }
     if (dginit > 0) {                      // fusion.h:976-997
         if (st.score_here > st.score_best) st.T = st.Tbest;
@@ -540,7 +559,8 @@ __device__ __noinline__ void linesearch_step(MatchState &st, const double *sums,
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
+template <int NN>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
     double *__restrict__ T16, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res)
 {
@@ -574,12 +594,15 @@ extern "C" __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel
     }
     __syncthreads();
 
+    long long cyc_eval = 0, cyc_solver = 0;
     while (!st.done) {
         const rigid Te = st.Teval;
         const int with_h = st.with_h;
         __syncthreads();   // everyone has read the request before thread 0 may rewrite it
-        if (with_h) eval_dispatch<true>(prm.n_neighbours, tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
-        else eval_dispatch<false>(prm.n_neighbours, tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
+        long long c0 = __builtin_readcyclecounter();
+        if (with_h) eval_derivs<NN, true>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
+        else eval_derivs<NN, false>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
+        long long c1 = __builtin_readcyclecounter();
         if (threadIdx.x == 0) {
             if (st.phase == PH_NEWTON) newton_step(st, s_sums, prm);
             else if (st.phase == PH_LS_TRIAL) linesearch_step(st, s_sums, prm);
@@ -589,6 +612,8 @@ extern "C" __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel
                 if (st.score_here > st.score_best) st.T = st.Tbest;
                 st.done = 1;
             }
+            cyc_eval += c1 - c0;
+            cyc_solver += (long long)__builtin_readcyclecounter() - c1;
         }
         __syncthreads();
     }
@@ -608,13 +633,16 @@ extern "C" __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel
         o.score = (st.score_here > st.score_best) ? st.score_best : st.score_here;
         o.n_source = sv.n_cells;
         o.n_target = tg.n_cells;
+        o.cycles_eval = cyc_eval;
+        o.cycles_solver = cyc_solver;
         res[pair] = o;
     }
 }
 
 // NDTMatcherD2D::derivativesNDT as a stand-alone entry (host-driven matchFusion loop, FD tests).
-extern "C" __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_kernel(
-    NdtSetView tset, unsigned tmap, const NdtCell *__restrict__ src, unsigned m, int nn, int with_h, double lfd1,
+template <int NN>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_kernel(
+    NdtSetView tset, unsigned tmap, const NdtCell *__restrict__ src, unsigned m, int with_h, double lfd1,
     double lfd2, double *__restrict__ out28)
 {
     __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
@@ -627,8 +655,8 @@ extern "C" __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_
     I.t[0] = I.t[1] = I.t[2] = 0.0;
     if (threadIdx.x < 28) s_sums[threadIdx.x] = 0.0;
     __syncthreads();
-    if (with_h) eval_dispatch<true>(nn, tg, src, (int)m, I, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
-    else eval_dispatch<false>(nn, tg, src, (int)m, I, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
+    if (with_h) eval_derivs<NN, true>(tg, src, (int)m, I, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
+    else eval_derivs<NN, false>(tg, src, (int)m, I, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
     if (threadIdx.x < 28) out28[threadIdx.x] = s_sums[threadIdx.x];
 }
 
@@ -637,8 +665,17 @@ hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, co
                             NdtMatchResultDev *res_dev, hipStream_t stream)
 {
     if (n_pairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(ndt_match_kernel, dim3((unsigned)n_pairs), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev,
-                       sset, sidx_dev, T16_dev, prm, res_dev);
+#define NDT_LAUNCH_MATCH(NN)                                                                                         \
+    hipLaunchKernelGGL(ndt_match_kernel<NN>, dim3((unsigned)n_pairs), dim3(NDT_MATCH_THREADS), 0, stream, tset,      \
+                       tidx_dev, sset, sidx_dev, T16_dev, prm, res_dev)
+    switch (prm.n_neighbours) {
+    case 0: NDT_LAUNCH_MATCH(0); break;
+    case 1: NDT_LAUNCH_MATCH(1); break;
+    case 2: NDT_LAUNCH_MATCH(2); break;
+    case 3: NDT_LAUNCH_MATCH(3); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef NDT_LAUNCH_MATCH
     return hipGetLastError();
 }
 
@@ -646,7 +683,16 @@ hipError_t ndt_launch_derivatives(const NdtSetView &tset, size_t tmap, const Ndt
                                   int n_neighbours, int compute_hessian, double lfd1, double lfd2, double *out28_dev,
                                   hipStream_t stream)
 {
-    hipLaunchKernelGGL(ndt_derivatives_kernel, dim3(1), dim3(NDT_MATCH_THREADS), 0, stream, tset, (unsigned)tmap,
-                       src_cells_dev, (unsigned)m, n_neighbours, compute_hessian, lfd1, lfd2, out28_dev);
+#define NDT_LAUNCH_DERIV(NN)                                                                                         \
+    hipLaunchKernelGGL(ndt_derivatives_kernel<NN>, dim3(1), dim3(NDT_MATCH_THREADS), 0, stream, tset,                \
+                       (unsigned)tmap, src_cells_dev, (unsigned)m, compute_hessian, lfd1, lfd2, out28_dev)
+    switch (n_neighbours) {
+    case 0: NDT_LAUNCH_DERIV(0); break;
+    case 1: NDT_LAUNCH_DERIV(1); break;
+    case 2: NDT_LAUNCH_DERIV(2); break;
+    case 3: NDT_LAUNCH_DERIV(3); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef NDT_LAUNCH_DERIV
     return hipGetLastError();
 }

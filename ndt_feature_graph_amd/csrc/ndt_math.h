@@ -148,13 +148,113 @@ NDT_HD void jacobi_eig(int n, const double *A, double *evals, double *V)
     }
 }
 
+// Same cyclic Jacobi with compile-time size and fully unrolled loops: every index is a constant, so
+// the matrices live in registers (no scratch).  On exit the diagonal of `a` holds the eigenvalues
+// (unsorted) and, when WANT_V, the columns of `v` the eigenvectors.
+template <int N, bool WANT_V>
+NDT_HD void jacobi_static(double (&a)[N][N], double (&v)[N][N])
+{
+    if (WANT_V) {
+#pragma unroll
+        for (int i = 0; i < N; i++)
+#pragma unroll
+            for (int j = 0; j < N; j++) v[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = i + 1; j < N; j++) {
+            double s = 0.5 * (a[i][j] + a[j][i]);
+            a[i][j] = s;
+            a[j][i] = s;
+        }
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0, diag = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            diag += a[i][i] * a[i][i];
+#pragma unroll
+            for (int j = i + 1; j < N; j++) off += a[i][j] * a[i][j];
+        }
+        if (off == 0.0 || off <= 1e-60 * diag) break;
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+#pragma unroll
+            for (int q = p + 1; q < N; q++) {
+                double apq = a[p][q];
+                if (apq != 0.0) {
+                    double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        double akp = a[k][p], akq = a[k][q];
+                        a[k][p] = c * akp - s * akq;
+                        a[k][q] = s * akp + c * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        double apk = a[p][k], aqk = a[q][k];
+                        a[p][k] = c * apk - s * aqk;
+                        a[q][k] = s * apk + c * aqk;
+                    }
+                    if (WANT_V) {
+#pragma unroll
+                        for (int k = 0; k < N; k++) {
+                            double vkp = v[k][p], vkq = v[k][q];
+                            v[k][p] = c * vkp - s * vkq;
+                            v[k][q] = s * vkp + c * vkq;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// true when the symmetric matrix is positive definite (unpivoted Cholesky, registers only)
+template <int N>
+NDT_HD bool chol_is_pd(const double (&A)[N][N])
+{
+    double l[N][N];
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= l[j][k] * l[j][k];
+        pd = pd && (d > 0.0);
+        double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+        l[j][j] = d * inv;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            double s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= l[i][k] * l[j][k];
+            l[i][j] = s * inv;
+        }
+    }
+    return pd;
+}
+
 // x = A^-1 b by LDL^T with symmetric diagonal pivoting (Hessian.ldlt().solve, fusion.h:966);
 // zero pivots give a zero component like Eigen's LDLT::solve.
+template <int NMAX>
+NDT_HD void ldlt_solve_ws(int n, const double *A, const double *b, double *x, double *a, double *y, int *perm);
+
 template <int NMAX>
 NDT_HD void ldlt_solve(int n, const double *A, const double *b, double *x)
 {
     double a[NMAX * NMAX], y[NMAX];
     int perm[NMAX];
+    ldlt_solve_ws<NMAX>(n, A, b, x, a, y, perm);
+}
+
+// workspace variant: a[NMAX*NMAX], y[NMAX], perm[NMAX] supplied by the caller (LDS on the device,
+// so that the dynamically indexed arrays do not live in scratch memory)
+template <int NMAX>
+NDT_HD void ldlt_solve_ws(int n, const double *A, const double *b, double *x, double *a, double *y, int *perm)
+{
     for (int i = 0; i < n; i++) {
         perm[i] = i;
         for (int j = 0; j < n; j++) a[i * NMAX + j] = 0.5 * (A[i * n + j] + A[j * n + i]);

@@ -251,7 +251,8 @@ def test_match_batch_is_deterministic_and_order_free(N, O):
     idx = np.arange(5)
     Ta, ra = N.match_batch(tg, idx, sr, idx, T0)
     Tb, rb = N.match_batch(tg, idx, sr, idx, T0)
-    assert np.array_equal(Ta, Tb) and np.array_equal(ra, rb)                    # run-to-run identical
+    det = ["converged", "iterations", "fevals", "exit_code", "score", "n_source", "n_target"]   # not the cycle counters
+    assert np.array_equal(Ta, Tb) and all(np.array_equal(ra[k], rb[k]) for k in det)   # run-to-run identical
     perm = np.array([3, 0, 4, 1, 2])
     Tc, rc = N.match_batch(tg, idx[perm], sr, idx[perm], T0[perm])
     assert np.array_equal(Tc, Ta[perm])                                        # a pair's result ignores its batch
