@@ -166,6 +166,9 @@ ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *target_set, size_t target_map, ndt
  * of the most recent launch of kernel `which` (0 build, 1 match). */
 ndtgpu_status ndtgpu_profiling_enable(ndtgpu_mapset *set, int on);
 ndtgpu_status ndtgpu_last_kernel_ms(ndtgpu_mapset *set, int which, float *ms);
+/* raw per-map build counters: 8 x uint32 {n_alloc, n_cells, overflow, n_dropped, shader clocks of
+ * build phases A (accumulate), B (finalise), C (rank), D (clean)} */
+ndtgpu_status ndtgpu_mapset_counters(ndtgpu_mapset *set, size_t map, uint32_t out[8]);
 /* kernel names as they appear in rocprofv3 --kernel-trace, for bench.py / profiles/ */
 const char *ndtgpu_kernel_name(int which); /* 0 build, 1 match, 2 derivatives */
 

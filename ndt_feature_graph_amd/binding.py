@@ -74,7 +74,7 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_info", "ndtgpu_mapset_build", "ndtgpu_mapset_build_host", "ndtgpu_mapset_num_cells",
            "ndtgpu_mapset_export_cells", "ndtgpu_mapset_set_cells", "ndtgpu_derivatives", "ndtgpu_match_batch",
            "ndtgpu_match_batch_device", "ndtgpu_match_d2d", "ndtgpu_kernel_name", "ndtgpu_profiling_enable",
-           "ndtgpu_last_kernel_ms"]
+           "ndtgpu_last_kernel_ms", "ndtgpu_mapset_counters"]
 
 _lib = None
 
@@ -119,6 +119,7 @@ def lib():
     L.ndtgpu_match_d2d.argtypes = [vp, C.c_size_t, vp, C.c_size_t, dp, C.POINTER(MatchParams), C.POINTER(MatchResult)]
     L.ndtgpu_profiling_enable.argtypes = [vp, C.c_int]
     L.ndtgpu_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.ndtgpu_mapset_counters.argtypes = [vp, C.c_size_t, u32p]
     _lib = L
     return L
 
@@ -229,6 +230,11 @@ class MapSet:
         ms = C.c_float()
         _check(lib().ndtgpu_last_kernel_ms(self.h, int(which), C.byref(ms)))
         return ms.value
+
+    def counters(self, i=0):
+        out = (C.c_uint32 * 8)()
+        _check(lib().ndtgpu_mapset_counters(self.h, int(i), out))
+        return dict(n_alloc=out[0], n_cells=out[1], overflow=out[2], n_dropped=out[3], cyc=list(out[4:8]))
 
     def num_cells_all(self):
         """n_cells of every map (one D2H of the counters; synchronises)."""

@@ -8,162 +8,422 @@
 //   rescaleCovariance                                      ...fuser_hmt.cpp:227, ndt_odom_debug.cpp:179
 //
 // Design (DESIGN.md "Build kernel"):
-//   * one 1024-thread workgroup owns one map: its slot table, accumulators and cells are touched by
-//     this workgroup only, so every atomic is workgroup scope and nothing crosses XCDs; a batch of
-//     B scans is B workgroups (B >= 256 fills the chip; a single scan is latency-, not bandwidth-bound
-//     and is not the metric's case).
-//   * raw scan read once, coalesced; per point: key, range/NaN filter, offset from its cell centre in
-//     units of the cell size, converted to FIXED POINT so that the per-cell sums are integer sums:
-//     exactly associative -> bit-identical results whatever the order of the atomics.
-//   * wavefront pre-reduction: lanes of a wave that hit the same cell (the normal case for an
-//     angularly ordered laser sweep) are summed with shuffles and ONE lane issues the 10 atomics.
-//   * finalisation in the same launch: mean / sample covariance from the integer moments, 3x3 Jacobi
-//     eigen-decomposition, eigenvalue floor, then cells are ranked in slot order by a block scan over
-//     the dense table (deterministic cell order), and the scratch is left zeroed for the next build.
+//   * one 256-thread workgroup owns one map: its tables, accumulators and cells are touched by this
+//     workgroup only (workgroup-scope atomics, nothing crosses XCDs); a batch of B scans is B
+//     workgroups, three resident per CU.
+//   * phase A streams the raw scan ONCE.  Each wave owns a contiguous quarter of the scan and pulls
+//     tiles of 512 points with fully coalesced dword loads into a padded LDS tile; every lane then
+//     walks its own 8 CONSECUTIVE points (an angularly ordered sweep keeps them in one cell, range
+//     noise on a wall that hugs a cell face flips them between two), accumulating count, sum d and
+//     sum d d^T of d = p - cell_origin (|d| <= one cell: no cancellation) in fp64: the first cell
+//     ("run 0") in registers, a second one ("run 1") in LDS.  At the end of the tile contiguous lanes
+//     that hold the same cell are merged by a segmented wavefront scan and the segment heads add
+//     their partial sums to the cell's accumulator.
+//   * the partial sums are split into integer-valued hi/lo doubles (resolution 2^-(s+32)) before they
+//     are added, with scales that keep every accumulator below 2^53: global_atomic_add_f64 is then
+//     exact, hence associative -- the result does not depend on the order in which waves reach
+//     the atomics.
+//   * phase B: moments -> mean / sample covariance, 3x3 register-resident Jacobi, eigenvalue floor
+//     (NDTCell::rescaleCovariance).
+//   * phase C ranks the Gaussian cells in slot order from an occupancy BITMAP (slots/32 words, a few
+//     KB) instead of scanning the dense table, writes the 80-byte cell records and the slot -> rank
+//     table the matcher probes, and restores every scratch structure (work table, bitmap,
+//     accumulators) to its clean state: no memset is ever issued between builds.
 //   HBM algorithmic bytes per scan: 12*N (points) + 80*M (cell records)  (SURVEY.md 8d).
 #include "ndt_math.h"
+#include <cstdlib>
 
-#define NDT_BUILD_THREADS 1024
+#define NDT_BUILD_THREADS 256
+#define NDT_BUILD_WAVES (NDT_BUILD_THREADS / 64)
+#define NDT_PPL 8            // consecutive points per lane per tile
+#define NDT_TILE (64 * NDT_PPL)
+#define NDT_IDC 64           // entries of the per-wave slot -> id cache
+#define NDT_FLCAP 40         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 160 B)
+#define NDT_QRUNS 20         // per-wave, per-tile queue of evicted runs (third cell within a lane's points)
 #define NDT_EMPTY (-1)
-
-extern "C" __global__ void ndt_build_kernel(NdtSetView set, unsigned first, const char *__restrict__ xyz,
-                                            unsigned n_points, unsigned stride_bytes, size_t map_stride_bytes,
-                                            double range_limit, const double *__restrict__ range_origins, int n_min,
-                                            double eval_factor, int s2_shift);
 
 namespace {
 
-NDT_D long long wave_sum(long long v)
+NDT_D unsigned wave_incl_scan(unsigned v)
 {
+    const unsigned lane = threadIdx.x & 63u;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned t = __shfl_up(v, o, 64);
+        if (lane >= (unsigned)o) v += t;
+    }
     return v;
 }
 
-NDT_D unsigned long long lanemask_lt()
+struct BuildCtx {
+    int32_t *wtable;      // work table: slot -> accumulator id while building, EMPTY otherwise
+    uint32_t *bitmap;     // occupancy bit per slot (set when an id is assigned)
+    NdtAcc *acc;
+    uint32_t *acc_slot;
+    NdtMapCounters *ctr;
+    uint32_t cap;
+    double q1, q2;        // 2^s1 / res, 2^s2 / res^2: metres -> scaled cell units
+    int dbg;
+    unsigned long long *idc;   // per-wave LDS cache (slot << 32 | id), direct mapped, NDT_IDC entries
+};
+
+// one 64-bit LDS atomic: lanes that map to the same entry in the same instruction cannot tear it
+NDT_D void idc_put(unsigned long long *ce, int slot, int id)
 {
-    unsigned lane = threadIdx.x & 63u;
-    return (lane == 0) ? 0ull : (~0ull >> (64u - lane));
+    __hip_atomic_exchange(ce, ((unsigned long long)(unsigned)slot << 32) | (unsigned)id, __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // slot -> accumulator id, allocating on first touch.  Lock-free: a racing loser wastes one id
 // (left with n == 0, skipped by the finaliser).
-NDT_D int get_or_assign(int32_t *table, int slot, uint32_t *acc_slot, NdtMapCounters *ctr, uint32_t cap)
+NDT_D int get_or_assign(const BuildCtx &b, int slot)
 {
-    int id = table[slot];   // may be a stale EMPTY from L1; a non-EMPTY value is always final
-    if (id != NDT_EMPTY) return id;
-    unsigned nid = __hip_atomic_fetch_add(&ctr->n_alloc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // ids never change once assigned, so a per-wave LDS cache can answer without the global round trip
+    // that would otherwise stall the wave at every flush (consecutive tiles revisit the same cells)
+    unsigned long long *ce = b.idc + (slot & (NDT_IDC - 1));
+    unsigned long long c = *ce;
+    if ((int)(c >> 32) == slot) return (int)(unsigned)c;
+    int id = b.wtable[slot];   // may be a stale EMPTY from L1; a non-EMPTY value is always final
+    if (id != NDT_EMPTY) { idc_put(ce, slot, id); return id; }
+    unsigned nid = __hip_atomic_fetch_add(&b.ctr->n_alloc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     int expected = NDT_EMPTY;
-    if (__hip_atomic_compare_exchange_strong(&table[slot], &expected, (int)nid, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+    if (__hip_atomic_compare_exchange_strong(&b.wtable[slot], &expected, (int)nid, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_WORKGROUP)) {
-        if (nid < cap) acc_slot[nid] = (uint32_t)slot;
-        else __hip_atomic_store(&ctr->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_or(&b.bitmap[slot >> 5], 1u << (slot & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (nid < b.cap) b.acc_slot[nid] = (uint32_t)slot;
+        else __hip_atomic_store(&b.ctr->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        idc_put(ce, slot, (int)nid);
         return (int)nid;
     }
+    idc_put(ce, slot, expected);
     return expected;   // somebody else assigned it first
 }
 
-NDT_D void atomic_add_ll(long long *p, long long v)
+// One partial run {n, sum d (m), sum d d^T (m^2)} becomes a 20-double record in the per-wave flush list:
+// the sums are scaled to cell units * 2^s and split into integer-valued hi / lo doubles (see NdtAcc), so
+// that the fp64 atomic adds that consume the list are exact, hence order-independent.
+NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int slot, double n, const double *sd,
+                              const double *sdd)
 {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int id = get_or_assign(b, slot);
+    *rec_id = (id >= 0 && (uint32_t)id < b.cap) ? id : -1;
+    rec[0] = n;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double t = sd[k] * b.q1, hi = rint(t);
+        rec[1 + k] = hi;
+        rec[10 + k] = rint((t - hi) * 4294967296.0);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        double t = sdd[k] * b.q2, hi = rint(t);
+        rec[4 + k] = hi;
+        rec[13 + k] = rint((t - hi) * 4294967296.0);
+    }
 }
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel(
+// STRIDE_DW: 3 = packed xyz, 4 = pcl::PointXYZ (16-byte records), 0 = any other stride (slow path)
+template <int STRIDE_DW>
+__global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
     size_t map_stride_bytes, double range_limit, const double *__restrict__ range_origins, int n_min,
-    double eval_factor, int s2_shift)
+    double eval_factor, int s1_shift, int s2_shift, int dbg)
 {
+    constexpr int SD = STRIDE_DW ? STRIDE_DW : 3;
+    constexpr int LANE_DW = NDT_PPL * SD + 1;          // +1: odd stride -> conflict-free per-lane walks
+    __shared__ __attribute__((aligned(16))) float s_tile[NDT_BUILD_WAVES * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1))];
+    __shared__ int s_flid[NDT_BUILD_WAVES * NDT_FLCAP];
+    __shared__ double s_run1[NDT_BUILD_WAVES * 10 * 64];
+    __shared__ double s_qval[NDT_BUILD_WAVES * 10 * NDT_QRUNS];
+    __shared__ int s_qslot[NDT_BUILD_WAVES * NDT_QRUNS];
+    __shared__ unsigned s_qcnt[NDT_BUILD_WAVES];
+    __shared__ unsigned long long s_idc[NDT_BUILD_WAVES * NDT_IDC];
+    __shared__ unsigned s_wave_cnt[NDT_BUILD_WAVES];
+    __shared__ unsigned s_base;
+    __shared__ unsigned s_dropped;
+
     const unsigned tid = threadIdx.x;
-    const unsigned lane = tid & 63u;
+    const unsigned lane = tid & 63u, wave = tid >> 6;
     const unsigned map = first + blockIdx.x;
     const NdtGrid g = set.grid;
     const uint32_t cap = g.max_cells;
     int32_t *table = set.table + (size_t)map * g.slots;
-    NdtAcc *acc = set.acc + (size_t)map * cap;
+    const unsigned bm_words = (unsigned)((g.slots + 31) >> 5);
     NdtCell *cells = set.cells + (size_t)map * cap;
-    uint32_t *acc_slot = set.acc_slot + (size_t)map * cap;
     NdtMapCounters *ctr = set.counters + map;
     const double cx = set.centres[map * 3 + 0], cy = set.centres[map * 3 + 1], cz = set.centres[map * 3 + 2];
-    const double res = g.res;
+    const double res = g.res, inv_res = 1.0 / g.res;
+    const double hx = g.size[0] / 2.0, hy = g.size[1] / 2.0, hz = g.size[2] / 2.0;
+    BuildCtx bc;
+    bc.wtable = set.wtable + (size_t)map * g.slots;
+    bc.bitmap = set.bitmap + (size_t)map * bm_words;
+    bc.acc = set.acc + (size_t)map * cap;
+    bc.acc_slot = set.acc_slot + (size_t)map * cap;
+    bc.ctr = ctr;
+    bc.cap = cap;
+    bc.q1 = ldexp(inv_res, s1_shift);
+    bc.q2 = ldexp(inv_res * inv_res, s2_shift);
+    bc.dbg = dbg;
+    bc.idc = s_idc + wave * NDT_IDC;
+    bc.idc[lane & (NDT_IDC - 1)] = ~0ull;
     double ox = 0, oy = 0, oz = 0;
     if (range_origins) { ox = range_origins[blockIdx.x * 3]; oy = range_origins[blockIdx.x * 3 + 1]; oz = range_origins[blockIdx.x * 3 + 2]; }
     const char *pts = xyz + (size_t)blockIdx.x * map_stride_bytes;
-    const double S1 = (double)(1ull << NDT_S1_SHIFT), IS1 = 1.0 / S1;
-    const double S2 = (double)(1ull << s2_shift);
+    const float cx32 = (float)cx, cy32 = (float)cy, cz32 = (float)cz, inv32 = (float)inv_res;
+    const float hx32 = (float)hx, hy32 = (float)hy, hz32 = (float)hz;
+    const float ox32 = (float)ox, oy32 = (float)oy, oz32 = (float)oz;
+    const float r2 = (float)(range_limit * range_limit);
 
-    __shared__ unsigned s_wave_cnt[NDT_BUILD_THREADS / 64];
-    __shared__ unsigned s_base;
-    __shared__ unsigned s_dropped;
-    if (tid == 0) { s_base = 0; s_dropped = 0; }
+    // ---------------- phase 0: forget the previous content of the slot -> rank table -------------
+    {
+        unsigned old = ctr->n_cells;
+        if (old > cap) old = cap;
+        for (unsigned i = tid; i < old; i += NDT_BUILD_THREADS) table[cells[i].slot] = NDT_EMPTY;
+        if (tid == 0) { s_base = 0; s_dropped = 0; }
+    }
     __syncthreads();
 
-    // ---------------- phase A: key + accumulate --------------------------------------------
+    // ---------------- phase A: key + accumulate ----------------------------------------------------
+    long long t0 = __builtin_readcyclecounter();
     unsigned dropped = 0;
-    for (unsigned base = 0; base < n_points; base += NDT_BUILD_THREADS) {
-        unsigned i = base + tid;
-        int slot = -1;
-        long long q[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) q[k] = 0;
-        if (i < n_points) {
-            const float *pf = (const float *)(pts + (size_t)i * stride_bytes);
-            double px = (double)pf[0], py = (double)pf[1], pz = (double)pf[2];
-            bool ok = !(isnan(px) || isnan(py) || isnan(pz));
-            if (ok && range_limit > 0) {
-#pragma clang fp contract(off)
-                double dx = px - ox, dy = py - oy, dz = pz - oz;
-                ok = !(sqrt(dx * dx + dy * dy + dz * dz) > range_limit);
-            }
-            if (ok) {
-                int ix = lazygrid_index(px, cx, res, g.size[0]);
-                int iy = lazygrid_index(py, cy, res, g.size[1]);
-                int iz = lazygrid_index(pz, cz, res, g.size[2]);
-                ok = ix >= 0 && ix < g.size[0] && iy >= 0 && iy < g.size[1] && iz >= 0 && iz < g.size[2];
-                if (ok) {
-                    slot = (ix * g.size[1] + iy) * g.size[2] + iz;
-                    // offset from the cell origin in cell units, quantised to 2^-40
-                    double ux = (px - (cx + (ix - g.size[0] / 2.0) * res)) / res;
-                    double uy = (py - (cy + (iy - g.size[1] / 2.0) * res)) / res;
-                    double uz = (pz - (cz + (iz - g.size[2] / 2.0) * res)) / res;
-                    q[0] = __double2ll_rn(ux * S1);
-                    q[1] = __double2ll_rn(uy * S1);
-                    q[2] = __double2ll_rn(uz * S1);
-                    double qx = (double)q[0] * IS1, qy = (double)q[1] * IS1, qz = (double)q[2] * IS1;
-                    q[3] = __double2ll_rn(qx * qx * S2);
-                    q[4] = __double2ll_rn(qx * qy * S2);
-                    q[5] = __double2ll_rn(qx * qz * S2);
-                    q[6] = __double2ll_rn(qy * qy * S2);
-                    q[7] = __double2ll_rn(qy * qz * S2);
-                    q[8] = __double2ll_rn(qz * qz * S2);
-                }
-            }
-            if (!ok) dropped++;
+    const unsigned n_tiles = (n_points + NDT_TILE - 1) / NDT_TILE;
+    const unsigned tiles_per_wave = (n_tiles + NDT_BUILD_WAVES - 1) / NDT_BUILD_WAVES;
+    const unsigned tile_begin = wave * tiles_per_wave;
+    const unsigned tile_end = min(n_tiles, tile_begin + tiles_per_wave);
+    float *mytile = s_tile + wave * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1));
+    // flush list: after the point loop the tile buffer is dead and holds the records of the partial
+    // runs that must be added to their cells; ONE atomic instruction then serves up to 64 (record,
+    // component) items, instead of 19 dependent single-lane atomics per run.
+    double *fl_val = reinterpret_cast<double *>(mytile);
+    int *fl_id = s_flid + wave * NDT_FLCAP;
+    unsigned nfl = 0;   // wave-uniform
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
+    auto drain_list = [&]() {
+        const unsigned items = nfl * 20u;
+        for (unsigned it = lane; it < items; it += 64u) {
+            unsigned e = it / 20u, k = it % 20u;
+            int id = fl_id[e];
+            if (k < 19u && id >= 0 && !(dbg & 1))
+                unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + id) + k, fl_val[e * 20u + k]);
         }
-        // wavefront pre-reduction by cell: one round per distinct cell among the 64 lanes
-        unsigned long long active = __ballot(slot >= 0);
-        while (active) {
-            int leader = __ffsll((long long)active) - 1;
-            int s0 = __shfl(slot, leader, 64);
-            bool mine = (slot == s0);
-            unsigned long long mask = __ballot(mine);
-            long long v[9];
+        nfl = 0;
+    };
+    auto push_runs = [&](bool mine, int slot, double n, const double *sd3, const double *se6) {
+        unsigned long long m = __ballot(mine);
+        while (m) {
+            if (nfl == NDT_FLCAP) drain_list();
+            const unsigned room = NDT_FLCAP - nfl;
+            const unsigned rank = (unsigned)__popcll(m & lt_mask);
+            const bool now = mine && ((m >> lane) & 1ull) && rank < room;
+            if (now) write_flush_record(bc, fl_val + (nfl + rank) * 20u, fl_id + nfl + rank, slot, n, sd3, se6);
+            const unsigned long long done = __ballot(now);
+            nfl += (unsigned)__popcll(done);
+            m &= ~done;
+        }
+    };
+    // Run 1 of every lane (the second cell its consecutive points fall into, e.g. range noise on a wall
+    // that hugs a cell face) lives in LDS, SoA so that lane l only ever touches bank-distinct words;
+    // run 0 lives in registers.  A third cell within the lane's points evicts run 1 (rare).
+    double *r1 = s_run1 + wave * (10 * 64);
+    // evicted runs are queued in LDS and added to their cells at the end of the tile by all lanes in
+    // parallel: nothing in the point loop waits for global memory
+    double *q_val = s_qval + wave * (10 * NDT_QRUNS);
+    int *q_slot = s_qslot + wave * NDT_QRUNS;
+    const bool use_range = range_limit > 0;
+    float stage[NDT_PPL * SD];
+    auto fetch_tile = [&](unsigned t) {
+        // coalesced: lane l reads dwords l, l+64, ... of the tile
+        if (STRIDE_DW && t < tile_end) {
+            const unsigned q0 = t * NDT_TILE;
+            const float *src = (const float *)pts + (size_t)q0 * SD;
+            const unsigned tile_dw = min((unsigned)NDT_TILE, n_points - q0) * SD;
+            if (tile_dw == NDT_TILE * SD) {            // full tile: all loads in flight, no predicates
 #pragma unroll
-            for (int k = 0; k < 9; k++) v[k] = wave_sum(mine ? q[k] : 0ll);
-            if ((int)lane == leader) {
-                int id = get_or_assign(table, s0, acc_slot, ctr, cap);
-                if (id >= 0 && (uint32_t)id < cap) {
-                    NdtAcc *a = acc + id;
-                    __hip_atomic_fetch_add(&a->n, (unsigned long long)__popcll(mask), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int k = 0; k < NDT_PPL * SD; k++) stage[k] = src[lane + 64u * k];
+            } else {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) atomic_add_ll(&a->s1[k], v[k]);
-#pragma unroll
-                    for (int k = 0; k < 6; k++) atomic_add_ll(&a->s2[k], v[3 + k]);
+                for (int k = 0; k < NDT_PPL * SD; k++) {
+                    unsigned d = lane + 64u * k;
+                    stage[k] = src[d < tile_dw ? d : 0u];
                 }
             }
-            active &= ~mask;
+        }
+    };
+    fetch_tile(tile_begin);
+    for (unsigned tile = tile_begin; tile < tile_end; tile++) {
+        const unsigned p0 = tile * NDT_TILE;
+        if (STRIDE_DW) {
+            // the tile was fetched into registers one iteration ahead (see the end of the loop body):
+            // every dword lands in its owner lane's padded LDS row
+#pragma unroll
+            for (int k = 0; k < NDT_PPL * SD; k++) {
+                unsigned d = lane + 64u * k;
+                mytile[(d / (NDT_PPL * SD)) * LANE_DW + d % (NDT_PPL * SD)] = stage[k];
+            }
+        }
+        if (lane == 0) s_qcnt[wave] = 0;
+        int cs0 = -1, cs1 = -1;
+        double rn = 0;
+        double sd[3] = {0, 0, 0}, se[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+        for (int j = 0; j < NDT_PPL; j++) {
+            const unsigned i = p0 + lane * NDT_PPL + j;
+            const bool valid = (i < n_points) && !(dbg & 4);
+            float fx, fy, fz;
+            if (STRIDE_DW) {
+                const float *pf = mytile + lane * LANE_DW + j * SD;
+                fx = pf[0]; fy = pf[1]; fz = pf[2];
+            } else {
+                const float *pf = (const float *)(pts + (size_t)(valid ? i : 0u) * stride_bytes);
+                fx = pf[0]; fy = pf[1]; fz = pf[2];
+            }
+            const bool finite = valid && (fx == fx) && (fy == fy) && (fz == fz);   // NaN points are skipped
+            bool ok = finite;
+            // fp32 fast paths ...
+            const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
+            const float dd = dx * dx + dy * dy + dz * dz;
+            const bool near_r = use_range && (fabsf(dd - r2) < 1e-3f * r2);
+            if (use_range) ok = ok && !(dd > r2);
+            const float vx = (fx - cx32) * inv32 + 0.5f, vy = (fy - cy32) * inv32 + 0.5f, vz = (fz - cz32) * inv32 + 0.5f;
+            const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
+            const float frx = vx - flx, fry = vy - fly, frz = vz - flz;
+            const bool slow_x = !(frx > 1e-3f && frx < 0.999f && fabsf(vx) < 4096.0f);
+            const bool slow_y = !(fry > 1e-3f && fry < 0.999f && fabsf(vy) < 4096.0f);
+            const bool slow_z = !(frz > 1e-3f && frz < 0.999f && fabsf(vz) < 4096.0f);
+            int ix = (int)(flx + hx32), iy = (int)(fly + hy32), iz = (int)(flz + hz32);
+            // ... and the reference's fp64 formulas for the few points near a cell face / the range sphere
+            const bool need_exact = finite && (near_r || slow_x || slow_y || slow_z);
+            if (__ballot(need_exact)) {
+                if (need_exact) {
+                    if (near_r) {
+#pragma clang fp contract(off)
+                        double ex = (double)fx - ox, ey = (double)fy - oy, ez = (double)fz - oz;
+                        ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit);
+                    }
+                    if (slow_x) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
+                    if (slow_y) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
+                    if (slow_z) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
+                }
+            }
+            const bool inb = ok && ix >= 0 && ix < g.size[0] && iy >= 0 && iy < g.size[1] && iz >= 0 && iz < g.size[2];
+            const int slot = inb ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
+            dropped += (valid && !inb) ? 1u : 0u;
+            if (dbg & 16) continue;
+            // offset from the point's own cell origin: |d| <= one cell, no cancellation later on
+            const double x = (double)fx - (cx + ((double)ix - hx) * res);
+            const double y = (double)fy - (cy + ((double)iy - hy) * res);
+            const double z = (double)fz - (cz + ((double)iz - hz) * res);
+            if (inb && cs0 < 0) cs0 = slot;                  // first cell of the tile: run 0
+            const bool in0 = inb && (slot == cs0);
+            const bool other = inb && !in0;
+            if (__ballot(other)) {
+                if (other) {
+                    if (slot == cs1) {
+                        r1[0 * 64 + lane] += 1.0;
+                        r1[1 * 64 + lane] += x; r1[2 * 64 + lane] += y; r1[3 * 64 + lane] += z;
+                        r1[4 * 64 + lane] = fma(x, x, r1[4 * 64 + lane]); r1[5 * 64 + lane] = fma(x, y, r1[5 * 64 + lane]);
+                        r1[6 * 64 + lane] = fma(x, z, r1[6 * 64 + lane]); r1[7 * 64 + lane] = fma(y, y, r1[7 * 64 + lane]);
+                        r1[8 * 64 + lane] = fma(y, z, r1[8 * 64 + lane]); r1[9 * 64 + lane] = fma(z, z, r1[9 * 64 + lane]);
+                    } else {
+                        if (cs1 >= 0 && !(dbg & 8)) {        // a third cell -> evict run 1 into the queue
+                            unsigned pos = __hip_atomic_fetch_add(&s_qcnt[wave], 1u, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            if (pos < NDT_QRUNS) {
+                                q_slot[pos] = cs1;
+#pragma unroll
+                                for (int k = 0; k < 10; k++) q_val[k * NDT_QRUNS + pos] = r1[k * 64 + lane];
+                            } else {                         // queue full (unordered cloud): add directly
+                                double v3[3] = {r1[1 * 64 + lane], r1[2 * 64 + lane], r1[3 * 64 + lane]};
+                                double v6[6] = {r1[4 * 64 + lane], r1[5 * 64 + lane], r1[6 * 64 + lane],
+                                                r1[7 * 64 + lane], r1[8 * 64 + lane], r1[9 * 64 + lane]};
+                                double rec[20];
+                                int rid;
+                                write_flush_record(bc, rec, &rid, cs1, r1[lane], v3, v6);
+                                if (rid >= 0)
+                                    for (int k = 0; k < 19; k++)
+                                        unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + rid) + k, rec[k]);
+                            }
+                        }
+                        cs1 = slot;
+                        r1[0 * 64 + lane] = 1.0;
+                        r1[1 * 64 + lane] = x; r1[2 * 64 + lane] = y; r1[3 * 64 + lane] = z;
+                        r1[4 * 64 + lane] = x * x; r1[5 * 64 + lane] = x * y; r1[6 * 64 + lane] = x * z;
+                        r1[7 * 64 + lane] = y * y; r1[8 * 64 + lane] = y * z; r1[9 * 64 + lane] = z * z;
+                    }
+                }
+            }
+            if (in0) {
+                rn += 1.0;
+                sd[0] += x; sd[1] += y; sd[2] += z;
+                se[0] = fma(x, x, se[0]); se[1] = fma(x, y, se[1]); se[2] = fma(x, z, se[2]);
+                se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
+            }
+        }
+        // Fetch the next tile BEFORE this tile's atomics are issued: vmcnt retires in order, so loads
+        // issued after the atomics would have to wait for them.
+        fetch_tile(tile + 1);
+        if (!(dbg & 2)) {
+            // Canonical order of a lane's two runs (run 0 = smaller slot): along a wall that hugs a cell
+            // face neighbouring lanes then agree on which cell is run 0 and which is run 1, so both form
+            // long contiguous segments for the scans below instead of alternating lane by lane.
+            const bool swap = cs1 >= 0 && cs1 < cs0;
+            if (__ballot(swap)) {
+                if (swap) {
+                    double t;
+                    t = r1[0 * 64 + lane]; r1[0 * 64 + lane] = rn; rn = t;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { t = r1[(1 + k) * 64 + lane]; r1[(1 + k) * 64 + lane] = sd[k]; sd[k] = t; }
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { t = r1[(4 + k) * 64 + lane]; r1[(4 + k) * 64 + lane] = se[k]; se[k] = t; }
+                    int ti = cs0; cs0 = cs1; cs1 = ti;
+                }
+            }
+#pragma unroll 1
+            for (int pass = 0; pass < 2; pass++) {
+                int cs = cs0;
+                if (pass == 1) {
+                    if (!__ballot(cs1 >= 0)) break;
+                    // second pass: the lanes' run 1, fetched from LDS
+                    const bool has = cs1 >= 0;
+                    cs = cs1;
+                    rn = has ? r1[0 * 64 + lane] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) sd[k] = has ? r1[(1 + k) * 64 + lane] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) se[k] = has ? r1[(4 + k) * 64 + lane] : 0.0;
+                }
+                // segmented wavefront reduction over contiguous lanes that hold the same cell
+                int prev = __shfl_up(cs, 1, 64);
+                bool head = (lane == 0) || (prev != cs);
+                unsigned long long hm = __ballot(head);
+                // lanes remaining in my segment (me included): distance to the next head above me
+                unsigned long long above = (lane == 63) ? 0ull : (hm >> (lane + 1));
+                int rem = above ? (__ffsll((long long)above)) : (int)(64 - lane);
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    bool take = o < rem;
+                    double t;
+                    t = __shfl_down(rn, o, 64); if (take) rn += t;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { t = __shfl_down(sd[k], o, 64); if (take) sd[k] += t; }
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { t = __shfl_down(se[k], o, 64); if (take) se[k] += t; }
+                }
+                push_runs(head && cs >= 0, cs, rn, sd, se);
+            }
+            unsigned qn = s_qcnt[wave];
+            if (qn > NDT_QRUNS) qn = NDT_QRUNS;
+            if (qn) {
+                const bool has = lane < qn;
+                const unsigned ql = has ? lane : 0u;
+                double v3[3] = {q_val[1 * NDT_QRUNS + ql], q_val[2 * NDT_QRUNS + ql], q_val[3 * NDT_QRUNS + ql]};
+                double v6[6] = {q_val[4 * NDT_QRUNS + ql], q_val[5 * NDT_QRUNS + ql], q_val[6 * NDT_QRUNS + ql],
+                                q_val[7 * NDT_QRUNS + ql], q_val[8 * NDT_QRUNS + ql], q_val[9 * NDT_QRUNS + ql]};
+                push_runs(has, q_slot[ql], q_val[ql], v3, v6);
+            }
+            drain_list();
         }
     }
     if (dropped) atomicAdd(&s_dropped, dropped);
@@ -172,12 +432,14 @@ extern "C" __global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
 
-    // ---------------- phase B: moments -> Gaussian (in place in the scratch arena) -------------
+    // ---------------- phase B: moments -> Gaussian (in place in the scratch arena) -------------------
+    long long t1 = __builtin_readcyclecounter();
     unsigned n_alloc = ctr->n_alloc;
     if (n_alloc > cap) n_alloc = cap;
-    NdtCell *tmp = reinterpret_cast<NdtCell *>(acc);   // 80 B in, 80 B out
+    NdtAcc *tmp_base = bc.acc;                            // cell record written over its own accumulator
+    const double IS1 = ldexp(1.0, -s1_shift), IS2 = ldexp(1.0, -s2_shift);
     for (unsigned id = tid; id < n_alloc; id += NDT_BUILD_THREADS) {
-        NdtAcc a = acc[id];
+        NdtAcc a = bc.acc[id];
         NdtCell c;
         c.n = 0;
         c.slot = 0;
@@ -185,93 +447,124 @@ extern "C" __global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel
         for (int k = 0; k < 3; k++) c.mean[k] = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) c.cov[k] = 0;
-        unsigned long long n = a.n;
+        unsigned long long n = (unsigned long long)a.n;
         if (n >= 2 && n >= (unsigned long long)n_min) {
-            unsigned slot = acc_slot[id];
+            unsigned slot = bc.acc_slot[id];
             int iz = slot % g.size[2];
             int iy = (slot / g.size[2]) % g.size[1];
             int ix = slot / (g.size[2] * g.size[1]);
             double dn = (double)n;
-            double m[3], S[6];
-            for (int k = 0; k < 3; k++) m[k] = ((double)a.s1[k] / dn) * IS1;
-            const double IS2 = 1.0 / S2;
-            S[0] = (double)a.s2[0] * IS2 - dn * m[0] * m[0];
-            S[1] = (double)a.s2[1] * IS2 - dn * m[0] * m[1];
-            S[2] = (double)a.s2[2] * IS2 - dn * m[0] * m[2];
-            S[3] = (double)a.s2[3] * IS2 - dn * m[1] * m[1];
-            S[4] = (double)a.s2[4] * IS2 - dn * m[1] * m[2];
-            S[5] = (double)a.s2[5] * IS2 - dn * m[2] * m[2];
+            double m[3];   // mean offset in cell units
+#pragma unroll
+            for (int k = 0; k < 3; k++) m[k] = ((a.s1[k] + a.l1[k] * (1.0 / 4294967296.0)) / dn) * IS1;
+            double S[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) S[k] = (a.s2[k] + a.l2[k] * (1.0 / 4294967296.0)) * IS2;
             double sc = res * res / (dn - 1.0);
-            double C[9] = {S[0] * sc, S[1] * sc, S[2] * sc, S[1] * sc, S[3] * sc, S[4] * sc, S[2] * sc, S[4] * sc, S[5] * sc};
-            double ev[3], V[9];
-            jacobi_eig<3>(3, C, ev, V);
+            double C[3][3], V[3][3];
+            C[0][0] = (S[0] - dn * m[0] * m[0]) * sc;
+            C[0][1] = (S[1] - dn * m[0] * m[1]) * sc;
+            C[0][2] = (S[2] - dn * m[0] * m[2]) * sc;
+            C[1][1] = (S[3] - dn * m[1] * m[1]) * sc;
+            C[1][2] = (S[4] - dn * m[1] * m[2]) * sc;
+            C[2][2] = (S[5] - dn * m[2] * m[2]) * sc;
+            C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
+            double E[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int q2 = 0; q2 < 3; q2++) E[r][q2] = C[r][q2];
+            jacobi_static<3, true>(E, V);
+            double ev[3] = {E[0][0], E[1][1], E[2][2]};
+            double mx = dmax3(ev[0], ev[1], ev[2]), mn = dmin3(ev[0], ev[1], ev[2]);
             // NDTCell::rescaleCovariance
-            if (ev[2] > 0 && ev[0] > NDT_DEGENERATE_REL * ev[2]) {
+            if (mx > 0 && mn > NDT_DEGENERATE_REL * mx) {
                 bool recalc = false;
-                double mx = ev[2];
+#pragma unroll
                 for (int k = 0; k < 3; k++)
                     if (mx > ev[k] * eval_factor) { ev[k] = mx / eval_factor; recalc = true; }
                 if (recalc) {
+#pragma unroll
                     for (int r = 0; r < 3; r++)
+#pragma unroll
                         for (int q2 = r; q2 < 3; q2++) {
                             double s = 0;
-                            for (int k = 0; k < 3; k++) s += V[r * 3 + k] * ev[k] * V[q2 * 3 + k];
-                            C[r * 3 + q2] = s;
+#pragma unroll
+                            for (int k = 0; k < 3; k++) s += V[r][k] * ev[k] * V[q2][k];
+                            C[r][q2] = s;
                         }
                 }
-                c.mean[0] = cx + (ix - g.size[0] / 2.0) * res + m[0] * res;
-                c.mean[1] = cy + (iy - g.size[1] / 2.0) * res + m[1] * res;
-                c.mean[2] = cz + (iz - g.size[2] / 2.0) * res + m[2] * res;
-                c.cov[0] = C[0]; c.cov[1] = C[1]; c.cov[2] = C[2];
-                c.cov[3] = C[4]; c.cov[4] = C[5]; c.cov[5] = C[8];
+                c.mean[0] = cx + (ix - hx) * res + m[0] * res;
+                c.mean[1] = cy + (iy - hy) * res + m[1] * res;
+                c.mean[2] = cz + (iz - hz) * res + m[2] * res;
+                c.cov[0] = C[0][0]; c.cov[1] = C[0][1]; c.cov[2] = C[0][2];
+                c.cov[3] = C[1][1]; c.cov[4] = C[1][2]; c.cov[5] = C[2][2];
                 c.n = (uint32_t)n;
                 c.slot = slot;
             }
         }
-        tmp[id] = c;
+        *reinterpret_cast<NdtCell *>(tmp_base + id) = c;
     }
     __syncthreads();
 
-    // ---------------- phase C: rank Gaussian cells in slot order (block scan over the table) ---
-    const unsigned wave = tid >> 6;
-    for (unsigned sbase = 0; sbase < (unsigned)g.slots; sbase += NDT_BUILD_THREADS) {
-        unsigned slot = sbase + tid;
-        int id = (slot < (unsigned)g.slots) ? table[slot] : NDT_EMPTY;
-        bool touched = id != NDT_EMPTY;
-        bool valid = touched && (uint32_t)id < n_alloc && tmp[id].n > 0;
-        unsigned long long bal = __ballot(valid);
-        if (lane == 0) s_wave_cnt[wave] = (unsigned)__popcll(bal);
-        __syncthreads();
-        unsigned before = s_base;
-        for (unsigned w = 0; w < wave; w++) before += s_wave_cnt[w];
-        unsigned total = 0;
-        for (unsigned w = 0; w < NDT_BUILD_THREADS / 64; w++) total += s_wave_cnt[w];
-        if (valid) {
-            unsigned rank = before + (unsigned)__popcll(bal & lanemask_lt());
-            cells[rank] = tmp[id];
-            table[slot] = (int)rank;
-        } else if (touched) {
-            table[slot] = NDT_EMPTY;
+    // ---------------- phase C: rank Gaussian cells in slot order from the occupancy bitmap ------------
+    long long t2 = __builtin_readcyclecounter();
+    for (unsigned wbase = 0; wbase < bm_words; wbase += NDT_BUILD_THREADS) {
+        unsigned w = wbase + tid;
+        unsigned bits = (w < bm_words) ? bc.bitmap[w] : 0u;
+        unsigned vmask = 0;
+        for (unsigned b = bits; b; b &= b - 1) {
+            int bit = __ffs((int)b) - 1;
+            int id = bc.wtable[w * 32 + bit];
+            if (id >= 0 && (uint32_t)id < n_alloc && reinterpret_cast<const NdtCell *>(tmp_base + id)->n > 0) vmask |= 1u << bit;
         }
+        unsigned cnt = (unsigned)__popc(vmask);
+        unsigned incl = wave_incl_scan(cnt);
+        if (lane == 63) s_wave_cnt[wave] = incl;
+        __syncthreads();
+        unsigned before = s_base + incl - cnt;
+        unsigned total = 0;
+        for (unsigned k = 0; k < NDT_BUILD_WAVES; k++) {
+            unsigned c2 = s_wave_cnt[k];
+            if (k < wave) before += c2;
+            total += c2;
+        }
+        for (unsigned b = bits; b; b &= b - 1) {
+            int bit = __ffs((int)b) - 1;
+            unsigned slot = w * 32 + bit;
+            int id = bc.wtable[slot];
+            if (vmask & (1u << bit)) {
+                cells[before] = *reinterpret_cast<const NdtCell *>(tmp_base + id);
+                table[slot] = (int)before;
+                before++;
+            }
+            bc.wtable[slot] = NDT_EMPTY;      // work table back to its clean state
+        }
+        if (bits) bc.bitmap[w] = 0u;
         __syncthreads();
         if (tid == 0) s_base += total;
     }
     __syncthreads();
 
-    // ---------------- phase D: leave the scratch zeroed, publish counters ----------------------
+    // ---------------- phase D: leave the scratch zeroed, publish counters -----------------------------
+    long long t3 = __builtin_readcyclecounter();
     {
-        unsigned long long *z = reinterpret_cast<unsigned long long *>(acc);
-        for (unsigned k = tid; k < n_alloc * 10u; k += NDT_BUILD_THREADS) z[k] = 0ull;
+        unsigned long long *z = reinterpret_cast<unsigned long long *>(bc.acc);
+        for (unsigned k = tid; k < n_alloc * 20u; k += NDT_BUILD_THREADS) z[k] = 0ull;
     }
     if (tid == 0) {
         ctr->n_cells = s_base;
         ctr->n_alloc = 0;
         ctr->n_dropped = s_dropped;
+        ctr->cyc[0] = (uint32_t)(t1 - t0);
+        ctr->cyc[1] = (uint32_t)(t2 - t1);
+        ctr->cyc[2] = (uint32_t)(t3 - t2);
+        ctr->cyc[3] = (uint32_t)((long long)__builtin_readcyclecounter() - t3);
     }
 }
 
-// Installs ready-made Gaussians (CellVector-like maps, KATs): cells must arrive sorted by slot,
-// one per slot (the host wrapper guarantees it).
+// Installs ready-made Gaussians (CellVector-like maps, KATs): cells arrive sorted by slot, one per
+// slot (the host wrapper guarantees it).  The slot -> rank table was reset by the launcher.
 extern "C" __global__ void ndt_install_cells_kernel(NdtSetView set, unsigned map, const NdtCell *__restrict__ src,
                                                     unsigned n_cells)
 {
@@ -292,41 +585,43 @@ extern "C" __global__ void ndt_install_cells_kernel(NdtSetView set, unsigned map
     }
 }
 
-// reset the dense tables of the maps being rebuilt (-1 everywhere); must precede ndt_launch_build
-hipError_t ndt_launch_table_reset(const NdtSetView &set, size_t first, size_t count, hipStream_t stream)
-{
-    if (count == 0) return hipSuccess;
-    return hipMemsetAsync(set.table + first * (size_t)set.grid.slots, 0xFF,
-                          count * (size_t)set.grid.slots * sizeof(int32_t), stream);
-}
-
 hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                             size_t stride_bytes, size_t map_stride_bytes, double range_limit,
                             const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream)
 {
     if (count == 0) return hipSuccess;
-    // second-moment scale: N * max|u_a u_b| * 2^shift < 2^63 with |u| < 2  ->  shift <= 61 - ceil(log2 N)
+    // scales that keep every accumulator an exact integer below 2^53.  Even grid sizes: |u| <= 1/2
+    // (+ rounding), so N/2 * 2^s1 and N/4 * 2^s2 must stay below 2^52.  An odd size lets the reference's
+    // double->int truncation put offsets of up to 1.5 cells into index 0: bound |u| < 2 there.
     int lg = 1;
     while ((1ull << lg) < (unsigned long long)(n_points ? n_points : 1)) lg++;
-    int s2_shift = 61 - lg;
-    if (s2_shift > 46) s2_shift = 46;
-    if (s2_shift < 20) s2_shift = 20;
-    hipLaunchKernelGGL(ndt_build_kernel, dim3((unsigned)count), dim3(NDT_BUILD_THREADS), 0, stream, set, (unsigned)first,
-                       (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes, map_stride_bytes, range_limit,
-                       range_origins_dev, n_min, eval_factor, s2_shift);
+    const bool odd = (set.grid.size[0] | set.grid.size[1] | set.grid.size[2]) & 1;
+    int s1_shift = (odd ? 51 : 53) - lg;
+    int s2_shift = (odd ? 50 : 54) - lg;
+    if (s1_shift > 44) s1_shift = 44;
+    if (s2_shift > 44) s2_shift = 44;
+    const int dbg = getenv("NDT_BUILD_DBG") ? atoi(getenv("NDT_BUILD_DBG")) : 0;
+    const bool aligned4 = (((uintptr_t)xyz_dev | map_stride_bytes) & 3u) == 0;
+#define NDT_LAUNCH_BUILD(SDW)                                                                                        \
+    hipLaunchKernelGGL(ndt_build_kernel<SDW>, dim3((unsigned)count), dim3(NDT_BUILD_THREADS), 0, stream, set,        \
+                       (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,           \
+                       map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg)
+    if (stride_bytes == 12 && aligned4) NDT_LAUNCH_BUILD(3);
+    else if (stride_bytes == 16 && aligned4) NDT_LAUNCH_BUILD(4);
+    else NDT_LAUNCH_BUILD(0);
+#undef NDT_LAUNCH_BUILD
     return hipGetLastError();
 }
 
-hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const double *mean3_dev, const double *cov9_dev,
-                                    size_t n_cells, hipStream_t stream)
+hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const NdtCell *cells_dev, size_t n_cells,
+                                    hipStream_t stream)
 {
-    (void)mean3_dev; (void)cov9_dev;   // the host wrapper passes packed NdtCell records through mean3_dev
     hipError_t e = hipMemsetAsync(set.table + map * (size_t)set.grid.slots, 0xFF,
                                   (size_t)set.grid.slots * sizeof(int32_t), stream);
     if (e != hipSuccess) return e;
     unsigned blocks = (unsigned)((n_cells + 255) / 256);
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(ndt_install_cells_kernel, dim3(blocks), dim3(256), 0, stream, set, (unsigned)map,
-                       reinterpret_cast<const NdtCell *>(mean3_dev), (unsigned)n_cells);
+    hipLaunchKernelGGL(ndt_install_cells_kernel, dim3(blocks), dim3(256), 0, stream, set, (unsigned)map, cells_dev,
+                       (unsigned)n_cells);
     return hipGetLastError();
 }

@@ -3,8 +3,10 @@
 // Data layout in HBM (DESIGN.md "Layout"):
 //   table  int32 [n_maps][slots]        dense LazyGrid slot -> cell rank (-1 = no Gaussian);
 //                                       slot = (ix*sy + iy)*sz + iz, like dataArray[x][y][z]
+//   wtable int32 [n_maps][slots]        build-time slot -> accumulator id (all -1 between builds)
+//   bitmap u32   [n_maps][slots/32]     build-time occupancy bits (all 0 between builds)
 //   cells  NdtCell [n_maps][max_cells]  80-byte records, Gaussian cells only, in slot order
-//   acc    NdtAcc  [n_maps][max_cells]  80-byte int64 fixed-point moment accumulators
+//   acc    NdtAcc  [n_maps][max_cells]  160-byte integer-valued fp64 moment accumulators (hi/lo)
 //                                       (build scratch; all-zero between builds)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,14 +29,21 @@ struct alignas(16) NdtCell {   // 80 B: the algorithmic per-cell record (SURVEY 
 };
 static_assert(sizeof(NdtCell) == 80, "NdtCell must be 80 bytes");
 
-struct alignas(16) NdtAcc {    // 80 B fixed-point moments of u = (p - cell_centre)/res
-    unsigned long long n;
-    long long s1[3];           // sum round(u * 2^40)
-    long long s2[6];           // sum round(u_a u_b * 2^s2_shift)
+// Moment accumulators of u = (p - cell_origin)/res.  Each partial sum v handed to the accumulator is
+// split as  v * 2^s = hi + lo * 2^-32  with hi = rint(v 2^s), lo = rint((v 2^s - hi) 2^32): every
+// addend is an INTEGER-VALUED double and the scales keep every accumulator below 2^53, so the fp64
+// atomic additions are exact -- associative, order-independent, bit-reproducible -- using the native
+// global_atomic_add_f64 instead of emulated 64-bit integer arithmetic.  Resolution 2^-(s+32).
+struct alignas(16) NdtAcc {    // 160 B
+    double n;                  // point count
+    double s1[3];              // hi parts of sum u * 2^s1
+    double s2[6];              // hi parts of sum u_a u_b * 2^s2
+    double l1[3];              // lo parts (* 2^32)
+    double l2[6];
+    double pad;
 };
-static_assert(sizeof(NdtAcc) == 80, "NdtAcc must be 80 bytes");
-
-#define NDT_S1_SHIFT 40
+static_assert(sizeof(NdtAcc) == 160, "NdtAcc must be 160 bytes");
+static_assert(sizeof(NdtAcc) >= sizeof(NdtCell), "the finaliser writes the cell record over its accumulator");
 
 struct NdtGrid {               // geometry shared by all maps of a set
     double res;
@@ -48,11 +57,14 @@ struct NdtMapCounters {        // per map, device resident
     uint32_t n_cells;          // Gaussian cells after finalize
     uint32_t overflow;         // ids requested beyond max_cells
     uint32_t n_dropped;        // points dropped (NaN / range / outside grid)
+    uint32_t cyc[4];           // shader clocks of build phases A, B, C, D (profiling aid)
 };
 
 struct NdtSetView {            // what kernels see of a mapset
     NdtGrid grid;
     int32_t *table;            // [n_maps][slots]
+    int32_t *wtable;           // [n_maps][slots]      build scratch
+    uint32_t *bitmap;          // [n_maps][(slots+31)/32] build scratch
     NdtCell *cells;            // [n_maps][max_cells]
     NdtAcc *acc;               // [n_maps][max_cells]
     uint32_t *acc_slot;        // [n_maps][max_cells] slot of each accumulator id
@@ -73,12 +85,11 @@ struct NdtMatchResultDev {     // mirrors ndtgpu_match_result
 };
 
 // host launchers (defined next to their kernels)
-hipError_t ndt_launch_table_reset(const NdtSetView &set, size_t first, size_t count, hipStream_t stream);
 hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                             size_t stride_bytes, size_t map_stride_bytes, double range_limit,
                             const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream);
-hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const double *mean3_dev,
-                                    const double *cov9_dev, size_t n_cells, hipStream_t stream);
+hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const NdtCell *cells_dev, size_t n_cells,
+                                    hipStream_t stream);
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
                             NdtMatchResultDev *res_dev, hipStream_t stream);

@@ -15,6 +15,9 @@ NDT_HD d3 ex_cross(d3 v) { return {0.0, -v.z, v.y}; }
 NDT_HD d3 ey_cross(d3 v) { return {v.z, 0.0, -v.x}; }
 NDT_HD d3 ez_cross(d3 v) { return {-v.y, v.x, 0.0}; }
 
+NDT_HD double dmax3(double a, double b, double c) { double m = a > b ? a : b; return m > c ? m : c; }
+NDT_HD double dmin3(double a, double b, double c) { double m = a < b ? a : b; return m < c ? m : c; }
+
 struct sym3 { double xx, xy, xz, yy, yz, zz; };
 NDT_HD sym3 operator+(sym3 a, sym3 b) { return {a.xx + b.xx, a.xy + b.xy, a.xz + b.xz, a.yy + b.yy, a.yz + b.yz, a.zz + b.zz}; }
 NDT_HD d3 mul(sym3 a, d3 v)

@@ -139,6 +139,8 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
         return fail(NDTGPU_ERR_ALLOC, "mapset_create: hipMalloc " #ptr, e);        \
     }
     ALLOC(s->v.table, n_maps * (size_t)g.slots * sizeof(int32_t));
+    ALLOC(s->v.wtable, n_maps * (size_t)g.slots * sizeof(int32_t));
+    ALLOC(s->v.bitmap, n_maps * (size_t)((g.slots + 31) / 32) * sizeof(uint32_t));
     ALLOC(s->v.cells, n_maps * (size_t)cap * sizeof(NdtCell));
     ALLOC(s->v.acc, n_maps * (size_t)cap * sizeof(NdtAcc));
     ALLOC(s->v.acc_slot, n_maps * (size_t)cap * sizeof(uint32_t));
@@ -146,6 +148,8 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
     ALLOC(s->v.centres, n_maps * 3 * sizeof(double));
 #undef ALLOC
     if ((e = hipMemset(s->v.table, 0xFF, n_maps * (size_t)g.slots * sizeof(int32_t))) != hipSuccess ||
+        (e = hipMemset(s->v.wtable, 0xFF, n_maps * (size_t)g.slots * sizeof(int32_t))) != hipSuccess ||
+        (e = hipMemset(s->v.bitmap, 0, n_maps * (size_t)((g.slots + 31) / 32) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemset(s->v.acc, 0, n_maps * (size_t)cap * sizeof(NdtAcc))) != hipSuccess ||
         (e = hipMemset(s->v.counters, 0, n_maps * sizeof(NdtMapCounters))) != hipSuccess ||
         (e = hipMemcpy(s->v.centres, s->centres_host.data(), n_maps * 3 * sizeof(double), hipMemcpyHostToDevice)) !=
@@ -162,6 +166,8 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (!s) return NDTGPU_OK;
     (void)hipDeviceSynchronize();
     if (s->v.table) (void)hipFree(s->v.table);
+    if (s->v.wtable) (void)hipFree(s->v.wtable);
+    if (s->v.bitmap) (void)hipFree(s->v.bitmap);
     if (s->v.cells) (void)hipFree(s->v.cells);
     if (s->v.acc) (void)hipFree(s->v.acc);
     if (s->v.acc_slot) (void)hipFree(s->v.acc_slot);
@@ -217,10 +223,8 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
         orig_dev = s->origins_dev;
     }
     s->last_stream = st;
-    hipError_t e = ndt_launch_table_reset(s->v, first, count, st);
-    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: table reset", e);
     if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
-    e = ndt_launch_build(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit,
+    hipError_t e = ndt_launch_build(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit,
                          orig_dev, cp.n_min, cp.eval_factor, st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: launch", e);
     if (s->profiling) { HIP_TRY(hipEventRecord(s->ev[1], st)); s->ev_valid[0] = true; }
@@ -267,6 +271,17 @@ static ndtgpu_status read_counters(ndtgpu_mapset *s, size_t map, NdtMapCounters 
 {
     HIP_TRY(hipStreamSynchronize(s->last_stream));
     HIP_TRY(hipMemcpy(c, s->v.counters + map, sizeof *c, hipMemcpyDeviceToHost));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_counters(ndtgpu_mapset *s, size_t map, uint32_t out[8])
+{
+    if (!s || !out || map >= s->n_maps) return fail(NDTGPU_ERR_INVALID, "counters: bad argument");
+    static_assert(sizeof(NdtMapCounters) == 32, "counter layout");
+    NdtMapCounters c;
+    ndtgpu_status rc = read_counters(s, map, &c);
+    if (rc != NDTGPU_OK) return rc;
+    memcpy(out, &c, 32);
     return NDTGPU_OK;
 }
 
@@ -362,7 +377,7 @@ ndtgpu_status ndtgpu_mapset_set_cells(ndtgpu_mapset *s, size_t map, const double
     if (rc != NDTGPU_OK) return rc;
     if (!uniq.empty()) HIP_TRY(hipMemcpy(s->stage, uniq.data(), uniq.size() * sizeof(NdtCell), hipMemcpyHostToDevice));
     s->last_stream = nullptr;
-    hipError_t e = ndt_launch_install_cells(s->v, map, (const double *)s->stage, nullptr, uniq.size(), nullptr);
+    hipError_t e = ndt_launch_install_cells(s->v, map, (const NdtCell *)s->stage, uniq.size(), nullptr);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "set_cells: launch", e);
     HIP_TRY(hipStreamSynchronize(nullptr));
     return NDTGPU_OK;

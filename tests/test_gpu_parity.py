@@ -118,14 +118,19 @@ def test_build_edge_cases(N, O):
 
 
 def test_build_unordered_points_same_result(N):
+    """Shuffled input: same cells, same counts (integer work: bit-exact); moments agree to fp64 rounding
+    (per-lane partial sums are formed in input order, the cross-wave adds are exact)."""
     from ndt_feature_graph_amd import synth
     pts = synth.pair_2d([31], 50000)["fixed"][0].numpy()
     perm = np.random.default_rng(0).permutation(len(pts))
-    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2)
-    ms.build(np.stack([pts, pts[perm]]), range_limit=30.0)
-    a, b = ms.export_cells(0), ms.export_cells(1)
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)          # integer moments: order-independent, bit-identical
+    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=3)
+    ms.build(np.stack([pts, pts[perm], pts]), range_limit=30.0)
+    a, b, c = ms.export_cells(0), ms.export_cells(1), ms.export_cells(2)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert np.max(np.abs(a[0] - b[0])) < 1e-12
+    assert np.max(np.abs(a[1] - b[1]) / np.max(np.abs(a[1]), axis=(1, 2), keepdims=True)) < 1e-10
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)          # same input order: bit-identical, whatever the atomic order
 
 
 def test_capacity_overflow_is_reported(N):

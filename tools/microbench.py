@@ -45,6 +45,8 @@ def t_match(**kw):
 
 bm = t_build()
 gb = (12.0 * a.points * B) / bm / 1e6
+cy = np.array([ts.counters(i)["cyc"] for i in range(0, B, max(1, B // 32))])
+print("build phases (k cycles, mean over sampled maps): A %.0f  B %.0f  C %.0f  D %.0f" % tuple(cy.mean(axis=0) / 1e3))
 print("build: %.3f ms per %d scans  (%.1f GB/s of point bytes, %.2f us/scan)" % (bm, B, gb, 1e3 * bm / B))
 for name, kw in [("full", {}), ("no step control", dict(step_control=0)), ("itr_max=0 (3 newton iters)", dict(itr_max=0)),
                  ("nn=1", dict(n_neighbours=1)), ("nn=0", dict(n_neighbours=0)), ("3dof", dict(dof_mask=0x23))]:
