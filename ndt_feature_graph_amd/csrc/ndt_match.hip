@@ -27,7 +27,7 @@
 #include "ndt_math.h"
 #include <float.h>
 
-#define NDT_MATCH_THREADS 256
+#define NDT_MATCH_THREADS 512
 #define NDT_MATCH_WAVES (NDT_MATCH_THREADS / 64)
 #define NDT_QN 512
 

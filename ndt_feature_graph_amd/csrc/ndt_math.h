@@ -179,7 +179,8 @@ NDT_HD void jacobi_static(double (&a)[N][N], double (&v)[N][N])
 #pragma unroll
             for (int j = i + 1; j < N; j++) off += a[i][j] * a[i][j];
         }
-        if (off == 0.0 || off <= 1e-60 * diag) break;
+        // off-diagonal mass below 1e-15 of the diagonal: eigenvalue errors ~ off^2/gap < 1e-30 relative
+        if (off == 0.0 || off <= 1e-30 * diag) break;
 #pragma unroll
         for (int p = 0; p < N; p++) {
 #pragma unroll
