@@ -39,7 +39,7 @@
 #define NDT_TILE (64 * NDT_PPL)
 #define NDT_IDC 64           // entries of the per-wave slot -> id cache
 #define NDT_FLCAP 40         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 160 B)
-#define NDT_QRUNS 20         // per-wave, per-tile queue of evicted runs (third cell within a lane's points)
+#define NDT_QRUNS 12         // per-wave, per-tile queue of evicted runs (third cell within a lane's points)
 #define NDT_EMPTY (-1)
 
 namespace {
@@ -126,7 +126,7 @@ NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int s
 
 // STRIDE_DW: 3 = packed xyz, 4 = pcl::PointXYZ (16-byte records), 0 = any other stride (slow path)
 template <int STRIDE_DW>
-__global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel(
+__global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
     size_t map_stride_bytes, double range_limit, const double *__restrict__ range_origins, int n_min,
     double eval_factor, int s1_shift, int s2_shift, int dbg)
@@ -171,8 +171,13 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel(
     double ox = 0, oy = 0, oz = 0;
     if (range_origins) { ox = range_origins[blockIdx.x * 3]; oy = range_origins[blockIdx.x * 3 + 1]; oz = range_origins[blockIdx.x * 3 + 2]; }
     const char *pts = xyz + (size_t)blockIdx.x * map_stride_bytes;
-    const float cx32 = (float)cx, cy32 = (float)cy, cz32 = (float)cz, inv32 = (float)inv_res;
-    const float hx32 = (float)hx, hy32 = (float)hy, hz32 = (float)hz;
+    const float inv32 = (float)inv_res;
+    // fast-path constants: idx = floor(p*inv + k), k = 0.5 + size/2 - c*inv.  Only for EVEN sizes (size/2
+    // integral); with an odd size the reference's double->int truncation makes the index formula
+    // non-monotone, so every point takes the exact path then (force_exact).
+    const bool force_exact = ((g.size[0] | g.size[1] | g.size[2]) & 1) != 0;
+    const float kx32 = (float)(0.5 + hx - cx * inv_res), ky32 = (float)(0.5 + hy - cy * inv_res),
+                kz32 = (float)(0.5 + hz - cz * inv_res);
     const float ox32 = (float)ox, oy32 = (float)oy, oz32 = (float)oz;
     const float r2 = (float)(range_limit * range_limit);
 
@@ -232,35 +237,32 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel(
     double *q_val = s_qval + wave * (10 * NDT_QRUNS);
     int *q_slot = s_qslot + wave * NDT_QRUNS;
     const bool use_range = range_limit > 0;
-    float stage[NDT_PPL * SD];
-    auto fetch_tile = [&](unsigned t) {
-        // coalesced: lane l reads dwords l, l+64, ... of the tile
-        if (STRIDE_DW && t < tile_end) {
-            const unsigned q0 = t * NDT_TILE;
-            const float *src = (const float *)pts + (size_t)q0 * SD;
-            const unsigned tile_dw = min((unsigned)NDT_TILE, n_points - q0) * SD;
-            if (tile_dw == NDT_TILE * SD) {            // full tile: all loads in flight, no predicates
-#pragma unroll
-                for (int k = 0; k < NDT_PPL * SD; k++) stage[k] = src[lane + 64u * k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < NDT_PPL * SD; k++) {
-                    unsigned d = lane + 64u * k;
-                    stage[k] = src[d < tile_dw ? d : 0u];
-                }
-            }
-        }
-    };
-    fetch_tile(tile_begin);
     for (unsigned tile = tile_begin; tile < tile_end; tile++) {
         const unsigned p0 = tile * NDT_TILE;
         if (STRIDE_DW) {
-            // the tile was fetched into registers one iteration ahead (see the end of the loop body):
-            // every dword lands in its owner lane's padded LDS row
+            // coalesced: lane l reads dwords l, l+64, ... of the tile; each lands in its owner lane's row
+            const float *src = (const float *)pts + (size_t)p0 * SD;
+            const unsigned tile_dw = min((unsigned)NDT_TILE, n_points - p0) * SD;
+            constexpr int CH = 8;
+            static_assert((NDT_PPL * SD) % CH == 0, "staging chunk");
 #pragma unroll
-            for (int k = 0; k < NDT_PPL * SD; k++) {
-                unsigned d = lane + 64u * k;
-                mytile[(d / (NDT_PPL * SD)) * LANE_DW + d % (NDT_PPL * SD)] = stage[k];
+            for (int h = 0; h < NDT_PPL * SD / CH; h++) {
+                float tmp[CH];
+                if (tile_dw == NDT_TILE * SD) {            // full tile: all loads in flight, no predicates
+#pragma unroll
+                    for (int k = 0; k < CH; k++) tmp[k] = src[lane + 64u * (h * CH + k)];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < CH; k++) {
+                        unsigned d = lane + 64u * (h * CH + k);
+                        tmp[k] = src[d < tile_dw ? d : 0u];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    unsigned d = lane + 64u * (h * CH + k);
+                    mytile[(d / (NDT_PPL * SD)) * LANE_DW + d % (NDT_PPL * SD)] = tmp[k];
+                }
             }
         }
         if (lane == 0) s_qcnt[wave] = 0;
@@ -286,15 +288,16 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel(
             const float dd = dx * dx + dy * dy + dz * dz;
             const bool near_r = use_range && (fabsf(dd - r2) < 1e-3f * r2);
             if (use_range) ok = ok && !(dd > r2);
-            const float vx = (fx - cx32) * inv32 + 0.5f, vy = (fy - cy32) * inv32 + 0.5f, vz = (fz - cz32) * inv32 + 0.5f;
+            // v = (p - c)/res + 0.5 + size/2 in one fma per axis; the integer part is the cell index
+            const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
             const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
             const float frx = vx - flx, fry = vy - fly, frz = vz - flz;
             const bool slow_x = !(frx > 1e-3f && frx < 0.999f && fabsf(vx) < 4096.0f);
             const bool slow_y = !(fry > 1e-3f && fry < 0.999f && fabsf(vy) < 4096.0f);
             const bool slow_z = !(frz > 1e-3f && frz < 0.999f && fabsf(vz) < 4096.0f);
-            int ix = (int)(flx + hx32), iy = (int)(fly + hy32), iz = (int)(flz + hz32);
+            int ix = (int)flx, iy = (int)fly, iz = (int)flz;
             // ... and the reference's fp64 formulas for the few points near a cell face / the range sphere
-            const bool need_exact = finite && (near_r || slow_x || slow_y || slow_z);
+            const bool need_exact = finite && (force_exact || near_r || slow_x || slow_y || slow_z);
             if (__ballot(need_exact)) {
                 if (need_exact) {
                     if (near_r) {
@@ -302,12 +305,13 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel(
                         double ex = (double)fx - ox, ey = (double)fy - oy, ez = (double)fz - oz;
                         ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit);
                     }
-                    if (slow_x) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
-                    if (slow_y) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
-                    if (slow_z) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
+                    if (slow_x || force_exact) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
+                    if (slow_y || force_exact) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
+                    if (slow_z || force_exact) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
                 }
             }
-            const bool inb = ok && ix >= 0 && ix < g.size[0] && iy >= 0 && iy < g.size[1] && iz >= 0 && iz < g.size[2];
+            const bool inb = ok && (unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] &&
+                             (unsigned)iz < (unsigned)g.size[2];
             const int slot = inb ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
             dropped += (valid && !inb) ? 1u : 0u;
             if (dbg & 16) continue;
@@ -361,9 +365,6 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS) void ndt_build_kernel(
                 se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
             }
         }
-        // Fetch the next tile BEFORE this tile's atomics are issued: vmcnt retires in order, so loads
-        // issued after the atomics would have to wait for them.
-        fetch_tile(tile + 1);
         if (!(dbg & 2)) {
             // Canonical order of a lane's two runs (run 0 = smaller slot): along a wall that hugs a cell
             // face neighbouring lanes then agree on which cell is run 0 and which is run 1, so both form
