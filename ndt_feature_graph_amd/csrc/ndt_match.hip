@@ -166,9 +166,13 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
         }
     };
 
-    for (int base = (int)wave * 64; base < msrc; base += NDT_MATCH_THREADS) {
+    // every wave owns a contiguous, equally sized range of source cells (even a small map keeps all
+    // waves busy: 372 cells -> 47 per wave instead of 6 full waves + 2 idle ones)
+    const int per_wave = (msrc + NDT_MATCH_WAVES - 1) / NDT_MATCH_WAVES;
+    const int w_begin = (int)wave * per_wave, w_end = min(msrc, w_begin + per_wave);
+    for (int base = w_begin; base < w_end; base += 64) {
         int i = base + (int)lane;
-        bool vi = i < msrc;
+        bool vi = i < w_end;
         int ix = 0, iy = 0, iz = 0;
         if (vi) {
             const NdtCell *sc = src + i;
