@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--res", type=float, default=0.5)
-    ap.add_argument("--cpu-sample", type=int, default=128, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=768, help="pairs timed on the CPU oracle (0 = skip); ~14 s")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -134,9 +134,21 @@ def main():
     }
     dominant = "ndt_build_kernel" if 2 * build_ms >= match_ms else "ndt_match_kernel"
     dk = kern[dominant]
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
+    # (tools/collect_profiles.sh -> profiles/rNN_pmc_traffic.json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+    traffic = None
+    try:
+        if B == 1024 and NP == 100000:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            for k in kern:
+                kern[k]["pmc_hbm_bytes_per_launch"] = pmc["kernels"][k]["hbm_bytes_per_launch"]
+            traffic = pmc["kernels"][dominant]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": None,
-                "note": "algorithmic bytes / HIP-event kernel duration; PMC traffic: profiles/ (rocprofv3 --pmc)"}
+                "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "note": "achieved = algorithmic bytes per launch / HIP-event kernel duration (live); traffic = HBM bytes "
+                        "per launch from the rocprofv3 PMC passes committed under profiles/ (not collected live)"}
 
     out = {
         "metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)",

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + HBM PMC counters of the bench command.
+# PMC passes are separate (--pmc never combined with trace domains) and restricted to our kernels.
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+CMD="python bench.py --steps 5 --warmup 1 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o bench -- $CMD > gpurun_out/bench_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_fetch -o bench -- $CMD > gpurun_out/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_write -o bench -- $CMD > gpurun_out/bench_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_sq -o bench -- $CMD > gpurun_out/bench_sq.log 2>&1
+python bench.py --steps 5 --warmup 1 > gpurun_out/bench_full.log 2>&1
+tail -1 gpurun_out/bench_full.log
+find gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq -name "*.csv" | head -20
