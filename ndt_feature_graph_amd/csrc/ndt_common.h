@@ -93,6 +93,10 @@ hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const Ndt
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
                             NdtMatchResultDev *res_dev, hipStream_t stream);
+struct rigid;
+hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,
+                           int n_neighbours, int with_h, double lfd1, double lfd2, unsigned n_groups, double *partials_dev,
+                           hipStream_t stream);
 hipError_t ndt_launch_derivatives(const NdtSetView &tset, size_t tmap, const NdtCell *src_cells_dev, size_t m,
                                   int n_neighbours, int compute_hessian, double lfd1, double lfd2, double *out28_dev,
                                   hipStream_t stream);

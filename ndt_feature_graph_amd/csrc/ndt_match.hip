@@ -25,6 +25,7 @@
 //   * 1+6+21 fp64 partial sums per lane -> wave xor-shuffle tree -> 4 LDS partials -> fixed-order sum.
 //   * MFMA is not used: nothing here is a dense contraction (3x3 / 6x6 per-pair expressions).
 #include "ndt_math.h"
+#include "ndt_solver.h"
 #include <float.h>
 
 #define NDT_MATCH_THREADS 512
@@ -233,334 +234,6 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
     __syncthreads();
 }
 
-// ------------------------------------------------------------------------------------------------
-// serial part (thread 0): Newton step + More-Thuente state machine
-// ------------------------------------------------------------------------------------------------
-enum { PH_NEWTON = 0, PH_LS_TRIAL = 1, PH_FINAL = 2 };
-
-struct MatchState {
-    rigid T, Tbest, Teval;
-    double score_best, score_here;
-    double incr[6];
-    // More-Thuente (fusion.h:400-408, 485-521)
-    double stp, finit, dginit, dgtest, width, width1, stx, fx, dgx, sty, fy, dgy, stmin, stmax;
-    int brackt, stage1, nfev, infoc;
-    int itr_ctr, fevals, ret, exit_code, phase, with_h, done;
-    // workspace of the pivoted LDL^T (dynamically indexed -> kept in LDS, not in scratch)
-    double ws_a[36], ws_y[6], ws_H[36], ws_g[6], ws_dx[6];
-    int ws_perm[6];
-};
-
-NDT_D double dmin(double a, double b) { return a < b ? a : b; }
-NDT_D double dmax(double a, double b) { return a > b ? a : b; }
-NDT_D double absmax3(double a, double b, double c) { return dmax(dmax(fabs(a), fabs(b)), fabs(c)); }
-
-// MoreThuente::cstep = MINPACK mcstep (published algorithm: More & Thuente, ACM TOMS 20(3), 1994);
-// call sites fusion.h:756,775.
-__device__ __noinline__ int mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
-                                     double &stp, double fp, double dp, int &brackt, double stmin, double stmax)
-{
-    int info = 0;
-    bool bound;
-    double theta, s, gamma, p, q, r, stpc, stpq, stpf;
-    if ((brackt && ((stp <= dmin(stx, sty)) || (stp >= dmax(stx, sty)))) || (dx * (stp - stx) >= 0.0) ||
-        (stmax < stmin))
-        return info;
-    double sgnd = dp * (dx / fabs(dx));
-    if (fp > fx) {
-        info = 1; bound = true;
-        theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        s = absmax3(theta, dx, dp);
-        gamma = s * sqrt(((theta / s) * (theta / s)) - (dx / s) * (dp / s));
-        if (stp < stx) gamma = -gamma;
-        p = (gamma - dx) + theta;
-        q = ((gamma - dx) + gamma) + dp;
-        r = p / q;
-        stpc = stx + r * (stp - stx);
-        stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2) * (stp - stx);
-        if (fabs(stpc - stx) < fabs(stpq - stx)) stpf = stpc;
-        else stpf = stpc + (stpq - stpc) / 2;
-        brackt = 1;
-    } else if (sgnd < 0.0) {
-        info = 2; bound = false;
-        theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        s = absmax3(theta, dx, dp);
-        gamma = s * sqrt(((theta / s) * (theta / s)) - (dx / s) * (dp / s));
-        if (stp > stx) gamma = -gamma;
-        p = (gamma - dp) + theta;
-        q = ((gamma - dp) + gamma) + dx;
-        r = p / q;
-        stpc = stp + r * (stx - stp);
-        stpq = stp + (dp / (dp - dx)) * (stx - stp);
-        if (fabs(stpc - stp) > fabs(stpq - stp)) stpf = stpc;
-        else stpf = stpq;
-        brackt = 1;
-    } else if (fabs(dp) < fabs(dx)) {
-        info = 3; bound = true;
-        theta = 3 * (fx - fp) / (stp - stx) + dx + dp;
-        s = absmax3(theta, dx, dp);
-        gamma = s * sqrt(dmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
-        if (stp > stx) gamma = -gamma;
-        p = (gamma - dp) + theta;
-        q = (gamma + (dx - dp)) + gamma;
-        r = p / q;
-        if ((r < 0.0) && (gamma != 0.0)) stpc = stp + r * (stx - stp);
-        else if (stp > stx) stpc = stmax;
-        else stpc = stmin;
-        stpq = stp + (dp / (dp - dx)) * (stx - stp);
-        if (brackt) {
-            if (fabs(stp - stpc) < fabs(stp - stpq)) stpf = stpc;
-            else stpf = stpq;
-        } else {
-            if (fabs(stp - stpc) > fabs(stp - stpq)) stpf = stpc;
-            else stpf = stpq;
-        }
-    } else {
-        info = 4; bound = false;
-        if (brackt) {
-            theta = 3 * (fp - fy) / (sty - stp) + dy + dp;
-            s = absmax3(theta, dy, dp);
-            gamma = s * sqrt(((theta / s) * (theta / s)) - (dy / s) * (dp / s));
-            if (stp > sty) gamma = -gamma;
-            p = (gamma - dp) + theta;
-            q = ((gamma - dp) + gamma) + dy;
-            r = p / q;
-            stpc = stp + r * (sty - stp);
-            stpf = stpc;
-        } else if (stp > stx)
-            stpf = stmax;
-        else
-            stpf = stmin;
-    }
-    if (fp > fx) {
-        sty = stp; fy = fp; dy = dp;
-    } else {
-        if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-        stx = stp; fx = fp; dx = dp;
-    }
-    stpf = dmin(stmax, stpf);
-    stpf = dmax(stmin, stpf);
-    stp = stpf;
-    if (brackt && bound) {
-        if (sty > stx) stp = dmin(stx + 0.66 * (sty - stx), stp);
-        else stp = dmax(stx + 0.66 * (sty - stx), stp);
-    }
-    return info;
-}
-
-// head of the More-Thuente while(1) body (fusion.h:523-561): pick the trial step and request its evaluation
-__device__ __noinline__ void mt_request_trial(MatchState &st)
-{
-    const double stpmax = 4.0, stpmin = 0.001, xtol = 0.01;
-    const int maxfev = 40;
-    if (st.brackt) {
-        st.stmin = dmin(st.stx, st.sty);
-        st.stmax = dmax(st.stx, st.sty);
-    } else {
-        st.stmin = st.stx;
-        st.stmax = st.stp + 4 * (st.stp - st.stx);
-    }
-    st.stp = dmax(st.stp, stpmin);
-    st.stp = dmin(st.stp, stpmax);
-    if ((st.brackt && ((st.stp <= st.stmin) || (st.stp >= st.stmax))) || (st.nfev >= maxfev - 1) ||
-        (st.infoc == 0) || (st.brackt && (st.stmax - st.stmin <= xtol * st.stmax)))
-        st.stp = st.stx;
-    double pincr[6];
-    for (int a = 0; a < 6; a++) pincr[a] = st.stp * st.incr[a];
-    rigid ps;
-    pose_to_rigid(pincr, ps);
-    rigid_mul(ps, st.T, st.Teval);     // trial cells = ps * nextNDT (fusion.h:556-589)
-    st.with_h = 0;
-    st.phase = PH_LS_TRIAL;
-}
-
-// pose update + convergence tests (fusion.h:1032-1080)
-__device__ __noinline__ void apply_step(MatchState &st, double step_size, const NdtMatchParamsDev &prm)
-{
-    double inorm = 0;
-    for (int a = 0; a < 6; a++) {
-        st.incr[a] *= step_size;
-        inorm += st.incr[a] * st.incr[a];
-    }
-    inorm = sqrt(inorm);
-    rigid TR;
-    pose_to_rigid(st.incr, TR);
-    rigid_mul(TR, st.T, st.T);          // T = TR*T
-    bool convergence = false;
-    if (st.itr_ctr > 0) convergence = (inorm < prm.delta_score);
-    if (st.itr_ctr > prm.itr_max) {
-        convergence = true;
-        st.ret = 0;
-        st.exit_code = 3;
-    }
-    st.itr_ctr++;
-    st.Teval = st.T;
-    if (convergence) { st.phase = PH_FINAL; st.with_h = 0; }
-    else { st.phase = PH_NEWTON; st.with_h = 1; }
-}
-
-__device__ __noinline__ void newton_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
-{
-    st.fevals++;
-    st.score_here = sums[0];
-    if (st.score_here < st.score_best) {   // fusion.h:914-920
-        st.Tbest = st.T;
-        st.score_best = st.score_here;
-    }
-    // Hessian in registers (static indices).  Inactive dofs (NDTMatcherD2D_2D) are decoupled and given
-    // the diagonal value of the first active dof, which leaves lambda_min / lambda_max of the active
-    // block unchanged (a diagonal entry is a Rayleigh quotient) and yields a zero increment for them.
-    double H[6][6], g[6];
-    {
-        int o = 7;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = a; b < 6; b++) { H[a][b] = sums[o]; H[b][a] = sums[o]; o++; }
-    }
-    double pad = 0.0;
-    bool havepad = false;
-    double gnorm = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        bool on = (prm.dof_mask >> a) & 1;
-        g[a] = on ? sums[1 + a] : 0.0;
-        if (on && !havepad) { pad = H[a][a]; havepad = true; }
-    }
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        bool on_a = (prm.dof_mask >> a) & 1;
-#pragma unroll
-        for (int b = 0; b < 6; b++) {
-            bool on_b = (prm.dof_mask >> b) & 1;
-            if (!(on_a && on_b)) H[a][b] = (a == b) ? pad : 0.0;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 6; a++) gnorm += g[a] * g[a];
-    gnorm = sqrt(gnorm);
-    // fusion.h:922-940.  evals += regularizer with the same regularizer for every eigenvalue, then
-    // H = V diag(evals) V^T, i.e. H + regularizer*I: only lambda_min and lambda_max are needed.  A
-    // positive definite H (the usual case near the optimum) is certified by an unpivoted Cholesky
-    // and skips the eigen-decomposition altogether.
-    if (!chol_is_pd<6>(H)) {
-        double A[6][6], V[6][6];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = 0; b < 6; b++) A[a][b] = H[a][b];
-        jacobi_static<6, false>(A, V);
-        double minC = A[0][0], maxC = A[0][0];
-#pragma unroll
-        for (int a = 1; a < 6; a++) { minC = dmin(minC, A[a][a]); maxC = dmax(maxC, A[a][a]); }
-        if (minC < 0) {
-            double regularizer = gnorm;
-            regularizer = (regularizer + minC > 0) ? regularizer : 0.001 * maxC - minC;
-#pragma unroll
-            for (int a = 0; a < 6; a++) H[a][a] += regularizer;
-        }
-    }
-    if (gnorm <= prm.delta_score) {        // fusion.h:943-965
-        if (st.score_here > st.score_best) st.T = st.Tbest;
-        st.exit_code = 1;
-        st.done = 1;
-        return;
-    }
-    // fusion.h:966  pose_increment_v = -Hessian.ldlt().solve(score_gradient).  The padded 6x6 system
-    // performs exactly the arithmetic of the active block (the padding is decoupled, its solution 0).
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        st.ws_g[a] = g[a];
-#pragma unroll
-        for (int b = 0; b < 6; b++) st.ws_H[a * 6 + b] = H[a][b];
-    }
-    ldlt_solve_ws<6>(6, st.ws_H, st.ws_g, st.ws_dx, st.ws_a, st.ws_y, st.ws_perm);
-    double dginit = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        bool on = (prm.dof_mask >> a) & 1;
-        double d = on ? -st.ws_dx[a] : 0.0;
-        st.incr[a] = d;
-        dginit += d * g[a];
-    }
-    if (dginit > 0) {                      // fusion.h:976-997
-        if (st.score_here > st.score_best) st.T = st.Tbest;
-        st.exit_code = 2;
-        st.done = 1;
-        return;
-    }
-    if (!prm.step_control) {
-        apply_step(st, 1.0, prm);
-        return;
-    }
-    // lineSearchMT: its initial derivativesNDT(nextNDT) equals this evaluation (same cells), so the
-    // score and gradient are reused instead of being recomputed (fusion.h:444-453).
-    st.finit = st.score_here;
-    st.dginit = dginit;
-    if (st.dginit >= 0.0) {                // fusion.h:456-479
-        for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
-        st.dginit = -st.dginit;
-        if (st.dginit >= 0.0) {
-            apply_step(st, 0.1, prm);
-            return;
-        }
-    }
-    st.stp = 1.0;
-    st.brackt = 0; st.stage1 = 1; st.nfev = 0; st.infoc = 1;
-    st.dgtest = 0.11111 * st.dginit;
-    st.width = 4.0 - 0.001;
-    st.width1 = 2 * st.width;
-    st.stx = 0.0; st.fx = st.finit; st.dgx = st.dginit;
-    st.sty = 0.0; st.fy = st.finit; st.dgy = st.dginit;
-    mt_request_trial(st);
-}
-
-// tail of the More-Thuente while(1) body after the trial evaluation (fusion.h:637-790)
-__device__ __noinline__ void linesearch_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
-{
-    const double ftol = 0.11111, gtol = 0.99999, stpmax = 4.0, stpmin = 0.001, xtol = 0.01, recoverystep = 0.1;
-    const int maxfev = 40;
-    st.fevals++;
-    double f = sums[0];
-    double dg = 0;
-    for (int a = 0; a < 6; a++) dg += st.incr[a] * sums[1 + a];
-    st.nfev++;
-    double ftest1 = st.finit + st.stp * st.dgtest;
-    int info = 0;
-    if ((st.brackt && ((st.stp <= st.stmin) || (st.stp >= st.stmax))) || (st.infoc == 0)) info = 6;
-    if ((st.stp == stpmax) && (f <= ftest1) && (dg <= st.dgtest)) info = 5;
-    if ((st.stp == stpmin) && ((f > ftest1) || (dg >= st.dgtest))) info = 4;
-    if (st.nfev >= maxfev) info = 3;
-    if (st.brackt && (st.stmax - st.stmin <= xtol * st.stmax)) info = 2;
-    if ((f <= ftest1) && (fabs(dg) <= gtol * (-st.dginit))) info = 1;
-    if (info != 0) {
-        apply_step(st, (info == 1) ? st.stp : recoverystep, prm);
-        return;
-    }
-    if (st.stage1 && (f <= ftest1) && (dg >= dmin(ftol, gtol) * st.dginit)) st.stage1 = 0;
-    if (st.stage1 && (f <= st.fx) && (f > ftest1)) {
-        double fm = f - st.stp * st.dgtest;
-        double fxm = st.fx - st.stx * st.dgtest;
-        double fym = st.fy - st.sty * st.dgtest;
-        double dgm = dg - st.dgtest;
-        double dgxm = st.dgx - st.dgtest;
-        double dgym = st.dgy - st.dgtest;
-        st.infoc = mt_cstep(st.stx, fxm, dgxm, st.sty, fym, dgym, st.stp, fm, dgm, st.brackt, st.stmin, st.stmax);
-        st.fx = fxm + st.stx * st.dgtest;
-        st.fy = fym + st.sty * st.dgtest;
-        st.dgx = dgxm + st.dgtest;
-        st.dgy = dgym + st.dgtest;
-    } else {
-        st.infoc = mt_cstep(st.stx, st.fx, st.dgx, st.sty, st.fy, st.dgy, st.stp, f, dg, st.brackt, st.stmin, st.stmax);
-    }
-    if (st.brackt) {
-        if (fabs(st.sty - st.stx) >= 0.66 * st.width1) st.stp = st.stx + 0.5 * (st.sty - st.stx);
-        st.width1 = st.width;
-        st.width = fabs(st.sty - st.stx);
-    }
-    mt_request_trial(st);
-}
-
 }  // namespace
 
 template <int NN>
@@ -579,23 +252,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     const MapView sv = map_view(sset, sidx[pair]);
     double *Tio = T16 + (size_t)pair * 16;
 
-    if (threadIdx.x == 0) {
-        rigid T0;
-        if (prm.use_initial_guess) {
-            for (int r = 0; r < 3; r++) {
-                for (int c = 0; c < 3; c++) T0.r[r * 3 + c] = Tio[c * 4 + r];   // column-major Affine3d
-                T0.t[r] = Tio[12 + r];
-            }
-        } else {
-            for (int k = 0; k < 9; k++) T0.r[k] = (k % 4 == 0) ? 1.0 : 0.0;
-            T0.t[0] = T0.t[1] = T0.t[2] = 0.0;
-        }
-        st.T = T0; st.Tbest = T0; st.Teval = T0;
-        st.score_best = DBL_MAX; st.score_here = 0;
-        st.itr_ctr = 0; st.fevals = 0; st.ret = 1; st.exit_code = 0;
-        st.phase = PH_NEWTON; st.with_h = 1; st.done = 0;
-        if ((prm.dof_mask & 0x3f) == 0 || prm.n_neighbours < 0 || prm.n_neighbours > 3) { st.done = 1; st.ret = 0; st.exit_code = -1; }
-    }
+    if (threadIdx.x == 0) match_state_init(st, Tio, prm);
     __syncthreads();
 
     long long cyc_eval = 0, cyc_solver = 0;
@@ -608,14 +265,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
         else eval_derivs<NN, false>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
         long long c1 = __builtin_readcyclecounter();
         if (threadIdx.x == 0) {
-            if (st.phase == PH_NEWTON) newton_step(st, s_sums, prm);
-            else if (st.phase == PH_LS_TRIAL) linesearch_step(st, s_sums, prm);
-            else {   // PH_FINAL: fusion.h:1085-1121
-                st.fevals++;
-                st.score_here = s_sums[0];
-                if (st.score_here > st.score_best) st.T = st.Tbest;
-                st.done = 1;
-            }
+            match_state_step(st, s_sums, prm);
             cyc_eval += c1 - c0;
             cyc_solver += (long long)__builtin_readcyclecounter() - c1;
         }
@@ -623,18 +273,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     }
 
     if (threadIdx.x == 0) {
-        for (int r = 0; r < 3; r++) {
-            for (int c = 0; c < 3; c++) Tio[c * 4 + r] = st.T.r[r * 3 + c];
-            Tio[12 + r] = st.T.t[r];
-            Tio[r * 4 + 3] = 0.0;
-        }
-        Tio[15] = 1.0;
         NdtMatchResultDev o;
-        o.converged = st.ret;
-        o.iterations = st.itr_ctr;
-        o.fevals = st.fevals;
-        o.exit_code = st.exit_code;
-        o.score = (st.score_here > st.score_best) ? st.score_best : st.score_here;
+        match_state_result(st, Tio, o);
         o.n_source = sv.n_cells;
         o.n_target = tg.n_cells;
         o.cycles_eval = cyc_eval;
@@ -662,6 +302,48 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_kernel(
     if (with_h) eval_derivs<NN, true>(tg, src, (int)m, I, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
     else eval_derivs<NN, false>(tg, src, (int)m, I, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
     if (threadIdx.x < 28) out28[threadIdx.x] = s_sums[threadIdx.x];
+}
+
+// One evaluation of derivativesNDT for ONE pair spread over many workgroups (host-driven matcher for
+// small batches / large maps: a single registration then uses the whole chip instead of one CU).
+// Workgroup g evaluates a contiguous share of the source cells and writes its 28 partial sums;
+// the host adds the partials in workgroup order.
+template <int NN>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_eval_kernel(
+    NdtSetView tset, unsigned tmap, NdtSetView sset, unsigned smap, rigid T, int with_h, double lfd1, double lfd2,
+    double *__restrict__ partials)
+{
+    __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
+    __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
+    __shared__ double s_part[NDT_MATCH_WAVES * 28];
+    __shared__ double s_sums[28];
+    const MapView tg = map_view(tset, tmap);
+    const MapView sv = map_view(sset, smap);
+    const int per = (sv.n_cells + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int begin = min(sv.n_cells, (int)blockIdx.x * per), count = min(sv.n_cells - begin, per);
+    if (threadIdx.x < 28) s_sums[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
+    else eval_derivs<NN, false>(tg, sv.cells + begin, count, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
+    if (threadIdx.x < 28) partials[blockIdx.x * 28 + threadIdx.x] = s_sums[threadIdx.x];
+}
+
+hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,
+                           int n_neighbours, int with_h, double lfd1, double lfd2, unsigned n_groups, double *partials_dev,
+                           hipStream_t stream)
+{
+#define NDT_LAUNCH_EVAL(NN)                                                                                          \
+    hipLaunchKernelGGL(ndt_eval_kernel<NN>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, (unsigned)tmap, \
+                       sset, (unsigned)smap, T, with_h, lfd1, lfd2, partials_dev)
+    switch (n_neighbours) {
+    case 0: NDT_LAUNCH_EVAL(0); break;
+    case 1: NDT_LAUNCH_EVAL(1); break;
+    case 2: NDT_LAUNCH_EVAL(2); break;
+    case 3: NDT_LAUNCH_EVAL(3); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef NDT_LAUNCH_EVAL
+    return hipGetLastError();
 }
 
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,

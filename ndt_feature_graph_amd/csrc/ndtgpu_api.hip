@@ -3,6 +3,7 @@
 // device every compute entry point fails with NDTGPU_ERR_NO_DEVICE.
 #include "../../include/ndtgpu.h"
 #include "ndt_math.h"
+#include "ndt_solver.h"
 
 #include <algorithm>
 #include <cmath>
@@ -451,6 +452,53 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
     return NDTGPU_OK;
 }
 
+// Small batches: the host runs the Newton / More-Thuente state machine (the same ndt_solver.h code the
+// persistent kernel runs on the device) and every derivative evaluation is one multi-workgroup kernel,
+// so a single registration uses the whole chip instead of one CU.  Used below NDTGPU_HOST_LOOP_MAX pairs.
+#define NDTGPU_HOST_LOOP_MAX 8
+static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                       double *T16, size_t n_pairs, const NdtMatchParamsDev &p,
+                                       ndtgpu_match_result *results, hipStream_t st)
+{
+    const unsigned max_groups = 128;
+    ndtgpu_status rc = ts->ensure_stage(max_groups * 28 * sizeof(double));
+    if (rc != NDTGPU_OK) return rc;
+    double *partials_dev = (double *)ts->stage;
+    std::vector<double> partials(max_groups * 28);
+    for (size_t k = 0; k < n_pairs; k++) {
+        NdtMapCounters cs, ct;
+        HIP_TRY(hipMemcpy(&cs, ss->v.counters + sidx[k], sizeof cs, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&ct, ts->v.counters + tidx[k], sizeof ct, hipMemcpyDeviceToHost));
+        unsigned groups = (cs.n_cells + 511u) / 512u;
+        if (groups < 1) groups = 1;
+        if (groups > max_groups) groups = max_groups;
+        MatchState ms;
+        match_state_init(ms, T16 + 16 * k, p);
+        while (!ms.done) {
+            hipError_t e = ndt_launch_eval(ts->v, tidx[k], ss->v, sidx[k], ms.Teval, p.n_neighbours, ms.with_h, p.lfd1,
+                                           p.lfd2, groups, partials_dev, st);
+            if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: eval launch", e);
+            HIP_TRY(hipMemcpyAsync(partials.data(), partials_dev, groups * 28 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            double sums[28];
+            for (int q = 0; q < 28; q++) {
+                double s = 0;
+                for (unsigned g = 0; g < groups; g++) s += partials[g * 28 + q];
+                sums[q] = s;
+            }
+            match_state_step(ms, sums, p);
+        }
+        NdtMatchResultDev o;
+        match_state_result(ms, T16 + 16 * k, o);
+        o.n_source = (int32_t)cs.n_cells;
+        o.n_target = (int32_t)ct.n_cells;
+        o.cycles_eval = 0;
+        o.cycles_solver = 0;
+        memcpy(&results[k], &o, sizeof o);
+    }
+    return NDTGPU_OK;
+}
+
 ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                  double *T16, size_t n_pairs, const ndtgpu_match_params *prm,
                                  ndtgpu_match_result *results, ndtgpu_stream stream)
@@ -461,12 +509,18 @@ ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu
     for (size_t k = 0; k < n_pairs; k++)
         if (tidx[k] >= ts->n_maps || sidx[k] >= ss->n_maps) return fail(NDTGPU_ERR_INVALID, "match_batch: map index");
     hipStream_t st = (hipStream_t)stream;
-    size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
-    size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
-           off_si = (off_ti + bI + 255) & ~(size_t)255, total = off_si + bI;
     // builds on other streams must have finished before the maps are read
     HIP_TRY(hipStreamSynchronize(ts->last_stream));
     HIP_TRY(hipStreamSynchronize(ss->last_stream));
+    if (n_pairs <= NDTGPU_HOST_LOOP_MAX) {
+        NdtMatchParamsDev p = to_dev(prm);
+        if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
+            return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
+        return match_host_driven(ts, tidx, ss, sidx, T16, n_pairs, p, results, st);
+    }
+    size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
+    size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
+           off_si = (off_ti + bI + 255) & ~(size_t)255, total = off_si + bI;
     ndtgpu_status rc = ts->ensure_stage(total);
     if (rc != NDTGPU_OK) return rc;
     char *base = (char *)ts->stage;

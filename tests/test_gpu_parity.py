@@ -265,6 +265,23 @@ def test_match_batch_is_deterministic_and_order_free(N, O):
     assert np.array_equal(T1, Ta[2])
 
 
+def test_persistent_and_host_driven_paths_agree(N, O):
+    """<= 8 pairs: host-driven Newton loop + multi-workgroup derivative kernel; more: one persistent
+    workgroup per pair.  Same state machine (csrc/ndt_solver.h), different summation order."""
+    pr, tg, sr, om = _pair_maps(N, O, list(range(1, 13)), 20000, 0.5)
+    T0 = pr["T_init"].numpy()
+    idx = np.arange(12)
+    Tb, rb = N.match_batch(tg, idx, sr, idx, T0)                 # persistent kernel
+    for b in (0, 5, 11):
+        Ts, rs = N.match_d2d(tg, b, sr, b, T0[b])                # host-driven
+        dt, dr = pose_close(Ts, Tb[b])
+        assert dt < 1e-9 and dr < 1e-9
+        assert rs["iterations"] == rb["iterations"][b] and rs["converged"] == rb["converged"][b]
+        To, ro = O.match_d2d(om[b][0], om[b][1], T0[b])
+        dt, dr = pose_close(Ts, To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
 def test_self_match_and_empty_maps(N):
     from ndt_feature_graph_amd import synth
     pts = synth.pair_2d([9], 20000)["fixed"].numpy()
