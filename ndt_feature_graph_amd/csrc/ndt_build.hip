@@ -35,6 +35,7 @@
 
 #define NDT_BUILD_THREADS 256
 #define NDT_BUILD_WAVES (NDT_BUILD_THREADS / 64)
+#define NDT_FIN_THREADS 1024  // finalise-only launch (MODE 2): more waves to hide the dependent table loads
 #define NDT_PPL 8            // consecutive points per lane per tile
 #define NDT_TILE (64 * NDT_PPL)
 #define NDT_IDC 64           // entries of the per-wave slot -> id cache
@@ -125,8 +126,12 @@ NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int s
 }  // namespace
 
 // STRIDE_DW: 3 = packed xyz, 4 = pcl::PointXYZ (16-byte records), 0 = any other stride (slow path)
-template <int STRIDE_DW>
-__global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
+// MODE 0: fused build, one workgroup per map (batches: B workgroups fill the chip)
+// MODE 1: accumulate only, gridDim.x workgroups share one map (gridDim.y maps): a single scan or a small
+//         batch then streams on many CUs; the atomics are memory-side, hence coherent across XCDs
+// MODE 2: finalise only (phases 0, B, C, D), one workgroup per map, after a MODE 1 launch
+template <int STRIDE_DW, int MODE>
+__global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS, MODE == 2 ? 1 : 3) void ndt_build_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
     size_t map_stride_bytes, double range_limit, const double *__restrict__ range_origins, int n_min,
     double eval_factor, int s1_shift, int s2_shift, int dbg)
@@ -140,13 +145,15 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
     __shared__ int s_qslot[NDT_BUILD_WAVES * NDT_QRUNS];
     __shared__ unsigned s_qcnt[NDT_BUILD_WAVES];
     __shared__ unsigned long long s_idc[NDT_BUILD_WAVES * NDT_IDC];
-    __shared__ unsigned s_wave_cnt[NDT_BUILD_WAVES];
+    __shared__ unsigned s_wave_cnt[NDT_FIN_THREADS / 64];
     __shared__ unsigned s_base;
     __shared__ unsigned s_dropped;
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u, wave = tid >> 6;
-    const unsigned map = first + blockIdx.x;
+    const unsigned nthreads = (MODE == 2) ? NDT_FIN_THREADS : NDT_BUILD_THREADS, nwaves = nthreads / 64;
+    const unsigned map_local = (MODE == 1) ? blockIdx.y : blockIdx.x;
+    const unsigned map = first + map_local;
     const NdtGrid g = set.grid;
     const uint32_t cap = g.max_cells;
     int32_t *table = set.table + (size_t)map * g.slots;
@@ -166,11 +173,11 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
     bc.q1 = ldexp(inv_res, s1_shift);
     bc.q2 = ldexp(inv_res * inv_res, s2_shift);
     bc.dbg = dbg;
-    bc.idc = s_idc + wave * NDT_IDC;
-    bc.idc[lane & (NDT_IDC - 1)] = ~0ull;
+    bc.idc = s_idc + ((MODE == 2) ? 0u : wave) * NDT_IDC;
+    if (MODE != 2) bc.idc[lane & (NDT_IDC - 1)] = ~0ull;
     double ox = 0, oy = 0, oz = 0;
-    if (range_origins) { ox = range_origins[blockIdx.x * 3]; oy = range_origins[blockIdx.x * 3 + 1]; oz = range_origins[blockIdx.x * 3 + 2]; }
-    const char *pts = xyz + (size_t)blockIdx.x * map_stride_bytes;
+    if (range_origins) { ox = range_origins[map_local * 3]; oy = range_origins[map_local * 3 + 1]; oz = range_origins[map_local * 3 + 2]; }
+    const char *pts = xyz + (size_t)map_local * map_stride_bytes;
     const float inv32 = (float)inv_res;
     // fast-path constants: idx = floor(p*inv + k), k = 0.5 + size/2 - c*inv.  Only for EVEN sizes (size/2
     // integral); with an odd size the reference's double->int truncation makes the index formula
@@ -182,27 +189,33 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
     const float r2 = (float)(range_limit * range_limit);
 
     // ---------------- phase 0: forget the previous content of the slot -> rank table -------------
-    {
+    if (MODE != 1) {
         unsigned old = ctr->n_cells;
         if (old > cap) old = cap;
-        for (unsigned i = tid; i < old; i += NDT_BUILD_THREADS) table[cells[i].slot] = NDT_EMPTY;
-        if (tid == 0) { s_base = 0; s_dropped = 0; }
+        for (unsigned i = tid; i < old; i += nthreads) table[cells[i].slot] = NDT_EMPTY;
+        if (MODE == 0 && tid == 0) ctr->overflow = 0;
     }
+    if (tid == 0) { s_base = 0; s_dropped = 0; }
     __syncthreads();
 
     // ---------------- phase A: key + accumulate ----------------------------------------------------
     long long t0 = __builtin_readcyclecounter();
     unsigned dropped = 0;
     const unsigned n_tiles = (n_points + NDT_TILE - 1) / NDT_TILE;
-    const unsigned tiles_per_wave = (n_tiles + NDT_BUILD_WAVES - 1) / NDT_BUILD_WAVES;
-    const unsigned tile_begin = wave * tiles_per_wave;
-    const unsigned tile_end = min(n_tiles, tile_begin + tiles_per_wave);
-    float *mytile = s_tile + wave * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1));
+    // MODE 1: this workgroup's share of the map's tiles; otherwise all of them.  Waves split the share.
+    const unsigned n_parts = (MODE == 1) ? gridDim.x : 1u, part = (MODE == 1) ? blockIdx.x : 0u;
+    const unsigned tiles_per_part = (n_tiles + n_parts - 1) / n_parts;
+    const unsigned part_begin = min(n_tiles, part * tiles_per_part), part_end = min(n_tiles, part_begin + tiles_per_part);
+    const unsigned tiles_per_wave = (part_end - part_begin + NDT_BUILD_WAVES - 1) / NDT_BUILD_WAVES;
+    const unsigned tile_begin = (MODE == 2) ? 0u : min(part_end, part_begin + wave * tiles_per_wave);
+    const unsigned tile_end = (MODE == 2) ? 0u : min(part_end, tile_begin + tiles_per_wave);
+    const unsigned awave = (MODE == 2) ? 0u : wave;   // phase-A per-wave LDS regions (unused when finalising)
+    float *mytile = s_tile + awave * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1));
     // flush list: after the point loop the tile buffer is dead and holds the records of the partial
     // runs that must be added to their cells; ONE atomic instruction then serves up to 64 (record,
     // component) items, instead of 19 dependent single-lane atomics per run.
     double *fl_val = reinterpret_cast<double *>(mytile);
-    int *fl_id = s_flid + wave * NDT_FLCAP;
+    int *fl_id = s_flid + awave * NDT_FLCAP;
     unsigned nfl = 0;   // wave-uniform
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
     auto drain_list = [&]() {
@@ -231,11 +244,11 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
     // Run 1 of every lane (the second cell its consecutive points fall into, e.g. range noise on a wall
     // that hugs a cell face) lives in LDS, SoA so that lane l only ever touches bank-distinct words;
     // run 0 lives in registers.  A third cell within the lane's points evicts run 1 (rare).
-    double *r1 = s_run1 + wave * (10 * 64);
+    double *r1 = s_run1 + awave * (10 * 64);
     // evicted runs are queued in LDS and added to their cells at the end of the tile by all lanes in
     // parallel: nothing in the point loop waits for global memory
-    double *q_val = s_qval + wave * (10 * NDT_QRUNS);
-    int *q_slot = s_qslot + wave * NDT_QRUNS;
+    double *q_val = s_qval + awave * (10 * NDT_QRUNS);
+    int *q_slot = s_qslot + awave * NDT_QRUNS;
     const bool use_range = range_limit > 0;
     for (unsigned tile = tile_begin; tile < tile_end; tile++) {
         const unsigned p0 = tile * NDT_TILE;
@@ -429,6 +442,10 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
     }
     if (dropped) atomicAdd(&s_dropped, dropped);
     __syncthreads();
+    if (MODE == 1) {   // the finalise launch does the rest
+        if (tid == 0 && s_dropped) atomicAdd(&ctr->n_dropped, s_dropped);
+        return;
+    }
     // atomics bypass the vector L1: drop lines that phase A cached before they were updated
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
@@ -439,7 +456,7 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
     if (n_alloc > cap) n_alloc = cap;
     NdtAcc *tmp_base = bc.acc;                            // cell record written over its own accumulator
     const double IS1 = ldexp(1.0, -s1_shift), IS2 = ldexp(1.0, -s2_shift);
-    for (unsigned id = tid; id < n_alloc; id += NDT_BUILD_THREADS) {
+    for (unsigned id = tid; id < n_alloc; id += nthreads) {
         NdtAcc a = bc.acc[id];
         NdtCell c;
         c.n = 0;
@@ -510,26 +527,45 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
 
     // ---------------- phase C: rank Gaussian cells in slot order from the occupancy bitmap ------------
     long long t2 = __builtin_readcyclecounter();
-    for (unsigned wbase = 0; wbase < bm_words; wbase += NDT_BUILD_THREADS) {
-        unsigned w = wbase + tid;
-        unsigned bits = (w < bm_words) ? bc.bitmap[w] : 0u;
+    // Every wave owns a contiguous share of the bitmap.  Pass 1 counts its Gaussian cells, one barrier
+    // turns the wave totals into bases, pass 2 assigns ranks with a running per-wave base: no barrier
+    // inside the loops (a 3D grid has 200 k bitmap words).
+    auto valid_bits = [&](unsigned w, unsigned bits) {
         unsigned vmask = 0;
         for (unsigned b = bits; b; b &= b - 1) {
             int bit = __ffs((int)b) - 1;
             int id = bc.wtable[w * 32 + bit];
             if (id >= 0 && (uint32_t)id < n_alloc && reinterpret_cast<const NdtCell *>(tmp_base + id)->n > 0) vmask |= 1u << bit;
         }
-        unsigned cnt = (unsigned)__popc(vmask);
+        return vmask;
+    };
+    const unsigned words_per_wave = (bm_words + nwaves - 1) / nwaves;
+    const unsigned wb = min(bm_words, wave * words_per_wave), we = min(bm_words, wb + words_per_wave);
+    {
+        unsigned cnt = 0;
+        for (unsigned w = wb + lane; w < we; w += 64u) {
+            unsigned bits = bc.bitmap[w];
+            if (bits) cnt += (unsigned)__popc(valid_bits(w, bits));
+        }
         unsigned incl = wave_incl_scan(cnt);
         if (lane == 63) s_wave_cnt[wave] = incl;
-        __syncthreads();
-        unsigned before = s_base + incl - cnt;
-        unsigned total = 0;
-        for (unsigned k = 0; k < NDT_BUILD_WAVES; k++) {
-            unsigned c2 = s_wave_cnt[k];
-            if (k < wave) before += c2;
-            total += c2;
-        }
+    }
+    __syncthreads();
+    unsigned running = 0, total_cells = 0;
+    for (unsigned k = 0; k < nwaves; k++) {
+        unsigned c2 = s_wave_cnt[k];
+        if (k < wave) running += c2;
+        total_cells += c2;
+    }
+    for (unsigned step = wb; step < we; step += 64u) {
+        unsigned w = step + lane;
+        unsigned bits = (w < we) ? bc.bitmap[w] : 0u;
+        if (!__ballot(bits != 0u)) continue;
+        unsigned vmask = bits ? valid_bits(w, bits) : 0u;
+        unsigned cnt = (unsigned)__popc(vmask);
+        unsigned incl = wave_incl_scan(cnt);
+        unsigned before = running + incl - cnt;
+        running += __shfl(incl, 63, 64);
         for (unsigned b = bits; b; b &= b - 1) {
             int bit = __ffs((int)b) - 1;
             unsigned slot = w * 32 + bit;
@@ -542,21 +578,20 @@ __global__ __launch_bounds__(NDT_BUILD_THREADS, 3) void ndt_build_kernel(
             bc.wtable[slot] = NDT_EMPTY;      // work table back to its clean state
         }
         if (bits) bc.bitmap[w] = 0u;
-        __syncthreads();
-        if (tid == 0) s_base += total;
     }
+    if (tid == 0) s_base = total_cells;
     __syncthreads();
 
     // ---------------- phase D: leave the scratch zeroed, publish counters -----------------------------
     long long t3 = __builtin_readcyclecounter();
     {
         unsigned long long *z = reinterpret_cast<unsigned long long *>(bc.acc);
-        for (unsigned k = tid; k < n_alloc * 20u; k += NDT_BUILD_THREADS) z[k] = 0ull;
+        for (unsigned k = tid; k < n_alloc * 20u; k += nthreads) z[k] = 0ull;
     }
     if (tid == 0) {
         ctr->n_cells = s_base;
         ctr->n_alloc = 0;
-        ctr->n_dropped = s_dropped;
+        if (MODE == 0) ctr->n_dropped = s_dropped;
         ctr->cyc[0] = (uint32_t)(t1 - t0);
         ctr->cyc[1] = (uint32_t)(t2 - t1);
         ctr->cyc[2] = (uint32_t)(t3 - t2);
@@ -603,13 +638,38 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
     if (s2_shift > 44) s2_shift = 44;
     const int dbg = getenv("NDT_BUILD_DBG") ? atoi(getenv("NDT_BUILD_DBG")) : 0;
     const bool aligned4 = (((uintptr_t)xyz_dev | map_stride_bytes) & 3u) == 0;
-#define NDT_LAUNCH_BUILD(SDW)                                                                                        \
-    hipLaunchKernelGGL(ndt_build_kernel<SDW>, dim3((unsigned)count), dim3(NDT_BUILD_THREADS), 0, stream, set,        \
-                       (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,           \
-                       map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg)
-    if (stride_bytes == 12 && aligned4) NDT_LAUNCH_BUILD(3);
-    else if (stride_bytes == 16 && aligned4) NDT_LAUNCH_BUILD(4);
-    else NDT_LAUNCH_BUILD(0);
+    const int sdw = (stride_bytes == 12 && aligned4) ? 3 : (stride_bytes == 16 && aligned4) ? 4 : 0;
+    // Few maps: spread each scan over several workgroups (accumulate) and finalise in a second launch.
+    const unsigned n_tiles = (unsigned)((n_points + NDT_TILE - 1) / NDT_TILE);
+    unsigned parts = 1;
+    if (count < 256 && n_tiles > 8) {
+        parts = (unsigned)(1024 / count);
+        if (parts > n_tiles / 4) parts = n_tiles / 4;
+        if (parts < 1) parts = 1;
+    }
+#define NDT_LAUNCH_BUILD(SDW, MODE, GRID)                                                                            \
+    hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set, (unsigned)first, \
+                       (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes, map_stride_bytes,          \
+                       range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg)
+#define NDT_LAUNCH_BUILD_SD(MODE, GRID)                                                                              \
+    do {                                                                                                             \
+        if (sdw == 3) NDT_LAUNCH_BUILD(3, MODE, GRID);                                                               \
+        else if (sdw == 4) NDT_LAUNCH_BUILD(4, MODE, GRID);                                                          \
+        else NDT_LAUNCH_BUILD(0, MODE, GRID);                                                                        \
+    } while (0)
+    if (parts == 1) {
+        NDT_LAUNCH_BUILD_SD(0, dim3((unsigned)count));
+    } else {
+        // reset {overflow, n_dropped} of the maps, accumulate on `parts` workgroups per map, finalise
+        hipError_t e = hipMemset2DAsync(&set.counters[first].overflow, sizeof(NdtMapCounters), 0, 2 * sizeof(uint32_t),
+                                        count, stream);
+        if (e != hipSuccess) return e;
+        NDT_LAUNCH_BUILD_SD(1, dim3(parts, (unsigned)count));
+        hipLaunchKernelGGL((ndt_build_kernel<0, 2>), dim3((unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
+                           (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
+                           map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg);
+    }
+#undef NDT_LAUNCH_BUILD_SD
 #undef NDT_LAUNCH_BUILD
     return hipGetLastError();
 }
