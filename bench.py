@@ -188,6 +188,39 @@ def main():
         out["parity"] = {"pairs_checked": S, "max_dt_m": max_dt, "max_drot_rad": max_dr,
                          "tolerance": "1e-4 m / 1e-4 rad", "ok": bool(max_dt <= 1e-4 and max_dr <= 1e-4)}
         out["speedup_vs_cpu_1thread"] = value / cpu_rate
+    # ---- single-pair latency of the other single-GPU configs (outside the timed region; rank 0, N=1) ---
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle as O
+
+        def one_pair(fx, mv, T0, res_, size_, rng_, cap):
+            ms = N.MapSet(res_, [0, 0, 0], size_, n_maps=2, max_cells=cap)
+            scans = torch.stack([fx, mv]).contiguous()
+            best = 1e9
+            for _ in range(5):
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                ms.build(scans, range_limit=rng_, stream=stream)
+                T, r = N.match_d2d(ms, 0, ms, 1, T0)
+                best = min(best, time.perf_counter() - c0)
+            f_h, m_h = fx.cpu().numpy(), mv.cpu().numpy()
+            c0 = time.perf_counter()
+            ot = O.OracleMap(res_, [0, 0, 0], size_); ot.load_points(f_h, rng_); ot.compute_cells()
+            os_ = O.OracleMap(res_, [0, 0, 0], size_); os_.load_points(m_h, rng_); os_.compute_cells()
+            To, ro = O.match_d2d(ot, os_, T0)
+            t_cpu = time.perf_counter() - c0
+            dt = float(np.linalg.norm(T[:3, 3] - To[:3, 3]))
+            dr = float(np.arccos(np.clip((np.trace(T[:3, :3].T @ To[:3, :3]) - 1) / 2, -1, 1)))
+            return {"gpu_ms": 1e3 * best, "cpu_1thread_ms": 1e3 * t_cpu, "speedup": t_cpu / best,
+                    "cells": [int(r["n_target"]), int(r["n_source"])], "iterations": int(r["iterations"]),
+                    "dt_m": dt, "drot_rad": dr}
+
+        lat = {}
+        lat["configs[1] single 2D pair, %d pts, %.2f m cells (build x2 + match, host-synchronous call)" % (NP, res)] = \
+            one_pair(fixed[0], moving[0], pr["T_init"][0].cpu().numpy(), res, size_m, rng_lim, 4096)
+        p3 = synth.pair_3d(torch.tensor([1], device=dev), device=dev)
+        lat["configs[4] single 3D pair, 200000 pts, 0.25 m voxels, 100x100x10 m, 6-DoF"] = \
+            one_pair(p3["fixed"][0], p3["moving"][0], p3["T_init"][0].cpu().numpy(), 0.25, [100.0, 100.0, 10.0], 70.0, 120000)
+        out["single_pair_latency"] = lat
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
