@@ -38,6 +38,7 @@
 #define NDT_FIN_THREADS 1024  // finalise-only launch (MODE 2): more waves to hide the dependent table loads
 #define NDT_PPL 8            // consecutive points per lane per tile
 #define NDT_TILE (64 * NDT_PPL)
+#define NDT_ROUNDS 4         // sub-tiles per super-tile (one wavefront merge + flush per 2048 points)
 #define NDT_IDC 64           // entries of the per-wave slot -> id cache
 #define NDT_FLCAP 40         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 160 B)
 #define NDT_QRUNS 12         // per-wave, per-tile queue of evicted runs (third cell within a lane's points)
@@ -131,7 +132,7 @@ NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int s
 //         batch then streams on many CUs; the atomics are memory-side, hence coherent across XCDs
 // MODE 2: finalise only (phases 0, B, C, D), one workgroup per map, after a MODE 1 launch
 template <int STRIDE_DW, int MODE>
-__global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS, MODE == 2 ? 1 : 3) void ndt_build_kernel(
+__global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) void ndt_build_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
     size_t map_stride_bytes, double range_limit, const double *__restrict__ range_origins, int n_min,
     double eval_factor, int s1_shift, int s2_shift, int dbg)
@@ -201,8 +202,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS, MO
     // ---------------- phase A: key + accumulate ----------------------------------------------------
     long long t0 = __builtin_readcyclecounter();
     unsigned dropped = 0;
+    // The scan is cut into sub-tiles of 512 points (64 lanes x 8 points).  A wave owns a contiguous range of
+    // sub-tiles and walks it in SUPER-TILES of up to NDT_ROUNDS sub-tiles: lane l owns 8*R consecutive points of
+    // the super-tile and visits them in R rounds through the same 8-point LDS row, so the wavefront merge and
+    // the flush run once per up to 2048 points while the LDS tile stays 6.4 KB.
     const unsigned n_tiles = (n_points + NDT_TILE - 1) / NDT_TILE;
-    // MODE 1: this workgroup's share of the map's tiles; otherwise all of them.  Waves split the share.
+    // MODE 1: this workgroup's share of the map's sub-tiles; otherwise all of them.  Waves split the share.
     const unsigned n_parts = (MODE == 1) ? gridDim.x : 1u, part = (MODE == 1) ? blockIdx.x : 0u;
     const unsigned tiles_per_part = (n_tiles + n_parts - 1) / n_parts;
     const unsigned part_begin = min(n_tiles, part * tiles_per_part), part_end = min(n_tiles, part_begin + tiles_per_part);
@@ -250,41 +255,44 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS, MO
     double *q_val = s_qval + awave * (10 * NDT_QRUNS);
     int *q_slot = s_qslot + awave * NDT_QRUNS;
     const bool use_range = range_limit > 0;
-    for (unsigned tile = tile_begin; tile < tile_end; tile++) {
-        const unsigned p0 = tile * NDT_TILE;
-        if (STRIDE_DW) {
-            // coalesced: lane l reads dwords l, l+64, ... of the tile; each lands in its owner lane's row
-            const float *src = (const float *)pts + (size_t)p0 * SD;
-            const unsigned tile_dw = min((unsigned)NDT_TILE, n_points - p0) * SD;
-            constexpr int CH = 8;
-            static_assert((NDT_PPL * SD) % CH == 0, "staging chunk");
-#pragma unroll
-            for (int h = 0; h < NDT_PPL * SD / CH; h++) {
-                float tmp[CH];
-                if (tile_dw == NDT_TILE * SD) {            // full tile: all loads in flight, no predicates
-#pragma unroll
-                    for (int k = 0; k < CH; k++) tmp[k] = src[lane + 64u * (h * CH + k)];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < CH; k++) {
-                        unsigned d = lane + 64u * (h * CH + k);
-                        tmp[k] = src[d < tile_dw ? d : 0u];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < CH; k++) {
-                    unsigned d = lane + 64u * (h * CH + k);
-                    mytile[(d / (NDT_PPL * SD)) * LANE_DW + d % (NDT_PPL * SD)] = tmp[k];
-                }
-            }
-        }
+    for (unsigned tile = tile_begin; tile < tile_end;) {
+        const unsigned R = min((unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
+        const unsigned p0 = tile * NDT_TILE;                              // its first point
+        tile += R;
         if (lane == 0) s_qcnt[wave] = 0;
         int cs0 = -1, cs1 = -1;
         double rn = 0;
         double sd[3] = {0, 0, 0}, se[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll 1
+        for (unsigned r = 0; r < R; r++) {
+        if (STRIDE_DW) {
+            // Round r of the super-tile: lane `owner` needs its points [8r, 8r+8) = dwords
+            // (owner*R + r)*8*SD + e, e < 8*SD, of the super-tile.  Lane l fetches item d = l + 64k
+            // (owner = d / (8*SD), e = d % (8*SD)): consecutive lanes read consecutive dwords of 96-byte pieces.
+            const float *src = (const float *)pts + (size_t)p0 * SD;
+            const bool full = (size_t)p0 + (size_t)NDT_TILE * R <= (size_t)n_points;
+            const unsigned lim_dw = (n_points - p0) * SD;                   // valid dwords from p0 on
+            constexpr int CH = 8;
+            static_assert((NDT_PPL * SD) % CH == 0, "staging chunk");
+#pragma unroll
+            for (int h = 0; h < NDT_PPL * SD / CH; h++) {
+                float tmp[CH];
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const unsigned d = lane + 64u * (h * CH + k);
+                    const unsigned g = ((d / (NDT_PPL * SD)) * R + r) * (NDT_PPL * SD) + d % (NDT_PPL * SD);
+                    tmp[k] = src[(full || g < lim_dw) ? g : 0u];
+                }
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const unsigned d = lane + 64u * (h * CH + k);
+                    mytile[(d / (NDT_PPL * SD)) * LANE_DW + d % (NDT_PPL * SD)] = tmp[k];
+                }
+            }
+        }
+#pragma unroll 1
         for (int j = 0; j < NDT_PPL; j++) {
-            const unsigned i = p0 + lane * NDT_PPL + j;
+            const unsigned i = p0 + (lane * R + r) * NDT_PPL + j;
             const bool valid = (i < n_points) && !(dbg & 4);
             float fx, fy, fz;
             if (STRIDE_DW) {
@@ -378,6 +386,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS, MO
                 se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
             }
         }
+        }   // rounds
         if (!(dbg & 2)) {
             // Canonical order of a lane's two runs (run 0 = smaller slot): along a wall that hugs a cell
             // face neighbouring lanes then agree on which cell is run 0 and which is run 1, so both form
