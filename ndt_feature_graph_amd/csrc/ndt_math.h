@@ -294,6 +294,103 @@ NDT_HD void ldlt_solve_ws(int n, const double *A, const double *b, double *x, do
     for (int i = 0; i < n; i++) x[perm[i]] = y[i];
 }
 
+// 6x6 version of ldlt_solve with every index a compile-time constant (the matrix lives in registers):
+// the data-dependent pivot only selects which statically indexed swap runs.  Same pivot rule (largest
+// |diagonal| of the remaining block, first one on ties), same elimination and substitution formulas,
+// hence the same arithmetic as ldlt_solve / Eigen's LDLT::solve on a 6x6 system.
+namespace ndt_ldlt6 {
+template <int K, int C>
+NDT_HD void swap_kc(double (&a)[6][6], double (&y)[6])
+{
+#pragma unroll
+    for (int j = 0; j < 6; j++) { double t = a[K][j]; a[K][j] = a[C][j]; a[C][j] = t; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { double t = a[i][K]; a[i][K] = a[i][C]; a[i][C] = t; }
+    double t = y[K]; y[K] = y[C]; y[C] = t;
+}
+template <int K>
+NDT_HD void swap_k(double (&a)[6][6], double (&y)[6], int piv)
+{
+    switch (piv) {
+    case 1: if (K < 1) swap_kc<K, (K < 1 ? 1 : K)>(a, y); break;
+    case 2: if (K < 2) swap_kc<K, (K < 2 ? 2 : K)>(a, y); break;
+    case 3: if (K < 3) swap_kc<K, (K < 3 ? 3 : K)>(a, y); break;
+    case 4: if (K < 4) swap_kc<K, (K < 4 ? 4 : K)>(a, y); break;
+    case 5: if (K < 5) swap_kc<K, (K < 5 ? 5 : K)>(a, y); break;
+    default: break;
+    }
+}
+template <int K>
+NDT_HD void unswap_k(double (&y)[6], int piv)
+{
+    // x[perm[i]] = y[i]: undo the row exchanges in reverse order
+#pragma unroll
+    for (int c = K + 1; c < 6; c++)
+        if (piv == c) { double t = y[K]; y[K] = y[c]; y[c] = t; }
+}
+template <int K>
+NDT_HD void step(double (&a)[6][6], double (&y)[6], int (&pivs)[6])
+{
+    int piv = K;
+    double best = fabs(a[K][K]);
+#pragma unroll
+    for (int i = K + 1; i < 6; i++)
+        if (fabs(a[i][i]) > best) { best = fabs(a[i][i]); piv = i; }
+    pivs[K] = piv;
+    if (piv != K) swap_k<K>(a, y, piv);
+    const double d = a[K][K];
+    if (fabs(d) > 2.2250738585072014e-308) {
+#pragma unroll
+        for (int i = K + 1; i < 6; i++) {
+            const double l = a[i][K] / d;
+#pragma unroll
+            for (int j = K + 1; j < 6; j++) a[i][j] -= l * a[K][j];
+            a[i][K] = l;
+        }
+#pragma unroll
+        for (int j = K + 1; j < 6; j++) a[K][j] = 0.0;
+    }
+}
+}  // namespace ndt_ldlt6
+
+NDT_HD void ldlt_solve_static6(const double (&A)[6][6], const double (&b)[6], double (&x)[6])
+{
+    double a[6][6], y[6];
+    int pivs[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        y[i] = b[i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) a[i][j] = 0.5 * (A[i][j] + A[j][i]);
+    }
+    ndt_ldlt6::step<0>(a, y, pivs);
+    ndt_ldlt6::step<1>(a, y, pivs);
+    ndt_ldlt6::step<2>(a, y, pivs);
+    ndt_ldlt6::step<3>(a, y, pivs);
+    ndt_ldlt6::step<4>(a, y, pivs);
+    pivs[5] = 5;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) y[i] -= a[i][j] * y[j];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double d = a[i][i];
+        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--)
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) y[i] -= a[j][i] * y[j];
+    ndt_ldlt6::unswap_k<4>(y, pivs[4]);
+    ndt_ldlt6::unswap_k<3>(y, pivs[3]);
+    ndt_ldlt6::unswap_k<2>(y, pivs[2]);
+    ndt_ldlt6::unswap_k<1>(y, pivs[1]);
+    ndt_ldlt6::unswap_k<0>(y, pivs[0]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = y[i];
+}
+
 // LazyGrid::getIndexForPoint: idx = floor((p - centre)/res + 0.5) + size/2.0, double -> int.
 // Contraction is off so that the host oracle and the device agree bit-for-bit at cell faces.
 NDT_HD int lazygrid_index(double p, double centre, double res, int size)

@@ -22,9 +22,6 @@ struct MatchState {
     double stp, finit, dginit, dgtest, width, width1, stx, fx, dgx, sty, fy, dgy, stmin, stmax;
     int brackt, stage1, nfev, infoc;
     int itr_ctr, fevals, ret, exit_code, phase, with_h, done;
-    // workspace of the pivoted LDL^T (dynamically indexed -> kept in LDS, not in scratch)
-    double ws_a[36], ws_y[6], ws_H[36], ws_g[6], ws_dx[6];
-    int ws_perm[6];
 };
 
 NDT_HD double dmin(double a, double b) { return a < b ? a : b; }
@@ -244,18 +241,13 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     }
     // fusion.h:966  pose_increment_v = -Hessian.ldlt().solve(score_gradient).  The padded 6x6 system
     // performs exactly the arithmetic of the active block (the padding is decoupled, its solution 0).
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        st.ws_g[a] = g[a];
-#pragma unroll
-        for (int b = 0; b < 6; b++) st.ws_H[a * 6 + b] = H[a][b];
-    }
-    ldlt_solve_ws<6>(6, st.ws_H, st.ws_g, st.ws_dx, st.ws_a, st.ws_y, st.ws_perm);
+    double dxs[6];
+    ldlt_solve_static6(H, g, dxs);
     double dginit = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         bool on = (prm.dof_mask >> a) & 1;
-        double d = on ? -st.ws_dx[a] : 0.0;
+        double d = on ? -dxs[a] : 0.0;
         st.incr[a] = d;
         dginit += d * g[a];
     }
