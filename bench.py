@@ -68,7 +68,7 @@ def main():
     fixed, moving = pr["fixed"].contiguous(), pr["moving"].contiguous()
     T_init_cm = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)     # column-major Affine3d
     T16 = T_init_cm.clone()
-    results = torch.zeros((B, 48), dtype=torch.uint8, device=dev)
+    results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
     idx = torch.arange(B, dtype=torch.int32, device=dev)
 
     tset = N.MapSet(res, [0, 0, 0], size_m, n_maps=B, max_cells=4096)
@@ -79,7 +79,7 @@ def main():
     gathered = None
     if world > 1:
         gathered = [torch.empty((world * B, 16), dtype=torch.float64, device=dev),
-                    torch.empty((world * B, 48), dtype=torch.uint8, device=dev)]
+                    torch.empty((world * B, 64), dtype=torch.uint8, device=dev)]
 
     def step():
         tset.build(fixed, range_limit=rng_lim, stream=stream)
@@ -128,10 +128,20 @@ def main():
                              "GBps": build_bytes / build_ms / 1e6},
         "ndt_match_kernel": {"ms_per_launch": match_ms, "launches_per_step": 1, "algorithmic_bytes": match_bytes,
                              "GBps": match_bytes / match_ms / 1e6,
+                             # k-bar, E and the matcher's fp64 work (SURVEY.md 8d asks for them as measured outputs)
+                             "pair_terms_per_launch": int(res_np["pair_terms_g"].sum() + res_np["pair_terms_h"].sum()),
+                             "mean_neighbours_kbar": float((res_np["pair_terms_g"].sum() + res_np["pair_terms_h"].sum())
+                                                           / max(1, int((res_np["fevals"].astype(np.int64) * m_s).sum()))),
+                             "fp64_gflop_per_launch": (130.0 * float(res_np["pair_terms_g"].sum())
+                                                       + 610.0 * float(res_np["pair_terms_h"].sum())) / 1e9,
                              "mean_iterations": float(res_np["iterations"].mean()),
                              "mean_fevals": float(res_np["fevals"].mean()),
                              "converged_frac": float(res_np["converged"].mean())},
     }
+    mk = kern["ndt_match_kernel"]
+    mk["fp64_tflops"] = mk["fp64_gflop_per_launch"] / match_ms          # GFLOP / ms = TFLOP/s
+    mk["fp64_note"] = ("pair-term flops counted from csrc/ndt_match.hip: 130 per gradient term, 610 per Hessian term; "
+                       "MI355X fp64 vector peak 78.6 TFLOP/s (AMD datasheet) -> frac %.4f" % (mk["fp64_tflops"] / 78.6))
     dominant = "ndt_build_kernel" if 2 * build_ms >= match_ms else "ndt_match_kernel"
     dk = kern[dominant]
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command

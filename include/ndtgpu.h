@@ -78,6 +78,8 @@ typedef struct {
     int32_t n_target;
     int64_t cycles_eval;   /* shader clocks spent in derivative evaluations (profiling aid) */
     int64_t cycles_solver; /* shader clocks spent in the serial Newton / line-search code */
+    int64_t pair_terms_g;  /* (source cell, target cell) terms summed in gradient-only evaluations */
+    int64_t pair_terms_h;  /* ... and in evaluations with the Hessian (k-bar = terms / (fevals * n_source)) */
 } ndtgpu_match_result;
 
 /* ---- library ------------------------------------------------------------------------- */

@@ -60,12 +60,13 @@ class MatchParams(C.Structure):
 class MatchResult(C.Structure):
     _fields_ = [("converged", C.c_int32), ("iterations", C.c_int32), ("fevals", C.c_int32), ("exit_code", C.c_int32),
                 ("score", C.c_double), ("n_source", C.c_int32), ("n_target", C.c_int32),
-                ("cycles_eval", C.c_int64), ("cycles_solver", C.c_int64)]
+                ("cycles_eval", C.c_int64), ("cycles_solver", C.c_int64),
+                ("pair_terms_g", C.c_int64), ("pair_terms_h", C.c_int64)]
 
 
 RESULT_DTYPE = np.dtype([("converged", "<i4"), ("iterations", "<i4"), ("fevals", "<i4"), ("exit_code", "<i4"),
                          ("score", "<f8"), ("n_source", "<i4"), ("n_target", "<i4"), ("cycles_eval", "<i8"),
-                         ("cycles_solver", "<i8")])
+                         ("cycles_solver", "<i8"), ("pair_terms_g", "<i8"), ("pair_terms_h", "<i8")])
 assert RESULT_DTYPE.itemsize == C.sizeof(MatchResult)
 
 # every symbol include/ndtgpu.h declares (checked by tests/test_abi.py against the header text)
@@ -289,7 +290,7 @@ def match_batch(target_set, target_idx, source_set, source_idx, T, stream=None, 
 
 def match_batch_device(target_set, tidx_dev, source_set, sidx_dev, T16_dev, results_dev, n_pairs, stream=None, **params):
     """Asynchronous device-resident variant (torch CUDA tensors: uint32/int32 idx, float64 [n,16]
-    column-major poses, uint8 [n,48] results)."""
+    column-major poses, uint8 [n,64] results)."""
     p = match_params(**params)
     _check(lib().ndtgpu_match_batch_device(target_set.h, C.c_void_p(tidx_dev.data_ptr()), source_set.h,
                                            C.c_void_p(sidx_dev.data_ptr()), C.c_void_p(T16_dev.data_ptr()), int(n_pairs),

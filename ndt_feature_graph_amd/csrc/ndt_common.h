@@ -82,6 +82,7 @@ struct NdtMatchResultDev {     // mirrors ndtgpu_match_result
     double score;
     int32_t n_source, n_target;
     int64_t cycles_eval, cycles_solver;
+    int64_t pair_terms_g, pair_terms_h;
 };
 
 // host launchers (defined next to their kernels)

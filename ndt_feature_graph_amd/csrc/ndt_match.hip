@@ -144,6 +144,7 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
     double *mysrc = s_src + wave * (9 * 64);
     uint32_t *myq = s_queue + wave * NDT_QN;
     unsigned qhead = 0, qcount = 0;   // wave-uniform
+    unsigned terms = 0;               // pair terms evaluated by this wave (wave-uniform)
     const unsigned long long lt = lanemask_lt();
 
     // TERM stage: pops up to 64 (source lane, target cell) pairs; every lane does one dense pair term.
@@ -164,6 +165,7 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
             }
             qhead = (qhead + n) & (NDT_QN - 1);
             qcount -= n;
+            terms += n;
         }
     };
 
@@ -223,13 +225,14 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
 #pragma unroll
     for (int k = 0; k < NACC; k++) {
         double v = wave_sum_d(acc[k]);
-        if (lane == 0) s_part[wave * 28 + k] = v;
+        if (lane == 0) s_part[wave * 32 + k] = v;
     }
+    if (lane == 0) s_part[wave * 32 + 28] = (double)terms;
     __syncthreads();
-    if (tid < (unsigned)NACC) {
+    if (tid < (unsigned)NACC || tid == 28u) {
         double s = 0;
-        for (int w = 0; w < NDT_MATCH_WAVES; w++) s += s_part[w * 28 + tid];
-        s_sums[tid] = s;
+        for (int w = 0; w < NDT_MATCH_WAVES; w++) s += s_part[w * 32 + tid];
+        s_sums[tid] = s;             // [28]: number of (source, target) pair terms of this evaluation
     }
     __syncthreads();
 }
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
 {
     __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
     __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
-    __shared__ double s_part[NDT_MATCH_WAVES * 28];
-    __shared__ double s_sums[28];
+    __shared__ double s_part[NDT_MATCH_WAVES * 32];
+    __shared__ double s_sums[32];
     __shared__ MatchState st;
 
     const unsigned pair = blockIdx.x;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     if (threadIdx.x == 0) match_state_init(st, Tio, prm);
     __syncthreads();
 
-    long long cyc_eval = 0, cyc_solver = 0;
+    long long cyc_eval = 0, cyc_solver = 0, terms_g = 0, terms_h = 0;
     while (!st.done) {
         const rigid Te = st.Teval;
         const int with_h = st.with_h;
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
         else eval_derivs<NN, false>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
         long long c1 = __builtin_readcyclecounter();
         if (threadIdx.x == 0) {
+            if (with_h) terms_h += (long long)s_sums[28]; else terms_g += (long long)s_sums[28];
             match_state_step(st, s_sums, prm);
             cyc_eval += c1 - c0;
             cyc_solver += (long long)__builtin_readcyclecounter() - c1;
@@ -279,6 +283,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
         o.n_target = tg.n_cells;
         o.cycles_eval = cyc_eval;
         o.cycles_solver = cyc_solver;
+        o.pair_terms_g = terms_g;
+        o.pair_terms_h = terms_h;
         res[pair] = o;
     }
 }
@@ -291,8 +297,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_kernel(
 {
     __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
     __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
-    __shared__ double s_part[NDT_MATCH_WAVES * 28];
-    __shared__ double s_sums[28];
+    __shared__ double s_part[NDT_MATCH_WAVES * 32];
+    __shared__ double s_sums[32];
     const MapView tg = map_view(tset, tmap);
     rigid I;
     for (int k = 0; k < 9; k++) I.r[k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -315,17 +321,17 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_eval_kernel(
 {
     __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
     __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
-    __shared__ double s_part[NDT_MATCH_WAVES * 28];
-    __shared__ double s_sums[28];
+    __shared__ double s_part[NDT_MATCH_WAVES * 32];
+    __shared__ double s_sums[32];
     const MapView tg = map_view(tset, tmap);
     const MapView sv = map_view(sset, smap);
     const int per = (sv.n_cells + (int)gridDim.x - 1) / (int)gridDim.x;
     const int begin = min(sv.n_cells, (int)blockIdx.x * per), count = min(sv.n_cells - begin, per);
-    if (threadIdx.x < 28) s_sums[threadIdx.x] = 0.0;
+    if (threadIdx.x < 32) s_sums[threadIdx.x] = 0.0;
     __syncthreads();
     if (with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
     else eval_derivs<NN, false>(tg, sv.cells + begin, count, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
-    if (threadIdx.x < 28) partials[blockIdx.x * 28 + threadIdx.x] = s_sums[threadIdx.x];
+    if (threadIdx.x < 32) partials[blockIdx.x * 32 + threadIdx.x] = s_sums[threadIdx.x];
 }
 
 hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,

@@ -461,11 +461,12 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
                                        ndtgpu_match_result *results, hipStream_t st)
 {
     const unsigned max_groups = 128;
-    ndtgpu_status rc = ts->ensure_stage(max_groups * 28 * sizeof(double));
+    ndtgpu_status rc = ts->ensure_stage(max_groups * 32 * sizeof(double));
     if (rc != NDTGPU_OK) return rc;
     double *partials_dev = (double *)ts->stage;
-    std::vector<double> partials(max_groups * 28);
+    std::vector<double> partials(max_groups * 32);
     for (size_t k = 0; k < n_pairs; k++) {
+        long long terms_g = 0, terms_h = 0;
         NdtMapCounters cs, ct;
         HIP_TRY(hipMemcpy(&cs, ss->v.counters + sidx[k], sizeof cs, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(&ct, ts->v.counters + tidx[k], sizeof ct, hipMemcpyDeviceToHost));
@@ -478,14 +479,15 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
             hipError_t e = ndt_launch_eval(ts->v, tidx[k], ss->v, sidx[k], ms.Teval, p.n_neighbours, ms.with_h, p.lfd1,
                                            p.lfd2, groups, partials_dev, st);
             if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: eval launch", e);
-            HIP_TRY(hipMemcpyAsync(partials.data(), partials_dev, groups * 28 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(partials.data(), partials_dev, groups * 32 * sizeof(double), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            double sums[28];
-            for (int q = 0; q < 28; q++) {
+            double sums[29];
+            for (int q = 0; q < 29; q++) {
                 double s = 0;
-                for (unsigned g = 0; g < groups; g++) s += partials[g * 28 + q];
+                for (unsigned g = 0; g < groups; g++) s += partials[g * 32 + q];
                 sums[q] = s;
             }
+            if (ms.with_h) terms_h += (long long)sums[28]; else terms_g += (long long)sums[28];
             match_state_step(ms, sums, p);
         }
         NdtMatchResultDev o;
@@ -494,6 +496,8 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
         o.n_target = (int32_t)ct.n_cells;
         o.cycles_eval = 0;
         o.cycles_solver = 0;
+        o.pair_terms_g = terms_g;
+        o.pair_terms_h = terms_h;
         memcpy(&results[k], &o, sizeof o);
     }
     return NDTGPU_OK;

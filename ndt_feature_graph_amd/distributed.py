@@ -8,8 +8,8 @@ state), so there is NO data-path collective.  One process per GPU:
     scan, cheaper than shipping cell maps over xGMI and it removes the all-gather of phase B);
   * the edge list (identical on all ranks) is dealt block-cyclically, `chunk` edges at a time,
     because iteration counts vary per edge;
-  * the only collective is the FINAL all-gather of the edge results {T 16 f64, result 48 B}
-    (RCCL over xGMI on GPUs, gloo in the CPU tests): ~176 B/edge.
+  * the only collective is the FINAL all-gather of the edge results {T 16 f64, result 64 B}
+    (RCCL over xGMI on GPUs, gloo in the CPU tests): ~192 B/edge.
 """
 import numpy as np
 
@@ -29,8 +29,8 @@ def shard_sizes(n_edges, world, chunk=256):
 def gather_edge_results(T_local, res_local, n_edges, rank, world, chunk=256, group=None):
     """All-gathers per-edge results of the block-cyclic shards back into edge order.
 
-    T_local: torch tensor [k,16] float64, res_local: torch tensor [k,48] uint8 (k = this rank's
-    share, on the device the process group works on).  Returns (T [n_edges,16], res [n_edges,48])
+    T_local: torch tensor [k,16] float64, res_local: torch tensor [k,64] uint8 (k = this rank's
+    share, on the device the process group works on).  Returns (T [n_edges,16], res [n_edges,64])
     on every rank."""
     import torch
     import torch.distributed as dist
@@ -40,17 +40,17 @@ def gather_edge_results(T_local, res_local, n_edges, rank, world, chunk=256, gro
     kmax = max(sizes)
     dev = T_local.device
     Tp = torch.zeros((kmax, 16), dtype=torch.float64, device=dev)
-    Rp = torch.zeros((kmax, 48), dtype=torch.uint8, device=dev)
+    Rp = torch.zeros((kmax, 64), dtype=torch.uint8, device=dev)
     k = T_local.shape[0]
     assert k == sizes[rank], "shard size mismatch: %d vs %d" % (k, sizes[rank])
     Tp[:k] = T_local
     Rp[:k] = res_local
     Tg = torch.empty((world * kmax, 16), dtype=torch.float64, device=dev)
-    Rg = torch.empty((world * kmax, 48), dtype=torch.uint8, device=dev)
+    Rg = torch.empty((world * kmax, 64), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(Tg, Tp, group=group)
     dist.all_gather_into_tensor(Rg, Rp, group=group)
     T = torch.empty((n_edges, 16), dtype=torch.float64, device=dev)
-    R = torch.empty((n_edges, 48), dtype=torch.uint8, device=dev)
+    R = torch.empty((n_edges, 64), dtype=torch.uint8, device=dev)
     for r in range(world):
         ids = torch.as_tensor(shard_edges(n_edges, r, world, chunk), device=dev)
         T[ids] = Tg[r * kmax:r * kmax + sizes[r]]

@@ -41,7 +41,7 @@ def test_header_cites_reference_for_each_entry_point():
 
 def test_struct_layouts_match_header(N):
     from ndt_feature_graph_amd import binding
-    assert ctypes.sizeof(binding.MatchResult) == 48
+    assert ctypes.sizeof(binding.MatchResult) == 64
     assert ctypes.sizeof(binding.MatchParams) == 48
     assert ctypes.sizeof(binding.GridParams) == 64
     assert ctypes.sizeof(binding.CellParams) == 16

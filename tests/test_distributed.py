@@ -53,7 +53,7 @@ def _worker(rank, world, port, out_dir):
     node_T = synth.pose2d_to_T(poses).numpy()
     mine = D.shard_edges(len(edges), rank, world, chunk)
     T_loc = np.zeros((len(mine), 16))
-    R_loc = np.zeros((len(mine), 48), np.uint8)
+    R_loc = np.zeros((len(mine), 64), np.uint8)
     for q, e in enumerate(mine):
         i, j = edges[e]
         T0 = np.linalg.inv(node_T[i]) @ node_T[j]

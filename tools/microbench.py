@@ -20,7 +20,7 @@ pr = synth.pair_2d(torch.arange(1, B + 1, device=dev), a.points, device=dev, chu
 fixed, moving = pr["fixed"].contiguous(), pr["moving"].contiguous()
 Ti = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)
 T16 = Ti.clone()
-res = torch.zeros((B, 48), dtype=torch.uint8, device=dev)
+res = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
 idx = torch.arange(B, dtype=torch.int32, device=dev)
 ts = N.MapSet(a.res, [0, 0, 0], [100, 100, 1], n_maps=B, max_cells=4096)
 ss = N.MapSet(a.res, [0, 0, 0], [100, 100, 1], n_maps=B, max_cells=4096)
