@@ -117,6 +117,30 @@ def test_build_edge_cases(N, O):
     assert_cells_equal(ms.export_cells(0), m.export_cells(), 1.0)
 
 
+def test_build_odd_grid_and_generic_stride(N, O):
+    """Odd cell counts (the reference's double->int truncation quirk: every point takes the exact fp64
+    index path) and a record stride that is neither 12 nor 16 bytes (generic load path)."""
+    import torch
+    from ndt_feature_graph_amd import synth
+    pts = synth.pair_2d([51], 30000)["fixed"][0].numpy()
+    # 33 x 27 x 1 cells of 1.0 m around a centre that is not a multiple of the cell size
+    ms = N.MapSet(1.0, [0.37, -1.21, 0.0], [33, 27, 1])
+    ms.build(pts[None], range_limit=30.0)
+    cpu = oracle_map(O, pts, 1.0, [33, 27, 1], centre=(0.37, -1.21, 0.0))
+    assert_cells_equal(ms.export_cells(0), cpu.export_cells(), 1.0)
+    # stride 20 bytes: xyz + two floats of payload
+    p5 = torch.cat([torch.from_numpy(pts), torch.full((len(pts), 2), 3.0)], dim=1).contiguous().cuda()
+    ms2 = N.MapSet(0.5, [0, 0, 0], [100, 100, 1])
+    from ndt_feature_graph_amd import binding
+    import ctypes as C
+    cp = binding.CellParams(3, 1000.0)
+    binding._check(binding.lib().ndtgpu_mapset_build(ms2.h, 0, 1, C.c_void_p(p5.data_ptr()), len(pts), 20, 20 * len(pts),
+                                                      30.0, None, C.byref(cp), None))
+    torch.cuda.synchronize()
+    cpu2 = oracle_map(O, pts, 0.5, [100, 100, 1])
+    assert_cells_equal(ms2.export_cells(0), cpu2.export_cells(), 0.5)
+
+
 def test_build_unordered_points_same_result(N):
     """Shuffled input: same cells, same counts (integer work: bit-exact); moments agree to fp64 rounding
     (per-lane partial sums are formed in input order, the cross-wave adds are exact)."""
