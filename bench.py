@@ -188,7 +188,7 @@ def main():
             To, ro = O.match_d2d(ot, os_, Ti[b])
             t_cpu += time.perf_counter() - c0
             dt = float(np.linalg.norm(T_out[b][:3, 3] - To[:3, 3]))
-            dr = float(np.arccos(np.clip((np.trace(T_out[b][:3, :3].T @ To[:3, :3]) - 1) / 2, -1, 1)))
+            dr = float(2 * np.arcsin(min(1.0, np.linalg.norm(T_out[b][:3, :3] - To[:3, :3]) / (2 * np.sqrt(2)))))
             max_dt, max_dr = max(max_dt, dt), max(max_dr, dr)
         cpu_rate = S / t_cpu
         out["cpu_baseline"] = {"value": cpu_rate, "unit": "registrations/s", "cores": 1, "kind": "port",
@@ -219,7 +219,7 @@ def main():
             To, ro = O.match_d2d(ot, os_, T0)
             t_cpu = time.perf_counter() - c0
             dt = float(np.linalg.norm(T[:3, 3] - To[:3, 3]))
-            dr = float(np.arccos(np.clip((np.trace(T[:3, :3].T @ To[:3, :3]) - 1) / 2, -1, 1)))
+            dr = float(2 * np.arcsin(min(1.0, np.linalg.norm(T[:3, :3] - To[:3, :3]) / (2 * np.sqrt(2)))))
             return {"gpu_ms": 1e3 * best, "cpu_1thread_ms": 1e3 * t_cpu, "speedup": t_cpu / best,
                     "cells": [int(r["n_target"]), int(r["n_source"])], "iterations": int(r["iterations"]),
                     "dt_m": dt, "drot_rad": dr}

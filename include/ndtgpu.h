@@ -156,6 +156,18 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *target_set, const uint32_
                                         ndtgpu_mapset *source_set, const uint32_t *source_idx_dev,
                                         double *T16_dev, size_t n_pairs, const ndtgpu_match_params *prm,
                                         ndtgpu_match_result *results_dev, ndtgpu_stream stream);
+/* ndt_feature::matchFusion(target, source, <empty feature maps>, T, Tcov, useInitialGuess, useNDT = true,
+ * useFeat = false, step_control, ITR_MAX, n_neighbours, DELTA_SCORE, useSoftConstraints, ...,
+ * useTikhonovRegularization = false)  (ndt_matcher_d2d_fusion.h:797-1155; call site
+ * ndt_feature_fuser_hmt.cpp:356-357): the D2D matcher plus the odometry soft constraint
+ * x^T Tcov^-1 x on the accumulated pose increment (fusion.h:875-890, 1098-1110).
+ * Tcov36: HOST, n_pairs x 36 doubles, row-major 6x6 covariance of (x,y,z,roll,pitch,yaw).
+ * use_soft_constraints == 0 degenerates to ndtgpu_match_batch.  Feature terms (FLIRT) and the Tikhonov
+ * variant are not part of the path (disabled in every shipped configuration). */
+ndtgpu_status ndtgpu_match_fusion_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx,
+                                        ndtgpu_mapset *source_set, const uint32_t *source_idx, double *T16,
+                                        const double *Tcov36, size_t n_pairs, const ndtgpu_match_params *prm,
+                                        int use_soft_constraints, ndtgpu_match_result *results, ndtgpu_stream stream);
 /* single pair convenience == graph.cpp:273 */
 ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *target_set, size_t target_map, ndtgpu_mapset *source_set,
                                size_t source_map, double T16[16], const ndtgpu_match_params *prm,

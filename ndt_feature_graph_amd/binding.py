@@ -75,7 +75,7 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_info", "ndtgpu_mapset_build", "ndtgpu_mapset_build_host", "ndtgpu_mapset_num_cells",
            "ndtgpu_mapset_export_cells", "ndtgpu_mapset_set_cells", "ndtgpu_derivatives", "ndtgpu_match_batch",
            "ndtgpu_match_batch_device", "ndtgpu_match_d2d", "ndtgpu_kernel_name", "ndtgpu_profiling_enable",
-           "ndtgpu_last_kernel_ms", "ndtgpu_mapset_counters"]
+           "ndtgpu_last_kernel_ms", "ndtgpu_mapset_counters", "ndtgpu_match_fusion_batch"]
 
 _lib = None
 
@@ -116,6 +116,7 @@ def lib():
     L.ndtgpu_derivatives.argtypes = [vp, C.c_size_t, dp, dp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double,
                                      dp, dp, dp]
     L.ndtgpu_match_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, C.POINTER(MatchParams), vp, vp]
+    L.ndtgpu_match_fusion_batch.argtypes = [vp, u32p, vp, u32p, dp, dp, C.c_size_t, C.POINTER(MatchParams), C.c_int, vp, vp]
     L.ndtgpu_match_batch_device.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(MatchParams), vp, vp]
     L.ndtgpu_match_d2d.argtypes = [vp, C.c_size_t, vp, C.c_size_t, dp, C.POINTER(MatchParams), C.POINTER(MatchResult)]
     L.ndtgpu_profiling_enable.argtypes = [vp, C.c_int]
@@ -285,6 +286,22 @@ def match_batch(target_set, target_idx, source_set, source_idx, T, stream=None, 
     _check(lib().ndtgpu_match_batch(target_set.h, ti.ctypes.data_as(C.POINTER(C.c_uint32)), source_set.h,
                                     si.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), n, C.byref(p),
                                     C.c_void_p(res.ctypes.data), _stream_ptr(stream)))
+    return np.transpose(Tc, (0, 2, 1)).copy(), res
+
+
+def match_fusion_batch(target_set, target_idx, source_set, source_idx, T, Tcov, use_soft_constraints=True, stream=None,
+                       **params):
+    """ndt_feature::matchFusion (NDT term + odometry soft constraint) for every pair.  Tcov: [n,6,6]."""
+    ti = np.ascontiguousarray(target_idx, dtype=np.uint32)
+    si = np.ascontiguousarray(source_idx, dtype=np.uint32)
+    n = ti.shape[0]
+    Tc = np.ascontiguousarray(np.transpose(np.asarray(T, dtype=np.float64).reshape(n, 4, 4), (0, 2, 1))).copy()
+    cov = np.ascontiguousarray(np.asarray(Tcov, dtype=np.float64).reshape(n, 36))
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    p = match_params(**params)
+    _check(lib().ndtgpu_match_fusion_batch(target_set.h, ti.ctypes.data_as(C.POINTER(C.c_uint32)), source_set.h,
+                                           si.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), _dp(cov), n, C.byref(p),
+                                           int(bool(use_soft_constraints)), C.c_void_p(res.ctypes.data), _stream_ptr(stream)))
     return np.transpose(Tc, (0, 2, 1)).copy(), res
 
 

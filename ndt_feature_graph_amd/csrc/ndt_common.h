@@ -93,7 +93,7 @@ hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const Ndt
                                     hipStream_t stream);
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                            NdtMatchResultDev *res_dev, hipStream_t stream);
+                            NdtMatchResultDev *res_dev, const double *Q36_dev, hipStream_t stream);
 struct rigid;
 hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,
                            int n_neighbours, int with_h, double lfd1, double lfd2, unsigned n_groups, double *partials_dev,

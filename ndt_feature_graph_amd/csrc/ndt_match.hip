@@ -242,7 +242,8 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
 template <int NN>
 __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
-    double *__restrict__ T16, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res)
+    double *__restrict__ T16, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res,
+    const double *__restrict__ Q36 /* per pair Tcov^-1 (matchFusion soft constraint) or NULL */)
 {
     __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
     __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     const MapView sv = map_view(sset, sidx[pair]);
     double *Tio = T16 + (size_t)pair * 16;
 
-    if (threadIdx.x == 0) match_state_init(st, Tio, prm);
+    if (threadIdx.x == 0) match_state_init(st, Tio, prm, Q36 ? Q36 + (size_t)pair * 36 : nullptr);
     __syncthreads();
 
     long long cyc_eval = 0, cyc_solver = 0, terms_g = 0, terms_h = 0;
@@ -354,12 +355,12 @@ hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView
 
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                            NdtMatchResultDev *res_dev, hipStream_t stream)
+                            NdtMatchResultDev *res_dev, const double *Q36_dev, hipStream_t stream)
 {
     if (n_pairs == 0) return hipSuccess;
 #define NDT_LAUNCH_MATCH(NN)                                                                                         \
     hipLaunchKernelGGL(ndt_match_kernel<NN>, dim3((unsigned)n_pairs), dim3(NDT_MATCH_THREADS), 0, stream, tset,      \
-                       tidx_dev, sset, sidx_dev, T16_dev, prm, res_dev)
+                       tidx_dev, sset, sidx_dev, T16_dev, prm, res_dev, Q36_dev)
     switch (prm.n_neighbours) {
     case 0: NDT_LAUNCH_MATCH(0); break;
     case 1: NDT_LAUNCH_MATCH(1); break;

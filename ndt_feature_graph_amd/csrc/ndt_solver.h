@@ -22,7 +22,20 @@ struct MatchState {
     double stp, finit, dginit, dgtest, width, width1, stx, fx, dgx, sty, fy, dgy, stmin, stmax;
     int brackt, stage1, nfev, infoc;
     int itr_ctr, fevals, ret, exit_code, phase, with_h, done;
+    // matchFusion soft constraint (fusion.h:875-890): X = pose_local_v, Q = Tcov^-1 (row-major)
+    int use_prior;
+    double pose_local[6];
+    double Q[36];
 };
+
+// computeScoreMahalanobis (fusion.h:24-27): x^T Q x
+NDT_HD double prior_score(const MatchState &st)
+{
+    double s = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) s += st.pose_local[i] * st.Q[i * 6 + j] * st.pose_local[j];
+    return s;
+}
 
 NDT_HD double dmin(double a, double b) { return a < b ? a : b; }
 NDT_HD double dmax(double a, double b) { return a > b ? a : b; }
@@ -156,6 +169,7 @@ NDT_HDN void apply_step(MatchState &st, double step_size, const NdtMatchParamsDe
         inorm += st.incr[a] * st.incr[a];
     }
     inorm = sqrt(inorm);
+    for (int a = 0; a < 6; a++) st.pose_local[a] += st.incr[a];   // fusion.h:1045
     rigid TR;
     pose_to_rigid(st.incr, TR);
     rigid_mul(TR, st.T, st.T);          // T = TR*T
@@ -176,6 +190,7 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
 {
     st.fevals++;
     st.score_here = sums[0];
+    if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:875-890
     if (st.score_here < st.score_best) {   // fusion.h:914-920
         st.Tbest = st.T;
         st.score_best = st.score_here;
@@ -191,6 +206,12 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
 #pragma unroll
             for (int b = a; b < 6; b++) { H[a][b] = sums[o]; H[b][a] = sums[o]; o++; }
     }
+    if (st.use_prior) {                    // + computeHessianMahalanobis = Q + Q^T   (fusion.h:11-22)
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b < 6; b++) H[a][b] += st.Q[a * 6 + b] + st.Q[b * 6 + a];
+    }
     double pad = 0.0;
     bool havepad = false;
     double gnorm = 0;
@@ -198,6 +219,11 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     for (int a = 0; a < 6; a++) {
         bool on = (prm.dof_mask >> a) & 1;
         g[a] = on ? sums[1 + a] : 0.0;
+        if (st.use_prior && on) {          // + computeGradientMahalanobis = (Q + Q^T) X   (fusion.h:29-32)
+            double gp = 0;
+            for (int j = 0; j < 6; j++) gp += (st.Q[a * 6 + j] + st.Q[j * 6 + a]) * st.pose_local[j];
+            g[a] += gp;
+        }
         if (on && !havepad) { pad = H[a][a]; havepad = true; }
     }
 #pragma unroll
@@ -263,8 +289,15 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     }
     // lineSearchMT: its initial derivativesNDT(nextNDT) equals this evaluation (same cells), so the
     // score and gradient are reused instead of being recomputed (fusion.h:444-453).
-    st.finit = st.score_here;
-    st.dginit = dginit;
+    // With the soft constraint the reference also runs lineSearchMTFusionTcov first (fusion.h:1008-1010) but
+    // throws its step away (:1018-1023: step_size = max(step_size_ndt, 0)); its only possible side effect,
+    // flipping the increment when dginit >= 0, cannot trigger here because dginit <= 0 was just checked on
+    // the same total gradient.  The step is decided by the NDT-only line search on the NDT-only score.
+    st.finit = sums[0];
+    st.dginit = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) st.dginit += st.incr[a] * sums[1 + a];
+    if (!st.use_prior) st.dginit = dginit;
     if (st.dginit >= 0.0) {                // fusion.h:456-479
         for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
         st.dginit = -st.dginit;
@@ -331,8 +364,12 @@ NDT_HDN void linesearch_step(MatchState &st, const double *sums, const NdtMatchP
 
 
 // T0: column-major 4x4 (Eigen::Affine3d storage) or NULL for identity
-NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchParamsDev &prm)
+// Q36: Tcov^-1 row-major, or NULL for NDTMatcherD2D::match (no soft constraint)
+NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchParamsDev &prm, const double *Q36 = nullptr)
 {
+    st.use_prior = Q36 != nullptr;
+    for (int a = 0; a < 6; a++) st.pose_local[a] = 0.0;
+    for (int a = 0; a < 36; a++) st.Q[a] = Q36 ? Q36[a] : 0.0;
     rigid T0;
     if (prm.use_initial_guess && T16) {
         for (int r = 0; r < 3; r++) {
@@ -359,6 +396,7 @@ NDT_HD void match_state_step(MatchState &st, const double *sums, const NdtMatchP
     else {   // PH_FINAL: fusion.h:1085-1121
         st.fevals++;
         st.score_here = sums[0];
+        if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:1098-1110
         if (st.score_here > st.score_best) st.T = st.Tbest;
         st.done = 1;
     }

@@ -434,10 +434,23 @@ static NdtMatchParamsDev to_dev(const ndtgpu_match_params *p)
 
 static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result layouts must agree");
 
+static ndtgpu_status match_device_q(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
+                                    const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
+                                    const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
+                                    const double *Q36_dev, ndtgpu_stream stream);
+
 ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
                                         const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
                                         const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
                                         ndtgpu_stream stream)
+{
+    return match_device_q(ts, tidx_dev, ss, sidx_dev, T16_dev, n_pairs, prm, results_dev, nullptr, stream);
+}
+
+static ndtgpu_status match_device_q(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
+                                    const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
+                                    const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
+                                    const double *Q36_dev, ndtgpu_stream stream)
 {
     if (!ts || !ss || (n_pairs && (!tidx_dev || !sidx_dev || !T16_dev || !results_dev)))
         return fail(NDTGPU_ERR_INVALID, "match_batch_device: bad argument");
@@ -446,7 +459,7 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
     if (ts->profiling) HIP_TRY(hipEventRecord(ts->ev[2], (hipStream_t)stream));
     hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
-                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), (hipStream_t)stream);
+                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, (hipStream_t)stream);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
     if (ts->profiling) { HIP_TRY(hipEventRecord(ts->ev[3], (hipStream_t)stream)); ts->ev_valid[1] = true; }
     return NDTGPU_OK;
@@ -457,7 +470,7 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
 // so a single registration uses the whole chip instead of one CU.  Used below NDTGPU_HOST_LOOP_MAX pairs.
 #define NDTGPU_HOST_LOOP_MAX 8
 static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
-                                       double *T16, size_t n_pairs, const NdtMatchParamsDev &p,
+                                       double *T16, size_t n_pairs, const NdtMatchParamsDev &p, const double *Q36,
                                        ndtgpu_match_result *results, hipStream_t st)
 {
     const unsigned max_groups = 128;
@@ -474,7 +487,7 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
         if (groups < 1) groups = 1;
         if (groups > max_groups) groups = max_groups;
         MatchState ms;
-        match_state_init(ms, T16 + 16 * k, p);
+        match_state_init(ms, T16 + 16 * k, p, Q36 ? Q36 + 36 * k : nullptr);
         while (!ms.done) {
             hipError_t e = ndt_launch_eval(ts->v, tidx[k], ss->v, sidx[k], ms.Teval, p.n_neighbours, ms.with_h, p.lfd1,
                                            p.lfd2, groups, partials_dev, st);
@@ -503,9 +516,60 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
     return NDTGPU_OK;
 }
 
+static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                        double *T16, size_t n_pairs, const ndtgpu_match_params *prm, const double *Q36,
+                                        ndtgpu_match_result *results, ndtgpu_stream stream);
+
 ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                  double *T16, size_t n_pairs, const ndtgpu_match_params *prm,
                                  ndtgpu_match_result *results, ndtgpu_stream stream)
+{
+    return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, nullptr, results, stream);
+}
+
+// 6x6 inverse by Gauss-Jordan with partial pivoting (Eigen: Tcov.inverse(), fusion.h:845)
+static bool invert6(const double *A, double *inv)
+{
+    double a[6][12];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) { a[i][j] = A[i * 6 + j]; a[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++)
+            if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return false;
+        if (piv != c)
+            for (int j = 0; j < 12; j++) std::swap(a[c][j], a[piv][j]);
+        double d = a[c][c];
+        for (int j = 0; j < 12; j++) a[c][j] /= d;
+        for (int r = 0; r < 6; r++) {
+            if (r == c) continue;
+            double f = a[r][c];
+            if (f != 0.0)
+                for (int j = 0; j < 12; j++) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) inv[i * 6 + j] = a[i][6 + j];
+    return true;
+}
+
+ndtgpu_status ndtgpu_match_fusion_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                        double *T16, const double *Tcov36, size_t n_pairs,
+                                        const ndtgpu_match_params *prm, int use_soft_constraints,
+                                        ndtgpu_match_result *results, ndtgpu_stream stream)
+{
+    if (!use_soft_constraints) return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, nullptr, results, stream);
+    if (!Tcov36) return fail(NDTGPU_ERR_INVALID, "match_fusion: Tcov missing");
+    std::vector<double> Q(36 * n_pairs);
+    for (size_t k = 0; k < n_pairs; k++)
+        if (!invert6(Tcov36 + 36 * k, Q.data() + 36 * k)) return fail(NDTGPU_ERR_INVALID, "match_fusion: singular Tcov");
+    return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, Q.data(), results, stream);
+}
+
+static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                        double *T16, size_t n_pairs, const ndtgpu_match_params *prm, const double *Q36,
+                                        ndtgpu_match_result *results, ndtgpu_stream stream)
 {
     if (!ts || !ss || (n_pairs && (!tidx || !sidx || !T16 || !results)))
         return fail(NDTGPU_ERR_INVALID, "match_batch: bad argument");
@@ -520,19 +584,22 @@ ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu
         NdtMatchParamsDev p = to_dev(prm);
         if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
             return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
-        return match_host_driven(ts, tidx, ss, sidx, T16, n_pairs, p, results, st);
+        return match_host_driven(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st);
     }
     size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
     size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
-           off_si = (off_ti + bI + 255) & ~(size_t)255, total = off_si + bI;
+           off_si = (off_ti + bI + 255) & ~(size_t)255, off_Q = (off_si + bI + 255) & ~(size_t)255,
+           total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
     ndtgpu_status rc = ts->ensure_stage(total);
     if (rc != NDTGPU_OK) return rc;
     char *base = (char *)ts->stage;
     HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
-    rc = ndtgpu_match_batch_device(ts, (const uint32_t *)(base + off_ti), ss, (const uint32_t *)(base + off_si),
-                                   (double *)base, n_pairs, prm, (ndtgpu_match_result *)(base + off_R), stream);
+    if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
+    rc = match_device_q(ts, (const uint32_t *)(base + off_ti), ss, (const uint32_t *)(base + off_si), (double *)base,
+                        n_pairs, prm, (ndtgpu_match_result *)(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr,
+                        stream);
     if (rc != NDTGPU_OK) return rc;
     HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));

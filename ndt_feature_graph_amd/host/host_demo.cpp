@@ -93,5 +93,21 @@ int main()
     double d, a;
     distanceBetweenAffine3d(Affine3d::Identity(), T, d, a);
     if (!conv || d > 1e-6) { std::printf("FAIL: self match moved by %g\n", d); fails++; }
+    // matchFusion with a tight odometry prior stays at the initial guess, with a loose one it equals match()
+    {
+        Affine3d Tg = Affine3d::fromPose(0.05, -0.02, 0, 0, 0, 0.003), Ta = Tg, Tb = Tg, Tc = Tg;
+        double tight[36] = {0}, loose[36] = {0};
+        for (int q = 0; q < 6; q++) { tight[q * 7] = 1e-12; loose[q * 7] = 1e12; }
+        matchFusion(*graph.getMap(0), ndglobal, Ta, tight, true, true, 30, 2, 1e-6, true);
+        matchFusion(*graph.getMap(0), ndglobal, Tb, loose, true, true, 30, 2, 1e-6, true);
+        lslgeneric::NDTMatcherD2D m2; m2.n_neighbours = 2; m2.ITR_MAX = 30; m2.DELTA_SCORE = 1e-6;
+        m2.match(*graph.getMap(0), ndglobal, Tc, true);
+        double d1, a1, d2, a2;
+        distanceBetweenAffine3d(Tg, Ta, d1, a1);
+        distanceBetweenAffine3d(Tc, Tb, d2, a2);
+        std::printf("matchFusion: tight prior moved %.2e m, loose prior differs from match() by %.2e m\n", d1, d2);
+        if (d1 > 1e-6 || d2 > 1e-6) fails++;
+    }
+    std::printf("%d failures in total\n", fails);
     return fails ? 1 : 0;
 }

@@ -29,6 +29,26 @@ inline void distanceBetweenAffine3d(const Affine3d &p1, const Affine3d &p2, doub
     angularDist = std::fabs(getRobustYawFromAffine3d(tmp));
 }
 
+// ndt_feature::matchFusion (ndt_matcher_d2d_fusion.h:797-1155) for the shipped configurations
+// (useNDT, no FLIRT features, no Tikhonov): D2D-NDT + the odometry soft constraint.  The feature-map
+// arguments of the reference signature are dropped (they are empty maps there).
+inline bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, Affine3d &T, const double Tcov[36],
+                        bool useInitialGuess, bool step_control, int ITR_MAX = 30, int n_neighbours = 2,
+                        double DELTA_SCORE = 10e-4, bool useSoftConstraints = true)
+{
+    lslgeneric::NDTMatcherD2D m;
+    m.n_neighbours = n_neighbours;
+    m.ITR_MAX = ITR_MAX;
+    m.DELTA_SCORE = DELTA_SCORE;
+    m.step_control = step_control;
+    ndtgpu_match_params p = m.params(0x3f, useInitialGuess);
+    ndtgpu_match_result r;
+    uint32_t ti = (uint32_t)targetNDT.slot(), si = (uint32_t)sourceNDT.slot();
+    ndtgpu_host::check(ndtgpu_match_fusion_batch(targetNDT.handle(), &ti, sourceNDT.handle(), &si, ndtgpu_host::affine_data(T),
+                                                 Tcov, 1, &p, useSoftConstraints ? 1 : 0, &r, nullptr), "ndtgpu_match_fusion_batch");
+    return r.converged != 0;
+}
+
 class NDTFeatureLink {
 public:
     NDTFeatureLink() : ref_idx(0), mov_idx(0), score(0.) {}

@@ -60,6 +60,7 @@ def lib():
     L.oracle_score_at.restype = C.c_double
     L.oracle_score_at.argtypes = [C.c_void_p, C.c_void_p, dp, dp, C.c_int, C.c_double, C.c_double]
     L.oracle_match_d2d.argtypes = [C.c_void_p, C.c_void_p, dp, C.POINTER(MatchParams), C.POINTER(MatchResult)]
+    L.oracle_match_fusion.argtypes = [C.c_void_p, C.c_void_p, dp, C.POINTER(MatchParams), dp, C.c_int, C.POINTER(MatchResult)]
     L.oracle_mt_cstep.argtypes = [dp, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, ip, C.c_double, C.c_double]
     L.oracle_mt_linesearch.restype = C.c_double
     L.oracle_mt_linesearch.argtypes = [PHI_FN, C.c_void_p, C.c_double, C.c_double, ip, ip]
@@ -166,6 +167,21 @@ def match_d2d(target, source, T0, **kw):
     T = Tc.reshape(4, 4).T.copy()
     return T, dict(converged=bool(R.converged), iterations=R.iterations, fevals=R.fevals, score=R.score,
                    exit_code=R.exit_code)
+
+
+def match_fusion(target, source, T0, Tcov, use_soft_constraints=True, **kw):
+    """ndt_feature::matchFusion with empty feature maps (NDT + odometry soft constraint)."""
+    prm = dict(DEFAULT_PARAMS)
+    prm.update(kw)
+    P = MatchParams(**prm)
+    R = MatchResult()
+    Tc = _f64(np.asarray(T0, dtype=np.float64).T.reshape(-1)).copy()
+    cov = _f64(np.asarray(Tcov, dtype=np.float64).reshape(-1))
+    rc = lib().oracle_match_fusion(target.h, source.h, _dp(Tc), C.byref(P), _dp(cov), int(bool(use_soft_constraints)), C.byref(R))
+    if rc:
+        raise RuntimeError("oracle_match_fusion rc=%d" % rc)
+    return Tc.reshape(4, 4).T.copy(), dict(converged=bool(R.converged), iterations=R.iterations, fevals=R.fevals,
+                                           score=R.score, exit_code=R.exit_code)
 
 
 def pose_to_T(p):

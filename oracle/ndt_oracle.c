@@ -917,8 +917,61 @@ static double line_search_mt(double incr[6], const oracle_map *target, const oce
     return oracle_mt_linesearch(ls_phi, &ctx, score_init, dginit, NULL, NULL);
 }
 
+/* Gauss-Jordan with partial pivoting: Eigen's Tcov.inverse() ([fusion.h]:845) */
+static int invert6(const double *A, double *inv)
+{
+    double a[6][12];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) { a[i][j] = A[i * 6 + j]; a[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return 0;
+        if (piv != c)
+            for (int j = 0; j < 12; j++) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+        double d = a[c][c];
+        for (int j = 0; j < 12; j++) a[c][j] /= d;
+        for (int r = 0; r < 6; r++) {
+            if (r == c) continue;
+            double f = a[r][c];
+            if (f != 0.0)
+                for (int j = 0; j < 12; j++) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) inv[i * 6 + j] = a[i][6 + j];
+    return 1;
+}
+
+static int match_common(const oracle_map *target, const oracle_map *source, double T[16],
+                        const oracle_match_params *prm, const double *Q /* Tcov^-1 or NULL */, oracle_match_result *res);
+
 int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double T[16],
                      const oracle_match_params *prm, oracle_match_result *res)
+{
+    return match_common(target, source, T, prm, NULL, res);
+}
+
+/* ndt_feature::matchFusion ([fusion.h]:797-1155) with useNDT = true, useFeat = false (empty feature
+ * maps: their derivativesNDT terms are zero), useTikhonovRegularization = false.  With
+ * useSoftConstraints the score / gradient / Hessian get the Mahalanobis terms of X = pose_local_v
+ * ([fusion.h]:875-890, 1098-1110); the step length comes from NDTMatcherD2D::lineSearchMT because the
+ * result of lineSearchMTFusionTcov is overwritten ([fusion.h]:1008-1023: step_size_feat == 0 ->
+ * step_size = max(step_size_ndt, 0)); that discarded search can only flip the increment when
+ * dginit >= 0, which the loop has just excluded ([fusion.h]:976), so it is not evaluated here. */
+int oracle_match_fusion(const oracle_map *target, const oracle_map *source, double T[16],
+                        const oracle_match_params *prm, const double Tcov[36], int use_soft_constraints,
+                        oracle_match_result *res)
+{
+    double Q[36];
+    if (!use_soft_constraints) return match_common(target, source, T, prm, NULL, res);
+    if (!invert6(Tcov, Q)) return -2;
+    return match_common(target, source, T, prm, Q, res);
+}
+
+static int match_common(const oracle_map *target, const oracle_map *source, double T[16],
+                        const oracle_match_params *prm, const double *Q, oracle_match_result *res)
 {
     int dofs[6], nd = 0;
     for (int a = 0; a < 6; a++)
@@ -935,6 +988,7 @@ int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double 
     memcpy(Tbest, T, sizeof Tbest);
 
     size_t n;
+    double pose_local[6] = {0, 0, 0, 0, 0, 0};
     ocell *next = pseudo_transform(source, T, &n); /* [fusion.h]:840 */
     ocell *scratch = (ocell *)calloc(n ? n : 1, sizeof(ocell));
     double g6[6], H36[36];
@@ -942,6 +996,12 @@ int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double 
     while (!convergence) {
         score_here = derivatives_cells(target, next, n, prm->n_neighbours, 1, prm->lfd1, prm->lfd2, g6, H36);
         fevals++;
+        if (Q) { /* [fusion.h]:875-890 */
+            double gq[6], Hq[36];
+            score_here += oracle_mahalanobis(pose_local, Q, gq, Hq);
+            for (int i = 0; i < 6; i++) g6[i] += gq[i];
+            for (int i = 0; i < 36; i++) H36[i] += Hq[i];
+        }
         /* restrict to the active dofs (6-DoF: identity) */
         double g[6], H[36];
         for (int i = 0; i < nd; i++) {
@@ -1002,6 +1062,7 @@ int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double 
             inorm += incr[a] * incr[a];
         }
         inorm = sqrt(inorm);
+        for (int a = 0; a < 6; a++) pose_local[a] += incr[a]; /* [fusion.h]:1045 */
         /* [fusion.h]:1035-1066 */
         double TR[16];
         oracle_pose_to_T(incr, TR);
@@ -1019,6 +1080,10 @@ int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double 
     /* [fusion.h]:1085-1121 */
     score_here = derivatives_cells(target, next, n, prm->n_neighbours, 0, prm->lfd1, prm->lfd2, g6, H36);
     fevals++;
+    if (Q) { /* [fusion.h]:1098-1110 */
+        double gq[6], Hq[36];
+        score_here += oracle_mahalanobis(pose_local, Q, gq, Hq);
+    }
     if (score_here > score_best) memcpy(T, Tbest, sizeof Tbest);
 
 done_early:

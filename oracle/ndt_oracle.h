@@ -94,6 +94,13 @@ double oracle_score_at(const oracle_map *target, const oracle_map *source, const
 int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double T[16],
                      const oracle_match_params *prm, oracle_match_result *res);
 
+/* ndt_feature::matchFusion (ndt_matcher_d2d_fusion.h:797-1155) with empty feature maps and without the
+ * Tikhonov variant: NDT term + (optionally) the odometry soft constraint x^T Tcov^-1 x.
+ * Tcov: 6x6 row-major.  Returns -2 when Tcov is singular. */
+int oracle_match_fusion(const oracle_map *target, const oracle_map *source, double T[16],
+                        const oracle_match_params *prm, const double Tcov[36], int use_soft_constraints,
+                        oracle_match_result *res);
+
 /* MoreThuente::cstep (MINPACK-2 dcstep; called at ndt_matcher_d2d_fusion.h:756,775). */
 int oracle_mt_cstep(double *stx, double *fx, double *dx, double *sty, double *fy, double *dy,
                     double *stp, double fp, double dp, int *brackt, double stmin, double stmax);

@@ -27,8 +27,9 @@ def O():
 
 
 def rot_angle(Ra, Rb):
-    c = (np.trace(Ra.T @ Rb) - 1.0) / 2.0
-    return float(np.arccos(np.clip(c, -1.0, 1.0)))
+    # angle of Ra^T Rb from the chord ||Ra - Rb||_F = 2 sqrt(2) sin(angle/2): well conditioned near 0
+    # (arccos of the trace loses half the digits there)
+    return float(2.0 * np.arcsin(min(1.0, np.linalg.norm(Ra - Rb) / (2.0 * np.sqrt(2.0)))))
 
 
 def pose_close(Ta, Tb):
@@ -337,3 +338,33 @@ def test_config5_3d_small(N, O):
     dt, dr = pose_close(T, To)
     assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
     assert pose_close(T, pr["T_gt"][0].numpy())[0] < 0.05
+
+
+def test_match_fusion_soft_constraint_parity(N, O):
+    """ndt_feature::matchFusion (NDT + odometry soft constraint x^T Tcov^-1 x), the scan-to-map call of
+    NDTFeatureFuserHMT::update (fuser_hmt.cpp:356): HIP vs oracle, both execution paths."""
+    pr, tg, sr, om = _pair_maps(N, O, list(range(1, 11)), 20000, 0.5)
+    T0 = pr["T_init"].numpy()
+    B = len(T0)
+    rng = np.random.default_rng(5)
+    covs = []
+    for b in range(B):
+        A = rng.normal(size=(6, 6)) * 0.02
+        covs.append(A @ A.T + np.diag([1e-3, 1e-3, 1.0, 1.0, 1.0, 1e-4]))     # MotionModel2d-like: z, roll, pitch loose
+    covs = np.stack(covs)
+    idx = np.arange(B)
+    Tb, rb = N.match_fusion_batch(tg, idx, sr, idx, T0, covs)                  # persistent kernel (10 pairs)
+    for b in range(B):
+        To, ro = O.match_fusion(om[b][0], om[b][1], T0[b], covs[b])
+        dt, dr = pose_close(Tb[b], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
+        assert abs(rb["score"][b] - ro["score"]) < 1e-6 * abs(ro["score"])
+    Ts, rs = N.match_fusion_batch(tg, idx[:3], sr, idx[:3], T0[:3], covs[:3])    # host-driven path
+    for b in range(3):
+        dt, dr = pose_close(Ts[b], Tb[b])
+        assert dt < 1e-9 and dr < 1e-9
+    # the prior matters: results differ from the plain matcher, and switching it off gives the plain matcher
+    Tp, _ = N.match_batch(tg, idx, sr, idx, T0)
+    assert max(pose_close(Tp[b], Tb[b])[0] for b in range(B)) > 1e-5
+    Tn, _ = N.match_fusion_batch(tg, idx, sr, idx, T0, covs, use_soft_constraints=False)
+    assert np.array_equal(Tn, Tp)

@@ -234,3 +234,21 @@ def test_no_step_control_and_no_initial_guess():
     Tn, rn = O.match_d2d(tg, sr, T0, use_initial_guess=0)
     Ti, ri = O.match_d2d(tg, sr, np.eye(4))
     np.testing.assert_allclose(Tn, Ti, atol=0)
+
+
+# ---- matchFusion soft constraint (next row 8f-3) --------------------------------------------------
+def test_match_fusion_prior_limits():
+    """A weak odometry prior (huge Tcov) reproduces NDTMatcherD2D::match; a strong one (tiny Tcov) keeps
+    the pose at the initial guess; without soft constraints matchFusion IS match."""
+    tg, sr, T0, Tgt = _scan_maps(3, 10000, 1.0)
+    Tm, rm = O.match_d2d(tg, sr, T0)
+    Tn, rn = O.match_fusion(tg, sr, T0, np.eye(6), use_soft_constraints=False)
+    assert np.array_equal(Tm, Tn) and rm == rn
+    Tw, rw = O.match_fusion(tg, sr, T0, 1e12 * np.eye(6))
+    assert np.max(np.abs(Tw - Tm)) < 1e-6
+    Ts, rs = O.match_fusion(tg, sr, T0, 1e-10 * np.eye(6))
+    assert np.max(np.abs(Ts - T0)) < 1e-6
+    # in between the prior pulls the solution towards the guess
+    Tmid, _ = O.match_fusion(tg, sr, T0, np.diag([1e-4, 1e-4, 1.0, 1.0, 1.0, 1e-5]))
+    d_free, d_mid = np.linalg.norm(Tm[:3, 3] - T0[:3, 3]), np.linalg.norm(Tmid[:3, 3] - T0[:3, 3])
+    assert 0 < d_mid < d_free
