@@ -368,3 +368,39 @@ def test_match_fusion_soft_constraint_parity(N, O):
     assert max(pose_close(Tp[b], Tb[b])[0] for b in range(B)) > 1e-5
     Tn, _ = N.match_fusion_batch(tg, idx, sr, idx, T0, covs, use_soft_constraints=False)
     assert np.array_equal(Tn, Tp)
+
+
+def test_config4_replay_small(N, O):
+    """configs[3] at CI size: a short trajectory of nodes in one building, one NDT map per node, ALL node
+    pairs as candidate edges (NDTFeatureGraph::computeAllPossibleLinks order), edges dealt block-cyclically
+    to `world` shards (ndt_feature_graph_amd.distributed), every shard registered as one batch, results
+    reassembled in edge order -- against the CPU matcher on every edge, plus the reference's link gates."""
+    from ndt_feature_graph_amd import distributed as D, synth
+    n_nodes = 7
+    poses = np.array([[0.3 * k, 0.05 * k * (-1) ** k, 0.015 * k] for k in range(n_nodes)])
+    scans = synth.scan_2d([123] * n_nodes, poses, 30000).numpy()
+    pool = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=n_nodes)
+    pool.build(scans, range_limit=30.0)
+    omaps = [oracle_map(O, scans[k], 0.5, [100, 100, 1]) for k in range(n_nodes)]
+    node_T = synth.pose2d_to_T(poses).numpy()
+    rng = np.random.default_rng(3)
+    odo_T = node_T.copy()
+    odo_T[:, 0, 3] += rng.normal(scale=0.03, size=n_nodes)          # odometry-like node poses
+    odo_T[:, 1, 3] += rng.normal(scale=0.03, size=n_nodes)
+    edges = D.all_pairs(n_nodes)
+    T0 = np.stack([np.linalg.inv(odo_T[i]) @ odo_T[j] for i, j in edges])
+    world, chunk = 3, 4
+    T_all = np.zeros((len(edges), 4, 4))
+    it_all = np.zeros(len(edges), dtype=int)
+    for rank in range(world):                                        # what each GPU of the node would do
+        mine = D.shard_edges(len(edges), rank, world, chunk)
+        Tm, rm = N.match_batch(pool, edges[mine, 0], pool, edges[mine, 1], T0[mine], delta_score=1e-3)   # "edge" preset
+        T_all[mine], it_all[mine] = Tm, rm["iterations"]
+    for e, (i, j) in enumerate(edges):
+        To, ro = O.match_d2d(omaps[i], omaps[j], T0[e], delta_score=1e-3)
+        dt, dr = pose_close(T_all[e], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and it_all[e] == ro["iterations"], (e, dt, dr)
+        gt = np.linalg.inv(node_T[i]) @ node_T[j]
+        assert pose_close(T_all[e], gt)[0] < 0.05
+    keep = D.gate_links(edges, node_T, max_dist=1.0, max_angle=0.2, min_idx_dist=2)
+    assert 0 < len(keep) < len(edges)
