@@ -202,6 +202,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     // ---------------- phase A: key + accumulate ----------------------------------------------------
     long long t0 = __builtin_readcyclecounter();
     unsigned dropped = 0;
+#ifdef NDT_PROFILE_SECTIONS
+    long long ps[4] = {0, 0, 0, 0}, pt = clock64();
+#define NDT_PS(k) { long long now_ = clock64(); ps[k] += now_ - pt; pt = now_; }
+#else
+#define NDT_PS(k)
+#endif
     // The scan is cut into sub-tiles of 512 points (64 lanes x 8 points).  A wave owns a contiguous range of
     // sub-tiles and walks it in SUPER-TILES of up to NDT_ROUNDS sub-tiles: lane l owns 8*R consecutive points of
     // the super-tile and visits them in R rounds through the same 8-point LDS row, so the wavefront merge and
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 }
             }
         }
+        NDT_PS(0)
 #pragma unroll 1
         for (int j = 0; j < NDT_PPL; j++) {
             const unsigned i = p0 + (lane * R + r) * NDT_PPL + j;
@@ -335,22 +342,28 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                              (unsigned)iz < (unsigned)g.size[2];
             const int slot = inb ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
             dropped += (valid && !inb) ? 1u : 0u;
+            NDT_PS(1)
             if (dbg & 16) continue;
             // offset from the point's own cell origin: |d| <= one cell, no cancellation later on
             const double x = (double)fx - (cx + ((double)ix - hx) * res);
             const double y = (double)fy - (cy + ((double)iy - hy) * res);
             const double z = (double)fz - (cz + ((double)iz - hz) * res);
-            if (inb && cs0 < 0) cs0 = slot;                  // first cell of the tile: run 0
-            const bool in0 = inb && (slot == cs0);
-            const bool other = inb && !in0;
+            // Move-to-front: the cell of the current point is always run 0 (registers); the previous cell is run 1
+            // (LDS).  A lane that crosses into the next cell pays ONE exchange instead of an LDS read-modify-write
+            // for every remaining point of the super-tile; range noise on a wall that hugs a cell face costs one
+            // exchange per flip.  A third cell evicts run 1 into the queue.
+            if (inb && cs0 < 0) cs0 = slot;                  // first cell of the super-tile
+            const bool other = inb && (slot != cs0);
             if (__ballot(other)) {
                 if (other) {
-                    if (slot == cs1) {
-                        r1[0 * 64 + lane] += 1.0;
-                        r1[1 * 64 + lane] += x; r1[2 * 64 + lane] += y; r1[3 * 64 + lane] += z;
-                        r1[4 * 64 + lane] = fma(x, x, r1[4 * 64 + lane]); r1[5 * 64 + lane] = fma(x, y, r1[5 * 64 + lane]);
-                        r1[6 * 64 + lane] = fma(x, z, r1[6 * 64 + lane]); r1[7 * 64 + lane] = fma(y, y, r1[7 * 64 + lane]);
-                        r1[8 * 64 + lane] = fma(y, z, r1[8 * 64 + lane]); r1[9 * 64 + lane] = fma(z, z, r1[9 * 64 + lane]);
+                    if (slot == cs1) {                       // back to the previous cell: exchange the runs
+                        double t;
+                        t = r1[0 * 64 + lane]; r1[0 * 64 + lane] = rn; rn = t;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { t = r1[(1 + k) * 64 + lane]; r1[(1 + k) * 64 + lane] = sd[k]; sd[k] = t; }
+#pragma unroll
+                        for (int k = 0; k < 6; k++) { t = r1[(4 + k) * 64 + lane]; r1[(4 + k) * 64 + lane] = se[k]; se[k] = t; }
+                        cs1 = cs0;
                     } else {
                         if (cs1 >= 0 && !(dbg & 8)) {        // a third cell -> evict run 1 into the queue
                             unsigned pos = __hip_atomic_fetch_add(&s_qcnt[wave], 1u, __ATOMIC_RELAXED,
@@ -371,20 +384,23 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                                         unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + rid) + k, rec[k]);
                             }
                         }
-                        cs1 = slot;
-                        r1[0 * 64 + lane] = 1.0;
-                        r1[1 * 64 + lane] = x; r1[2 * 64 + lane] = y; r1[3 * 64 + lane] = z;
-                        r1[4 * 64 + lane] = x * x; r1[5 * 64 + lane] = x * y; r1[6 * 64 + lane] = x * z;
-                        r1[7 * 64 + lane] = y * y; r1[8 * 64 + lane] = y * z; r1[9 * 64 + lane] = z * z;
+                        cs1 = cs0;                           // run 0 becomes run 1, a fresh run 0 starts
+                        r1[0 * 64 + lane] = rn; rn = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { r1[(1 + k) * 64 + lane] = sd[k]; sd[k] = 0; }
+#pragma unroll
+                        for (int k = 0; k < 6; k++) { r1[(4 + k) * 64 + lane] = se[k]; se[k] = 0; }
                     }
+                    cs0 = slot;
                 }
             }
-            if (in0) {
+            if (inb) {
                 rn += 1.0;
                 sd[0] += x; sd[1] += y; sd[2] += z;
                 se[0] = fma(x, x, se[0]); se[1] = fma(x, y, se[1]); se[2] = fma(x, z, se[2]);
                 se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
             }
+            NDT_PS(2)
         }
         }   // rounds
         if (!(dbg & 2)) {
@@ -448,6 +464,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             }
             drain_list();
         }
+        NDT_PS(3)
     }
     if (dropped) atomicAdd(&s_dropped, dropped);
     __syncthreads();
@@ -605,6 +622,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         ctr->cyc[1] = (uint32_t)(t2 - t1);
         ctr->cyc[2] = (uint32_t)(t3 - t2);
         ctr->cyc[3] = (uint32_t)((long long)__builtin_readcyclecounter() - t3);
+#ifdef NDT_PROFILE_SECTIONS
+        for (int k = 0; k < 4; k++) ctr->cyc[k] = (uint32_t)(ps[k] >> 4);   // wave 0: load, bin, accumulate, merge+flush (x16 cycles)
+#endif
     }
 }
 

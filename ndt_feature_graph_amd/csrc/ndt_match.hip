@@ -61,6 +61,50 @@ NDT_D double wave_sum_d(double v)
     return v;
 }
 
+// Sum of N (power of two) per-lane values over the 64 lanes of a wave, all N at once: a butterfly that halves the
+// number of values a lane carries at every step (the lane keeps the half selected by its lane bit and receives
+// the partner's copy of it), then finishes the single remaining value over the unused low lane bits.
+// 2N - 1 exchanges instead of 6N, and the association order is the one of the plain xor tree
+// v += shfl_xor(v, 32), 16, ..., 1 -- the result is bit-identical to it.  Lane l ends with the total of value
+// l >> (6 - log2 N).  Lane bits 5 and 4 use gfx950's v_permlane32_swap / v_permlane16_swap (no LDS, no selects).
+NDT_D double pl_swap_add(double a, double b, bool rows16)
+{
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if (rows16) {
+        auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+    }
+    auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+
+template <int N>
+NDT_D double wave_sum_all(double (&v)[N])
+{
+    static_assert(N == 8 || N == 32, "padded value count");
+    const unsigned lane = threadIdx.x & 63u;
+    int o = 32;
+#pragma unroll
+    for (int n = N / 2; n >= 1; n >>= 1, o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < n; k++) {
+            if (o >= 16) {
+                v[k] = pl_swap_add(v[k], v[k + n], o == 16);
+            } else {
+                const bool up = (lane & (unsigned)o) != 0;
+                const double keep = up ? v[k + n] : v[k], send = up ? v[k] : v[k + n];
+                v[k] = keep + __shfl_xor(send, o, 64);
+            }
+        }
+    }
+    double t = v[0];
+    for (; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+}
+
 NDT_D unsigned long long lanemask_lt()
 {
     unsigned lane = threadIdx.x & 63u;
@@ -145,6 +189,12 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
     uint32_t *myq = s_queue + wave * NDT_QN;
     unsigned qhead = 0, qcount = 0;   // wave-uniform
     unsigned terms = 0;               // pair terms evaluated by this wave (wave-uniform)
+#if defined(NDT_ABL_TERM2) || defined(NDT_ABL_PROBE2) || defined(NDT_ABL_RED2)
+    double acc2[NACC];
+    for (int k = 0; k < NACC; k++) acc2[k] = 0.0;
+    const double abl_eps = lfd1 * 1e-30;
+    unsigned abl_dummy = 0;
+#endif
     const unsigned long long lt = lanemask_lt();
 
     // TERM stage: pops up to 64 (source lane, target cell) pairs; every lane does one dense pair term.
@@ -162,6 +212,9 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
                 d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
                 sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
                 pair_term<WITH_H>(m, C, mu, Cj, lfd1, lfd2, acc);
+#ifdef NDT_ABL_TERM2
+                { d3 m2 = {m.x + abl_eps, m.y, m.z}; pair_term<WITH_H>(m2, C, mu, Cj, lfd1, lfd2, acc2); }
+#endif
             }
             qhead = (qhead + n) & (NDT_QN - 1);
             qcount -= n;
@@ -190,7 +243,19 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
             iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy);
             iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
         }
-        // PROBE stage: (2n+1)^3 dense-table slots around the lane's cell; one row of W loads in flight
+        // PROBE stage: (2n+1)^3 dense-table slots around the lane's cell; one row of W loads in flight.
+        // 32-bit byte offsets into this map's table (slots * 4 < 4 GiB) = scalar base + vector offset addressing;
+        // out-of-grid neighbours read slot 0 (always a valid address) and are masked afterwards: no branches.
+        const char *tbl = reinterpret_cast<const char *>(tg.table);
+        const unsigned sz4 = (unsigned)tg.sz * 4u, xstride = (unsigned)tg.sy * sz4;
+        unsigned ycol[W];
+        bool yok[W];
+#pragma unroll
+        for (int dy = 0; dy < W; dy++) {
+            int yy = iy + dy - NN;
+            yok[dy] = vi && yy >= 0 && yy < tg.sy;
+            ycol[dy] = yok[dy] ? (unsigned)yy * sz4 : 0u;
+        }
         for (int dz = -NN; dz <= NN; dz++) {
             int zz = iz + dz;
             bool zok = vi && zz >= 0 && zz < tg.sz;
@@ -199,34 +264,68 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
             for (int dx = -NN; dx <= NN; dx++) {
                 int xx = ix + dx;
                 bool xok = zok && xx >= 0 && xx < tg.sx;
+                const unsigned rowb = xok ? (unsigned)xx * xstride + (unsigned)zz * 4u : 0u;
                 int ids[W];
 #pragma unroll
-                for (int dy = 0; dy < W; dy++) {
-                    int yy = iy + dy - NN;
-                    bool ok = xok && yy >= 0 && yy < tg.sy;
-                    ids[dy] = ok ? tg.table[((size_t)xx * tg.sy + yy) * tg.sz + zz] : -1;
-                }
+                for (int dy = 0; dy < W; dy++) ids[dy] = *reinterpret_cast<const int *>(tbl + (rowb + ycol[dy]));
 #pragma unroll
                 for (int k = 0; k < W; k++) {
-                    bool hit = ids[k] >= 0;
-                    unsigned long long mask = __ballot(hit);
-                    if (hit)
-                        myq[(qhead + qcount + (unsigned)__popcll(mask & lt)) & (NDT_QN - 1)] =
-                            (lane << 24) | (uint32_t)ids[k];
+                    bool hit = xok && yok[k] && ids[k] >= 0;
+                    unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (hit) myq[(qhead + qcount + rank) & (NDT_QN - 1)] = (lane << 24) | (uint32_t)ids[k];
                     qcount += (unsigned)__popcll(mask);
                 }
                 drain(64);
             }
         }
+#ifdef NDT_ABL_PROBE2
+        for (int dz = -NN; dz <= NN; dz++) {
+            int zz = iz + dz;
+            bool zok = vi && zz >= 0 && zz < tg.sz;
+            if (!__ballot(zok)) continue;
+#pragma unroll 1
+            for (int dx = -NN; dx <= NN; dx++) {
+                int xx = ix + dx;
+                bool xok = zok && xx >= 0 && xx < tg.sx;
+                const unsigned rowb = xok ? (unsigned)xx * xstride + (unsigned)zz * 4u : 0u;
+                int ids[W];
+#pragma unroll
+                for (int dy = 0; dy < W; dy++) ids[dy] = *reinterpret_cast<const int *>(tbl + (rowb + ycol[dy]));
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    bool hit = xok && yok[k] && ids[k] >= 0;
+                    unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (hit) abl_dummy += rank + (uint32_t)ids[k];
+                    abl_dummy += (unsigned)__popcll(mask);
+                }
+            }
+        }
+#endif
         drain(1);   // the per-wave source tile is overwritten by the next batch
     }
 
     // 28 (or 7) sums: wave tree, then fixed-order sum of the wave partials
+    {
+        constexpr int NP = WITH_H ? 32 : 8, SH = WITH_H ? 1 : 3;
+        double vv[NP];
 #pragma unroll
-    for (int k = 0; k < NACC; k++) {
-        double v = wave_sum_d(acc[k]);
-        if (lane == 0) s_part[wave * 32 + k] = v;
+        for (int k = 0; k < NP; k++) vv[k] = k < NACC ? acc[k] : 0.0;
+        const double tot = wave_sum_all<NP>(vv);
+        if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) s_part[wave * 32 + (lane >> SH)] = tot;
     }
+#ifdef NDT_ABL_RED2
+    for (int k = 0; k < NACC; k++) acc2[k] = acc[k] * 0.5;
+#endif
+#if defined(NDT_ABL_TERM2) || defined(NDT_ABL_PROBE2) || defined(NDT_ABL_RED2)
+    {
+        double junk = 0;
+#pragma unroll
+        for (int k = 0; k < NACC; k++) junk += wave_sum_d(acc2[k]);
+        if (junk == 1.2345e300 || abl_dummy == 0xdeadbeefu) terms += 1;   // never: keeps the duplicated work alive
+    }
+#endif
     if (lane == 0) s_part[wave * 32 + 28] = (double)terms;
     __syncthreads();
     if (tid < (unsigned)NACC || tid == 28u) {

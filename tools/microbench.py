@@ -62,3 +62,11 @@ print("cycles: eval mean %.0f k  solver mean %.0f k per pair; per eval %.1f k, p
 print("pair total cycles: mean %.0f k max %.0f k; sum/256CU = %.3f ms at 2.4GHz" % (
     (r["cycles_eval"] + r["cycles_solver"]).mean() / 1e3, (r["cycles_eval"] + r["cycles_solver"]).max() / 1e3,
     (r["cycles_eval"] + r["cycles_solver"]).sum() / 256 / clk * 1e3))
+tot = (r["cycles_eval"] + r["cycles_solver"]).astype(np.float64)
+order = np.argsort(-tot)
+print("slowest pairs: (idx, kcycles, iterations, fevals, pair_terms_g+h, converged)")
+for i in order[:8]:
+    print("   ", i, int(tot[i] / 1e3), r["iterations"][i], r["fevals"][i], r["pair_terms_g"][i] + r["pair_terms_h"][i], r["converged"][i])
+q = np.percentile(tot, [50, 90, 95, 99, 100]) / 1e3
+print("pair kcycles percentiles 50/90/95/99/100:", q.round(0), " fevals pct:", np.percentile(r["fevals"], [50, 90, 95, 99, 100]))
+print("iterations histogram:", np.bincount(r["iterations"], minlength=32))
