@@ -158,6 +158,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     const NdtGrid g = set.grid;
     const uint32_t cap = g.max_cells;
     int32_t *table = set.table + (size_t)map * g.slots;
+    uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     const unsigned bm_words = (unsigned)((g.slots + 31) >> 5);
     NdtCell *cells = set.cells + (size_t)map * cap;
     NdtMapCounters *ctr = set.counters + map;
@@ -193,7 +194,11 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     if (MODE != 1) {
         unsigned old = ctr->n_cells;
         if (old > cap) old = cap;
-        for (unsigned i = tid; i < old; i += nthreads) table[cells[i].slot] = NDT_EMPTY;
+        for (unsigned i = tid; i < old; i += nthreads) {
+            const uint32_t sl = cells[i].slot;
+            table[sl] = NDT_EMPTY;
+            rankmap[sl >> 5].x = 0u;
+        }
         if (MODE == 0 && tid == 0) ctr->overflow = 0;
     }
     if (tid == 0) { s_base = 0; s_dropped = 0; }
@@ -592,6 +597,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         unsigned incl = wave_incl_scan(cnt);
         unsigned before = running + incl - cnt;
         running += __shfl(incl, 63, 64);
+        if (vmask) rankmap[w] = make_uint2(vmask, before);
         for (unsigned b = bits; b; b &= b - 1) {
             int bit = __ffs((int)b) - 1;
             unsigned slot = w * 32 + bit;
@@ -635,12 +641,15 @@ extern "C" __global__ void ndt_install_cells_kernel(NdtSetView set, unsigned map
 {
     const NdtGrid g = set.grid;
     int32_t *table = set.table + (size_t)map * g.slots;
+    uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     NdtCell *cells = set.cells + (size_t)map * g.max_cells;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_cells) {
         NdtCell c = src[i];
         cells[i] = c;
         table[c.slot] = (int)i;
+        atomicOr(&rankmap[c.slot >> 5].x, 1u << (c.slot & 31u));
+        if (i == 0 || (src[i - 1].slot >> 5) != (c.slot >> 5)) rankmap[c.slot >> 5].y = i;   // sorted by slot
     }
     if (i == 0) {
         set.counters[map].n_cells = n_cells;
@@ -708,6 +717,8 @@ hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const Ndt
 {
     hipError_t e = hipMemsetAsync(set.table + map * (size_t)set.grid.slots, 0xFF,
                                   (size_t)set.grid.slots * sizeof(int32_t), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(set.rankmap + map * ndt_rm_stride(set.grid), 0, ndt_rm_stride(set.grid) * sizeof(uint2), stream);
     if (e != hipSuccess) return e;
     unsigned blocks = (unsigned)((n_cells + 255) / 256);
     if (blocks == 0) blocks = 1;

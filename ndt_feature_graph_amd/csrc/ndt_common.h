@@ -62,7 +62,9 @@ struct NdtMapCounters {        // per map, device resident
 
 struct NdtSetView {            // what kernels see of a mapset
     NdtGrid grid;
-    int32_t *table;            // [n_maps][slots]
+    int32_t *table;            // [n_maps][slots]      slot -> cell rank, -1 = no Gaussian
+    uint2 *rankmap;            // [n_maps][rm_stride]  per 32 slots: {.x = Gaussian-cell bits, .y = rank of the word's
+                               //                      first Gaussian cell (valid when .x != 0)}: what the matcher probes
     int32_t *wtable;           // [n_maps][slots]      build scratch
     uint32_t *bitmap;          // [n_maps][(slots+31)/32] build scratch
     NdtCell *cells;            // [n_maps][max_cells]
@@ -71,6 +73,9 @@ struct NdtSetView {            // what kernels see of a mapset
     NdtMapCounters *counters;  // [n_maps]
     double *centres;           // [n_maps][3]
 };
+
+// words per map of NdtSetView::rankmap (+1: a probe window may read one word past its first)
+static inline __host__ __device__ size_t ndt_rm_stride(const NdtGrid &g) { return (size_t)((g.slots + 31) / 32) + 1; }
 
 struct NdtMatchParamsDev {
     int n_neighbours, itr_max, step_control, dof_mask, use_initial_guess;
@@ -91,9 +96,11 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
                             const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream);
 hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const NdtCell *cells_dev, size_t n_cells,
                                     hipStream_t stream);
+size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups);
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                            NdtMatchResultDev *res_dev, const double *Q36_dev, hipStream_t stream);
+                            NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters,
+                            void *work_dev, hipStream_t stream);
 struct rigid;
 hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,
                            int n_neighbours, int with_h, double lfd1, double lfd2, unsigned n_groups, double *partials_dev,

@@ -35,7 +35,7 @@
 namespace {
 
 struct MapView {
-    const int32_t *table;
+    const uint2 *rankmap;
     const NdtCell *cells;
     int n_cells;
     int sx, sy, sz;
@@ -45,7 +45,7 @@ struct MapView {
 NDT_D MapView map_view(const NdtSetView &s, unsigned map)
 {
     MapView v;
-    v.table = s.table + (size_t)map * s.grid.slots;
+    v.rankmap = s.rankmap + (size_t)map * ndt_rm_stride(s.grid);
     v.cells = s.cells + (size_t)map * s.grid.max_cells;
     v.n_cells = (int)s.counters[map].n_cells;
     v.sx = s.grid.size[0]; v.sy = s.grid.size[1]; v.sz = s.grid.size[2];
@@ -189,13 +189,6 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
     uint32_t *myq = s_queue + wave * NDT_QN;
     unsigned qhead = 0, qcount = 0;   // wave-uniform
     unsigned terms = 0;               // pair terms evaluated by this wave (wave-uniform)
-#if defined(NDT_ABL_TERM2) || defined(NDT_ABL_PROBE2) || defined(NDT_ABL_RED2)
-    double acc2[NACC];
-    for (int k = 0; k < NACC; k++) acc2[k] = 0.0;
-    const double abl_eps = lfd1 * 1e-30;
-    unsigned abl_dummy = 0;
-#endif
-    const unsigned long long lt = lanemask_lt();
 
     // TERM stage: pops up to 64 (source lane, target cell) pairs; every lane does one dense pair term.
     // `min_fill` = 64 while probing (only full batches), 1 for the final flush of a source tile.
@@ -212,9 +205,6 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
                 d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
                 sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
                 pair_term<WITH_H>(m, C, mu, Cj, lfd1, lfd2, acc);
-#ifdef NDT_ABL_TERM2
-                { d3 m2 = {m.x + abl_eps, m.y, m.z}; pair_term<WITH_H>(m2, C, mu, Cj, lfd1, lfd2, acc2); }
-#endif
             }
             qhead = (qhead + n) & (NDT_QN - 1);
             qcount -= n;
@@ -243,66 +233,46 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
             iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy);
             iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
         }
-        // PROBE stage: (2n+1)^3 dense-table slots around the lane's cell; one row of W loads in flight.
-        // 32-bit byte offsets into this map's table (slots * 4 < 4 GiB) = scalar base + vector offset addressing;
-        // out-of-grid neighbours read slot 0 (always a valid address) and are masked afterwards: no branches.
-        const char *tbl = reinterpret_cast<const char *>(tg.table);
-        const unsigned sz4 = (unsigned)tg.sz * 4u, xstride = (unsigned)tg.sy * sz4;
-        unsigned ycol[W];
-        bool yok[W];
-#pragma unroll
-        for (int dy = 0; dy < W; dy++) {
-            int yy = iy + dy - NN;
-            yok[dy] = vi && yy >= 0 && yy < tg.sy;
-            ycol[dy] = yok[dy] ? (unsigned)yy * sz4 : 0u;
-        }
-        for (int dz = -NN; dz <= NN; dz++) {
-            int zz = iz + dz;
-            bool zok = vi && zz >= 0 && zz < tg.sz;
-            if (!__ballot(zok)) continue;
+        // PROBE stage: the (2n+1)^3 slots around the lane's cell, read as bit windows of the map's rank bitmap
+        // (1 bit per slot + the rank of every 32-slot word's first Gaussian cell): slots are z-fastest, so the
+        // neighbours along z are one run of <= W bits, and in a flat map (sz <= n+1: every z-layer is a
+        // neighbour) the whole (y, z) block of one x is a single run of <= W*sz bits.  Cells are ranked in slot
+        // order, so the k-th set bit of a run is cell `first + k`: no per-slot lookups.
+        const bool flat = tg.sz <= NN + 1;                       // wave-uniform
+        const int n_runs = flat ? 1 : W;
+        const int zlo = flat ? 0 : max(iz - NN, 0), zhi = flat ? tg.sz - 1 : min(iz + NN, tg.sz - 1);
+        const char *rmb = reinterpret_cast<const char *>(tg.rankmap);
 #pragma unroll 1
-            for (int dx = -NN; dx <= NN; dx++) {
-                int xx = ix + dx;
-                bool xok = zok && xx >= 0 && xx < tg.sx;
-                const unsigned rowb = xok ? (unsigned)xx * xstride + (unsigned)zz * 4u : 0u;
-                int ids[W];
-#pragma unroll
-                for (int dy = 0; dy < W; dy++) ids[dy] = *reinterpret_cast<const int *>(tbl + (rowb + ycol[dy]));
-#pragma unroll
-                for (int k = 0; k < W; k++) {
-                    bool hit = xok && yok[k] && ids[k] >= 0;
-                    unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (hit) myq[(qhead + qcount + rank) & (NDT_QN - 1)] = (lane << 24) | (uint32_t)ids[k];
+        for (int dx = -NN; dx <= NN; dx++) {
+            const int xx = ix + dx;
+            const bool xok = vi && xx >= 0 && xx < tg.sx && zlo <= zhi;
+#pragma unroll 1
+            for (int t = 0; t < n_runs; t++) {
+                const int ylo = flat ? max(iy - NN, 0) : iy - NN + t;
+                const int yhi = flat ? min(iy + NN, tg.sy - 1) : ylo;
+                const bool ok = xok && ylo <= yhi && ylo >= 0 && yhi < tg.sy;
+                const unsigned s0 = ok ? (unsigned)((xx * tg.sy + ylo) * tg.sz + zlo) : 0u;
+                const int len = ok ? (flat ? (yhi - ylo + 1) * tg.sz : zhi - zlo + 1) : 0;   // <= 28 bits
+                const unsigned sh = s0 & 31u;
+                const uint2 wa = *reinterpret_cast<const uint2 *>(rmb + (size_t)(s0 >> 5) * 8u);
+                const uint2 wb = *reinterpret_cast<const uint2 *>(rmb + (size_t)(s0 >> 5) * 8u + 8u);
+                unsigned bits = __builtin_amdgcn_alignbit(wb.x, wa.x, sh) & ((1u << len) - 1u);
+                const unsigned lowa = wa.x >> sh;                // the window's part of the first word
+                unsigned id = lowa ? wa.y + (unsigned)__popc(wa.x & ((1u << sh) - 1u)) : wb.y;
+                // every lane pops its lowest remaining bit per round: ids count up from the run's first cell
+                while (true) {
+                    const bool hit = bits != 0u;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    if (!mask) break;
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                    if (hit) myq[(qhead + qcount + rank) & (NDT_QN - 1)] = (lane << 24) | id;
                     qcount += (unsigned)__popcll(mask);
-                }
-                drain(64);
-            }
-        }
-#ifdef NDT_ABL_PROBE2
-        for (int dz = -NN; dz <= NN; dz++) {
-            int zz = iz + dz;
-            bool zok = vi && zz >= 0 && zz < tg.sz;
-            if (!__ballot(zok)) continue;
-#pragma unroll 1
-            for (int dx = -NN; dx <= NN; dx++) {
-                int xx = ix + dx;
-                bool xok = zok && xx >= 0 && xx < tg.sx;
-                const unsigned rowb = xok ? (unsigned)xx * xstride + (unsigned)zz * 4u : 0u;
-                int ids[W];
-#pragma unroll
-                for (int dy = 0; dy < W; dy++) ids[dy] = *reinterpret_cast<const int *>(tbl + (rowb + ycol[dy]));
-#pragma unroll
-                for (int k = 0; k < W; k++) {
-                    bool hit = xok && yok[k] && ids[k] >= 0;
-                    unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (hit) abl_dummy += rank + (uint32_t)ids[k];
-                    abl_dummy += (unsigned)__popcll(mask);
+                    id += 1u;
+                    bits &= bits - 1u;
+                    drain(64);
                 }
             }
         }
-#endif
         drain(1);   // the per-wave source tile is overwritten by the next batch
     }
 
@@ -315,17 +285,6 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
         const double tot = wave_sum_all<NP>(vv);
         if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) s_part[wave * 32 + (lane >> SH)] = tot;
     }
-#ifdef NDT_ABL_RED2
-    for (int k = 0; k < NACC; k++) acc2[k] = acc[k] * 0.5;
-#endif
-#if defined(NDT_ABL_TERM2) || defined(NDT_ABL_PROBE2) || defined(NDT_ABL_RED2)
-    {
-        double junk = 0;
-#pragma unroll
-        for (int k = 0; k < NACC; k++) junk += wave_sum_d(acc2[k]);
-        if (junk == 1.2345e300 || abl_dummy == 0xdeadbeefu) terms += 1;   // never: keeps the duplicated work alive
-    }
-#endif
     if (lane == 0) s_part[wave * 32 + 28] = (double)terms;
     __syncthreads();
     if (tid < (unsigned)NACC || tid == 28u) {
@@ -338,54 +297,141 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
 
 }  // namespace
 
+// Work distribution of the persistent matcher.  Registrations differ 10x in length (most converge in 5-9
+// Newton iterations, a few run into ITR_MAX with long line searches) and a long one that STARTS late sets the
+// launch time.  Workgroups therefore pull pairs from a ticket counter, and a registration that is still running
+// after `park_iters` iterations is parked (its solver state, ~1 KB, goes to global memory) whenever a pair that
+// has not started yet can be taken instead: every registration starts before any long tail is run, and the
+// tails then run side by side on otherwise idle CUs.
+//   fresh   : next pair that has not started
+//   reserve : parked-list slots handed out;  head : parked-list slots consumed
+//   ids[s]  : 0 = slot not written yet, 1 = cancelled, pair + 2 = parked pair
+// A slot is reserved BEFORE the fresh ticket is drawn, so a workgroup whose own ticket draw failed and that then
+// sees head == reserve knows that no registration can be parked any more, and may exit.
+struct NdtMatchWork {
+    unsigned fresh, reserve, head, pad;
+};
+struct NdtParkedState {
+    MatchState st;
+    long long cyc_eval, cyc_solver, terms_g, terms_h;
+};
+size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups)
+{
+    return sizeof(NdtMatchWork) + (n_pairs + n_groups + 1) * sizeof(unsigned) + 8 + n_pairs * sizeof(NdtParkedState);
+}
+
 template <int NN>
 __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
     double *__restrict__ T16, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res,
-    const double *__restrict__ Q36 /* per pair Tcov^-1 (matchFusion soft constraint) or NULL */)
+    const double *__restrict__ Q36 /* per pair Tcov^-1 (matchFusion soft constraint) or NULL */,
+    unsigned n_pairs, int park_iters, char *__restrict__ work_mem)
 {
     __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
     __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
     __shared__ double s_part[NDT_MATCH_WAVES * 32];
     __shared__ double s_sums[32];
     __shared__ MatchState st;
+    __shared__ int s_job, s_next;
 
-    const unsigned pair = blockIdx.x;
-    const MapView tg = map_view(tset, tidx[pair]);
-    const MapView sv = map_view(sset, sidx[pair]);
-    double *Tio = T16 + (size_t)pair * 16;
+    NdtMatchWork *work = reinterpret_cast<NdtMatchWork *>(work_mem);
+    unsigned *ids = reinterpret_cast<unsigned *>(work_mem + sizeof(NdtMatchWork));
+    const unsigned n_ids = n_pairs + gridDim.x + 1;
+    NdtParkedState *parked =
+        reinterpret_cast<NdtParkedState *>(work_mem + ((sizeof(NdtMatchWork) + n_ids * sizeof(unsigned) + 7) & ~(size_t)7));
 
-    if (threadIdx.x == 0) match_state_init(st, Tio, prm, Q36 ? Q36 + (size_t)pair * 36 : nullptr);
-    __syncthreads();
-
-    long long cyc_eval = 0, cyc_solver = 0, terms_g = 0, terms_h = 0;
-    while (!st.done) {
-        const rigid Te = st.Teval;
-        const int with_h = st.with_h;
-        __syncthreads();   // everyone has read the request before thread 0 may rewrite it
-        long long c0 = __builtin_readcyclecounter();
-        if (with_h) eval_derivs<NN, true>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
-        else eval_derivs<NN, false>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
-        long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) s_next = -1;
+    for (;;) {
+        // ---- take a job: the one drawn while parking, else a fresh pair, else a parked registration ----------
         if (threadIdx.x == 0) {
-            if (with_h) terms_h += (long long)s_sums[28]; else terms_g += (long long)s_sums[28];
-            match_state_step(st, s_sums, prm);
-            cyc_eval += c1 - c0;
-            cyc_solver += (long long)__builtin_readcyclecounter() - c1;
+            int job = s_next;               // >= 0: fresh pair, <= -2: resume parked pair (-2 - pair), -1: none
+            s_next = -1;
+            if (job == -1) {
+                unsigned f = atomicAdd(&work->fresh, 1u);
+                if (f < n_pairs) job = (int)f;
+            }
+            while (job == -1) {
+                unsigned h = __hip_atomic_load(&work->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned r = __hip_atomic_load(&work->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (h >= r) break;          // nothing parked, nothing can be parked any more
+                if (atomicCAS(&work->head, h, h + 1u) != h) continue;
+                unsigned v;
+                while ((v = __hip_atomic_load(&ids[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
+                    __builtin_amdgcn_s_sleep(8);
+                if (v >= 2u) job = -2 - (int)(v - 2u);
+            }
+            s_job = job;
         }
         __syncthreads();
-    }
+        const int job = s_job;
+        if (job == -1) return;
+        const bool resumed = job <= -2;
+        const unsigned pair = resumed ? (unsigned)(-2 - job) : (unsigned)job;
 
-    if (threadIdx.x == 0) {
-        NdtMatchResultDev o;
-        match_state_result(st, Tio, o);
-        o.n_source = sv.n_cells;
-        o.n_target = tg.n_cells;
-        o.cycles_eval = cyc_eval;
-        o.cycles_solver = cyc_solver;
-        o.pair_terms_g = terms_g;
-        o.pair_terms_h = terms_h;
-        res[pair] = o;
+        const MapView tg = map_view(tset, tidx[pair]);
+        const MapView sv = map_view(sset, sidx[pair]);
+        double *Tio = T16 + (size_t)pair * 16;
+        long long cyc_eval = 0, cyc_solver = 0, terms_g = 0, terms_h = 0;
+        if (threadIdx.x == 0) {
+            if (resumed) {
+                const NdtParkedState &ps = parked[pair];
+                st = ps.st;
+                cyc_eval = ps.cyc_eval; cyc_solver = ps.cyc_solver; terms_g = ps.terms_g; terms_h = ps.terms_h;
+            } else {
+                match_state_init(st, Tio, prm, Q36 ? Q36 + (size_t)pair * 36 : nullptr);
+            }
+        }
+        __syncthreads();
+
+        bool parked_now = false;
+        while (!st.done) {
+            const rigid Te = st.Teval;
+            const int with_h = st.with_h;
+            __syncthreads();   // everyone has read the request before thread 0 may rewrite it
+            long long c0 = __builtin_readcyclecounter();
+            if (with_h) eval_derivs<NN, true>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
+            else eval_derivs<NN, false>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
+            long long c1 = __builtin_readcyclecounter();
+            if (threadIdx.x == 0) {
+                if (with_h) terms_h += (long long)s_sums[28]; else terms_g += (long long)s_sums[28];
+                match_state_step(st, s_sums, prm);
+                cyc_eval += c1 - c0;
+                cyc_solver += (long long)__builtin_readcyclecounter() - c1;
+                // about to start another Newton iteration of a long registration: hand the CU to a pair that has
+                // not started yet, if there is one
+                s_job = 0;
+                if (!st.done && st.phase == PH_NEWTON && park_iters > 0 && st.itr_ctr >= park_iters &&
+                    __hip_atomic_load(&work->fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_pairs) {
+                    const unsigned slot = atomicAdd(&work->reserve, 1u);
+                    const unsigned f = atomicAdd(&work->fresh, 1u);
+                    if (f < n_pairs) {
+                        NdtParkedState &ps = parked[pair];
+                        ps.st = st;
+                        ps.cyc_eval = cyc_eval; ps.cyc_solver = cyc_solver; ps.terms_g = terms_g; ps.terms_h = terms_h;
+                        __hip_atomic_store(&ids[slot], pair + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        s_next = (int)f;
+                        s_job = 1;
+                    } else {
+                        __hip_atomic_store(&ids[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_job == 1) { parked_now = true; break; }
+        }
+
+        if (threadIdx.x == 0 && !parked_now) {
+            NdtMatchResultDev o;
+            match_state_result(st, Tio, o);
+            o.n_source = sv.n_cells;
+            o.n_target = tg.n_cells;
+            o.cycles_eval = cyc_eval;
+            o.cycles_solver = cyc_solver;
+            o.pair_terms_g = terms_g;
+            o.pair_terms_h = terms_h;
+            res[pair] = o;
+        }
+        __syncthreads();
     }
 }
 
@@ -454,12 +500,16 @@ hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView
 
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                            NdtMatchResultDev *res_dev, const double *Q36_dev, hipStream_t stream)
+                            NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters,
+                            void *work_dev, hipStream_t stream)
 {
     if (n_pairs == 0) return hipSuccess;
+    // ticket counters and the parked list start at zero
+    hipError_t e = hipMemsetAsync(work_dev, 0, sizeof(NdtMatchWork) + (n_pairs + n_groups + 1) * sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
 #define NDT_LAUNCH_MATCH(NN)                                                                                         \
-    hipLaunchKernelGGL(ndt_match_kernel<NN>, dim3((unsigned)n_pairs), dim3(NDT_MATCH_THREADS), 0, stream, tset,      \
-                       tidx_dev, sset, sidx_dev, T16_dev, prm, res_dev, Q36_dev)
+    hipLaunchKernelGGL(ndt_match_kernel<NN>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev, sset, \
+                       sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, (char *)work_dev)
     switch (prm.n_neighbours) {
     case 0: NDT_LAUNCH_MATCH(0); break;
     case 1: NDT_LAUNCH_MATCH(1); break;

@@ -216,11 +216,11 @@ NDT_HD void jacobi_static(double (&a)[N][N], double (&v)[N][N])
     }
 }
 
-// true when the symmetric matrix is positive definite (unpivoted Cholesky, registers only)
+// true when the symmetric matrix is positive definite (unpivoted Cholesky, registers only).  The factor is
+// returned for chol_solve: l = L below the diagonal, dinv[j] = 1 / L[j][j].
 template <int N>
-NDT_HD bool chol_is_pd(const double (&A)[N][N])
+NDT_HD bool chol_is_pd(const double (&A)[N][N], double (&l)[N][N], double (&dinv)[N])
 {
-    double l[N][N];
     bool pd = true;
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -230,6 +230,7 @@ NDT_HD bool chol_is_pd(const double (&A)[N][N])
         pd = pd && (d > 0.0);
         double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
         l[j][j] = d * inv;
+        dinv[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < N; i++) {
             double s = A[i][j];
@@ -239,6 +240,27 @@ NDT_HD bool chol_is_pd(const double (&A)[N][N])
         }
     }
     return pd;
+}
+
+// x = A^-1 b from the Cholesky factor of a positive definite A (forward + back substitution)
+template <int N>
+NDT_HD void chol_solve(const double (&l)[N][N], const double (&dinv)[N], const double (&b)[N], double (&x)[N])
+{
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= l[i][k] * y[k];
+        y[i] = s * dinv[i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) s -= l[k][i] * x[k];
+        x[i] = s * dinv[i];
+    }
 }
 
 // x = A^-1 b by LDL^T with symmetric diagonal pivoting (Hessian.ldlt().solve, fusion.h:966);

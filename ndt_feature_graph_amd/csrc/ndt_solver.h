@@ -242,7 +242,9 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     // H = V diag(evals) V^T, i.e. H + regularizer*I: only lambda_min and lambda_max are needed.  A
     // positive definite H (the usual case near the optimum) is certified by an unpivoted Cholesky
     // and skips the eigen-decomposition altogether.
-    if (!chol_is_pd<6>(H)) {
+    double Lf[6][6], Ldinv[6];
+    const bool is_pd = chol_is_pd<6>(H, Lf, Ldinv);
+    if (!is_pd) {
         double A[6][6], V[6][6];
 #pragma unroll
         for (int a = 0; a < 6; a++)
@@ -267,8 +269,11 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     }
     // fusion.h:966  pose_increment_v = -Hessian.ldlt().solve(score_gradient).  The padded 6x6 system
     // performs exactly the arithmetic of the active block (the padding is decoupled, its solution 0).
+    // A Hessian that the Cholesky test certified positive definite is solved with that factor (same
+    // solution up to rounding, a fraction of the pivoted factorisation's serial latency).
     double dxs[6];
-    ldlt_solve_static6(H, g, dxs);
+    if (is_pd) chol_solve<6>(Lf, Ldinv, g, dxs);
+    else ldlt_solve_static6(H, g, dxs);
     double dginit = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {

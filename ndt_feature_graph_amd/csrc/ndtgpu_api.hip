@@ -50,11 +50,24 @@ struct ndtgpu_mapset {
     size_t stage_bytes = 0;
     double *origins_dev = nullptr;
     size_t origins_cap = 0;
+    // matcher work area: ticket counters, parked list, parked solver states
+    void *work = nullptr;
+    size_t work_bytes = 0;
     // profiling hooks: [0,1] bracket the build kernel, [2,3] the match kernel
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid[2] = {false, false};
 
+    ndtgpu_status ensure_work(size_t bytes)
+    {
+        if (bytes <= work_bytes) return NDTGPU_OK;
+        if (work) (void)hipFree(work);
+        work = nullptr;
+        work_bytes = 0;
+        HIP_TRY(hipMalloc(&work, bytes));
+        work_bytes = bytes;
+        return NDTGPU_OK;
+    }
     ndtgpu_status ensure_stage(size_t bytes)
     {
         if (bytes <= stage_bytes) return NDTGPU_OK;
@@ -140,6 +153,7 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
         return fail(NDTGPU_ERR_ALLOC, "mapset_create: hipMalloc " #ptr, e);        \
     }
     ALLOC(s->v.table, n_maps * (size_t)g.slots * sizeof(int32_t));
+    ALLOC(s->v.rankmap, n_maps * ndt_rm_stride(g) * sizeof(uint2));
     ALLOC(s->v.wtable, n_maps * (size_t)g.slots * sizeof(int32_t));
     ALLOC(s->v.bitmap, n_maps * (size_t)((g.slots + 31) / 32) * sizeof(uint32_t));
     ALLOC(s->v.cells, n_maps * (size_t)cap * sizeof(NdtCell));
@@ -149,6 +163,7 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
     ALLOC(s->v.centres, n_maps * 3 * sizeof(double));
 #undef ALLOC
     if ((e = hipMemset(s->v.table, 0xFF, n_maps * (size_t)g.slots * sizeof(int32_t))) != hipSuccess ||
+        (e = hipMemset(s->v.rankmap, 0, n_maps * ndt_rm_stride(g) * sizeof(uint2))) != hipSuccess ||
         (e = hipMemset(s->v.wtable, 0xFF, n_maps * (size_t)g.slots * sizeof(int32_t))) != hipSuccess ||
         (e = hipMemset(s->v.bitmap, 0, n_maps * (size_t)((g.slots + 31) / 32) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemset(s->v.acc, 0, n_maps * (size_t)cap * sizeof(NdtAcc))) != hipSuccess ||
@@ -167,6 +182,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (!s) return NDTGPU_OK;
     (void)hipDeviceSynchronize();
     if (s->v.table) (void)hipFree(s->v.table);
+    if (s->v.rankmap) (void)hipFree(s->v.rankmap);
     if (s->v.wtable) (void)hipFree(s->v.wtable);
     if (s->v.bitmap) (void)hipFree(s->v.bitmap);
     if (s->v.cells) (void)hipFree(s->v.cells);
@@ -175,6 +191,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (s->v.counters) (void)hipFree(s->v.counters);
     if (s->v.centres) (void)hipFree(s->v.centres);
     if (s->stage) (void)hipFree(s->stage);
+    if (s->work) (void)hipFree(s->work);
     if (s->origins_dev) (void)hipFree(s->origins_dev);
     for (int k = 0; k < 4; k++)
         if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
@@ -457,9 +474,22 @@ static ndtgpu_status match_device_q(ndtgpu_mapset *ts, const uint32_t *tidx_dev,
     NdtMatchParamsDev p = to_dev(prm);
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
+    if (n_pairs == 0) return NDTGPU_OK;
+    // one persistent workgroup per CU (the kernel's registers and LDS allow exactly one); pairs are pulled from
+    // a ticket counter.  NDTGPU_PARK_ITERS: iterations after which a long registration yields to a fresh pair.
+    static const int n_cu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    static const int park_iters = [] { const char *e = getenv("NDTGPU_PARK_ITERS"); return e ? atoi(e) : 6; }();
+    const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
+    ndtgpu_status wrc = ts->ensure_work(ndt_match_work_bytes(n_pairs, n_groups));
+    if (wrc != NDTGPU_OK) return wrc;
     if (ts->profiling) HIP_TRY(hipEventRecord(ts->ev[2], (hipStream_t)stream));
     hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
-                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, (hipStream_t)stream);
+                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, n_groups, park_iters,
+                                    ts->work, (hipStream_t)stream);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
     if (ts->profiling) { HIP_TRY(hipEventRecord(ts->ev[3], (hipStream_t)stream)); ts->ev_valid[1] = true; }
     return NDTGPU_OK;
