@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--res", type=float, default=0.5)
     ap.add_argument("--cpu-sample", type=int, default=768, help="pairs timed on the CPU oracle (0 = skip); ~14 s")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--buffers", type=int, default=2, help="pipeline depth (mapset pairs / streams)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="one stream, one mapset pair: every step waits for the previous one (default: two buffers, the "
+                         "grid builds of step k+1 run on the CUs the matcher of step k has already left)")
     args = ap.parse_args()
 
     import torch
@@ -67,46 +71,89 @@ def main():
     pr = synth.pair_2d(seeds, NP, device=dev, chunk_bytes=2 << 30)
     fixed, moving = pr["fixed"].contiguous(), pr["moving"].contiguous()
     T_init_cm = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)     # column-major Affine3d
-    T16 = T_init_cm.clone()
-    results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
     idx = torch.arange(B, dtype=torch.int32, device=dev)
 
-    tset = N.MapSet(res, [0, 0, 0], size_m, n_maps=B, max_cells=4096)
-    sset = N.MapSet(res, [0, 0, 0], size_m, n_maps=B, max_cells=4096)
-    tset.profiling(True)
-    sset.profiling(True)
-    stream = torch.cuda.current_stream()
-    gathered = None
-    if world > 1:
-        gathered = [torch.empty((world * B, 16), dtype=torch.float64, device=dev),
-                    torch.empty((world * B, 64), dtype=torch.uint8, device=dev)]
+    # Two buffers (mapset pair + outputs + stream).  Steps alternate between them; the builds of step k+1 are
+    # released when the matcher of step k starts: its workgroups leave their CUs as soon as no registration is
+    # left to start (csrc/ndt_match.hip), so the next step's builds fill the CUs that the few long registrations
+    # of this step do not occupy.  Every step still does all of its work; results are identical to the serial run.
+    n_buf = 1 if args.no_pipeline else args.buffers
 
-    def step():
-        tset.build(fixed, range_limit=rng_lim, stream=stream)
-        sset.build(moving, range_limit=rng_lim, stream=stream)
-        T16.copy_(T_init_cm)
-        binding.match_batch_device(tset, idx, sset, idx, T16, results, B, stream=stream)
-        if world > 1:   # final gather of the edge transforms (the only collective on the path)
-            dist.all_gather_into_tensor(gathered[0], T16)
-            dist.all_gather_into_tensor(gathered[1], results)
+    class Buf:
+        pass
+    bufs = []
+    for _ in range(n_buf):
+        b = Buf()
+        b.tset = N.MapSet(res, [0, 0, 0], size_m, n_maps=B, max_cells=4096)
+        b.sset = N.MapSet(res, [0, 0, 0], size_m, n_maps=B, max_cells=4096)
+        b.T16 = T_init_cm.clone()
+        b.results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+        b.stream = torch.cuda.Stream(device=dev)
+        b.gathered = None
+        if world > 1:
+            b.gathered = [torch.empty((world * B, 16), dtype=torch.float64, device=dev),
+                          torch.empty((world * B, 64), dtype=torch.uint8, device=dev)]
+        bufs.append(b)
+    state = {"k": 0, "match_started": None}
+
+    def step(ev=None):
+        b = bufs[state["k"] % n_buf]
+        state["k"] += 1
+        st = b.stream
+        with torch.cuda.stream(st):
+            if n_buf > 1 and state["match_started"] is not None:
+                st.wait_event(state["match_started"])
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if ev is not None else None
+            if marks: marks[0].record(st)
+            b.tset.build(fixed, range_limit=rng_lim, stream=st)
+            if marks: marks[1].record(st)
+            b.sset.build(moving, range_limit=rng_lim, stream=st)
+            if marks: marks[2].record(st)
+            b.T16.copy_(T_init_cm)
+            started = torch.cuda.Event()
+            started.record(st)
+            state["match_started"] = started
+            if marks:
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[4].record(st)
+            binding.match_batch_device(b.tset, idx, b.sset, idx, b.T16, b.results, B, stream=st)
+            if marks:
+                marks[3].record(st)
+                ev.append(marks)
+            if world > 1:   # final gather of the edge transforms (the only collective on the path)
+                dist.all_gather_into_tensor(b.gathered[0], b.T16)
+                dist.all_gather_into_tensor(b.gathered[1], b.results)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    barrier()
+    # isolated kernel durations (one serial step, events inside the library), outside the timed region
+    for b in bufs[:1]:
+        b.tset.profiling(True); b.sset.profiling(True)
+    step(); barrier()
+    iso_build_ms = 0.5 * (bufs[0].tset.last_kernel_ms(0) + bufs[0].sset.last_kernel_ms(0))
+    iso_match_ms = bufs[0].tset.last_kernel_ms(1)
+    for b in bufs[:1]:
+        b.tset.profiling(False); b.sset.profiling(False)
+    state["k"] = 0
+    state["match_started"] = None
+
     for _ in range(args.warmup):
         step()
     barrier()
-    k_build, k_match = [], []
+    marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        # per-kernel HIP-event durations (events recorded on the launch stream inside the library)
-        k_build.append((tset.last_kernel_ms(0), sset.last_kernel_ms(0)))
-        k_match.append(tset.last_kernel_ms(1))
+        step(marks)          # HIP events on the launch stream bracket every kernel of the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    k_build = [(m[0].elapsed_time(m[1]), m[1].elapsed_time(m[2])) for m in marks]
+    k_match = [m[4].elapsed_time(m[3]) for m in marks]
+    last = bufs[(state["k"] - 1) % n_buf]
+    T16, results = last.T16, last.results
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -124,9 +171,11 @@ def main():
     build_bytes = 0.5 * (2 * B * 12.0 * NP + 80.0 * float(m_t.sum() + m_s.sum()))   # per launch
     match_bytes = 80.0 * float(m_t.sum() + m_s.sum())
     kern = {
-        "ndt_build_kernel": {"ms_per_launch": build_ms, "launches_per_step": 2, "algorithmic_bytes": build_bytes,
-                             "GBps": build_bytes / build_ms / 1e6},
-        "ndt_match_kernel": {"ms_per_launch": match_ms, "launches_per_step": 1, "algorithmic_bytes": match_bytes,
+        "ndt_build_kernel": {"ms_per_launch": build_ms, "ms_isolated": iso_build_ms, "launches_per_step": 2,
+                             "algorithmic_bytes": build_bytes, "GBps": build_bytes / build_ms / 1e6,
+                             "GBps_isolated": build_bytes / iso_build_ms / 1e6},
+        "ndt_match_kernel": {"ms_per_launch": match_ms, "ms_isolated": iso_match_ms, "launches_per_step": 1,
+                             "algorithmic_bytes": match_bytes,
                              "GBps": match_bytes / match_ms / 1e6,
                              # k-bar, E and the matcher's fp64 work (SURVEY.md 8d asks for them as measured outputs)
                              "pair_terms_per_launch": int(res_np["pair_terms_g"].sum() + res_np["pair_terms_h"].sum()),
@@ -157,8 +206,10 @@ def main():
         traffic = None
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                "note": "achieved = algorithmic bytes per launch / HIP-event kernel duration (live); traffic = HBM bytes "
-                        "per launch from the rocprofv3 PMC passes committed under profiles/ (not collected live)"}
+                "note": "achieved = algorithmic bytes per launch / HIP-event kernel duration over the timed region (events on "
+                        "the launch stream; with the 2-buffer pipeline a kernel shares the chip with the other step's "
+                        "kernels, kernels.*.ms_isolated is its duration alone); traffic = HBM bytes per launch from the "
+                        "rocprofv3 PMC passes committed under profiles/ (not collected live)"}
 
     out = {
         "metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)",
@@ -169,6 +220,9 @@ def main():
                                "map 100x100x1 m, range 30 m, n_neighbours 2, ITR_MAX 30, DELTA_SCORE 1e-6, 6-DoF, "
                                "grid build of both scans + D2D match per registration" % (B, NP, res),
                    "pairs_per_gpu": B, "points_per_scan": NP, "cell_m": res,
+                   "pipeline": ("serial: one stream" if n_buf == 1 else
+                                "%d buffers / streams: builds of step k+1 start when the matcher of step k starts and run "
+                                "on the CUs its finished workgroups have left" % n_buf),
                    "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2)},
         "roofline": roofline, "kernels": kern,
     }
@@ -209,7 +263,7 @@ def main():
             for _ in range(5):
                 torch.cuda.synchronize()
                 c0 = time.perf_counter()
-                ms.build(scans, range_limit=rng_, stream=stream)
+                ms.build(scans, range_limit=rng_, stream=torch.cuda.current_stream())
                 T, r = N.match_d2d(ms, 0, ms, 1, T0)
                 best = min(best, time.perf_counter() - c0)
             f_h, m_h = fx.cpu().numpy(), mv.cpu().numpy()
