@@ -38,7 +38,7 @@
 #define NDT_FIN_THREADS 1024  // finalise-only launch (MODE 2): more waves to hide the dependent table loads
 #define NDT_PPL 8            // consecutive points per lane per tile
 #define NDT_TILE (64 * NDT_PPL)
-#define NDT_ROUNDS 4         // sub-tiles per super-tile (one wavefront merge + flush per 2048 points)
+#define NDT_ROUNDS 8         // sub-tiles per super-tile (one wavefront merge + flush per 2048 points)
 #define NDT_IDC 64           // entries of the per-wave slot -> id cache
 #define NDT_FLCAP 40         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 160 B)
 #define NDT_QRUNS 12         // per-wave, per-tile queue of evicted runs (third cell within a lane's points)
@@ -141,7 +141,6 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     constexpr int LANE_DW = NDT_PPL * SD + 1;          // +1: odd stride -> conflict-free per-lane walks
     __shared__ __attribute__((aligned(16))) float s_tile[NDT_BUILD_WAVES * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1))];
     __shared__ int s_flid[NDT_BUILD_WAVES * NDT_FLCAP];
-    __shared__ double s_run1[NDT_BUILD_WAVES * 10 * 64];
     __shared__ double s_qval[NDT_BUILD_WAVES * 10 * NDT_QRUNS];
     __shared__ int s_qslot[NDT_BUILD_WAVES * NDT_QRUNS];
     __shared__ unsigned s_qcnt[NDT_BUILD_WAVES];
@@ -189,6 +188,16 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 kz32 = (float)(0.5 + hz - cz * inv_res);
     const float ox32 = (float)ox, oy32 = (float)oy, oz32 = (float)oz;
     const float r2 = (float)(range_limit * range_limit);
+    // fp32 error of v = fma(p, inv32, k32) against (p - c)/res + 0.5 + size/2 for a point in or next to the grid:
+    // inv32, k32 and the fma each round once (2^-24 relative), |p/res| <= |v| + |k|  =>  |error| <= 1.2e-7 (|v| + |k|),
+    // |v| <= size + 1.  Points whose fraction is within twice that bound of a cell face take the exact path; a
+    // point further outside the grid is out of bounds on either path (error < 1 cell up to 2^23 cells, above
+    // that the float -> int conversion saturates).
+    const float kmax = fmaxf(fmaxf(fabsf(kx32), fabsf(ky32)), fabsf(kz32));
+    const float smax = (float)max(max(g.size[0], g.size[1]), g.size[2]) + 1.0f;
+    const float face_guard = 2.4e-7f * (smax + kmax);
+    const float frac_lim = 0.5f - face_guard;            // fast path: |frac - 0.5| <= frac_lim on every axis
+    const bool guard_ok = face_guard < 0.25f;            // absurd centres / sizes: exact path for everything
 
     // ---------------- phase 0: forget the previous content of the slot -> rank table -------------
     if (MODE != 1) {
@@ -257,10 +266,6 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             m &= ~done;
         }
     };
-    // Run 1 of every lane (the second cell its consecutive points fall into, e.g. range noise on a wall
-    // that hugs a cell face) lives in LDS, SoA so that lane l only ever touches bank-distinct words;
-    // run 0 lives in registers.  A third cell within the lane's points evicts run 1 (rare).
-    double *r1 = s_run1 + awave * (10 * 64);
     // evicted runs are queued in LDS and added to their cells at the end of the tile by all lanes in
     // parallel: nothing in the point loop waits for global memory
     double *q_val = s_qval + awave * (10 * NDT_QRUNS);
@@ -272,8 +277,10 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         tile += R;
         if (lane == 0) s_qcnt[wave] = 0;
         int cs0 = -1, cs1 = -1;
-        double rn = 0;
+        bool mru0 = true;                      // run 0 was used more recently than run 1
+        double rn = 0, rn1 = 0;
         double sd[3] = {0, 0, 0}, se[6] = {0, 0, 0, 0, 0, 0};
+        double sd1[3] = {0, 0, 0}, se1[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll 1
         for (unsigned r = 0; r < R; r++) {
         if (STRIDE_DW) {
@@ -314,7 +321,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 const float *pf = (const float *)(pts + (size_t)(valid ? i : 0u) * stride_bytes);
                 fx = pf[0]; fy = pf[1]; fz = pf[2];
             }
-            const bool finite = valid && (fx == fx) && (fy == fy) && (fz == fz);   // NaN points are skipped
+            // NaN points are skipped (an Inf is out of range and out of the grid on any path)
+            const float fsum = fx + fy + fz;
+            const bool finite = valid && (fsum == fsum);
             bool ok = finite;
             // fp32 fast paths ...
             const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
@@ -324,13 +333,11 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             // v = (p - c)/res + 0.5 + size/2 in one fma per axis; the integer part is the cell index
             const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
             const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
-            const float frx = vx - flx, fry = vy - fly, frz = vz - flz;
-            const bool slow_x = !(frx > 1e-3f && frx < 0.999f && fabsf(vx) < 4096.0f);
-            const bool slow_y = !(fry > 1e-3f && fry < 0.999f && fabsf(vy) < 4096.0f);
-            const bool slow_z = !(frz > 1e-3f && frz < 0.999f && fabsf(vz) < 4096.0f);
+            const float tx = fabsf((vx - flx) - 0.5f), ty = fabsf((vy - fly) - 0.5f), tz = fabsf((vz - flz) - 0.5f);
+            const bool slow = !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim);
             int ix = (int)flx, iy = (int)fly, iz = (int)flz;
             // ... and the reference's fp64 formulas for the few points near a cell face / the range sphere
-            const bool need_exact = finite && (force_exact || near_r || slow_x || slow_y || slow_z);
+            const bool need_exact = finite && (force_exact || !guard_ok || near_r || slow);
             if (__ballot(need_exact)) {
                 if (need_exact) {
                     if (near_r) {
@@ -338,9 +345,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                         double ex = (double)fx - ox, ey = (double)fy - oy, ez = (double)fz - oz;
                         ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit);
                     }
-                    if (slow_x || force_exact) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
-                    if (slow_y || force_exact) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
-                    if (slow_z || force_exact) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
+                    if (tx > frac_lim || force_exact || !guard_ok) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
+                    if (ty > frac_lim || force_exact || !guard_ok) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
+                    if (tz > frac_lim || force_exact || !guard_ok) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
                 }
             }
             const bool inb = ok && (unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] &&
@@ -349,61 +356,76 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             dropped += (valid && !inb) ? 1u : 0u;
             NDT_PS(1)
             if (dbg & 16) continue;
+            // A lane keeps the moments of TWO cells in registers (range noise on a wall that hugs a cell face makes
+            // its consecutive points alternate between two cells; a lane that walks into the next cell keeps the
+            // old one as well).  A third cell replaces the run that was used least recently; the replaced run goes
+            // to the wave's LDS queue.  Nothing in the loop touches LDS or memory on the common path.
+            bool in0 = inb && slot == cs0, in1 = inb && slot == cs1;
+            const bool newc = inb && !in0 && !in1;
+            if (__ballot(newc)) {
+                if (newc) {
+                    const bool to1 = cs0 >= 0 && (cs1 < 0 || mru0);   // an empty run first, else the older one
+                    const int victim = to1 ? cs1 : cs0;
+                    if (victim >= 0 && !(dbg & 8)) {
+                        double vn = to1 ? rn1 : rn, v3[3], v6[6];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) v3[k] = to1 ? sd1[k] : sd[k];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) v6[k] = to1 ? se1[k] : se[k];
+                        unsigned pos = __hip_atomic_fetch_add(&s_qcnt[wave], 1u, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        if (pos < NDT_QRUNS) {
+                            q_slot[pos] = victim;
+                            q_val[0 * NDT_QRUNS + pos] = vn;
+#pragma unroll
+                            for (int k = 0; k < 3; k++) q_val[(1 + k) * NDT_QRUNS + pos] = v3[k];
+#pragma unroll
+                            for (int k = 0; k < 6; k++) q_val[(4 + k) * NDT_QRUNS + pos] = v6[k];
+                        } else {                             // queue full (unordered cloud): add directly
+                            double rec[20];
+                            int rid;
+                            write_flush_record(bc, rec, &rid, victim, vn, v3, v6);
+                            if (rid >= 0)
+                                for (int k = 0; k < 19; k++)
+                                    unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + rid) + k, rec[k]);
+                        }
+                    }
+                    if (to1) {
+                        cs1 = slot; rn1 = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) sd1[k] = 0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) se1[k] = 0;
+                        in1 = true;
+                    } else {
+                        cs0 = slot; rn = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) sd[k] = 0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) se[k] = 0;
+                        in0 = true;
+                    }
+                }
+            }
             // offset from the point's own cell origin: |d| <= one cell, no cancellation later on
             const double x = (double)fx - (cx + ((double)ix - hx) * res);
             const double y = (double)fy - (cy + ((double)iy - hy) * res);
             const double z = (double)fz - (cz + ((double)iz - hz) * res);
-            // Move-to-front: the cell of the current point is always run 0 (registers); the previous cell is run 1
-            // (LDS).  A lane that crosses into the next cell pays ONE exchange instead of an LDS read-modify-write
-            // for every remaining point of the super-tile; range noise on a wall that hugs a cell face costs one
-            // exchange per flip.  A third cell evicts run 1 into the queue.
-            if (inb && cs0 < 0) cs0 = slot;                  // first cell of the super-tile
-            const bool other = inb && (slot != cs0);
-            if (__ballot(other)) {
-                if (other) {
-                    if (slot == cs1) {                       // back to the previous cell: exchange the runs
-                        double t;
-                        t = r1[0 * 64 + lane]; r1[0 * 64 + lane] = rn; rn = t;
-#pragma unroll
-                        for (int k = 0; k < 3; k++) { t = r1[(1 + k) * 64 + lane]; r1[(1 + k) * 64 + lane] = sd[k]; sd[k] = t; }
-#pragma unroll
-                        for (int k = 0; k < 6; k++) { t = r1[(4 + k) * 64 + lane]; r1[(4 + k) * 64 + lane] = se[k]; se[k] = t; }
-                        cs1 = cs0;
-                    } else {
-                        if (cs1 >= 0 && !(dbg & 8)) {        // a third cell -> evict run 1 into the queue
-                            unsigned pos = __hip_atomic_fetch_add(&s_qcnt[wave], 1u, __ATOMIC_RELAXED,
-                                                                  __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            if (pos < NDT_QRUNS) {
-                                q_slot[pos] = cs1;
-#pragma unroll
-                                for (int k = 0; k < 10; k++) q_val[k * NDT_QRUNS + pos] = r1[k * 64 + lane];
-                            } else {                         // queue full (unordered cloud): add directly
-                                double v3[3] = {r1[1 * 64 + lane], r1[2 * 64 + lane], r1[3 * 64 + lane]};
-                                double v6[6] = {r1[4 * 64 + lane], r1[5 * 64 + lane], r1[6 * 64 + lane],
-                                                r1[7 * 64 + lane], r1[8 * 64 + lane], r1[9 * 64 + lane]};
-                                double rec[20];
-                                int rid;
-                                write_flush_record(bc, rec, &rid, cs1, r1[lane], v3, v6);
-                                if (rid >= 0)
-                                    for (int k = 0; k < 19; k++)
-                                        unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + rid) + k, rec[k]);
-                            }
-                        }
-                        cs1 = cs0;                           // run 0 becomes run 1, a fresh run 0 starts
-                        r1[0 * 64 + lane] = rn; rn = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; k++) { r1[(1 + k) * 64 + lane] = sd[k]; sd[k] = 0; }
-#pragma unroll
-                        for (int k = 0; k < 6; k++) { r1[(4 + k) * 64 + lane] = se[k]; se[k] = 0; }
-                    }
-                    cs0 = slot;
-                }
-            }
-            if (inb) {
+            if (in0) {
                 rn += 1.0;
                 sd[0] += x; sd[1] += y; sd[2] += z;
                 se[0] = fma(x, x, se[0]); se[1] = fma(x, y, se[1]); se[2] = fma(x, z, se[2]);
                 se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
+                mru0 = true;
+            }
+            if (__ballot(in1)) {
+                if (in1) {
+                    rn1 += 1.0;
+                    sd1[0] += x; sd1[1] += y; sd1[2] += z;
+                    se1[0] = fma(x, x, se1[0]); se1[1] = fma(x, y, se1[1]); se1[2] = fma(x, z, se1[2]);
+                    se1[3] = fma(y, y, se1[3]); se1[4] = fma(y, z, se1[4]); se1[5] = fma(z, z, se1[5]);
+                    mru0 = false;
+                }
             }
             NDT_PS(2)
         }
@@ -416,11 +438,11 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             if (__ballot(swap)) {
                 if (swap) {
                     double t;
-                    t = r1[0 * 64 + lane]; r1[0 * 64 + lane] = rn; rn = t;
+                    t = rn1; rn1 = rn; rn = t;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { t = r1[(1 + k) * 64 + lane]; r1[(1 + k) * 64 + lane] = sd[k]; sd[k] = t; }
+                    for (int k = 0; k < 3; k++) { t = sd1[k]; sd1[k] = sd[k]; sd[k] = t; }
 #pragma unroll
-                    for (int k = 0; k < 6; k++) { t = r1[(4 + k) * 64 + lane]; r1[(4 + k) * 64 + lane] = se[k]; se[k] = t; }
+                    for (int k = 0; k < 6; k++) { t = se1[k]; se1[k] = se[k]; se[k] = t; }
                     int ti = cs0; cs0 = cs1; cs1 = ti;
                 }
             }
@@ -429,14 +451,14 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 int cs = cs0;
                 if (pass == 1) {
                     if (!__ballot(cs1 >= 0)) break;
-                    // second pass: the lanes' run 1, fetched from LDS
+                    // second pass: the lanes' run 1
                     const bool has = cs1 >= 0;
                     cs = cs1;
-                    rn = has ? r1[0 * 64 + lane] : 0.0;
+                    rn = has ? rn1 : 0.0;
 #pragma unroll
-                    for (int k = 0; k < 3; k++) sd[k] = has ? r1[(1 + k) * 64 + lane] : 0.0;
+                    for (int k = 0; k < 3; k++) sd[k] = has ? sd1[k] : 0.0;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) se[k] = has ? r1[(4 + k) * 64 + lane] : 0.0;
+                    for (int k = 0; k < 6; k++) se[k] = has ? se1[k] : 0.0;
                 }
                 // segmented wavefront reduction over contiguous lanes that hold the same cell
                 int prev = __shfl_up(cs, 1, 64);
