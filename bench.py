@@ -134,6 +134,9 @@ def main():
     for b in bufs[:1]:
         b.tset.profiling(True); b.sset.profiling(True)
     step(); barrier()
+    state["k"] = 0
+    state["match_started"] = None
+    step(); barrier()          # the second serial step on buffer 0: code objects loaded, allocations done
     iso_build_ms = 0.5 * (bufs[0].tset.last_kernel_ms(0) + bufs[0].sset.last_kernel_ms(0))
     iso_match_ms = bufs[0].tset.last_kernel_ms(1)
     for b in bufs[:1]:

@@ -41,7 +41,7 @@
 #define NDT_ROUNDS 8         // sub-tiles per super-tile (one wavefront merge + flush per 2048 points)
 #define NDT_IDC 64           // entries of the per-wave slot -> id cache
 #define NDT_FLCAP 40         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 160 B)
-#define NDT_QRUNS 12         // per-wave, per-tile queue of evicted runs (third cell within a lane's points)
+#define NDT_QRUNS 16         // per-wave table of replaced runs, keyed by cell (power of two)
 #define NDT_EMPTY (-1)
 
 namespace {
@@ -211,6 +211,11 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         if (MODE == 0 && tid == 0) ctr->overflow = 0;
     }
     if (tid == 0) { s_base = 0; s_dropped = 0; }
+    if (MODE != 2) {
+        for (unsigned i = tid; i < NDT_BUILD_WAVES * NDT_QRUNS; i += nthreads) s_qslot[i] = -1;
+        for (unsigned i = tid; i < NDT_BUILD_WAVES * 10 * NDT_QRUNS; i += nthreads) s_qval[i] = 0.0;
+        if (tid < NDT_BUILD_WAVES) s_qcnt[tid] = 0u;
+    }
     __syncthreads();
 
     // ---------------- phase A: key + accumulate ----------------------------------------------------
@@ -218,9 +223,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     unsigned dropped = 0;
 #ifdef NDT_PROFILE_SECTIONS
     long long ps[4] = {0, 0, 0, 0}, pt = clock64();
+    long long qs[4] = {0, 0, 0, 0};
+#define NDT_QS(k) { long long now_ = clock64(); qs[k] += now_ - pt; ps[2] += now_ - pt; pt = now_; }
 #define NDT_PS(k) { long long now_ = clock64(); ps[k] += now_ - pt; pt = now_; }
 #else
 #define NDT_PS(k)
+#define NDT_QS(k)
 #endif
     // The scan is cut into sub-tiles of 512 points (64 lanes x 8 points).  A wave owns a contiguous range of
     // sub-tiles and walks it in SUPER-TILES of up to NDT_ROUNDS sub-tiles: lane l owns 8*R consecutive points of
@@ -275,7 +283,6 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         const unsigned R = min((unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
         const unsigned p0 = tile * NDT_TILE;                              // its first point
         tile += R;
-        if (lane == 0) s_qcnt[wave] = 0;
         int cs0 = -1, cs1 = -1;
         bool mru0 = true;                      // run 0 was used more recently than run 1
         double rn = 0, rn1 = 0;
@@ -361,7 +368,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             // old one as well).  A third cell replaces the run that was used least recently; the replaced run goes
             // to the wave's LDS queue.  Nothing in the loop touches LDS or memory on the common path.
             bool in0 = inb && slot == cs0, in1 = inb && slot == cs1;
-            const bool newc = inb && !in0 && !in1;
+            bool newc = inb && !in0 && !in1;
+            if (dbg & 32) { in0 = inb; in1 = false; newc = false; }
+            if (dbg & 64) { newc = newc && (cs0 < 0 || cs1 < 0); }
             if (__ballot(newc)) {
                 if (newc) {
                     const bool to1 = cs0 >= 0 && (cs1 < 0 || mru0);   // an empty run first, else the older one
@@ -372,16 +381,29 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                         for (int k = 0; k < 3; k++) v3[k] = to1 ? sd1[k] : sd[k];
 #pragma unroll
                         for (int k = 0; k < 6; k++) v6[k] = to1 ? se1[k] : se[k];
-                        unsigned pos = __hip_atomic_fetch_add(&s_qcnt[wave], 1u, __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        if (pos < NDT_QRUNS) {
-                            q_slot[pos] = victim;
-                            q_val[0 * NDT_QRUNS + pos] = vn;
+                        // the replaced run is ADDED to the wave's LDS table entry of its cell (lanes that bounce
+                        // between three or four cells at a cell corner replace a run at almost every point: the
+                        // table keeps one record per cell however often that happens).  All additions to a
+                        // wave's table come from that wave, in program order.
+                        unsigned e = ((unsigned)victim * 0x9E3779B1u) >> 28;
+                        bool placed = false;
+#pragma unroll 1
+                        for (int probe = 0; probe < 4 && !placed; probe++) {
+                            const int old = atomicCAS(&q_slot[e], -1, victim);
+                            if (old == -1 || old == victim) {
+                                unsafeAtomicAdd(&q_val[0 * NDT_QRUNS + e], vn);
 #pragma unroll
-                            for (int k = 0; k < 3; k++) q_val[(1 + k) * NDT_QRUNS + pos] = v3[k];
+                                for (int k = 0; k < 3; k++) unsafeAtomicAdd(&q_val[(1 + k) * NDT_QRUNS + e], v3[k]);
 #pragma unroll
-                            for (int k = 0; k < 6; k++) q_val[(4 + k) * NDT_QRUNS + pos] = v6[k];
-                        } else {                             // queue full (unordered cloud): add directly
+                                for (int k = 0; k < 6; k++) unsafeAtomicAdd(&q_val[(4 + k) * NDT_QRUNS + e], v6[k]);
+                                placed = true;
+                            } else {
+                                e = (e + 1u) & (NDT_QRUNS - 1u);
+                            }
+                        }
+                        if (placed) {
+                            s_qcnt[wave] = 1u;
+                        } else {                             // table full (unordered cloud): add directly
                             double rec[20];
                             int rid;
                             write_flush_record(bc, rec, &rid, victim, vn, v3, v6);
@@ -407,6 +429,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                     }
                 }
             }
+            NDT_QS(0)
             // offset from the point's own cell origin: |d| <= one cell, no cancellation later on
             const double x = (double)fx - (cx + ((double)ix - hx) * res);
             const double y = (double)fy - (cy + ((double)iy - hy) * res);
@@ -418,6 +441,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
                 mru0 = true;
             }
+            NDT_QS(1)
             if (__ballot(in1)) {
                 if (in1) {
                     rn1 += 1.0;
@@ -427,7 +451,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                     mru0 = false;
                 }
             }
-            NDT_PS(2)
+            NDT_QS(2)
         }
         }   // rounds
         if (!(dbg & 2)) {
@@ -479,15 +503,21 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 }
                 push_runs(head && cs >= 0, cs, rn, sd, se);
             }
-            unsigned qn = s_qcnt[wave];
-            if (qn > NDT_QRUNS) qn = NDT_QRUNS;
-            if (qn) {
-                const bool has = lane < qn;
-                const unsigned ql = has ? lane : 0u;
+            if (s_qcnt[wave]) {                  // records of the replaced runs; the table goes back to empty
+                const unsigned ql = lane & (NDT_QRUNS - 1u);
+                const int qs = q_slot[ql];
+                const bool has = lane < NDT_QRUNS && qs >= 0;
                 double v3[3] = {q_val[1 * NDT_QRUNS + ql], q_val[2 * NDT_QRUNS + ql], q_val[3 * NDT_QRUNS + ql]};
                 double v6[6] = {q_val[4 * NDT_QRUNS + ql], q_val[5 * NDT_QRUNS + ql], q_val[6 * NDT_QRUNS + ql],
                                 q_val[7 * NDT_QRUNS + ql], q_val[8 * NDT_QRUNS + ql], q_val[9 * NDT_QRUNS + ql]};
-                push_runs(has, q_slot[ql], q_val[ql], v3, v6);
+                const double vn = q_val[ql];
+                if (lane < NDT_QRUNS) {
+                    q_slot[ql] = -1;
+#pragma unroll
+                    for (int k = 0; k < 10; k++) q_val[k * NDT_QRUNS + ql] = 0.0;
+                }
+                if (lane == 0) s_qcnt[wave] = 0u;
+                push_runs(has, qs, vn, v3, v6);
             }
             drain_list();
         }
@@ -652,6 +682,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         ctr->cyc[3] = (uint32_t)((long long)__builtin_readcyclecounter() - t3);
 #ifdef NDT_PROFILE_SECTIONS
         for (int k = 0; k < 4; k++) ctr->cyc[k] = (uint32_t)(ps[k] >> 4);   // wave 0: load, bin, accumulate, merge+flush (x16 cycles)
+#ifdef NDT_PROFILE_ACC
+        for (int k = 0; k < 4; k++) ctr->cyc[k] = (uint32_t)(qs[k] >> 4);   // cell bookkeeping, offsets + run 0, run 1, -
+#endif
 #endif
     }
 }
