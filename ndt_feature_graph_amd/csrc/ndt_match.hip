@@ -81,27 +81,31 @@ NDT_D double pl_swap_add(double a, double b, bool rows16)
     return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
 }
 
+template <int N, int HALF, int O>
+NDT_D void wave_sum_step(double (&v)[N], unsigned lane)
+{
+#pragma unroll
+    for (int k = 0; k < HALF; k++) {
+        if constexpr (O >= 16) {
+            v[k] = pl_swap_add(v[k], v[k + HALF], O == 16);
+        } else {
+            const bool up = (lane & (unsigned)O) != 0;
+            const double keep = up ? v[k + HALF] : v[k], send = up ? v[k] : v[k + HALF];
+            v[k] = keep + __shfl_xor(send, O, 64);
+        }
+    }
+    if constexpr (HALF > 1) wave_sum_step<N, HALF / 2, O / 2>(v, lane);   // static indices only: v stays in registers
+}
+
 template <int N>
 NDT_D double wave_sum_all(double (&v)[N])
 {
     static_assert(N == 8 || N == 32, "padded value count");
     const unsigned lane = threadIdx.x & 63u;
-    int o = 32;
-#pragma unroll
-    for (int n = N / 2; n >= 1; n >>= 1, o >>= 1) {
-#pragma unroll
-        for (int k = 0; k < n; k++) {
-            if (o >= 16) {
-                v[k] = pl_swap_add(v[k], v[k + n], o == 16);
-            } else {
-                const bool up = (lane & (unsigned)o) != 0;
-                const double keep = up ? v[k + n] : v[k], send = up ? v[k] : v[k + n];
-                v[k] = keep + __shfl_xor(send, o, 64);
-            }
-        }
-    }
+    wave_sum_step<N, N / 2, 32>(v, lane);
     double t = v[0];
-    for (; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+#pragma unroll
+    for (int o = 64 / (2 * N); o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
     return t;
 }
 

@@ -22,6 +22,11 @@ struct MatchState {
     double stp, finit, dginit, dgtest, width, width1, stx, fx, dgx, sty, fy, dgy, stmin, stmax;
     int brackt, stage1, nfev, infoc;
     int itr_ctr, fevals, ret, exit_code, phase, with_h, done;
+    // The first More-Thuente trial (stp = 1) is usually accepted, and the next Newton iteration then evaluates
+    // score, gradient AND Hessian at exactly the pose of that trial.  While trials keep being accepted first
+    // time (spec_ok) the trial is evaluated with its Hessian and the Newton iteration consumes those sums
+    // instead of a second evaluation of the same pose (it still counts as an evaluation in `fevals`).
+    int spec_ok, trial_has_h, reuse_sums;
     // matchFusion soft constraint (fusion.h:875-890): X = pose_local_v, Q = Tcov^-1 (row-major)
     int use_prior;
     double pose_local[6];
@@ -156,7 +161,8 @@ NDT_HDN void mt_request_trial(MatchState &st)
     rigid ps;
     pose_to_rigid(pincr, ps);
     rigid_mul(ps, st.T, st.Teval);     // trial cells = ps * nextNDT (fusion.h:556-589)
-    st.with_h = 0;
+    st.trial_has_h = (st.nfev == 0 && st.spec_ok) ? 1 : 0;
+    st.with_h = st.trial_has_h;
     st.phase = PH_LS_TRIAL;
 }
 
@@ -322,6 +328,16 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
 }
 
 // tail of the More-Thuente while(1) body after the trial evaluation (fusion.h:637-790)
+// last evaluation at the returned pose (fusion.h:1085-1121)
+NDT_HD void match_state_final(MatchState &st, const double *sums)
+{
+    st.fevals++;
+    st.score_here = sums[0];
+    if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:1098-1110
+    if (st.score_here > st.score_best) st.T = st.Tbest;
+    st.done = 1;
+}
+
 NDT_HDN void linesearch_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
 {
     const double ftol = 0.11111, gtol = 0.99999, stpmax = 4.0, stpmin = 0.001, xtol = 0.01, recoverystep = 0.1;
@@ -340,7 +356,12 @@ NDT_HDN void linesearch_step(MatchState &st, const double *sums, const NdtMatchP
     if (st.brackt && (st.stmax - st.stmin <= xtol * st.stmax)) info = 2;
     if ((f <= ftest1) && (fabs(dg) <= gtol * (-st.dginit))) info = 1;
     if (info != 0) {
+        const bool first_accepted = (info == 1) && (st.nfev == 1);
+
+        const bool reuse = first_accepted && st.trial_has_h;      // sums hold the Hessian at the accepted pose
+        st.spec_ok = first_accepted ? 1 : 0;
         apply_step(st, (info == 1) ? st.stp : recoverystep, prm);
+        st.reuse_sums = (reuse && !st.done) ? 1 : 0;   // match_state_step consumes the sums once more
         return;
     }
     if (st.stage1 && (f <= ftest1) && (dg >= dmin(ftol, gtol) * st.dginit)) st.stage1 = 0;
@@ -389,6 +410,7 @@ NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchPa
     st.score_best = DBL_MAX; st.score_here = 0;
     st.itr_ctr = 0; st.fevals = 0; st.ret = 1; st.exit_code = 0;
     st.phase = PH_NEWTON; st.with_h = 1; st.done = 0;
+    st.spec_ok = 0; st.trial_has_h = 0; st.reuse_sums = 0;   // the first line search is rarely a full step
     if ((prm.dof_mask & 0x3f) == 0 || prm.n_neighbours < 0 || prm.n_neighbours > 3) { st.done = 1; st.ret = 0; st.exit_code = -1; }
 }
 
@@ -396,15 +418,15 @@ NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchPa
 // triangle of the Hessian) and either requests the next evaluation or finishes
 NDT_HD void match_state_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
 {
-    if (st.phase == PH_NEWTON) newton_step(st, sums, prm);
-    else if (st.phase == PH_LS_TRIAL) linesearch_step(st, sums, prm);
-    else {   // PH_FINAL: fusion.h:1085-1121
-        st.fevals++;
-        st.score_here = sums[0];
-        if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:1098-1110
-        if (st.score_here > st.score_best) st.T = st.Tbest;
-        st.done = 1;
+    if (st.phase == PH_LS_TRIAL) {
+        st.reuse_sums = 0;
+        linesearch_step(st, sums, prm);
+        // an accepted first trial that was evaluated with its Hessian: the evaluation apply_step just requested
+        // is the one these sums come from (same cells, same pose)
+        if (!st.reuse_sums) return;
     }
+    if (st.phase == PH_NEWTON) newton_step(st, sums, prm);
+    else if (st.phase == PH_FINAL) match_state_final(st, sums);
 }
 
 NDT_HD void match_state_result(const MatchState &st, double *T16, NdtMatchResultDev &o)
