@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--res", type=float, default=0.5)
@@ -133,10 +133,11 @@ def main():
     # isolated kernel durations (one serial step, events inside the library), outside the timed region
     for b in bufs[:1]:
         b.tset.profiling(True); b.sset.profiling(True)
-    step(); barrier()
+    for _ in range(n_buf):     # one serial step per buffer: code objects loaded, every buffer's pages touched
+        step(); barrier()
+        state["match_started"] = None
     state["k"] = 0
-    state["match_started"] = None
-    step(); barrier()          # the second serial step on buffer 0: code objects loaded, allocations done
+    step(); barrier()          # isolated kernel durations: a warm serial step on buffer 0
     iso_build_ms = 0.5 * (bufs[0].tset.last_kernel_ms(0) + bufs[0].sset.last_kernel_ms(0))
     iso_match_ms = bufs[0].tset.last_kernel_ms(1)
     for b in bufs[:1]:

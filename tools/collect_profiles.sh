@@ -3,11 +3,13 @@
 # PMC passes are separate (--pmc never combined with trace domains) and restricted to our kernels.
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-CMD="python bench.py --steps 5 --warmup 1 --no-cpu"
+CMD="python bench.py --steps 10 --warmup 2 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o bench -- $CMD > gpurun_out/bench_kt.log 2>&1
+# the same workload without the two-buffer pipeline: kernel durations with the chip to themselves
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_serial -o bench -- $CMD --no-pipeline > gpurun_out/bench_kt_serial.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_fetch -o bench -- $CMD > gpurun_out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_write -o bench -- $CMD > gpurun_out/bench_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_sq -o bench -- $CMD > gpurun_out/bench_sq.log 2>&1
-python bench.py --steps 5 --warmup 1 > gpurun_out/bench_full.log 2>&1
+python bench.py > gpurun_out/bench_full.log 2>&1
 tail -1 gpurun_out/bench_full.log
-find gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq -name "*.csv" | head -20
+find gpurun_out/prof_kt gpurun_out/prof_kt_serial gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq -name "*.csv" | head -20

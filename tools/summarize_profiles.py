@@ -13,6 +13,16 @@ with open(os.path.join(pr, "%s_bench_kernel_stats.csv" % tag), "w", newline="") 
     for r in rows[:20]:
         w.writerow([(v[:110] if isinstance(v, str) else v) for v in r.values()])
 ours = {r["Name"][:24]: r for r in rows if "ndt_" in r["Name"]}
+serial = {}
+sp = os.path.join(go, "prof_kt_serial", "bench_kernel_stats.csv")
+if os.path.exists(sp):
+    srows = list(csv.DictReader(open(sp)))
+    with open(os.path.join(pr, "%s_bench_kernel_stats_serial.csv" % tag), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(list(srows[0].keys()))
+        for r in srows[:20]:
+            w.writerow([(v[:110] if isinstance(v, str) else v) for v in r.values()])
+    serial = {("ndt_build_kernel" if "build" in r["Name"] else "ndt_match_kernel"): r for r in srows if "ndt_build" in r["Name"] or "ndt_match" in r["Name"]}
 # PMC
 def pmc(dirname):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -21,7 +31,7 @@ def pmc(dirname):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 fetch, write, sq = pmc("prof_fetch"), pmc("prof_write"), pmc("prof_sq")
-out = {"command": "python bench.py --steps 5 --warmup 1 --no-cpu (1024 pairs x 100k pts)",
+out = {"command": "python bench.py --steps 10 --warmup 2 --no-cpu (1024 pairs x 100k pts, two-buffer pipeline; *_serial: same with --no-pipeline)",
        "note": "FETCH_SIZE / WRITE_SIZE are in KB per dispatch (rocprofv3, separate --pmc passes, --kernel-include-regex ndt_). "
                "On gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM): "
                "hbm_read_bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken at face value (uncalibrated).",
@@ -34,5 +44,7 @@ for k in ("ndt_build_kernel", "ndt_match_kernel"):
 for name, r in ours.items():
     key = "ndt_build_kernel" if "build" in r["Name"] else "ndt_match_kernel"
     out["kernels"][key]["avg_ns"] = float(r["AverageNs"]); out["kernels"][key]["calls"] = int(r["Calls"])
+for key, r in serial.items():
+    out["kernels"][key]["avg_ns_serial"] = float(r["AverageNs"])
 json.dump(out, open(os.path.join(pr, "%s_pmc_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
