@@ -229,6 +229,9 @@ def main():
                                 "on the CUs its finished workgroups have left" % n_buf),
                    "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2)},
         "roofline": roofline, "kernels": kern,
+        # SURVEY.md 8d (config 4): node maps and edges are separate units when node maps are reused across edges
+        "nodes_per_s_build_only": world * B / (iso_build_ms * 1e-3),
+        "edges_per_s_match_only_prebuilt_maps": world * B / (iso_match_ms * 1e-3),
     }
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ---------------------------

@@ -482,7 +482,8 @@ static ndtgpu_status match_device_q(ndtgpu_mapset *ts, const uint32_t *tidx_dev,
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
         return v;
     }();
-    static const int park_iters = [] { const char *e = getenv("NDTGPU_PARK_ITERS"); return e ? atoi(e) : 6; }();
+    const char *park_env = getenv("NDTGPU_PARK_ITERS");       // read per call: tests switch it
+    const int park_iters = park_env ? atoi(park_env) : 6;
     const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
     ndtgpu_status wrc = ts->ensure_work(ndt_match_work_bytes(n_pairs, n_groups));
     if (wrc != NDTGPU_OK) return wrc;

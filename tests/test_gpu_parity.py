@@ -210,7 +210,7 @@ def test_derivatives_on_scan_maps(N, O):
 
 
 # ---------------------------------------------------------------------------------------------
-def _pair_maps(N, O, seeds, n_pts, res):
+def _pair_maps(N, O, seeds, n_pts, res, oracle_maps=True):
     from ndt_feature_graph_amd import synth
     pr = synth.pair_2d(seeds, n_pts)
     B = len(seeds)
@@ -219,7 +219,7 @@ def _pair_maps(N, O, seeds, n_pts, res):
     tg.build(pr["fixed"].numpy(), range_limit=30.0)
     sr.build(pr["moving"].numpy(), range_limit=30.0)
     om = [(oracle_map(O, pr["fixed"][b].numpy(), res, [100, 100, 1]),
-           oracle_map(O, pr["moving"][b].numpy(), res, [100, 100, 1])) for b in range(B)]
+           oracle_map(O, pr["moving"][b].numpy(), res, [100, 100, 1])) for b in range(B)] if oracle_maps else None
     return pr, tg, sr, om
 
 
@@ -305,6 +305,28 @@ def test_persistent_and_host_driven_paths_agree(N, O):
         To, ro = O.match_d2d(om[b][0], om[b][1], T0[b])
         dt, dr = pose_close(Ts, To)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_scheduler_parking_is_bit_neutral(N, O, monkeypatch):
+    """The persistent matcher pulls pairs from a ticket counter and parks long registrations
+    (csrc/ndt_match.hip: NdtMatchWork).  Parking saves and restores the solver state bit for bit: more pairs than
+    CUs, parking after 0 (off) / 1 / 3 iterations -> identical transforms, iteration and evaluation counts."""
+    n = 600                                                      # > 256 workgroups: tickets are drawn twice
+    pr, tg, sr, om = _pair_maps(N, O, [1 + (k % 24) for k in range(24)], 6000, 1.0, oracle_maps=False)
+    idx = np.arange(n) % 24
+    T0 = pr["T_init"].numpy()[idx]
+    ref = None
+    for park in ("0", "1", "3"):
+        monkeypatch.setenv("NDTGPU_PARK_ITERS", park)
+        T, r = N.match_batch(tg, idx, sr, idx, T0)
+        if ref is None:
+            ref = (T, r)
+            # the same pair gives the same bits wherever it sits in the batch
+            assert np.array_equal(T[:24], T[24:48]) and np.array_equal(r["fevals"][:24], r["fevals"][576:600])
+        else:
+            assert np.array_equal(T, ref[0])
+            for f in ("iterations", "fevals", "converged", "exit_code", "score", "pair_terms_g", "pair_terms_h"):
+                assert np.array_equal(r[f], ref[1][f]), f
 
 
 def test_self_match_and_empty_maps(N):
