@@ -605,6 +605,13 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             }
         }
         *reinterpret_cast<NdtCell *>(tmp_base + id) = c;
+        // a touched cell without a Gaussian leaves the occupancy bitmap here, so that phase C finds exactly the
+        // Gaussian cells in it (n == 0: an id wasted by an allocation race, it has no slot)
+        if (n > 0 && c.n == 0) {
+            const unsigned sl = bc.acc_slot[id];
+            __hip_atomic_fetch_and(&bc.bitmap[sl >> 5], ~(1u << (sl & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bc.wtable[sl] = NDT_EMPTY;
+        }
     }
     __syncthreads();
 
@@ -624,12 +631,16 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     };
     const unsigned words_per_wave = (bm_words + nwaves - 1) / nwaves;
     const unsigned wb = min(bm_words, wave * words_per_wave), we = min(bm_words, wb + words_per_wave);
+    // More touched cells than accumulators (overflow): slots whose id is past the capacity still have their bit
+    // and must be filtered through the work table; otherwise the bitmap IS the set of Gaussian cells.
+    const bool ovf = __hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    auto gauss_bits = [&](unsigned w) {
+        unsigned bits = __hip_atomic_load(&bc.bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (ovf && bits) ? valid_bits(w, bits) : bits;
+    };
     {
         unsigned cnt = 0;
-        for (unsigned w = wb + lane; w < we; w += 64u) {
-            unsigned bits = bc.bitmap[w];
-            if (bits) cnt += (unsigned)__popc(valid_bits(w, bits));
-        }
+        for (unsigned w = wb + lane; w < we; w += 64u) cnt += (unsigned)__popc(gauss_bits(w));
         unsigned incl = wave_incl_scan(cnt);
         if (lane == 63) s_wave_cnt[wave] = incl;
     }
@@ -642,9 +653,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     }
     for (unsigned step = wb; step < we; step += 64u) {
         unsigned w = step + lane;
-        unsigned bits = (w < we) ? bc.bitmap[w] : 0u;
+        unsigned bits = (w < we) ? __hip_atomic_load(&bc.bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (!__ballot(bits != 0u)) continue;
-        unsigned vmask = bits ? valid_bits(w, bits) : 0u;
+        unsigned vmask = (ovf && bits) ? valid_bits(w, bits) : bits;
         unsigned cnt = (unsigned)__popc(vmask);
         unsigned incl = wave_incl_scan(cnt);
         unsigned before = running + incl - cnt;
