@@ -242,7 +242,9 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
         // neighbours along z are one run of <= W bits, and in a flat map (sz <= n+1: every z-layer is a
         // neighbour) the whole (y, z) block of one x is a single run of <= W*sz bits.  Cells are ranked in slot
         // order, so the k-th set bit of a run is cell `first + k`: no per-slot lookups.
-        const bool flat = tg.sz <= NN + 1;                       // wave-uniform
+        // flat form only when every lane's z-neighbourhood is the whole column (a source cell that lies two or
+        // more cells above / below a thin map sees only part of it, or nothing): wave-uniform
+        const bool flat = tg.sz <= NN + 1 && !__ballot(vi && !(iz - NN <= 0 && iz + NN >= tg.sz - 1));
         const int n_runs = flat ? 1 : W;
         const int zlo = flat ? 0 : max(iz - NN, 0), zhi = flat ? tg.sz - 1 : min(iz + NN, tg.sz - 1);
         const char *rmb = reinterpret_cast<const char *>(tg.rankmap);

@@ -192,6 +192,45 @@ def test_derivatives_golden_and_oracle(N, O, golden):
     assert np.max(np.abs(H - golden["d2d_hess_fd"])) < 2e-5 * np.max(np.abs(H))
 
 
+@pytest.mark.parametrize("size_cells,nn", [((12, 9, 7), 1), ((12, 9, 7), 2), ((12, 9, 7), 3), ((40, 33, 2), 2),
+                                           ((40, 33, 1), 3), ((5, 70, 3), 2), ((6, 6, 6), 0)])
+def test_probe_rank_bitmap_windows(N, O, size_cells, nn):
+    """The matcher finds the (2n+1)^3 neighbours through bit windows of the rank bitmap (csrc/ndt_match.hip PROBE):
+    random lattices of target cells (about half of the slots filled, so windows start at every bit offset and
+    straddle 32-slot words), source cells everywhere including outside the grid and on its border; both the
+    flat-map form (sz <= n+1: one window per x) and the general form (one window per (x, y)).  The pair set must
+    equal getCellsForPoint's: score, gradient and Hessian agree with the oracle to rounding."""
+    rng = np.random.default_rng(size_cells[0] * 100 + size_cells[2] * 10 + nn)
+    res = 0.5
+    size_m = [c * res for c in size_cells]
+    sx, sy, sz = size_cells
+    ix, iy, iz = np.meshgrid(np.arange(sx), np.arange(sy), np.arange(sz), indexing="ij")
+    keep = rng.random(ix.shape) < 0.5
+    idx = np.stack([ix[keep], iy[keep], iz[keep]], axis=1)
+    # LazyGrid: i = (int)(floor((p - c)/res + 0.5) + size/2.0)  =>  cell i is centred at c + (i - floor(size/2)) * res
+    ctr = (idx - np.array(size_cells) // 2) * res
+    mean = ctr + rng.uniform(-0.2, 0.2, ctr.shape) * res
+    A = rng.normal(size=(len(idx), 3, 3)) * 0.1
+    cov = A @ A.transpose(0, 2, 1) + 0.01 * np.eye(3)
+    tg = N.MapSet(res, [0, 0, 0], size_m, max_cells=max(4096, len(idx) + 8))
+    tg.set_cells(0, mean, cov)
+    assert tg.num_cells() == len(idx)
+    ot = O.OracleMap(res, [0, 0, 0], size_m)
+    ot.set_cells(mean, cov)
+    m = 700
+    half = np.array(size_m) / 2.0
+    smean = rng.uniform(-half - 1.2 * res, half + 1.2 * res, (m, 3))      # some sources outside the grid
+    smean[:40] = np.clip(smean[:40], -half + 1e-3, half - 1e-3)
+    B = rng.normal(size=(m, 3, 3)) * 0.1
+    scov = B @ B.transpose(0, 2, 1) + 0.01 * np.eye(3)
+    s, g, H = N.derivatives(tg, 0, smean, scov, n_neighbours=nn)
+    so, go, Ho = O.derivatives(ot, smean, scov, n_neighbours=nn)
+    assert so != 0.0
+    assert abs(s - so) < 1e-10 * abs(so)
+    assert np.max(np.abs(g - go)) < 1e-9 * np.max(np.abs(go))
+    assert np.max(np.abs(H - Ho)) < 1e-9 * np.max(np.abs(Ho))
+
+
 def test_derivatives_on_scan_maps(N, O):
     from ndt_feature_graph_amd import synth
     pr = synth.pair_2d([5], 60000)
