@@ -118,6 +118,47 @@ def test_build_edge_cases(N, O):
     assert_cells_equal(ms.export_cells(0), m.export_cells(), 1.0)
 
 
+@pytest.mark.parametrize("centre,rng,res", [((0.0, 0.0, 0.0), 20.0, 0.5), ((12.3, -7.65, 0.2), 0.0, 0.5),
+                                            ((-333.3, 200.05, 1.0), 0.0, 0.5), ((-333.3, 200.05, 1.0), 0.0, 0.3)])
+def test_build_binning_at_cell_faces(N, O, centre, rng, res):
+    """Binning must be bit-identical to floor((p - c)/res + 0.5) + size/2 in fp64 (reference LazyGrid).  The kernel
+    evaluates it in fp32 and falls back to the fp64 formula inside a derived guard band around every cell face
+    (csrc/ndt_build.hip: face_guard): points ON faces, 1..4 fp32 ulps on either side of them, and just inside /
+    outside that band, on an even grid whose centre is not a multiple of the cell size, far from the origin, with a
+    cell size whose reciprocal is not an fp32 number (the case where the fp32 evaluation really is off by ~1e-4
+    cell: with the guard disabled this test fails), and next to the range sphere."""
+    g = np.random.default_rng(7)
+    size_cells = np.array([200, 200, 2])
+    c = np.array(centre)
+    n = 60000
+    pts = c + g.uniform(-32.0, 32.0, (n, 3)) * res              # 64 x 64 cells, ~15 points each
+    pts[:, 2] = c[2] + g.uniform(-0.4, 0.4, n) * res
+    k = 24000
+    q = pts[:k].copy()
+    axis = g.integers(0, 2, k)                                  # put one coordinate on / next to a cell face
+    face = c[axis] + (g.integers(-31, 32, k) - 0.5) * res       # faces are at index-space half integers
+    f32 = face.astype(np.float32)
+    steps = g.integers(-4, 5, k)
+    for _ in range(4):
+        f32 = np.where(steps > 0, np.nextafter(f32, np.float32(np.inf)), f32); steps = steps - (steps > 0)
+    steps = -np.minimum(g.integers(-4, 5, k), 0)
+    for _ in range(4):
+        f32 = np.where(steps > 0, np.nextafter(f32, np.float32(-np.inf)), f32); steps = steps - (steps > 0)
+    band = g.choice([0.0, 5e-5, -5e-5, 2e-4, -2e-4, 9e-4, -9e-4], k) * res
+    q[np.arange(k), axis] = f32.astype(np.float64) + band
+    cloud = np.concatenate([q, pts[k:]]).astype(np.float32)
+    if rng > 0:                                                  # a ring of points hugging the range sphere
+        th = g.uniform(0, 2 * np.pi, 4000)
+        rr = rng * (1 + g.choice([0.0, 1e-7, -1e-7, 3e-4, -3e-4, 2e-3, -2e-3], 4000))
+        ring = np.stack([rr * np.cos(th), rr * np.sin(th), np.zeros(4000)], axis=1)
+        cloud = np.concatenate([cloud, ring.astype(np.float32)])
+    ms = N.MapSet(res, list(c), list(size_cells * res))
+    ms.build(cloud[None], range_limit=rng)
+    cpu = oracle_map(O, cloud, res, list(size_cells * res), centre=tuple(c), rng=rng)
+    assert cpu.num_cells() > 2000
+    assert_cells_equal(ms.export_cells(0), cpu.export_cells(), res)
+
+
 def test_build_odd_grid_and_generic_stride(N, O):
     """Odd cell counts (the reference's double->int truncation quirk: every point takes the exact fp64
     index path) and a record stride that is neither 12 nor 16 bytes (generic load path)."""
