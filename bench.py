@@ -210,6 +210,8 @@ def main():
         traffic = None
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                "achieved_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6,
+                "frac_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6 / HBM_PEAK_GBS,
                 "note": "achieved = algorithmic bytes per launch / HIP-event kernel duration over the timed region (events on "
                         "the launch stream; with the 2-buffer pipeline a kernel shares the chip with the other step's "
                         "kernels, kernels.*.ms_isolated is its duration alone); traffic = HBM bytes per launch from the "
