@@ -188,6 +188,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 kz32 = (float)(0.5 + hz - cz * inv_res);
     const float ox32 = (float)ox, oy32 = (float)oy, oz32 = (float)oz;
     const float r2 = (float)(range_limit * range_limit);
+    const float r2eff = range_limit > 0 ? r2 : __builtin_inff();
+    const float r2band = range_limit > 0 ? 1e-3f * r2 : -1.0f;
     // fp32 error of v = fma(p, inv32, k32) against (p - c)/res + 0.5 + size/2 for a point in or next to the grid:
     // inv32, k32 and the fma each round once (2^-24 relative), |p/res| <= |v| + |k|  =>  |error| <= 1.2e-7 (|v| + |k|),
     // |v| <= size + 1.  Points whose fraction is within twice that bound of a cell face take the exact path; a
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     const float kmax = fmaxf(fmaxf(fabsf(kx32), fabsf(ky32)), fabsf(kz32));
     const float smax = (float)max(max(g.size[0], g.size[1]), g.size[2]) + 1.0f;
     const float face_guard = 2.4e-7f * (smax + kmax);
-    const float frac_lim = 0.5f - face_guard;            // fast path: |frac - 0.5| <= frac_lim on every axis
-    const bool guard_ok = face_guard < 0.25f;            // absurd centres / sizes: exact path for everything
+    // fast path: |frac - 0.5| <= frac_lim on every axis; odd sizes / absurd centres: exact path for every point
+    const float frac_lim = (force_exact || !(face_guard < 0.25f)) ? -1.0f : 0.5f - face_guard;
 
     // ---------------- phase 0: forget the previous content of the slot -> rank table -------------
     if (MODE != 1) {
@@ -220,7 +222,6 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
 
     // ---------------- phase A: key + accumulate ----------------------------------------------------
     long long t0 = __builtin_readcyclecounter();
-    unsigned dropped = 0;
 #ifdef NDT_PROFILE_SECTIONS
     long long ps[4] = {0, 0, 0, 0}, pt = clock64();
     long long qs[4] = {0, 0, 0, 0};
@@ -278,13 +279,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     // parallel: nothing in the point loop waits for global memory
     double *q_val = s_qval + awave * (10 * NDT_QRUNS);
     int *q_slot = s_qslot + awave * NDT_QRUNS;
-    const bool use_range = range_limit > 0;
     for (unsigned tile = tile_begin; tile < tile_end;) {
         const unsigned R = min((unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
         const unsigned p0 = tile * NDT_TILE;                              // its first point
         tile += R;
-        int cs0 = -1, cs1 = -1;
-        bool mru0 = true;                      // run 0 was used more recently than run 1
+        int cs0 = -2, cs1 = -3;                // empty (negative, and never equal to the "no cell" slot -1)
+        int mru1 = 0;                          // 1: run 1 was used more recently than run 0
         double rn = 0, rn1 = 0;
         double sd[3] = {0, 0, 0}, se[6] = {0, 0, 0, 0, 0, 0};
         double sd1[3] = {0, 0, 0}, se1[6] = {0, 0, 0, 0, 0, 0};
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 for (int k = 0; k < CH; k++) {
                     const unsigned d = lane + 64u * (h * CH + k);
                     const unsigned g = ((d / (NDT_PPL * SD)) * R + r) * (NDT_PPL * SD) + d % (NDT_PPL * SD);
-                    tmp[k] = src[(full || g < lim_dw) ? g : 0u];
+                    const bool have = full || g < lim_dw;
+                    const float v = src[have ? g : 0u];
+                    tmp[k] = have ? v : __builtin_nanf("");   // past the end of the scan: NaN points, skipped below
                 }
 #pragma unroll
                 for (int k = 0; k < CH; k++) {
@@ -318,62 +320,60 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         NDT_PS(0)
 #pragma unroll 1
         for (int j = 0; j < NDT_PPL; j++) {
-            const unsigned i = p0 + (lane * R + r) * NDT_PPL + j;
-            const bool valid = (i < n_points) && !(dbg & 4);
             float fx, fy, fz;
             if (STRIDE_DW) {
                 const float *pf = mytile + lane * LANE_DW + j * SD;
                 fx = pf[0]; fy = pf[1]; fz = pf[2];
             } else {
-                const float *pf = (const float *)(pts + (size_t)(valid ? i : 0u) * stride_bytes);
-                fx = pf[0]; fy = pf[1]; fz = pf[2];
+                const unsigned i = p0 + (lane * R + r) * NDT_PPL + j;
+                const bool have = i < n_points;
+                const float *pf = (const float *)(pts + (size_t)(have ? i : 0u) * stride_bytes);
+                fx = have ? pf[0] : __builtin_nanf(""); fy = pf[1]; fz = pf[2];
             }
-            // NaN points are skipped (an Inf is out of range and out of the grid on any path)
-            const float fsum = fx + fy + fz;
-            const bool finite = valid && (fsum == fsum);
-            bool ok = finite;
-            // fp32 fast paths ...
+            if (dbg & 4) fx = __builtin_nanf("");
+            // fp32 fast paths.  Every test below is false for a NaN (NaN points are skipped, like padding); an
+            // Inf passes the range test when no range is set and is then out of the grid.
             const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
             const float dd = dx * dx + dy * dy + dz * dz;
-            const bool near_r = use_range && (fabsf(dd - r2) < 1e-3f * r2);
-            if (use_range) ok = ok && !(dd > r2);
+            const bool okr = dd <= r2eff;                                   // r2eff = +inf without a range limit
+            const bool near_r = fabsf(dd - r2) < r2band;                    // r2band < 0 without a range limit
             // v = (p - c)/res + 0.5 + size/2 in one fma per axis; the integer part is the cell index
             const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
             const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
             const float tx = fabsf((vx - flx) - 0.5f), ty = fabsf((vy - fly) - 0.5f), tz = fabsf((vz - flz) - 0.5f);
-            const bool slow = !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim);
             int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+            int slot = (okr && (unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] &&
+                        (unsigned)iz < (unsigned)g.size[2]) ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
             // ... and the reference's fp64 formulas for the few points near a cell face / the range sphere
-            const bool need_exact = finite && (force_exact || !guard_ok || near_r || slow);
+            // (frac_lim < 0 sends every point here: odd grid sizes, absurd centres)
+            const bool need_exact = (okr || near_r) && (near_r || !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim));
             if (__ballot(need_exact)) {
                 if (need_exact) {
+                    bool ok = okr;
                     if (near_r) {
 #pragma clang fp contract(off)
                         double ex = (double)fx - ox, ey = (double)fy - oy, ez = (double)fz - oz;
                         ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit);
                     }
-                    if (tx > frac_lim || force_exact || !guard_ok) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
-                    if (ty > frac_lim || force_exact || !guard_ok) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
-                    if (tz > frac_lim || force_exact || !guard_ok) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
+                    if (!(tx <= frac_lim)) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
+                    if (!(ty <= frac_lim)) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
+                    if (!(tz <= frac_lim)) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
+                    slot = (ok && (unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] &&
+                            (unsigned)iz < (unsigned)g.size[2]) ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
                 }
             }
-            const bool inb = ok && (unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] &&
-                             (unsigned)iz < (unsigned)g.size[2];
-            const int slot = inb ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
-            dropped += (valid && !inb) ? 1u : 0u;
             NDT_PS(1)
             if (dbg & 16) continue;
             // A lane keeps the moments of TWO cells in registers (range noise on a wall that hugs a cell face makes
             // its consecutive points alternate between two cells; a lane that walks into the next cell keeps the
             // old one as well).  A third cell replaces the run that was used least recently; the replaced run goes
             // to the wave's LDS queue.  Nothing in the loop touches LDS or memory on the common path.
-            bool in0 = inb && slot == cs0, in1 = inb && slot == cs1;
-            bool newc = inb && !in0 && !in1;
-            if (dbg & 32) { in0 = inb; in1 = false; newc = false; }
+            bool newc = slot >= 0 && slot != cs0 && slot != cs1;
+            if (dbg & 32) { cs0 = slot >= 0 ? slot : cs0; newc = false; }
             if (dbg & 64) { newc = newc && (cs0 < 0 || cs1 < 0); }
             if (__ballot(newc)) {
                 if (newc) {
-                    const bool to1 = cs0 >= 0 && (cs1 < 0 || mru0);   // an empty run first, else the older one
+                    const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);   // an empty run first, else the older one
                     const int victim = to1 ? cs1 : cs0;
                     if (victim >= 0 && !(dbg & 8)) {
                         double vn = to1 ? rn1 : rn, v3[3], v6[6];
@@ -418,14 +418,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                         for (int k = 0; k < 3; k++) sd1[k] = 0;
 #pragma unroll
                         for (int k = 0; k < 6; k++) se1[k] = 0;
-                        in1 = true;
                     } else {
                         cs0 = slot; rn = 0;
 #pragma unroll
                         for (int k = 0; k < 3; k++) sd[k] = 0;
 #pragma unroll
                         for (int k = 0; k < 6; k++) se[k] = 0;
-                        in0 = true;
                     }
                 }
             }
@@ -434,12 +432,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             const double x = (double)fx - (cx + ((double)ix - hx) * res);
             const double y = (double)fy - (cy + ((double)iy - hy) * res);
             const double z = (double)fz - (cz + ((double)iz - hz) * res);
+            const bool in0 = slot == cs0, in1 = slot == cs1;          // cs0 / cs1 are never -1
             if (in0) {
                 rn += 1.0;
                 sd[0] += x; sd[1] += y; sd[2] += z;
                 se[0] = fma(x, x, se[0]); se[1] = fma(x, y, se[1]); se[2] = fma(x, z, se[2]);
                 se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
-                mru0 = true;
             }
             NDT_QS(1)
             if (__ballot(in1)) {
@@ -448,9 +446,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                     sd1[0] += x; sd1[1] += y; sd1[2] += z;
                     se1[0] = fma(x, x, se1[0]); se1[1] = fma(x, y, se1[1]); se1[2] = fma(x, z, se1[2]);
                     se1[3] = fma(y, y, se1[3]); se1[4] = fma(y, z, se1[4]); se1[5] = fma(z, z, se1[5]);
-                    mru0 = false;
                 }
             }
+            mru1 = in1 ? 1 : (in0 ? 0 : mru1);
             NDT_QS(2)
         }
         }   // rounds
@@ -523,12 +521,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         }
         NDT_PS(3)
     }
-    if (dropped) atomicAdd(&s_dropped, dropped);
     __syncthreads();
-    if (MODE == 1) {   // the finalise launch does the rest
-        if (tid == 0 && s_dropped) atomicAdd(&ctr->n_dropped, s_dropped);
-        return;
-    }
+    if (MODE == 1) return;   // the finalise launch does the rest
     // atomics bypass the vector L1: drop lines that phase A cached before they were updated
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
@@ -538,6 +532,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     unsigned n_alloc = ctr->n_alloc;
     if (n_alloc > cap) n_alloc = cap;
     NdtAcc *tmp_base = bc.acc;                            // cell record written over its own accumulator
+    unsigned binned = 0;
     const double IS1 = ldexp(1.0, -s1_shift), IS2 = ldexp(1.0, -s2_shift);
     for (unsigned id = tid; id < n_alloc; id += nthreads) {
         NdtAcc a = bc.acc[id];
@@ -549,6 +544,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
 #pragma unroll
         for (int k = 0; k < 6; k++) c.cov[k] = 0;
         unsigned long long n = (unsigned long long)a.n;
+        binned += (unsigned)n;               // points that reached a cell (the others were NaN, out of range / grid)
         if (n >= 2 && n >= (unsigned long long)n_min) {
             unsigned slot = bc.acc_slot[id];
             int iz = slot % g.size[2];
@@ -613,6 +609,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             bc.wtable[sl] = NDT_EMPTY;
         }
     }
+    if (binned) atomicAdd(&s_dropped, binned);
     __syncthreads();
 
     // ---------------- phase C: rank Gaussian cells in slot order from the occupancy bitmap ------------
@@ -686,7 +683,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     if (tid == 0) {
         ctr->n_cells = s_base;
         ctr->n_alloc = 0;
-        if (MODE == 0) ctr->n_dropped = s_dropped;
+        ctr->n_dropped = n_points - s_dropped;          // s_dropped holds the number of binned points here
         ctr->cyc[0] = (uint32_t)(t1 - t0);
         ctr->cyc[1] = (uint32_t)(t2 - t1);
         ctr->cyc[2] = (uint32_t)(t3 - t2);
