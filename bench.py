@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--res", type=float, default=0.5)
     ap.add_argument("--cpu-sample", type=int, default=768, help="pairs timed on the CPU oracle (0 = skip); ~14 s")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--buffers", type=int, default=2, help="pipeline depth (mapset pairs / streams)")
+    ap.add_argument("--buffers", type=int, default=3, help="pipeline depth (mapset pairs / streams)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one stream, one mapset pair: every step waits for the previous one (default: two buffers, the "
                          "grid builds of step k+1 run on the CUs the matcher of step k has already left)")
