@@ -195,7 +195,7 @@ def main():
     mk["fp64_tflops"] = mk["fp64_gflop_per_launch"] / match_ms          # GFLOP / ms = TFLOP/s
     mk["fp64_note"] = ("pair-term flops counted from csrc/ndt_match.hip: 130 per gradient term, 610 per Hessian term; "
                        "MI355X fp64 vector peak 78.6 TFLOP/s (AMD datasheet) -> frac %.4f" % (mk["fp64_tflops"] / 78.6))
-    dominant = "ndt_build_kernel" if 2 * build_ms >= match_ms else "ndt_match_kernel"
+    dominant = "ndt_build_kernel" if 2 * iso_build_ms >= iso_match_ms else "ndt_match_kernel"   # by time alone on the chip
     dk = kern[dominant]
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
     # (tools/collect_profiles.sh -> profiles/rNN_pmc_traffic.json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
