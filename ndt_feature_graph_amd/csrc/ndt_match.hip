@@ -486,6 +486,134 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_eval_kernel(
     if (threadIdx.x < 32) partials[blockIdx.x * 32 + threadIdx.x] = s_sums[threadIdx.x];
 }
 
+// ONE registration spread over the whole launch grid (small batches / large maps: the reference's
+// one-link-at-a-time call pattern).  Every workgroup evaluates a contiguous share of the source cells and leaves
+// 28 partial sums in global memory; after a grid barrier workgroup 0 adds the partials in workgroup order (fixed:
+// deterministic) and runs the solver step, publishes the next request, and a second barrier releases everybody.
+// Nothing goes back to the host between evaluations.  The launcher keeps gridDim.x <= number of CUs (one 512-thread
+// workgroup per CU is resident), the barrier spins with a bound and raises `abort` instead of hanging.
+struct NdtCoopCtrl {
+    unsigned bar, abort, pad0, pad1;
+    rigid Teval;
+    int with_h, done;
+};
+size_t ndt_match_coop_work_bytes(size_t n_groups) { return 256 + n_groups * 32 * sizeof(double); }
+
+NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &target)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        target += gridDim.x;
+        __threadfence();
+        atomicAdd(&c->bar, 1u);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&c->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24)) { __hip_atomic_store(&c->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((spins & 1023u) == 0u && __hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // partials / control block written by other workgroups
+    }
+    __syncthreads();
+    return __hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+}
+
+template <int NN>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
+    NdtSetView tset, unsigned tmap, NdtSetView sset, unsigned smap, double *__restrict__ T16, NdtMatchParamsDev prm,
+    NdtMatchResultDev *__restrict__ res, const double *__restrict__ Q36, char *__restrict__ work_mem)
+{
+    __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
+    __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
+    __shared__ double s_part[NDT_MATCH_WAVES * 32];
+    __shared__ double s_sums[32];
+    __shared__ MatchState st;       // workgroup 0 only
+    __shared__ rigid s_T;
+    __shared__ int s_with_h, s_done;
+
+    NdtCoopCtrl *ctrl = reinterpret_cast<NdtCoopCtrl *>(work_mem);
+    double *partials = reinterpret_cast<double *>(work_mem + 256);
+    const MapView tg = map_view(tset, tmap);
+    const MapView sv = map_view(sset, smap);
+    const unsigned g = blockIdx.x, G = gridDim.x;
+    const int per = (sv.n_cells + (int)G - 1) / (int)G;
+    const int begin = min(sv.n_cells, (int)g * per), count = min(sv.n_cells - begin, per);
+    unsigned target = 0;
+    long long terms_g = 0, terms_h = 0;
+
+    if (g == 0 && threadIdx.x == 0) {
+        match_state_init(st, T16, prm, Q36);
+        ctrl->Teval = st.Teval; ctrl->with_h = st.with_h; ctrl->done = st.done;
+    }
+    long long cyc_eval = 0, cyc_solver = 0, cyc_bar = 0;
+    for (;;) {
+        long long b0 = __builtin_readcyclecounter();
+        if (!coop_barrier(ctrl, target)) return;               // the request is published
+        cyc_bar += (long long)__builtin_readcyclecounter() - b0;
+        if (threadIdx.x == 0) { s_T = ctrl->Teval; s_with_h = ctrl->with_h; s_done = ctrl->done; }
+        __syncthreads();
+        if (s_done) break;
+        const rigid Te = s_T;
+        long long c0 = __builtin_readcyclecounter();
+        if (s_with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
+        else eval_derivs<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
+        if (threadIdx.x < 32) { partials[g * 32 + threadIdx.x] = s_sums[threadIdx.x]; __threadfence(); }
+        long long c1 = __builtin_readcyclecounter();
+        cyc_eval += c1 - c0;
+        if (!coop_barrier(ctrl, target)) return;               // all partials are in memory
+        cyc_bar += (long long)__builtin_readcyclecounter() - c1;
+        if (g == 0) {
+            if (threadIdx.x < 29) {
+                double a = 0;
+                for (unsigned w = 0; w < G; w++) a += partials[w * 32 + threadIdx.x];
+                s_sums[threadIdx.x] = a;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                long long d0 = __builtin_readcyclecounter();
+                if (s_with_h) terms_h += (long long)s_sums[28]; else terms_g += (long long)s_sums[28];
+                match_state_step(st, s_sums, prm);
+                ctrl->Teval = st.Teval; ctrl->with_h = st.with_h; ctrl->done = st.done;
+                cyc_solver += (long long)__builtin_readcyclecounter() - d0;
+            }
+        }
+    }
+    if (g == 0 && threadIdx.x == 0) {
+        NdtMatchResultDev o;
+        match_state_result(st, T16, o);
+        o.n_source = sv.n_cells;
+        o.n_target = tg.n_cells;
+        o.cycles_eval = cyc_eval;          // workgroup 0: its share of the evaluations
+        o.cycles_solver = cyc_solver;
+#ifdef NDT_COOP_PROF
+        o.cycles_eval = cyc_bar;           // profiling build: time at the grid barriers instead
+#endif
+        o.pair_terms_g = terms_g;
+        o.pair_terms_h = terms_h;
+        *res = o;
+    }
+}
+
+hipError_t ndt_launch_match_coop(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, double *T16_dev,
+                                 const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
+                                 unsigned n_groups, void *work_dev, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(work_dev, 0, 256, stream);
+    if (e != hipSuccess) return e;
+#define NDT_LAUNCH_COOP(NN)                                                                                           \
+    hipLaunchKernelGGL(ndt_match_coop_kernel<NN>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset,           \
+                       (unsigned)tmap, sset, (unsigned)smap, T16_dev, prm, res_dev, Q36_dev, (char *)work_dev)
+    switch (prm.n_neighbours) {
+    case 0: NDT_LAUNCH_COOP(0); break;
+    case 1: NDT_LAUNCH_COOP(1); break;
+    case 2: NDT_LAUNCH_COOP(2); break;
+    case 3: NDT_LAUNCH_COOP(3); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef NDT_LAUNCH_COOP
+    return hipGetLastError();
+}
+
 hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,
                            int n_neighbours, int with_h, double lfd1, double lfd2, unsigned n_groups, double *partials_dev,
                            hipStream_t stream)

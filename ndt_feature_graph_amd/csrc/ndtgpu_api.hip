@@ -547,6 +547,55 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
     return NDTGPU_OK;
 }
 
+// Small batches, device-resident: one cooperative launch per registration (csrc/ndt_match.hip
+// ndt_match_coop_kernel): the whole grid evaluates, workgroup 0 solves, no host round trip per evaluation.
+static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                double *T16, size_t n_pairs, const NdtMatchParamsDev &p, const double *Q36,
+                                ndtgpu_match_result *results, hipStream_t st)
+{
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    const size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result);
+    const size_t off_R = (bT + 255) & ~(size_t)255, off_Q = (off_R + bR + 255) & ~(size_t)255;
+    const size_t total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
+    ndtgpu_status rc = ts->ensure_stage(total);
+    if (rc != NDTGPU_OK) return rc;
+    rc = ts->ensure_work(n_pairs * ndt_match_coop_work_bytes((size_t)n_cu));
+    if (rc != NDTGPU_OK) return rc;
+    char *base = (char *)ts->stage;
+    HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
+    if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
+    std::vector<NdtMapCounters> cs(n_pairs);
+    for (size_t k = 0; k < n_pairs; k++)
+        HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t k = 0; k < n_pairs; k++) {
+        // 256 source cells per workgroup (32 per wave; more workgroups make the grid barrier, whose arrivals
+        // serialise on one L2 line, cost more than they save), at most one workgroup per CU: all are resident
+        const char *cpg = getenv("NDTGPU_COOP_CELLS");
+        const unsigned per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 256u;
+        unsigned groups = (cs[k].n_cells + per_group - 1u) / per_group;
+        if (groups < 1) groups = 1;
+        if (groups > (unsigned)n_cu) groups = (unsigned)n_cu;
+        char *work = (char *)ts->work + k * ndt_match_coop_work_bytes((size_t)n_cu);
+        hipError_t e = ndt_launch_match_coop(ts->v, tidx[k], ss->v, sidx[k], (double *)base + 16 * k, p,
+                                             reinterpret_cast<NdtMatchResultDev *>(base + off_R) + k,
+                                             Q36 ? (const double *)(base + off_Q) + 36 * k : nullptr, groups, work, st);
+        if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: cooperative launch", e);
+    }
+    std::vector<unsigned> ctrl(n_pairs * 4);
+    for (size_t k = 0; k < n_pairs; k++)
+        HIP_TRY(hipMemcpyAsync(&ctrl[4 * k], (char *)ts->work + k * ndt_match_coop_work_bytes((size_t)n_cu), 16,
+                               hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t k = 0; k < n_pairs; k++)
+        if (ctrl[4 * k + 1]) return fail(NDTGPU_ERR_HIP, "match: cooperative kernel gave up waiting at a grid barrier");
+    return NDTGPU_OK;
+}
+
 static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                         double *T16, size_t n_pairs, const ndtgpu_match_params *prm, const double *Q36,
                                         ndtgpu_match_result *results, ndtgpu_stream stream);
@@ -615,7 +664,10 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
         NdtMatchParamsDev p = to_dev(prm);
         if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
             return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
-        return match_host_driven(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st);
+        // NDTGPU_HOST_LOOP=1: the host runs the state machine, one launch per evaluation (A/B, debugging)
+        const char *hl = getenv("NDTGPU_HOST_LOOP");
+        if (hl && atoi(hl)) return match_host_driven(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st);
+        return match_coop(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st);
     }
     size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
     size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
