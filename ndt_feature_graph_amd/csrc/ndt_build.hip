@@ -77,7 +77,8 @@ NDT_D void idc_put(unsigned long long *ce, int slot, int id)
 }
 
 // slot -> accumulator id, allocating on first touch.  Lock-free: a racing loser wastes one id
-// (left with n == 0, skipped by the finaliser).
+// (left with n == 0, skipped by the finaliser).  Agent scope: with MODE 1 the workgroups of one map run on
+// different XCDs, whose L2s only agree on agent-scope atomics.
 NDT_D int get_or_assign(const BuildCtx &b, int slot)
 {
     // ids never change once assigned, so a per-wave LDS cache can answer without the global round trip
@@ -87,13 +88,13 @@ NDT_D int get_or_assign(const BuildCtx &b, int slot)
     if ((int)(c >> 32) == slot) return (int)(unsigned)c;
     int id = b.wtable[slot];   // may be a stale EMPTY from L1; a non-EMPTY value is always final
     if (id != NDT_EMPTY) { idc_put(ce, slot, id); return id; }
-    unsigned nid = __hip_atomic_fetch_add(&b.ctr->n_alloc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned nid = __hip_atomic_fetch_add(&b.ctr->n_alloc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int expected = NDT_EMPTY;
     if (__hip_atomic_compare_exchange_strong(&b.wtable[slot], &expected, (int)nid, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_WORKGROUP)) {
-        __hip_atomic_fetch_or(&b.bitmap[slot >> 5], 1u << (slot & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                             __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_fetch_or(&b.bitmap[slot >> 5], 1u << (slot & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (nid < b.cap) b.acc_slot[nid] = (uint32_t)slot;
-        else __hip_atomic_store(&b.ctr->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(&b.ctr->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         idc_put(ce, slot, (int)nid);
         return (int)nid;
     }

@@ -370,18 +370,28 @@ def test_match_batch_is_deterministic_and_order_free(N, O):
     assert np.array_equal(T1, Ta[2])
 
 
-def test_persistent_and_host_driven_paths_agree(N, O):
-    """<= 8 pairs: host-driven Newton loop + multi-workgroup derivative kernel; more: one persistent
-    workgroup per pair.  Same state machine (csrc/ndt_solver.h), different summation order."""
+def test_persistent_cooperative_and_host_driven_paths_agree(N, O, monkeypatch):
+    """> 8 pairs: persistent workgroups pulling pairs; <= 8 pairs: one cooperative launch per registration (grid
+    barrier, workgroup 0 solves), or with NDTGPU_HOST_LOOP=1 the host-driven Newton loop + one derivative launch
+    per evaluation.  Same state machine (csrc/ndt_solver.h), different summation order."""
     pr, tg, sr, om = _pair_maps(N, O, list(range(1, 13)), 20000, 0.5)
     T0 = pr["T_init"].numpy()
     idx = np.arange(12)
     Tb, rb = N.match_batch(tg, idx, sr, idx, T0)                 # persistent kernel
     for b in (0, 5, 11):
-        Ts, rs = N.match_d2d(tg, b, sr, b, T0[b])                # host-driven
-        dt, dr = pose_close(Ts, Tb[b])
-        assert dt < 1e-9 and dr < 1e-9
-        assert rs["iterations"] == rb["iterations"][b] and rs["converged"] == rb["converged"][b]
+        Ts, rs = N.match_d2d(tg, b, sr, b, T0[b])                # cooperative kernel
+        monkeypatch.setenv("NDTGPU_HOST_LOOP", "1")
+        Th, rh = N.match_d2d(tg, b, sr, b, T0[b])                # host-driven loop
+        monkeypatch.delenv("NDTGPU_HOST_LOOP")
+        for Tx, rx in ((Ts, rs), (Th, rh)):
+            dt, dr = pose_close(Tx, Tb[b])
+            assert dt < 1e-9 and dr < 1e-9
+            assert rx["iterations"] == rb["iterations"][b] and rx["converged"] == rb["converged"][b]
+        monkeypatch.setenv("NDTGPU_COOP_CELLS", "16")            # many workgroups: another partition, same answer
+        T3, r3 = N.match_d2d(tg, b, sr, b, T0[b])
+        monkeypatch.delenv("NDTGPU_COOP_CELLS")
+        dt, dr = pose_close(T3, Tb[b])
+        assert dt < 1e-9 and dr < 1e-9 and r3["fevals"] == rs["fevals"]
         To, ro = O.match_d2d(om[b][0], om[b][1], T0[b])
         dt, dr = pose_close(Ts, To)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
