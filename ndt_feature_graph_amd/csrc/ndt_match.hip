@@ -176,6 +176,13 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
     }
 }
 
+// per-wave LDS rows for the decoded probe windows (up to 7 runs x 64 lanes)
+NDT_D uint2 *probe_windows()
+{
+    __shared__ uint2 s_win[NDT_MATCH_WAVES * 7 * 64];
+    return s_win;
+}
+
 // One evaluation of derivativesNDT over all source cells, transformed by T.  All threads of the
 // workgroup participate; result in s_sums[0..6] (and [7..27] when WITH_H).  Ends with a barrier.
 template <int NN, bool WITH_H>
@@ -245,26 +252,43 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
         // flat form only when every lane's z-neighbourhood is the whole column (a source cell that lies two or
         // more cells above / below a thin map sees only part of it, or nothing): wave-uniform
         const bool flat = tg.sz <= NN + 1 && !__ballot(vi && !(iz - NN <= 0 && iz + NN >= tg.sz - 1));
-        const int n_runs = flat ? 1 : W;
         const int zlo = flat ? 0 : max(iz - NN, 0), zhi = flat ? tg.sz - 1 : min(iz + NN, tg.sz - 1);
         const char *rmb = reinterpret_cast<const char *>(tg.rankmap);
+        // The runs are fetched W at a time (flat map: the W runs of the W x-neighbours; otherwise, per x, the W
+        // runs of the y-neighbours): all 2 W loads are in flight together, the decoded windows (bits, first cell)
+        // wait in the wave's LDS staging rows, and a rolled loop pops them -- one L2 round trip per batch instead
+        // of one per run.
+        uint2 *win = probe_windows() + wave * (7 * 64) + lane;
 #pragma unroll 1
-        for (int dx = -NN; dx <= NN; dx++) {
-            const int xx = ix + dx;
-            const bool xok = vi && xx >= 0 && xx < tg.sx && zlo <= zhi;
-#pragma unroll 1
-            for (int t = 0; t < n_runs; t++) {
-                const int ylo = flat ? max(iy - NN, 0) : iy - NN + t;
+        for (int outer = 0; outer < (flat ? 1 : W); outer++) {
+            uint2 wa[W], wb[W];
+            unsigned sh[W];
+            int len[W];
+#pragma unroll
+            for (int q = 0; q < W; q++) {
+                const int dx = flat ? q - NN : outer - NN;
+                const int xx = ix + dx;
+                const bool xok = vi && xx >= 0 && xx < tg.sx && zlo <= zhi;
+                const int ylo = flat ? max(iy - NN, 0) : iy - NN + q;
                 const int yhi = flat ? min(iy + NN, tg.sy - 1) : ylo;
                 const bool ok = xok && ylo <= yhi && ylo >= 0 && yhi < tg.sy;
                 const unsigned s0 = ok ? (unsigned)((xx * tg.sy + ylo) * tg.sz + zlo) : 0u;
-                const int len = ok ? (flat ? (yhi - ylo + 1) * tg.sz : zhi - zlo + 1) : 0;   // <= 28 bits
-                const unsigned sh = s0 & 31u;
-                const uint2 wa = *reinterpret_cast<const uint2 *>(rmb + (size_t)(s0 >> 5) * 8u);
-                const uint2 wb = *reinterpret_cast<const uint2 *>(rmb + (size_t)(s0 >> 5) * 8u + 8u);
-                unsigned bits = __builtin_amdgcn_alignbit(wb.x, wa.x, sh) & ((1u << len) - 1u);
-                const unsigned lowa = wa.x >> sh;                // the window's part of the first word
-                unsigned id = lowa ? wa.y + (unsigned)__popc(wa.x & ((1u << sh) - 1u)) : wb.y;
+                len[q] = ok ? (flat ? (yhi - ylo + 1) * tg.sz : zhi - zlo + 1) : 0;   // <= 28 bits
+                sh[q] = s0 & 31u;
+                wa[q] = *reinterpret_cast<const uint2 *>(rmb + (size_t)(s0 >> 5) * 8u);
+                wb[q] = *reinterpret_cast<const uint2 *>(rmb + (size_t)(s0 >> 5) * 8u + 8u);
+            }
+#pragma unroll
+            for (int q = 0; q < W; q++) {
+                const unsigned bits = __builtin_amdgcn_alignbit(wb[q].x, wa[q].x, sh[q]) & ((1u << len[q]) - 1u);
+                const unsigned lowa = wa[q].x >> sh[q];          // the window's part of the first word
+                const unsigned id0 = lowa ? wa[q].y + (unsigned)__popc(wa[q].x & ((1u << sh[q]) - 1u)) : wb[q].y;
+                win[q * 64] = make_uint2(bits, id0);
+            }
+#pragma unroll 1
+            for (int q = 0; q < W; q++) {
+                const uint2 v = win[q * 64];
+                unsigned bits = v.x, id = v.y;
                 // every lane pops its lowest remaining bit per round: ids count up from the run's first cell
                 while (true) {
                     const bool hit = bits != 0u;
@@ -493,21 +517,29 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_eval_kernel(
 // Nothing goes back to the host between evaluations.  The launcher keeps gridDim.x <= number of CUs (one 512-thread
 // workgroup per CU is resident), the barrier spins with a bound and raises `abort` instead of hanging.
 struct NdtCoopCtrl {
-    unsigned bar, abort, pad0, pad1;
+    unsigned top, abort, pad0, pad1;     // top: groups that completed a barrier, summed over all barriers so far
     rigid Teval;
     int with_h, done;
+    alignas(64) unsigned grp[16 * 16];   // arrival counter of workgroup group i at grp[16 * i] (one 64-byte line each)
 };
-size_t ndt_match_coop_work_bytes(size_t n_groups) { return 256 + n_groups * 32 * sizeof(double); }
+static_assert(sizeof(NdtCoopCtrl) % 64 == 0, "control block keeps the partials aligned");
+size_t ndt_match_coop_work_bytes(size_t n_groups) { return sizeof(NdtCoopCtrl) + n_groups * 32 * sizeof(double); }   // multiple of 64
 
-NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &target)
+// Grid barrier number `epoch` (1, 2, ...).  Arrivals on ONE counter serialise at the L2 (~50-100 ns each: 30 us for
+// 256 workgroups), so workgroups arrive on one of up to 16 group counters and the last arrival of a group bumps
+// the top counter everybody polls: ~16 + 16 serialised atomics instead of 256.  Counters only grow (no reset
+// race); nobody can arrive for barrier e + 1 before every workgroup has arrived for barrier e.
+NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &epoch)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        target += gridDim.x;
+        epoch += 1u;
+        const unsigned G = gridDim.x, NG = G < 16u ? G : 16u, gi = blockIdx.x % NG;
+        const unsigned gsize = (G - gi + NG - 1u) / NG;            // workgroups w with w % NG == gi
         __threadfence();
-        atomicAdd(&c->bar, 1u);
+        if (atomicAdd(&c->grp[16u * gi], 1u) + 1u == gsize * epoch) atomicAdd(&c->top, 1u);
         unsigned spins = 0;
-        while (__hip_atomic_load(&c->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (__hip_atomic_load(&c->top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NG * epoch) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1u << 24)) { __hip_atomic_store(&c->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             if ((spins & 1023u) == 0u && __hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
@@ -532,7 +564,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     __shared__ int s_with_h, s_done;
 
     NdtCoopCtrl *ctrl = reinterpret_cast<NdtCoopCtrl *>(work_mem);
-    double *partials = reinterpret_cast<double *>(work_mem + 256);
+    double *partials = reinterpret_cast<double *>(work_mem + sizeof(NdtCoopCtrl));
     const MapView tg = map_view(tset, tmap);
     const MapView sv = map_view(sset, smap);
     const unsigned g = blockIdx.x, G = gridDim.x;
@@ -563,9 +595,19 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         if (!coop_barrier(ctrl, target)) return;               // all partials are in memory
         cyc_bar += (long long)__builtin_readcyclecounter() - c1;
         if (g == 0) {
+            // 16 x 32 threads: thread (r, k) adds value k of workgroups r, r + 16, ... (loads of different threads
+            // overlap: a single lane walking all G rows pays G dependent L2 round trips); the 16 rows are then
+            // added in order.  Fixed order: deterministic.
+            {
+                const unsigned k = threadIdx.x & 31u, r = threadIdx.x >> 5;
+                double a = 0;
+                for (unsigned w = r; w < G; w += 16u) a += partials[w * 32 + k];
+                s_src[r * 32 + k] = a;                     // the source tile buffer is free between evaluations
+            }
+            __syncthreads();
             if (threadIdx.x < 29) {
                 double a = 0;
-                for (unsigned w = 0; w < G; w++) a += partials[w * 32 + threadIdx.x];
+                for (unsigned r = 0; r < 16u; r++) a += s_src[r * 32 + threadIdx.x];
                 s_sums[threadIdx.x] = a;
             }
             __syncthreads();
@@ -598,7 +640,7 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, size_t tmap, const NdtS
                                  const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
                                  unsigned n_groups, void *work_dev, hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(work_dev, 0, 256, stream);
+    hipError_t e = hipMemsetAsync(work_dev, 0, sizeof(NdtCoopCtrl), stream);
     if (e != hipSuccess) return e;
 #define NDT_LAUNCH_COOP(NN)                                                                                           \
     hipLaunchKernelGGL(ndt_match_coop_kernel<NN>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset,           \

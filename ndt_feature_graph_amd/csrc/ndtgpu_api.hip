@@ -571,10 +571,10 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
         HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (size_t k = 0; k < n_pairs; k++) {
-        // 256 source cells per workgroup (32 per wave; more workgroups make the grid barrier, whose arrivals
-        // serialise on one L2 line, cost more than they save), at most one workgroup per CU: all are resident
+        // 128 source cells per workgroup (16 per wave; fewer cells per workgroup stop paying: barrier + solver
+        // latency dominate), at most one workgroup per CU: all of them are resident
         const char *cpg = getenv("NDTGPU_COOP_CELLS");
-        const unsigned per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 256u;
+        const unsigned per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 128u;
         unsigned groups = (cs[k].n_cells + per_group - 1u) / per_group;
         if (groups < 1) groups = 1;
         if (groups > (unsigned)n_cu) groups = (unsigned)n_cu;
