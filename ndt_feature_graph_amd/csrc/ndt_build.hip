@@ -632,45 +632,107 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     // More touched cells than accumulators (overflow): slots whose id is past the capacity still have their bit
     // and must be filtered through the work table; otherwise the bitmap IS the set of Gaussian cells.
     const bool ovf = __hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    auto gauss_bits = [&](unsigned w) {
-        unsigned bits = __hip_atomic_load(&bc.bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return (ovf && bits) ? valid_bits(w, bits) : bits;
-    };
+    // phase B cleared bits with atomics (performed at the memory side): drop what this CU's L1 may still hold,
+    // then plain loads, four words per lane and step so that four loads are in flight (a 3D grid has 200 k words)
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    constexpr unsigned WPL = 4;
     {
         unsigned cnt = 0;
-        for (unsigned w = wb + lane; w < we; w += 64u) cnt += (unsigned)__popc(gauss_bits(w));
+        for (unsigned w0 = wb + lane * WPL; w0 < we; w0 += 64u * WPL) {
+            unsigned bits[WPL];
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) bits[k] = (w0 + k < we) ? bc.bitmap[w0 + k] : 0u;
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) cnt += (unsigned)__popc((ovf && bits[k]) ? valid_bits(w0 + k, bits[k]) : bits[k]);
+        }
         unsigned incl = wave_incl_scan(cnt);
         if (lane == 63) s_wave_cnt[wave] = incl;
     }
     __syncthreads();
+#ifdef NDT_PROF_C
+    long long t2b = __builtin_readcyclecounter();
+#endif
     unsigned running = 0, total_cells = 0;
     for (unsigned k = 0; k < nwaves; k++) {
         unsigned c2 = s_wave_cnt[k];
         if (k < wave) running += c2;
         total_cells += c2;
     }
-    for (unsigned step = wb; step < we; step += 64u) {
-        unsigned w = step + lane;
-        unsigned bits = (w < we) ? __hip_atomic_load(&bc.bitmap[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        if (!__ballot(bits != 0u)) continue;
-        unsigned vmask = (ovf && bits) ? valid_bits(w, bits) : bits;
-        unsigned cnt = (unsigned)__popc(vmask);
+    if (!ovf) {
+        // Pass 2, usual case (the bitmap holds exactly the Gaussian cells): 32 words per wave and step, one half
+        // word per lane.  The lanes list their slots in LDS in slot order (rank = list position), then the whole
+        // wave walks the list: work table -> record -> cell array are dependent global accesses, 64 chains at a
+        // time instead of one per word (a wall of a 3D map fills whole 32-slot words).
+        // Stage 1: every Gaussian slot is written into the `slot` field of its final cell record (stores only; four
+        // bitmap words per lane are in flight).  Stage 2: the wave walks its rank range, 64 cells at a time:
+        // slot -> work table -> record -> cell array are dependent global accesses, but 64 independent chains
+        // overlap (a lane that walked the bits of its own words did them one after the other).
+        const unsigned rank_begin = running;
+        for (unsigned step = wb; step < we; step += 64u * WPL) {
+            const unsigned w0 = step + lane * WPL;
+            unsigned bits[WPL];
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) bits[k] = (w0 + k < we) ? bc.bitmap[w0 + k] : 0u;
+            if (!__ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u)) continue;
+            unsigned cnt = 0;
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) cnt += (unsigned)__popc(bits[k]);
+            const unsigned incl = wave_incl_scan(cnt);
+            unsigned before = running + incl - cnt;
+            running += __shfl(incl, 63, 64);
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) {
+                if (bits[k]) {
+                    rankmap[w0 + k] = make_uint2(bits[k], before);
+                    bc.bitmap[w0 + k] = 0u;
+                    for (unsigned b = bits[k]; b; b &= b - 1u)
+                        cells[before++].slot = (w0 + k) * 32u + (unsigned)(__ffs((int)b) - 1);
+                }
+            }
+        }
+        // the slots written above are read back below: wait for the stores (write-through to L2), read past the L1
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        for (unsigned r = rank_begin + lane; r < running; r += 64u) {
+            const unsigned slot = __hip_atomic_load(&cells[r].slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int id = bc.wtable[slot];
+            cells[r] = *reinterpret_cast<const NdtCell *>(tmp_base + id);
+            table[slot] = (int)r;
+            bc.wtable[slot] = NDT_EMPTY;                          // work table back to its clean state
+        }
+    } else
+    for (unsigned step = wb; step < we; step += 64u * WPL) {
+        const unsigned w0 = step + lane * WPL;
+        unsigned bits[WPL], vmask[WPL];
+#pragma unroll
+        for (unsigned k = 0; k < WPL; k++) bits[k] = (w0 + k < we) ? bc.bitmap[w0 + k] : 0u;
+        if (!__ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u)) continue;
+        unsigned cnt = 0;
+#pragma unroll
+        for (unsigned k = 0; k < WPL; k++) {
+            vmask[k] = (ovf && bits[k]) ? valid_bits(w0 + k, bits[k]) : bits[k];
+            cnt += (unsigned)__popc(vmask[k]);
+        }
         unsigned incl = wave_incl_scan(cnt);
         unsigned before = running + incl - cnt;
         running += __shfl(incl, 63, 64);
-        if (vmask) rankmap[w] = make_uint2(vmask, before);
-        for (unsigned b = bits; b; b &= b - 1) {
-            int bit = __ffs((int)b) - 1;
-            unsigned slot = w * 32 + bit;
-            int id = bc.wtable[slot];
-            if (vmask & (1u << bit)) {
-                cells[before] = *reinterpret_cast<const NdtCell *>(tmp_base + id);
-                table[slot] = (int)before;
-                before++;
+#pragma unroll
+        for (unsigned k = 0; k < WPL; k++) {
+            const unsigned w = w0 + k, bk = bits[k], vk = vmask[k];
+            if (vk) rankmap[w] = make_uint2(vk, before);
+            for (unsigned b = bk; b; b &= b - 1) {
+                int bit = __ffs((int)b) - 1;
+                unsigned slot = w * 32 + bit;
+                int id = bc.wtable[slot];
+                if (vk & (1u << bit)) {
+                    cells[before] = *reinterpret_cast<const NdtCell *>(tmp_base + id);
+                    table[slot] = (int)before;
+                    before++;
+                }
+                bc.wtable[slot] = NDT_EMPTY;      // work table back to its clean state
             }
-            bc.wtable[slot] = NDT_EMPTY;      // work table back to its clean state
+            if (bk) bc.bitmap[w] = 0u;
         }
-        if (bits) bc.bitmap[w] = 0u;
     }
     if (tid == 0) s_base = total_cells;
     __syncthreads();
@@ -689,6 +751,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         ctr->cyc[1] = (uint32_t)(t2 - t1);
         ctr->cyc[2] = (uint32_t)(t3 - t2);
         ctr->cyc[3] = (uint32_t)((long long)__builtin_readcyclecounter() - t3);
+#ifdef NDT_PROF_C
+        ctr->cyc[0] = (uint32_t)(t1 - t0); ctr->cyc[1] = (uint32_t)(t2 - t1); ctr->cyc[2] = (uint32_t)(t2b - t2); ctr->cyc[3] = (uint32_t)(t3 - t2b);
+#endif
 #ifdef NDT_PROFILE_SECTIONS
         for (int k = 0; k < 4; k++) ctr->cyc[k] = (uint32_t)(ps[k] >> 4);   // wave 0: load, bin, accumulate, merge+flush (x16 cycles)
 #ifdef NDT_PROFILE_ACC
