@@ -153,7 +153,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u, wave = tid >> 6;
     const unsigned nthreads = (MODE == 2) ? NDT_FIN_THREADS : NDT_BUILD_THREADS, nwaves = nthreads / 64;
-    const unsigned map_local = (MODE == 1) ? blockIdx.y : blockIdx.x;
+    const unsigned map_local = (MODE == 0) ? blockIdx.x : blockIdx.y;
+    // MODE 2: gridDim.x workgroups share phases 0 and B of one map; the last one to finish runs phases C and D
+    const unsigned fin_parts = (MODE == 2) ? gridDim.x : 1u, fin_part = (MODE == 2) ? blockIdx.x : 0u;
     const unsigned map = first + map_local;
     const NdtGrid g = set.grid;
     const uint32_t cap = g.max_cells;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     if (MODE != 1) {
         unsigned old = ctr->n_cells;
         if (old > cap) old = cap;
-        for (unsigned i = tid; i < old; i += nthreads) {
+        for (unsigned i = fin_part * nthreads + tid; i < old; i += nthreads * fin_parts) {
             const uint32_t sl = cells[i].slot;
             table[sl] = NDT_EMPTY;
             rankmap[sl >> 5].x = 0u;
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     NdtAcc *tmp_base = bc.acc;                            // cell record written over its own accumulator
     unsigned binned = 0;
     const double IS1 = ldexp(1.0, -s1_shift), IS2 = ldexp(1.0, -s2_shift);
-    for (unsigned id = tid; id < n_alloc; id += nthreads) {
+    for (unsigned id = fin_part * nthreads + tid; id < n_alloc; id += nthreads * fin_parts) {
         NdtAcc a = bc.acc[id];
         NdtCell c;
         c.n = 0;
@@ -612,6 +614,24 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     }
     if (binned) atomicAdd(&s_dropped, binned);
     __syncthreads();
+    if (MODE == 2 && fin_parts > 1u) {
+        // publish this workgroup's share (binned points, cell records, cleared bits) and draw a ticket: the
+        // workgroup that draws the last one has everybody's phase B behind it and goes on alone
+        __shared__ unsigned s_ticket;
+        if (tid == 0) {
+            if (s_dropped) atomicAdd(&ctr->n_dropped, s_dropped);
+            __threadfence();
+            s_ticket = atomicAdd(&ctr->cyc[3], 1u);
+        }
+        __syncthreads();
+        if (s_ticket != fin_parts - 1u) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_dropped = __hip_atomic_load(&ctr->n_dropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctr->cyc[3] = 0u;                              // the ticket counter rests at zero between builds
+        }
+        __syncthreads();
+    }
 
     // ---------------- phase C: rank Gaussian cells in slot order from the occupancy bitmap ------------
     long long t2 = __builtin_readcyclecounter();
@@ -650,9 +670,6 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         if (lane == 63) s_wave_cnt[wave] = incl;
     }
     __syncthreads();
-#ifdef NDT_PROF_C
-    long long t2b = __builtin_readcyclecounter();
-#endif
     unsigned running = 0, total_cells = 0;
     for (unsigned k = 0; k < nwaves; k++) {
         unsigned c2 = s_wave_cnt[k];
@@ -750,10 +767,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         ctr->cyc[0] = (uint32_t)(t1 - t0);
         ctr->cyc[1] = (uint32_t)(t2 - t1);
         ctr->cyc[2] = (uint32_t)(t3 - t2);
-        ctr->cyc[3] = (uint32_t)((long long)__builtin_readcyclecounter() - t3);
-#ifdef NDT_PROF_C
-        ctr->cyc[0] = (uint32_t)(t1 - t0); ctr->cyc[1] = (uint32_t)(t2 - t1); ctr->cyc[2] = (uint32_t)(t2b - t2); ctr->cyc[3] = (uint32_t)(t3 - t2b);
-#endif
+        ctr->cyc[3] = 0u;                                  // reserved: ticket counter of the multi-workgroup finalise
 #ifdef NDT_PROFILE_SECTIONS
         for (int k = 0; k < 4; k++) ctr->cyc[k] = (uint32_t)(ps[k] >> 4);   // wave 0: load, bin, accumulate, merge+flush (x16 cycles)
 #ifdef NDT_PROFILE_ACC
@@ -832,7 +846,11 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
                                         count, stream);
         if (e != hipSuccess) return e;
         NDT_LAUNCH_BUILD_SD(1, dim3(parts, (unsigned)count));
-        hipLaunchKernelGGL((ndt_build_kernel<0, 2>), dim3((unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
+        // phases 0 and B (moments -> Gaussians, one per thread) on up to 32 workgroups per map
+        unsigned fin_parts = (unsigned)(512 / count);
+        if (fin_parts > 32u) fin_parts = 32u;
+        if (fin_parts < 1u) fin_parts = 1u;
+        hipLaunchKernelGGL((ndt_build_kernel<0, 2>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
                            (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
                            map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg);
     }
