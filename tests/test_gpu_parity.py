@@ -419,6 +419,56 @@ def test_scheduler_parking_is_bit_neutral(N, O, monkeypatch):
                 assert np.array_equal(r[f], ref[1][f]), f
 
 
+def test_full_size_properties(N):
+    """configs[1] size (100 k points, 0.5 m cells), properties that need no oracle:
+    (a) grid translation equivariance: both scans and the grid centre moved by a whole number of cells give the same
+        cells (shifted) and the same registration; (b) a map matched against itself stays at the identity;
+    (c) every point is either binned or counted as dropped; (d) swapping the roles of the scans gives the inverse
+        transform up to the matcher's own convergence tolerance."""
+    from ndt_feature_graph_amd import synth
+    B, n = 8, 100000
+    pr = synth.pair_2d(list(range(101, 101 + B)), n)
+    f, m, T0 = pr["fixed"].numpy(), pr["moving"].numpy(), pr["T_init"].numpy()
+    size = [100, 100, 1]
+    a = N.MapSet(0.5, [0, 0, 0], size, n_maps=2 * B)
+    a.build(np.concatenate([f, m]), range_limit=30.0)
+    idx = np.arange(B)
+    Ta, ra = N.match_batch(a, idx, a, idx + B, T0)
+    # (a) shift by (+37, -12, 0) cells; the range limit is measured from the (shifted) sensor origin
+    sh = np.array([37 * 0.5, -12 * 0.5, 0.0])
+    b = N.MapSet(0.5, list(sh), size, n_maps=2 * B)
+    b.build((np.concatenate([f, m]) + sh.astype(np.float32)).astype(np.float32), range_limit=30.0,
+            range_origins=np.tile(sh, (2 * B, 1)))
+    for k in (0, B - 1, B, 2 * B - 1):
+        ca, cb = a.export_cells(k), b.export_cells(k)
+        assert np.array_equal(ca[2], cb[2]) and np.array_equal(ca[3], cb[3])            # same cells, same counts
+        assert np.max(np.abs(ca[0] + sh - cb[0])) < 2e-6                                  # fp32 inputs were re-rounded
+    S = np.eye(4); S[:3, 3] = sh
+    T0b = np.stack([S @ T0[k] @ np.linalg.inv(S) for k in range(B)])
+    Tb, rb = N.match_batch(b, idx, b, idx + B, T0b)
+    # the shifted fp32 inputs are re-rounded (cell means move by ~1e-6 m), and a registration stops inside its own
+    # convergence band: most pairs agree to micrometres, every pair to well below a millimetre
+    # (a registration that runs into ITR_MAX has no unique answer: compared only when both runs converged)
+    d = np.array([pose_close(np.linalg.inv(S) @ Tb[k] @ S, Ta[k]) for k in range(B)])
+    both = (ra["converged"] == 1) & (rb["converged"] == 1)
+    assert both.sum() >= B - 2
+    assert np.all(d[both, 0] < 2e-3) and np.all(d[both, 1] < 2e-4), (d, both)
+    assert np.sum((d[:, 0] < 5e-5) & (d[:, 1] < 5e-6)) >= B - 3, d
+    # (b) self match
+    Ts, rs = N.match_batch(a, idx, a, idx, np.tile(np.eye(4), (B, 1, 1)))
+    assert np.all(rs["converged"] == 1) and np.max(np.abs(Ts - np.eye(4))) < 1e-9
+    # (c) counters
+    for k in range(2 * B):
+        c = a.counters(k)
+        assert c["overflow"] == 0 and c["n_dropped"] <= n and a.export_cells(k)[3].sum() <= n - c["n_dropped"]
+    # (d) inverse consistency
+    Tinv, rinv = N.match_batch(a, idx + B, a, idx, np.stack([np.linalg.inv(T0[k]) for k in range(B)]))
+    for k in range(B):
+        if ra["converged"][k] and rinv["converged"][k]:
+            dt, dr = pose_close(Tinv[k] @ Ta[k], np.eye(4))
+            assert dt < 0.02 and dr < 0.005, (k, dt, dr)
+
+
 def test_self_match_and_empty_maps(N):
     from ndt_feature_graph_amd import synth
     pts = synth.pair_2d([9], 20000)["fixed"].numpy()
