@@ -98,9 +98,10 @@ hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const Ndt
                                     hipStream_t stream);
 size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups);
 size_t ndt_match_coop_work_bytes(size_t n_groups);
-hipError_t ndt_launch_match_coop(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, double *T16_dev,
-                                 const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
-                                 unsigned n_groups, void *work_dev, hipStream_t stream);
+hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
+                                 const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
+                                 NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups,
+                                 unsigned cells_per_group, void *work_dev, hipStream_t stream);
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
                             NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters,

@@ -529,12 +529,12 @@ size_t ndt_match_coop_work_bytes(size_t n_groups) { return sizeof(NdtCoopCtrl) +
 // 256 workgroups), so workgroups arrive on one of up to 16 group counters and the last arrival of a group bumps
 // the top counter everybody polls: ~16 + 16 serialised atomics instead of 256.  Counters only grow (no reset
 // race); nobody can arrive for barrier e + 1 before every workgroup has arrived for barrier e.
-NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &epoch)
+NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &epoch, unsigned G)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
         epoch += 1u;
-        const unsigned G = gridDim.x, NG = G < 16u ? G : 16u, gi = blockIdx.x % NG;
+        const unsigned NG = G < 16u ? G : 16u, gi = blockIdx.x % NG;
         const unsigned gsize = (G - gi + NG - 1u) / NG;            // workgroups w with w % NG == gi
         __threadfence();
         if (atomicAdd(&c->grp[16u * gi], 1u) + 1u == gsize * epoch) atomicAdd(&c->top, 1u);
@@ -552,8 +552,9 @@ NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &epoch)
 
 template <int NN>
 __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
-    NdtSetView tset, unsigned tmap, NdtSetView sset, unsigned smap, double *__restrict__ T16, NdtMatchParamsDev prm,
-    NdtMatchResultDev *__restrict__ res, const double *__restrict__ Q36, char *__restrict__ work_mem)
+    NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
+    double *__restrict__ T16_all, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res_all,
+    const double *__restrict__ Q36_all, char *__restrict__ work_all, size_t work_stride, unsigned cells_per_group)
 {
     __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
     __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
@@ -563,11 +564,23 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     __shared__ rigid s_T;
     __shared__ int s_with_h, s_done;
 
+    // blockIdx.y = registration: its gridDim.x workgroups have their own control block and barrier.  Workgroups
+    // are dispatched x-fastest, so the workgroups of one registration become resident together; registrations
+    // whose workgroups are all resident always finish and free their CUs for the next ones.
+    const unsigned pair = blockIdx.y;
+    char *work_mem = work_all + (size_t)pair * work_stride;
+    double *T16 = T16_all + (size_t)pair * 16;
+    NdtMatchResultDev *res = res_all + pair;
+    const double *Q36 = Q36_all ? Q36_all + (size_t)pair * 36 : nullptr;
     NdtCoopCtrl *ctrl = reinterpret_cast<NdtCoopCtrl *>(work_mem);
     double *partials = reinterpret_cast<double *>(work_mem + sizeof(NdtCoopCtrl));
-    const MapView tg = map_view(tset, tmap);
-    const MapView sv = map_view(sset, smap);
-    const unsigned g = blockIdx.x, G = gridDim.x;
+    const MapView tg = map_view(tset, tidx[pair]);
+    const MapView sv = map_view(sset, sidx[pair]);
+    // the number of workgroups of a registration depends on its own source map only (a pair's result does not
+    // depend on the batch it is in); the launch grid is sized for the largest map, surplus workgroups leave
+    const unsigned g = blockIdx.x;
+    const unsigned G = min(gridDim.x, max(1u, ((unsigned)sv.n_cells + cells_per_group - 1u) / cells_per_group));
+    if (g >= G) return;
     const int per = (sv.n_cells + (int)G - 1) / (int)G;
     const int begin = min(sv.n_cells, (int)g * per), count = min(sv.n_cells - begin, per);
     unsigned target = 0;
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     long long cyc_eval = 0, cyc_solver = 0, cyc_bar = 0;
     for (;;) {
         long long b0 = __builtin_readcyclecounter();
-        if (!coop_barrier(ctrl, target)) return;               // the request is published
+        if (!coop_barrier(ctrl, target, G)) return;               // the request is published
         cyc_bar += (long long)__builtin_readcyclecounter() - b0;
         if (threadIdx.x == 0) { s_T = ctrl->Teval; s_with_h = ctrl->with_h; s_done = ctrl->done; }
         __syncthreads();
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         if (threadIdx.x < 32) { partials[g * 32 + threadIdx.x] = s_sums[threadIdx.x]; __threadfence(); }
         long long c1 = __builtin_readcyclecounter();
         cyc_eval += c1 - c0;
-        if (!coop_barrier(ctrl, target)) return;               // all partials are in memory
+        if (!coop_barrier(ctrl, target, G)) return;               // all partials are in memory
         cyc_bar += (long long)__builtin_readcyclecounter() - c1;
         if (g == 0) {
             // 16 x 32 threads: thread (r, k) adds value k of workgroups r, r + 16, ... (loads of different threads
@@ -629,6 +642,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         o.cycles_solver = cyc_solver;
 #ifdef NDT_COOP_PROF
         o.cycles_eval = cyc_bar;           // profiling build: time at the grid barriers instead
+#else
+        (void)cyc_bar;
 #endif
         o.pair_terms_g = terms_g;
         o.pair_terms_h = terms_h;
@@ -636,15 +651,18 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     }
 }
 
-hipError_t ndt_launch_match_coop(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, double *T16_dev,
-                                 const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
-                                 unsigned n_groups, void *work_dev, hipStream_t stream)
+hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
+                                 const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
+                                 NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups,
+                                 unsigned cells_per_group, void *work_dev, hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(work_dev, 0, sizeof(NdtCoopCtrl), stream);
+    const size_t stride = ndt_match_coop_work_bytes(n_groups);
+    hipError_t e = hipMemset2DAsync(work_dev, stride, 0, sizeof(NdtCoopCtrl), n_pairs, stream);
     if (e != hipSuccess) return e;
 #define NDT_LAUNCH_COOP(NN)                                                                                           \
-    hipLaunchKernelGGL(ndt_match_coop_kernel<NN>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset,           \
-                       (unsigned)tmap, sset, (unsigned)smap, T16_dev, prm, res_dev, Q36_dev, (char *)work_dev)
+    hipLaunchKernelGGL(ndt_match_coop_kernel<NN>, dim3(n_groups, (unsigned)n_pairs), dim3(NDT_MATCH_THREADS), 0, stream, \
+                       tset, tidx_dev, sset, sidx_dev, T16_dev, prm, res_dev, Q36_dev, (char *)work_dev, stride,       \
+                       cells_per_group)
     switch (prm.n_neighbours) {
     case 0: NDT_LAUNCH_COOP(0); break;
     case 1: NDT_LAUNCH_COOP(1); break;

@@ -547,52 +547,66 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
     return NDTGPU_OK;
 }
 
-// Small batches, device-resident: one cooperative launch per registration (csrc/ndt_match.hip
-// ndt_match_coop_kernel): the whole grid evaluates, workgroup 0 solves, no host round trip per evaluation.
+// Batches that cannot fill the chip with one workgroup per registration: ONE cooperative launch, n_groups workgroups
+// per registration (csrc/ndt_match.hip ndt_match_coop_kernel): the group evaluates, its workgroup 0 solves, no
+// host round trip per evaluation.  Returns NDTGPU_OK with *done = false when one workgroup per registration is
+// the better shape (the caller then uses the persistent kernel).
 static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                 double *T16, size_t n_pairs, const NdtMatchParamsDev &p, const double *Q36,
-                                ndtgpu_match_result *results, hipStream_t st)
+                                ndtgpu_match_result *results, hipStream_t st, bool *done)
 {
+    *done = false;
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
         n_cu = 256;
-    const size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result);
-    const size_t off_R = (bT + 255) & ~(size_t)255, off_Q = (off_R + bR + 255) & ~(size_t)255;
+    if (n_pairs > (size_t)n_cu / 2) return NDTGPU_OK;
+    const char *coop_env = getenv("NDTGPU_COOP");             // NDTGPU_COOP=0: persistent kernel above 8 pairs (A/B)
+    if (coop_env && atoi(coop_env) == 0 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;
+    // source map sizes decide how many workgroups a registration can use
+    uint32_t max_cells = 0;
+    {
+        std::vector<NdtMapCounters> cs(n_pairs);
+        for (size_t k = 0; k < n_pairs; k++)
+            HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t k = 0; k < n_pairs; k++) max_cells = std::max(max_cells, cs[k].n_cells);
+    }
+    // 128 source cells per workgroup (16 per wave; fewer cells per workgroup stop paying: barrier + solver
+    // latency dominate), at most one workgroup per CU.  Every registration uses ceil(its cells / 128) workgroups
+    // whatever batch it is in; registrations that do not fit on the chip together run one after the other.
+    const char *cpg = getenv("NDTGPU_COOP_CELLS");
+    const unsigned per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 128u;
+    unsigned groups = (max_cells + per_group - 1u) / per_group;
+    if (groups > (unsigned)n_cu) groups = (unsigned)n_cu;
+    if (groups < 1) groups = 1;
+    if (groups == 1 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;      // persistent kernel instead
+
+    const size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
+    const size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
+                 off_si = (off_ti + bI + 255) & ~(size_t)255, off_Q = (off_si + bI + 255) & ~(size_t)255;
     const size_t total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
     ndtgpu_status rc = ts->ensure_stage(total);
     if (rc != NDTGPU_OK) return rc;
-    rc = ts->ensure_work(n_pairs * ndt_match_coop_work_bytes((size_t)n_cu));
+    const size_t stride = ndt_match_coop_work_bytes(groups);
+    rc = ts->ensure_work(n_pairs * stride);
     if (rc != NDTGPU_OK) return rc;
     char *base = (char *)ts->stage;
     HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
     if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
-    std::vector<NdtMapCounters> cs(n_pairs);
-    for (size_t k = 0; k < n_pairs; k++)
-        HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (size_t k = 0; k < n_pairs; k++) {
-        // 128 source cells per workgroup (16 per wave; fewer cells per workgroup stop paying: barrier + solver
-        // latency dominate), at most one workgroup per CU: all of them are resident
-        const char *cpg = getenv("NDTGPU_COOP_CELLS");
-        const unsigned per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 128u;
-        unsigned groups = (cs[k].n_cells + per_group - 1u) / per_group;
-        if (groups < 1) groups = 1;
-        if (groups > (unsigned)n_cu) groups = (unsigned)n_cu;
-        char *work = (char *)ts->work + k * ndt_match_coop_work_bytes((size_t)n_cu);
-        hipError_t e = ndt_launch_match_coop(ts->v, tidx[k], ss->v, sidx[k], (double *)base + 16 * k, p,
-                                             reinterpret_cast<NdtMatchResultDev *>(base + off_R) + k,
-                                             Q36 ? (const double *)(base + off_Q) + 36 * k : nullptr, groups, work, st);
-        if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: cooperative launch", e);
-    }
+    hipError_t e = ndt_launch_match_coop(ts->v, (const uint32_t *)(base + off_ti), ss->v, (const uint32_t *)(base + off_si),
+                                         (double *)base, n_pairs, p, reinterpret_cast<NdtMatchResultDev *>(base + off_R),
+                                         Q36 ? (const double *)(base + off_Q) : nullptr, groups, per_group, ts->work, st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: cooperative launch", e);
     std::vector<unsigned> ctrl(n_pairs * 4);
-    for (size_t k = 0; k < n_pairs; k++)
-        HIP_TRY(hipMemcpyAsync(&ctrl[4 * k], (char *)ts->work + k * ndt_match_coop_work_bytes((size_t)n_cu), 16,
-                               hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpy2DAsync(ctrl.data(), 16, ts->work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (size_t k = 0; k < n_pairs; k++)
         if (ctrl[4 * k + 1]) return fail(NDTGPU_ERR_HIP, "match: cooperative kernel gave up waiting at a grid barrier");
+    *done = true;
     return NDTGPU_OK;
 }
 
@@ -660,14 +674,17 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
     // builds on other streams must have finished before the maps are read
     HIP_TRY(hipStreamSynchronize(ts->last_stream));
     HIP_TRY(hipStreamSynchronize(ss->last_stream));
-    if (n_pairs <= NDTGPU_HOST_LOOP_MAX) {
+    {
         NdtMatchParamsDev p = to_dev(prm);
         if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
             return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
         // NDTGPU_HOST_LOOP=1: the host runs the state machine, one launch per evaluation (A/B, debugging)
         const char *hl = getenv("NDTGPU_HOST_LOOP");
-        if (hl && atoi(hl)) return match_host_driven(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st);
-        return match_coop(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st);
+        if (n_pairs <= NDTGPU_HOST_LOOP_MAX && hl && atoi(hl))
+            return match_host_driven(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st);
+        bool done = false;
+        ndtgpu_status crc = match_coop(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st, &done);
+        if (crc != NDTGPU_OK || done) return crc;
     }
     size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
     size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,

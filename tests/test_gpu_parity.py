@@ -371,15 +371,20 @@ def test_match_batch_is_deterministic_and_order_free(N, O):
 
 
 def test_persistent_cooperative_and_host_driven_paths_agree(N, O, monkeypatch):
-    """> 8 pairs: persistent workgroups pulling pairs; <= 8 pairs: one cooperative launch per registration (grid
-    barrier, workgroup 0 solves), or with NDTGPU_HOST_LOOP=1 the host-driven Newton loop + one derivative launch
-    per evaluation.  Same state machine (csrc/ndt_solver.h), different summation order."""
+    """Batches that fill the chip: persistent workgroups pulling pairs; smaller ones: one cooperative launch with
+    several workgroups per registration (grid barrier, workgroup 0 solves), or with NDTGPU_HOST_LOOP=1 (<= 8 pairs)
+    the host-driven Newton loop + one derivative launch per evaluation.  Same state machine
+    (csrc/ndt_solver.h), different summation order."""
     pr, tg, sr, om = _pair_maps(N, O, list(range(1, 13)), 20000, 0.5)
     T0 = pr["T_init"].numpy()
     idx = np.arange(12)
+    monkeypatch.setenv("NDTGPU_COOP", "0")
     Tb, rb = N.match_batch(tg, idx, sr, idx, T0)                 # persistent kernel
+    monkeypatch.delenv("NDTGPU_COOP")
+    Tc, rc = N.match_batch(tg, idx, sr, idx, T0)                 # one cooperative launch, a few workgroups per pair
+    assert np.max(np.abs(Tc - Tb)) < 1e-9 and np.array_equal(rc["iterations"], rb["iterations"])
     for b in (0, 5, 11):
-        Ts, rs = N.match_d2d(tg, b, sr, b, T0[b])                # cooperative kernel
+        Ts, rs = N.match_d2d(tg, b, sr, b, T0[b])                # cooperative kernel, whole chip
         monkeypatch.setenv("NDTGPU_HOST_LOOP", "1")
         Th, rh = N.match_d2d(tg, b, sr, b, T0[b])                # host-driven loop
         monkeypatch.delenv("NDTGPU_HOST_LOOP")
