@@ -144,14 +144,17 @@ ndtgpu_status ndtgpu_derivatives(ndtgpu_mapset *target, size_t target_map, const
  * the loop of NDTFeatureGraph::updateLinksUsingNDTRegistration (ndt_feature_graph.cpp:347-353).
  * Pair k matches target_set[target_idx[k]] (fixed) against source_set[source_idx[k]] (moving).
  * T16: HOST, n_pairs x 16 doubles, in: initial guess, out: result.  results: HOST, n_pairs.
- * One persistent workgroup per pair; the whole Newton / More-Thuente loop runs on the device.
+ * The whole Newton / More-Thuente loop runs on the device: persistent workgroups pulling pairs from a ticket
+ * counter when the batch fills the chip, one cooperative launch with several workgroups per registration when it
+ * does not (<= 128 pairs; the one-link-at-a-time call of ndt_feature_graph.cpp:273 is n_pairs = 1).
  * Synchronous (returns after the results are on the host). */
 ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx, ndtgpu_mapset *source_set,
                                  const uint32_t *source_idx, double *T16, size_t n_pairs,
                                  const ndtgpu_match_params *prm, ndtgpu_match_result *results,
                                  ndtgpu_stream stream);
 /* device-resident variant for pipelines: T16_dev / results_dev are DEVICE buffers, idx arrays
- * DEVICE uint32; asynchronous on `stream` (graph-capturable: no allocation, no sync). */
+ * DEVICE uint32; asynchronous on `stream`, no host synchronisation (the set's work area -- ticket counters,
+ * parked solver states -- is allocated by the first call of a given batch size).  Always the persistent kernel. */
 ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *target_set, const uint32_t *target_idx_dev,
                                         ndtgpu_mapset *source_set, const uint32_t *source_idx_dev,
                                         double *T16_dev, size_t n_pairs, const ndtgpu_match_params *prm,
