@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -595,6 +596,10 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
     if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
+    // Two cooperative launches in flight at once (two host threads, two streams) could each hold part of the chip
+    // and wait for the rest: one at a time per process; the call is synchronous anyway.
+    static std::mutex coop_mutex;
+    std::lock_guard<std::mutex> coop_lock(coop_mutex);
     hipError_t e = ndt_launch_match_coop(ts->v, (const uint32_t *)(base + off_ti), ss->v, (const uint32_t *)(base + off_si),
                                          (double *)base, n_pairs, p, reinterpret_cast<NdtMatchResultDev *>(base + off_R),
                                          Q36 ? (const double *)(base + off_Q) : nullptr, groups, per_group, ts->work, st);
