@@ -424,6 +424,27 @@ def test_scheduler_parking_is_bit_neutral(N, O, monkeypatch):
                 assert np.array_equal(r[f], ref[1][f]), f
 
 
+@pytest.mark.parametrize("res,n_pts,nn,step_control", [(0.3, 30000, 1, 1), (1.0, 8000, 3, 1), (0.25, 40000, 2, 1),
+                                                        (0.5, 20000, 2, 0)])
+def test_match_parity_sweep(N, O, res, n_pts, nn, step_control):
+    """Other cell sizes, neighbourhood radii 1 and 3, Newton without step control: 10 pairs each, through the
+    cooperative launch (10 pairs) and through the persistent kernel (the same pairs repeated to 200)."""
+    seeds = list(range(500, 510))
+    B = len(seeds)
+    pr, tg, sr, om = _pair_maps(N, O, seeds, n_pts, res)
+    T0 = pr["T_init"].numpy()
+    kw = dict(n_neighbours=nn, step_control=step_control)
+    Tc, rc = N.match_batch(tg, np.arange(B), sr, np.arange(B), T0, **kw)
+    rep = np.arange(200) % B
+    Tp, rp = N.match_batch(tg, rep, sr, rep, T0[rep], **kw)
+    for b in range(B):
+        To, ro = O.match_d2d(om[b][0], om[b][1], T0[b], **kw)
+        for Tx, rx in ((Tc[b], rc), (Tp[b], rp)):
+            dt, dr = pose_close(Tx, To)
+            assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
+            assert bool(rx["converged"][b]) == ro["converged"] and rx["iterations"][b] == ro["iterations"]
+
+
 def test_full_size_properties(N):
     """configs[1] size (100 k points, 0.5 m cells), properties that need no oracle:
     (a) grid translation equivariance: both scans and the grid centre moved by a whole number of cells give the same
