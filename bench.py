@@ -208,14 +208,25 @@ def main():
             traffic = pmc["kernels"][dominant]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
-    roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                "achieved_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6,
-                "frac_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6 / HBM_PEAK_GBS,
-                "note": "achieved = algorithmic bytes per launch / HIP-event kernel duration over the timed region (events on "
-                        "the launch stream; with the 2-buffer pipeline a kernel shares the chip with the other step's "
-                        "kernels, kernels.*.ms_isolated is its duration alone); traffic = HBM bytes per launch from the "
-                        "rocprofv3 PMC passes committed under profiles/ (not collected live)"}
+    note = ("achieved = algorithmic work per launch / HIP-event kernel duration over the timed region (events on the "
+            "launch stream; with the pipeline a kernel shares the chip with the other steps' kernels, *_isolated is the "
+            "kernel alone); traffic = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ "
+            "(not collected live)")
+    if dominant == "ndt_build_kernel":       # streaming pass over the points: HBM roof
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                    "achieved_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6,
+                    "frac_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6 / HBM_PEAK_GBS, "note": note}
+    else:
+        # the matcher re-reads two cell maps that live in L2 ~1000 times: its roof is fp64 arithmetic,
+        # 78.6 TFLOP/s on MI355X for matrix and vector fp64 alike.  Flops = the kernel's own pair-term counters x
+        # 130 (gradient term) / 610 (Hessian term), DESIGN.md 4.2.  kernels.ndt_match_kernel.GBps is the HBM view.
+        roofline = {"kernel": dominant, "bound": "mfma", "achieved": mk["fp64_tflops"], "peak": 78.6, "unit": "TFLOP/s",
+                    "frac": mk["fp64_tflops"] / 78.6, "traffic": traffic,
+                    "achieved_isolated": mk["fp64_gflop_per_launch"] / mk["ms_isolated"],
+                    "frac_isolated": mk["fp64_gflop_per_launch"] / mk["ms_isolated"] / 78.6,
+                    "note": note + "; fp64 vector work (no MFMA instruction is issued: every pair term has its own 3x3 "
+                                   "inverse), counted against the fp64 peak"}
 
     out = {
         "metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)",
