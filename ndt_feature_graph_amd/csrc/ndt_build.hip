@@ -41,6 +41,32 @@
 #define NDT_ROUNDS 8         // sub-tiles per super-tile (one wavefront merge + flush per 2048 points)
 #define NDT_IDC 64           // entries of the per-wave slot -> id cache
 #define NDT_FLCAP 40         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 160 B)
+#ifdef NDT_BUILD_ABLATION
+#define NDT_DBGV dbg
+#else
+#define NDT_DBGV 0
+#endif
+#ifndef NDT_D1
+#define NDT_D1 NDT_DBGV
+#endif
+#ifndef NDT_D2
+#define NDT_D2 NDT_DBGV
+#endif
+#ifndef NDT_D3
+#define NDT_D3 NDT_DBGV
+#endif
+#ifndef NDT_D4
+#define NDT_D4 NDT_DBGV
+#endif
+#ifndef NDT_D5
+#define NDT_D5 NDT_DBGV
+#endif
+#ifndef NDT_D6
+#define NDT_D6 NDT_DBGV
+#endif
+#ifndef NDT_D7
+#define NDT_D7 NDT_DBGV
+#endif
 #define NDT_QRUNS 16         // per-wave table of replaced runs, keyed by cell (power of two)
 #define NDT_EMPTY (-1)
 
@@ -247,7 +273,10 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     const unsigned tile_begin = (MODE == 2) ? 0u : min(part_end, part_begin + wave * tiles_per_wave);
     const unsigned tile_end = (MODE == 2) ? 0u : min(part_end, tile_begin + tiles_per_wave);
     const unsigned awave = (MODE == 2) ? 0u : wave;   // phase-A per-wave LDS regions (unused when finalising)
-    float *mytile = s_tile + awave * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1));
+    // the flush list below lives in the same bytes as doubles: the float view may alias it (no type-based reordering
+    // of the next round's staging stores against the list's loads)
+    typedef float __attribute__((may_alias)) tile_f32;
+    tile_f32 *mytile = s_tile + awave * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1));
     // flush list: after the point loop the tile buffer is dead and holds the records of the partial
     // runs that must be added to their cells; ONE atomic instruction then serves up to 64 (record,
     // component) items, instead of 19 dependent single-lane atomics per run.
@@ -256,13 +285,15 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     unsigned nfl = 0;   // wave-uniform
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
     auto drain_list = [&]() {
+        ndt_wave_sync();                                  // the records were written by other lanes
         const unsigned items = nfl * 20u;
         for (unsigned it = lane; it < items; it += 64u) {
             unsigned e = it / 20u, k = it % 20u;
             int id = fl_id[e];
-            if (k < 19u && id >= 0 && !(dbg & 1))
+            if (k < 19u && id >= 0 && !(NDT_D1 & 1))
                 unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + id) + k, fl_val[e * 20u + k]);
         }
+        ndt_wave_sync();                                  // the list may be overwritten now
         nfl = 0;
     };
     auto push_runs = [&](bool mine, int slot, double n, const double *sd3, const double *se6) {
@@ -320,12 +351,13 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 }
             }
         }
+        ndt_wave_sync();   // a lane's row of the tile was written by other lanes
         NDT_PS(0)
 #pragma unroll 1
         for (int j = 0; j < NDT_PPL; j++) {
             float fx, fy, fz;
             if (STRIDE_DW) {
-                const float *pf = mytile + lane * LANE_DW + j * SD;
+                const tile_f32 *pf = mytile + lane * LANE_DW + j * SD;
                 fx = pf[0]; fy = pf[1]; fz = pf[2];
             } else {
                 const unsigned i = p0 + (lane * R + r) * NDT_PPL + j;
@@ -333,7 +365,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 const float *pf = (const float *)(pts + (size_t)(have ? i : 0u) * stride_bytes);
                 fx = have ? pf[0] : __builtin_nanf(""); fy = pf[1]; fz = pf[2];
             }
-            if (dbg & 4) fx = __builtin_nanf("");
+            if (NDT_D2 & 4) fx = __builtin_nanf("");
             // fp32 fast paths.  Every test below is false for a NaN (NaN points are skipped, like padding); an
             // Inf passes the range test when no range is set and is then out of the grid.
             const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
@@ -366,19 +398,19 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 }
             }
             NDT_PS(1)
-            if (dbg & 16) continue;
+            if (NDT_D3 & 16) continue;
             // A lane keeps the moments of TWO cells in registers (range noise on a wall that hugs a cell face makes
             // its consecutive points alternate between two cells; a lane that walks into the next cell keeps the
             // old one as well).  A third cell replaces the run that was used least recently; the replaced run goes
             // to the wave's LDS queue.  Nothing in the loop touches LDS or memory on the common path.
             bool newc = slot >= 0 && slot != cs0 && slot != cs1;
-            if (dbg & 32) { cs0 = slot >= 0 ? slot : cs0; newc = false; }
-            if (dbg & 64) { newc = newc && (cs0 < 0 || cs1 < 0); }
+            if (NDT_D4 & 32) { cs0 = slot >= 0 ? slot : cs0; newc = false; }
+            if (NDT_D5 & 64) { newc = newc && (cs0 < 0 || cs1 < 0); }
             if (__ballot(newc)) {
                 if (newc) {
                     const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);   // an empty run first, else the older one
                     const int victim = to1 ? cs1 : cs0;
-                    if (victim >= 0 && !(dbg & 8)) {
+                    if (victim >= 0 && !(NDT_D6 & 8)) {
                         double vn = to1 ? rn1 : rn, v3[3], v6[6];
 #pragma unroll
                         for (int k = 0; k < 3; k++) v3[k] = to1 ? sd1[k] : sd[k];
@@ -455,7 +487,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             NDT_QS(2)
         }
         }   // rounds
-        if (!(dbg & 2)) {
+        if (!(NDT_D7 & 2)) {
+            ndt_wave_sync();   // table / flag written by other lanes during the rounds
             // Canonical order of a lane's two runs (run 0 = smaller slot): along a wall that hugs a cell
             // face neighbouring lanes then agree on which cell is run 0 and which is run 1, so both form
             // long contiguous segments for the scans below instead of alternating lane by lane.
@@ -504,6 +537,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                 }
                 push_runs(head && cs >= 0, cs, rn, sd, se);
             }
+            ndt_wave_sync();
             if (s_qcnt[wave]) {                  // records of the replaced runs; the table goes back to empty
                 const unsigned ql = lane & (NDT_QRUNS - 1u);
                 const int qs = q_slot[ql];
@@ -518,6 +552,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                     for (int k = 0; k < 10; k++) q_val[k * NDT_QRUNS + ql] = 0.0;
                 }
                 if (lane == 0) s_qcnt[wave] = 0u;
+                ndt_wave_sync();
                 push_runs(has, qs, vn, v3, v6);
             }
             drain_list();
@@ -817,7 +852,14 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
     int s2_shift = (odd ? 50 : 54) - lg;
     if (s1_shift > 44) s1_shift = 44;
     if (s2_shift > 44) s2_shift = 44;
+#ifdef NDT_BUILD_ABLATION
+    // ablation build only (-DNDT_BUILD_ABLATION): NDT_BUILD_DBG switches parts of phase A off to time the rest
+    // (1 no flush atomics, 2 no merge / flush, 4 no points, 8 no run replacement, 16 no accumulation,
+    //  32 one cell per lane, 64 no third cell)
     const int dbg = getenv("NDT_BUILD_DBG") ? atoi(getenv("NDT_BUILD_DBG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     const bool aligned4 = (((uintptr_t)xyz_dev | map_stride_bytes) & 3u) == 0;
     const int sdw = (stride_bytes == 12 && aligned4) ? 3 : (stride_bytes == 16 && aligned4) ? 4 : 0;
     // Few maps: spread each scan over several workgroups (accumulate) and finalise in a second launch.

@@ -74,6 +74,18 @@ struct NdtSetView {            // what kernels see of a mapset
     double *centres;           // [n_maps][3]
 };
 
+// Lanes of one wave that hand data to each other through LDS (queues, lists, tables): the hardware runs a wave's
+// LDS operations in program order, but the COMPILER only knows about one thread -- without a fence it may hoist a
+// load above the loop in which another lane stores (seen: a flag read constant-folded to its pre-loop value).
+// A wavefront-scope fence costs nothing at run time and pins the order.
+#ifdef __HIPCC__
+static __device__ __forceinline__ void ndt_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#endif
+
 // words per map of NdtSetView::rankmap (+1: a probe window may read one word past its first)
 static inline __host__ __device__ size_t ndt_rm_stride(const NdtGrid &g) { return (size_t)((g.slots + 31) / 32) + 1; }
 

@@ -204,6 +204,7 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
     // TERM stage: pops up to 64 (source lane, target cell) pairs; every lane does one dense pair term.
     // `min_fill` = 64 while probing (only full batches), 1 for the final flush of a source tile.
     auto drain = [&](unsigned min_fill) {
+        ndt_wave_sync();                 // queue entries and source tile columns were written by other lanes
         while (qcount >= min_fill && qcount > 0) {
             unsigned n = qcount < 64u ? qcount : 64u;
             if (lane < n) {
@@ -304,6 +305,7 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
             }
         }
         drain(1);   // the per-wave source tile is overwritten by the next batch
+        ndt_wave_sync();
     }
 
     // 28 (or 7) sums: wave tree, then fixed-order sum of the wave partials
