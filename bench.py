@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--buffers", type=int, default=3, help="pipeline depth (mapset pairs / streams)")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="one stream, one mapset pair: every step waits for the previous one (default: two buffers, the "
+                    help="one stream, one mapset pair: every step waits for the previous one (default: --buffers mapset pairs, the "
                          "grid builds of step k+1 run on the CUs the matcher of step k has already left)")
     args = ap.parse_args()
 
