@@ -243,6 +243,11 @@ def main():
                    "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2)},
         "roofline": roofline, "kernels": kern,
         # SURVEY.md 8d (config 4): node maps and edges are separate units when node maps are reused across edges
+        # north_star: scans/s and achieved HBM-bandwidth fraction (algorithmic bytes / time / 8 TB/s), per kernel
+        "scans_per_s": 2 * value,
+        "hbm_fraction": {k: {"timed_region": kern[k]["GBps"] / HBM_PEAK_GBS,
+                             "kernel_alone": kern[k]["algorithmic_bytes"] / kern[k]["ms_isolated"] / 1e6 / HBM_PEAK_GBS}
+                         for k in kern},
         "nodes_per_s_build_only": world * B / (iso_build_ms * 1e-3),
         "edges_per_s_match_only_prebuilt_maps": world * B / (iso_match_ms * 1e-3),
     }
