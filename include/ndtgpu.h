@@ -50,14 +50,28 @@ typedef struct {
     uint32_t max_cells; /* capacity of occupied cells per map; 0 = min(slots, 16384) */
 } ndtgpu_grid_params;
 
-/* NDTCell::computeGaussian / rescaleCovariance knobs. */
+/* NDTCell::computeGaussian / rescaleCovariance knobs.
+ * PROVENANCE: both constants live in perception_oru's ndt_map (un-vendored, no version pinned by the reference).
+ *   n_min        the reference never passes it; the perception_oru revisions of the reference's era test
+ *                `hasGaussian_ == false && points_.size() < 3` in the 5-argument computeGaussian that
+ *                ndt_feature_fuser_hmt.cpp:94, 227, 486 reach (older / "simple" variants use 6).  Default 3;
+ *                it decides which cells exist, so a deployment against a different perception_oru sets it here.
+ *   eval_factor  EVAL_FACTOR of NDTCell; the reference itself passes 1000 when it builds cells by hand
+ *                (ndt_feature/include/ndt_feature/utils.h:200). */
 typedef struct {
-    int32_t n_min;       /* points needed for a first Gaussian (upstream: 3) */
-    double eval_factor;  /* EVAL_FACTOR, eigenvalue floor lambda_max/eval_factor (1000; utils.h:200) */
+    int32_t n_min;       /* points needed for a first Gaussian (default 3, see above) */
+    double eval_factor;  /* EVAL_FACTOR, eigenvalue floor lambda_max/eval_factor (default 1000) */
 } ndtgpu_cell_params;
 
 /* NDTMatcherD2D members set by the callers (ndt_feature_graph.cpp:261-262;
- * ndt_feature_fuser_hmt.cpp:356-357; ndt_matcher_d2d_fusion.h:1170-1174). */
+ * ndt_feature_fuser_hmt.cpp:356-357; ndt_matcher_d2d_fusion.h:1170-1174).
+ * PROVENANCE of the defaults (ndtgpu_default_match_params): the "fuser" preset -- what matchFusion is called with
+ * in production: n_neighbours 2, ITR_MAX 30, DELTA_SCORE 1e-6 (launch/gustav_laser_tf.launch:56-59,
+ * ndt_graph_offline.cpp:310-313), step_control on, lfd1 1, lfd2 0.05 (NDTMatcherD2D constructor, perception_oru).
+ * The EDGE matcher of ndt_feature_graph.cpp:261 is default-constructed with only n_neighbours overridden; its
+ * DELTA_SCORE is perception_oru's constructor value `10e-3 * current_resolution` with current_resolution = 0.1,
+ * i.e. 1e-3 -- recalled, not readable in the reference: the host mirror
+ * (host/lslgeneric_gpu.h NDTMatcherD2D::DELTA_SCORE) exposes it as a member like upstream does. */
 typedef struct {
     int32_t n_neighbours;      /* matcher.n_neighbours */
     int32_t itr_max;           /* ITR_MAX */

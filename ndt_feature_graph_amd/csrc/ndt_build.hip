@@ -7,18 +7,20 @@
 //   NDTMap::computeNDTCells(CELL_UPDATE_MODE_SAMPLE_VARIANCE) -> NDTCell::computeGaussian +
 //   rescaleCovariance                                      ...fuser_hmt.cpp:227, ndt_odom_debug.cpp:179
 //
-// Design (DESIGN.md "Build kernel"):
-//   * one 256-thread workgroup owns one map: its tables, accumulators and cells are touched by this
-//     workgroup only (workgroup-scope atomics, nothing crosses XCDs); a batch of B scans is B
-//     workgroups, three resident per CU.
-//   * phase A streams the raw scan ONCE.  Each wave owns a contiguous quarter of the scan and pulls
-//     tiles of 512 points with fully coalesced dword loads into a padded LDS tile; every lane then
-//     walks its own 8 CONSECUTIVE points (an angularly ordered sweep keeps them in one cell, range
-//     noise on a wall that hugs a cell face flips them between two), accumulating count, sum d and
-//     sum d d^T of d = p - cell_origin (|d| <= one cell: no cancellation) in fp64: the first cell
-//     ("run 0") in registers, a second one ("run 1") in LDS.  At the end of the tile contiguous lanes
-//     that hold the same cell are merged by a segmented wavefront scan and the segment heads add
-//     their partial sums to the cell's accumulator.
+// Design:
+//   * batches (>= 256 maps): one 256-thread workgroup owns one map (MODE 0) -- its tables, accumulators and cells
+//     are touched by this workgroup only; 1024 scans = 1024 workgroups, 2 waves per SIMD (register bound).
+//     Few maps: MODE 1 spreads the accumulation of one scan over many workgroups (agent-scope atomics), MODE 2
+//     finalises on up to 32 workgroups per map.
+//   * phase A streams the raw scan ONCE.  Each wave owns a contiguous share of the scan and walks it in
+//     super-tiles of 8 rounds x 512 points; a round is pulled with fully coalesced dword loads into a padded LDS
+//     tile, every lane then walks its own 8 CONSECUTIVE points (an angularly ordered sweep keeps them in one cell,
+//     range noise on a wall that hugs a cell face flips them between two), accumulating count, sum d and
+//     sum d d^T of d = p - cell_origin (|d| <= one cell: no cancellation) in fp64 for TWO cells at once, both
+//     in registers; a third cell replaces the least recently used run, which is added to a small per-wave LDS
+//     table keyed by cell.  At the end of the super-tile contiguous lanes that hold the same cell are merged by a
+//     segmented wavefront scan and the segment heads (and the table entries) append one record each to a flush
+//     list that is drained with wide atomics.
 //   * the partial sums are split into integer-valued hi/lo doubles (resolution 2^-(s+32)) before they
 //     are added, with scales that keep every accumulator below 2^53: global_atomic_add_f64 is then
 //     exact, hence associative -- the result does not depend on the order in which waves reach
