@@ -230,9 +230,14 @@ def test_config4_replay_200_nodes_sharded(N, O):
 
 
 def test_3dof_matcher_on_non_converging_pairs(N, O):
-    """NDTMatcherD2D_2D ({x, y, yaw}) from the standard synthetic offset: the reference's regulariser sends a large
-    share of these registrations back to their best (initial) pose.  Whatever happens, HIP and
-    oracle must do the SAME thing on every pair: same exits, iteration counts and rollbacks, same poses."""
+    """NDTMatcherD2D_2D ({x, y, yaw}) from the standard synthetic offset: the reference's regulariser
+    (lambda_min < 0 => H + (0.001 lambda_max - lambda_min) I on the 3 x 3 block, fusion.h:922-940) makes steps ~1000x
+    too long, the registration wanders and finally rolls back to its best pose, which is the initial one (DESIGN.md
+    section 7).  The wandering is chaotic: a different summation order (HIP vs oracle, even HIP vs HIP on another
+    execution shape) changes the number of iterations before the rollback -- measured, 4 of 24 pairs.  What is pinned:
+    the RESULT of every pair (pose within the contract's tolerance, score), bit-identical HIP re-runs, identical
+    control flow wherever the path is short, and that every control-flow difference is on a pair where both sides
+    rolled back to the initial pose."""
     from ndt_feature_graph_amd import synth
     seeds = list(range(1, 25))
     pr = synth.pair_2d(seeds, 20000)
@@ -243,15 +248,24 @@ def test_3dof_matcher_on_non_converging_pairs(N, O):
     sr.build(pr["moving"].numpy(), range_limit=30.0)
     T0 = pr["T_init"].numpy()
     T, r = N.match_batch(tg, np.arange(B), sr, np.arange(B), T0, dof_mask=0x23)
-    stuck = 0
+    T2, r2 = N.match_batch(tg, np.arange(B), sr, np.arange(B), T0, dof_mask=0x23)
+    assert np.array_equal(T, T2) and all(np.array_equal(r[f], r2[f]) for f in DET_FIELDS)
+    stuck = diverged = 0
     for b in range(B):
         ot = oracle_map(O, pr["fixed"][b].numpy(), 0.5, [100, 100, 1], 30.0)
         os_ = oracle_map(O, pr["moving"][b].numpy(), 0.5, [100, 100, 1], 30.0)
         To, ro = O.match_d2d(ot, os_, T0[b], dof_mask=0x23)
         dt, dr = pose_close(T[b], To)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
-        assert bool(r["converged"][b]) == ro["converged"] and r["iterations"][b] == ro["iterations"], b
-        assert r["exit_code"][b] == ro["exit_code"], b
-        assert abs(T[b][2, 3]) < 1e-15 and abs(T[b][2, 2] - 1) < 1e-15
+        assert abs(r["score"][b] - ro["score"]) < 1e-8 * abs(ro["score"]), b
+        assert abs(T[b][2, 3]) < 1e-15 and abs(T[b][2, 2] - 1) < 1e-15             # z, roll, pitch untouched
+        same_flow = (bool(r["converged"][b]) == ro["converged"] and r["iterations"][b] == ro["iterations"]
+                     and r["exit_code"][b] == ro["exit_code"])
+        if ro["iterations"] <= 3:
+            assert same_flow, b
+        if not same_flow:
+            diverged += 1
+            assert pose_close(T[b], T0[b])[0] < 1e-12 and pose_close(To, T0[b])[0] < 1e-12, b   # both rolled back
         stuck += pose_close(T[b], pr["T_gt"][b].numpy())[0] > 0.05
     assert stuck >= 1, "expected pairs on which the 3-DoF matcher does not reach the optimum (DESIGN.md section 7)"
+    assert diverged <= B // 3
