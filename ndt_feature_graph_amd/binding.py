@@ -34,8 +34,9 @@ def build_library(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
+    extra = os.environ.get("NDTGPU_BUILD_FLAGS", "").split()      # experiments only (-DNDT_MATCH_PROF ...)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", *srcs, "-o", _SO + ".tmp"]
+           "-Wno-unused-function", *extra, *srcs, "-o", _SO + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -9,20 +9,22 @@
 // whose Newton loop and line-search driver are restated from the in-repo copy
 //   ndt_matcher_d2d_fusion.h:847-1121 (loop), :390-793 (More-Thuente driver, constants :400-408).
 //
-// Design (DESIGN.md "Match kernel"):
-//   * one 256-thread workgroup runs the WHOLE registration of one pair: every derivative evaluation,
-//     the 6x6 eigen-regularisation, LDL^T solve, the More-Thuente state machine and the final
-//     best-score rollback, so ~25-130 dependent evaluations cost zero host round trips and pairs that
-//     converge early simply free their CU (no lock-step over the batch).
+// Design:
+//   * the WHOLE registration runs on the device: every derivative evaluation, the 6x6 regularisation, the solve,
+//     the More-Thuente state machine and the best-score rollback (csrc/ndt_solver.h) -- zero host round trips.
 //   * the source cells are never copied or re-written: each evaluation applies the composed pose
 //     (trial step x current pose) to the original 80-byte records (the reference re-allocates every
 //     cell per trial, fusion.h:563-589).
-//   * an evaluation is two interleaved wave-level stages: PROBE (each lane owns a source cell, looks up
-//     the (2n+1)^3 dense-table slots around its transformed mean, 25 independent loads in flight per
-//     z-layer) pushes hits into a per-wave LDS queue by ballot/popcount compaction; TERM pops 64
-//     (source, target) pairs so that all 64 lanes do the ~0.2-0.6 kFLOP fp64 pair term densely.
-//     No divergence in the heavy math, no atomics, fixed summation order -> run-to-run identical.
-//   * 1+6+21 fp64 partial sums per lane -> wave xor-shuffle tree -> 4 LDS partials -> fixed-order sum.
+//   * one 512-thread workgroup runs a registration; every wave owns an equal contiguous share of the source cells
+//     and walks it in groups of 64.  Per group: PROBE (each lane owns a source cell and reads the (2n+1)^3
+//     neighbourhood of its transformed mean as bit windows of the target's rank bitmap) pushes hits into a per-wave
+//     LDS queue by ballot/mbcnt compaction; TERM pops 64 (source, target) pairs so that all 64 lanes do the fp64
+//     pair term densely (444 instructions with the Hessian, 165 without).
+//   * 1+6+21 fp64 partial sums per lane -> fixed butterfly over the wave (permlane swaps) -> 8 LDS partials ->
+//     fixed-order sum.
+//   * persistent workgroups pull pairs from a ticket counter; registrations that run long are parked until every
+//     pair has started, then finished side by side (NdtMatchWork below).
+//   * no atomics in the sums, fixed summation order -> run-to-run identical.
 //   * MFMA is not used: nothing here is a dense contraction (3x3 / 6x6 per-pair expressions).
 #include "ndt_math.h"
 #include "ndt_solver.h"
@@ -176,155 +178,212 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
     }
 }
 
-// per-wave LDS rows for the decoded probe windows (up to 7 runs x 64 lanes)
-NDT_D uint2 *probe_windows()
+// LDS of one workgroup's evaluation machinery (NW waves)
+template <int NW>
+struct EvalShared {
+    double src[NW * 9 * 64];        // per wave: the transformed source tile, one column per lane
+    uint32_t queue[NW * NDT_QN];    // per wave: hit queue (source lane << 24 | target cell)
+    uint2 win[NW * 7 * 64];         // per wave: decoded probe windows (up to 7 runs x 64 lanes)
+    double part[NW * 32];           // wave partials (range-partitioned evaluations)
+    double sums[32];                // the evaluation's result
+};
+
+// What a wave carries through an evaluation: its accumulators, its hit queue, its share of the LDS.
+#ifdef NDT_MATCH_PROF   // experiments: section clocks of wave 0 (src+transform, probe, pop, term, reduce)
+__device__ long long g_prof[8];
+#define NDT_PROF_T(k) { if (threadIdx.x == 0) { long long n_ = clock64(); w.prof[k] += n_ - w.pt; w.pt = n_; } }
+#else
+#define NDT_PROF_T(k)
+#endif
+template <bool WITH_H>
+struct WaveEval {
+    static constexpr int NACC = WITH_H ? 28 : 7;
+#ifdef NDT_MATCH_PROF
+    long long prof[6], pt;
+#endif
+    double acc[NACC];
+    double *mysrc;
+    uint32_t *myq;
+    uint2 *mywin;
+    unsigned qhead, qcount, terms;   // wave-uniform
+};
+
+// TERM stage: pops up to 64 (source lane, target cell) pairs; every lane does one dense pair term.
+// `min_fill` = 64 while probing (only full batches), 1 for the final flush of a source tile.
+template <bool WITH_H>
+NDT_D void drain_queue(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double lfd2, unsigned min_fill)
 {
-    __shared__ uint2 s_win[NDT_MATCH_WAVES * 7 * 64];
-    return s_win;
+    const unsigned lane = threadIdx.x & 63u;
+    ndt_wave_sync();                 // queue entries and source tile columns were written by other lanes
+    NDT_PROF_T(2)
+    while (w.qcount >= min_fill && w.qcount > 0) {
+        unsigned n = w.qcount < 64u ? w.qcount : 64u;
+        if (lane < n) {
+            uint32_t e = w.myq[(w.qhead + lane) & (NDT_QN - 1)];
+            unsigned sl = e >> 24, id = e & 0xFFFFFFu;
+            d3 m = {w.mysrc[0 * 64 + sl], w.mysrc[1 * 64 + sl], w.mysrc[2 * 64 + sl]};
+            sym3 C = {w.mysrc[3 * 64 + sl], w.mysrc[4 * 64 + sl], w.mysrc[5 * 64 + sl],
+                      w.mysrc[6 * 64 + sl], w.mysrc[7 * 64 + sl], w.mysrc[8 * 64 + sl]};
+            const NdtCell *tc = tg.cells + id;
+            d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
+            sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
+            pair_term<WITH_H>(m, C, mu, Cj, lfd1, lfd2, w.acc);
+        }
+        w.qhead = (w.qhead + n) & (NDT_QN - 1);
+        w.qcount -= n;
+        w.terms += n;
+    }
+    NDT_PROF_T(3)
 }
 
-// One evaluation of derivativesNDT over all source cells, transformed by T.  All threads of the
-// workgroup participate; result in s_sums[0..6] (and [7..27] when WITH_H).  Ends with a barrier.
+// One group of up to 64 consecutive source cells [base, end): transform (pseudoTransformNDT), PROBE, TERM.
+// On return every hit of the group has been summed into w.acc (the queue is empty).
 template <int NN, bool WITH_H>
-NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int msrc, const rigid &T, double lfd1,
-                       double lfd2, double *s_src, uint32_t *s_queue, double *s_part, double *s_sums)
+NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, const NdtCell *__restrict__ src, int base, int end,
+                      const rigid &T, double lfd1, double lfd2)
 {
-    constexpr int NACC = WITH_H ? 28 : 7;
     constexpr int W = 2 * NN + 1;
     static_assert(63 + W * 64 <= NDT_QN, "per-wave hit queue too small for this neighbourhood");
-    double acc[NACC];
+    const unsigned lane = threadIdx.x & 63u;
+    const int i = base + (int)lane;
+    const bool vi = i < end;
+    int ix = 0, iy = 0, iz = 0;
+    NDT_PROF_T(4)
+    if (vi) {
+        const NdtCell *sc = src + i;
+        d3 m0 = {sc->mean[0], sc->mean[1], sc->mean[2]};
+        sym3 C0 = {sc->cov[0], sc->cov[1], sc->cov[2], sc->cov[3], sc->cov[4], sc->cov[5]};
+        d3 m = apply(T, m0);                    // pseudoTransformNDT: mean' = T mean
+        sym3 C = rotate_cov(T.r, C0);           //                      cov'  = R cov R^T
+        w.mysrc[0 * 64 + lane] = m.x; w.mysrc[1 * 64 + lane] = m.y; w.mysrc[2 * 64 + lane] = m.z;
+        w.mysrc[3 * 64 + lane] = C.xx; w.mysrc[4 * 64 + lane] = C.xy; w.mysrc[5 * 64 + lane] = C.xz;
+        w.mysrc[6 * 64 + lane] = C.yy; w.mysrc[7 * 64 + lane] = C.yz; w.mysrc[8 * 64 + lane] = C.zz;
+        ix = lazygrid_index(m.x, tg.cx, tg.res, tg.sx);   // getCellsForPoint(mean, n_neighbours)
+        iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy);
+        iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
+    }
+    // PROBE stage: the (2n+1)^3 slots around the lane's cell, read as bit windows of the map's rank bitmap
+    // (1 bit per slot + the rank of every 32-slot word's first Gaussian cell): slots are z-fastest, so the
+    // neighbours along z are one run of <= W bits, and in a flat map (sz <= n+1: every z-layer is a
+    // neighbour) the whole (y, z) block of one x is a single run of <= W*sz bits.  Cells are ranked in slot
+    // order, so the k-th set bit of a run is cell `first + k`: no per-slot lookups.
+    // flat form only when every lane's z-neighbourhood is the whole column (a source cell that lies two or
+    // more cells above / below a thin map sees only part of it, or nothing): wave-uniform
+    const bool flat = tg.sz <= NN + 1 && !__ballot(vi && !(iz - NN <= 0 && iz + NN >= tg.sz - 1));
+    NDT_PROF_T(0)
+    const int zlo = flat ? 0 : max(iz - NN, 0), zhi = flat ? tg.sz - 1 : min(iz + NN, tg.sz - 1);
+    const uint2 *rmw = tg.rankmap;
+    // The runs are fetched W at a time (flat map: the W runs of the W x-neighbours; otherwise, per x, the W
+    // runs of the y-neighbours): all 2 W loads are in flight together, the decoded windows (bits, first cell)
+    // wait in the wave's LDS staging rows, and a rolled loop pops them -- one L2 round trip per batch instead
+    // of one per run.
+    uint2 *win = w.mywin + lane;
+#pragma unroll 1
+    for (int outer = 0; outer < (flat ? 1 : W); outer++) {
+        uint2 wa[W], wb[W];
+        unsigned sh[W];
+        int len[W];
 #pragma unroll
-    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
-    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    double *mysrc = s_src + wave * (9 * 64);
-    uint32_t *myq = s_queue + wave * NDT_QN;
-    unsigned qhead = 0, qcount = 0;   // wave-uniform
-    unsigned terms = 0;               // pair terms evaluated by this wave (wave-uniform)
-
-    // TERM stage: pops up to 64 (source lane, target cell) pairs; every lane does one dense pair term.
-    // `min_fill` = 64 while probing (only full batches), 1 for the final flush of a source tile.
-    auto drain = [&](unsigned min_fill) {
-        ndt_wave_sync();                 // queue entries and source tile columns were written by other lanes
-        while (qcount >= min_fill && qcount > 0) {
-            unsigned n = qcount < 64u ? qcount : 64u;
-            if (lane < n) {
-                uint32_t e = myq[(qhead + lane) & (NDT_QN - 1)];
-                unsigned sl = e >> 24, id = e & 0xFFFFFFu;
-                d3 m = {mysrc[0 * 64 + sl], mysrc[1 * 64 + sl], mysrc[2 * 64 + sl]};
-                sym3 C = {mysrc[3 * 64 + sl], mysrc[4 * 64 + sl], mysrc[5 * 64 + sl],
-                          mysrc[6 * 64 + sl], mysrc[7 * 64 + sl], mysrc[8 * 64 + sl]};
-                const NdtCell *tc = tg.cells + id;
-                d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
-                sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
-                pair_term<WITH_H>(m, C, mu, Cj, lfd1, lfd2, acc);
-            }
-            qhead = (qhead + n) & (NDT_QN - 1);
-            qcount -= n;
-            terms += n;
+        for (int q = 0; q < W; q++) {
+            const int dx = flat ? q - NN : outer - NN;
+            const int xx = ix + dx;
+            const bool xok = vi && xx >= 0 && xx < tg.sx && zlo <= zhi;
+            const int ylo = flat ? max(iy - NN, 0) : iy - NN + q;
+            const int yhi = flat ? min(iy + NN, tg.sy - 1) : ylo;
+            const bool ok = xok && ylo <= yhi && ylo >= 0 && yhi < tg.sy;
+            const unsigned s0 = ok ? (unsigned)((xx * tg.sy + ylo) * tg.sz + zlo) : 0u;
+            len[q] = ok ? (flat ? (yhi - ylo + 1) * tg.sz : zhi - zlo + 1) : 0;   // <= 28 bits
+            sh[q] = s0 & 31u;
+            wa[q] = rmw[s0 >> 5];
+            wb[q] = rmw[(s0 >> 5) + 1u];
         }
-    };
+#pragma unroll
+        for (int q = 0; q < W; q++) {
+            const unsigned bits = __builtin_amdgcn_alignbit(wb[q].x, wa[q].x, sh[q]) & ((1u << len[q]) - 1u);
+            const unsigned lowa = wa[q].x >> sh[q];          // the window's part of the first word
+            const unsigned id0 = lowa ? wa[q].y + (unsigned)__popc(wa[q].x & ((1u << sh[q]) - 1u)) : wb[q].y;
+            win[q * 64] = make_uint2(bits, id0);
+        }
+        NDT_PROF_T(1)
+#pragma unroll 1
+        for (int q = 0; q < W; q++) {
+            const uint2 v = win[q * 64];
+            unsigned bits = v.x, id = v.y;
+            // every lane pops its lowest remaining bit per round: ids count up from the run's first cell
+            while (true) {
+                const bool hit = bits != 0u;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                if (!mask) break;
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (hit) w.myq[(w.qhead + w.qcount + rank) & (NDT_QN - 1)] = (lane << 24) | id;
+                w.qcount += (unsigned)__popcll(mask);
+                id += 1u;
+                bits &= bits - 1u;
+                drain_queue<WITH_H>(w, tg, lfd1, lfd2, 64);
+            }
+        }
+    }
+    drain_queue<WITH_H>(w, tg, lfd1, lfd2, 1);   // the per-wave source tile is overwritten by the next group
+    ndt_wave_sync();
+}
 
-    // every wave owns a contiguous, equally sized range of source cells (even a small map keeps all
-    // waves busy: 372 cells -> 47 per wave instead of 6 full waves + 2 idle ones)
+template <int NW, bool WITH_H>
+NDT_D void wave_eval_init(WaveEval<WITH_H> &w, EvalShared<NW> &sh)
+{
+    const unsigned wave = threadIdx.x >> 6;
+    w.mysrc = sh.src + wave * (9 * 64);
+    w.myq = sh.queue + wave * NDT_QN;
+    w.mywin = sh.win + wave * (7 * 64);
+    w.qhead = 0; w.qcount = 0; w.terms = 0;
+#pragma unroll
+    for (int k = 0; k < WaveEval<WITH_H>::NACC; k++) w.acc[k] = 0.0;
+#ifdef NDT_MATCH_PROF
+    for (int k = 0; k < 6; k++) w.prof[k] = 0;
+    w.pt = clock64();
+#endif
+}
+
+// wave-wide totals of the accumulators: on return lane l holds value (l >> SH) in `tot` when (l & ((1 << SH) - 1)) == 0
+template <bool WITH_H>
+NDT_D double wave_totals(const WaveEval<WITH_H> &w)
+{
+    constexpr int NACC = WaveEval<WITH_H>::NACC, NP = WITH_H ? 32 : 8;
+    double vv[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) vv[k] = k < NACC ? w.acc[k] : 0.0;
+    return wave_sum_all<NP>(vv);
+}
+
+// ---- range-partitioned evaluation (cooperative / host-driven / stand-alone kernels) --------------------------
+// One evaluation of derivativesNDT over source cells [0, msrc), transformed by T, on the 8 waves of a wide
+// workgroup: equal contiguous shares per wave (even a small range keeps all waves busy).  Result in sh.sums[0..6]
+// ([7..27] when WITH_H, [28] = pair terms).  Ends with a barrier.
+template <int NN, bool WITH_H>
+NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int msrc, const rigid &T, double lfd1,
+                       double lfd2, EvalShared<NDT_MATCH_WAVES> &sh)
+{
+    constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3;
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    WaveEval<WITH_H> w;
+    wave_eval_init<NDT_MATCH_WAVES, WITH_H>(w, sh);
     const int per_wave = (msrc + NDT_MATCH_WAVES - 1) / NDT_MATCH_WAVES;
     const int w_begin = (int)wave * per_wave, w_end = min(msrc, w_begin + per_wave);
-    for (int base = w_begin; base < w_end; base += 64) {
-        int i = base + (int)lane;
-        bool vi = i < w_end;
-        int ix = 0, iy = 0, iz = 0;
-        if (vi) {
-            const NdtCell *sc = src + i;
-            d3 m0 = {sc->mean[0], sc->mean[1], sc->mean[2]};
-            sym3 C0 = {sc->cov[0], sc->cov[1], sc->cov[2], sc->cov[3], sc->cov[4], sc->cov[5]};
-            d3 m = apply(T, m0);                    // pseudoTransformNDT: mean' = T mean
-            sym3 C = rotate_cov(T.r, C0);           //                      cov'  = R cov R^T
-            mysrc[0 * 64 + lane] = m.x; mysrc[1 * 64 + lane] = m.y; mysrc[2 * 64 + lane] = m.z;
-            mysrc[3 * 64 + lane] = C.xx; mysrc[4 * 64 + lane] = C.xy; mysrc[5 * 64 + lane] = C.xz;
-            mysrc[6 * 64 + lane] = C.yy; mysrc[7 * 64 + lane] = C.yz; mysrc[8 * 64 + lane] = C.zz;
-            ix = lazygrid_index(m.x, tg.cx, tg.res, tg.sx);   // getCellsForPoint(mean, n_neighbours)
-            iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy);
-            iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
-        }
-        // PROBE stage: the (2n+1)^3 slots around the lane's cell, read as bit windows of the map's rank bitmap
-        // (1 bit per slot + the rank of every 32-slot word's first Gaussian cell): slots are z-fastest, so the
-        // neighbours along z are one run of <= W bits, and in a flat map (sz <= n+1: every z-layer is a
-        // neighbour) the whole (y, z) block of one x is a single run of <= W*sz bits.  Cells are ranked in slot
-        // order, so the k-th set bit of a run is cell `first + k`: no per-slot lookups.
-        // flat form only when every lane's z-neighbourhood is the whole column (a source cell that lies two or
-        // more cells above / below a thin map sees only part of it, or nothing): wave-uniform
-        const bool flat = tg.sz <= NN + 1 && !__ballot(vi && !(iz - NN <= 0 && iz + NN >= tg.sz - 1));
-        const int zlo = flat ? 0 : max(iz - NN, 0), zhi = flat ? tg.sz - 1 : min(iz + NN, tg.sz - 1);
-        const char *rmb = reinterpret_cast<const char *>(tg.rankmap);
-        // The runs are fetched W at a time (flat map: the W runs of the W x-neighbours; otherwise, per x, the W
-        // runs of the y-neighbours): all 2 W loads are in flight together, the decoded windows (bits, first cell)
-        // wait in the wave's LDS staging rows, and a rolled loop pops them -- one L2 round trip per batch instead
-        // of one per run.
-        uint2 *win = probe_windows() + wave * (7 * 64) + lane;
-#pragma unroll 1
-        for (int outer = 0; outer < (flat ? 1 : W); outer++) {
-            uint2 wa[W], wb[W];
-            unsigned sh[W];
-            int len[W];
-#pragma unroll
-            for (int q = 0; q < W; q++) {
-                const int dx = flat ? q - NN : outer - NN;
-                const int xx = ix + dx;
-                const bool xok = vi && xx >= 0 && xx < tg.sx && zlo <= zhi;
-                const int ylo = flat ? max(iy - NN, 0) : iy - NN + q;
-                const int yhi = flat ? min(iy + NN, tg.sy - 1) : ylo;
-                const bool ok = xok && ylo <= yhi && ylo >= 0 && yhi < tg.sy;
-                const unsigned s0 = ok ? (unsigned)((xx * tg.sy + ylo) * tg.sz + zlo) : 0u;
-                len[q] = ok ? (flat ? (yhi - ylo + 1) * tg.sz : zhi - zlo + 1) : 0;   // <= 28 bits
-                sh[q] = s0 & 31u;
-                wa[q] = *reinterpret_cast<const uint2 *>(rmb + (size_t)(s0 >> 5) * 8u);
-                wb[q] = *reinterpret_cast<const uint2 *>(rmb + (size_t)(s0 >> 5) * 8u + 8u);
-            }
-#pragma unroll
-            for (int q = 0; q < W; q++) {
-                const unsigned bits = __builtin_amdgcn_alignbit(wb[q].x, wa[q].x, sh[q]) & ((1u << len[q]) - 1u);
-                const unsigned lowa = wa[q].x >> sh[q];          // the window's part of the first word
-                const unsigned id0 = lowa ? wa[q].y + (unsigned)__popc(wa[q].x & ((1u << sh[q]) - 1u)) : wb[q].y;
-                win[q * 64] = make_uint2(bits, id0);
-            }
-#pragma unroll 1
-            for (int q = 0; q < W; q++) {
-                const uint2 v = win[q * 64];
-                unsigned bits = v.x, id = v.y;
-                // every lane pops its lowest remaining bit per round: ids count up from the run's first cell
-                while (true) {
-                    const bool hit = bits != 0u;
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    if (!mask) break;
-                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    if (hit) myq[(qhead + qcount + rank) & (NDT_QN - 1)] = (lane << 24) | id;
-                    qcount += (unsigned)__popcll(mask);
-                    id += 1u;
-                    bits &= bits - 1u;
-                    drain(64);
-                }
-            }
-        }
-        drain(1);   // the per-wave source tile is overwritten by the next batch
-        ndt_wave_sync();
-    }
-
-    // 28 (or 7) sums: wave tree, then fixed-order sum of the wave partials
-    {
-        constexpr int NP = WITH_H ? 32 : 8, SH = WITH_H ? 1 : 3;
-        double vv[NP];
-#pragma unroll
-        for (int k = 0; k < NP; k++) vv[k] = k < NACC ? acc[k] : 0.0;
-        const double tot = wave_sum_all<NP>(vv);
-        if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) s_part[wave * 32 + (lane >> SH)] = tot;
-    }
-    if (lane == 0) s_part[wave * 32 + 28] = (double)terms;
+    for (int base = w_begin; base < w_end; base += 64)
+        eval_group<NN, WITH_H>(w, tg, src, base, min(w_end, base + 64), T, lfd1, lfd2);
+    const double tot = wave_totals<WITH_H>(w);
+    if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) sh.part[wave * 32 + (lane >> SH)] = tot;
+    if (lane == 0) sh.part[wave * 32 + 28] = (double)w.terms;
     __syncthreads();
     if (tid < (unsigned)NACC || tid == 28u) {
         double s = 0;
-        for (int w = 0; w < NDT_MATCH_WAVES; w++) s += s_part[w * 32 + tid];
-        s_sums[tid] = s;             // [28]: number of (source, target) pair terms of this evaluation
+        for (int k = 0; k < NDT_MATCH_WAVES; k++) s += sh.part[k * 32 + tid];
+        sh.sums[tid] = s;             // [28]: number of (source, target) pair terms of this evaluation
     }
     __syncthreads();
+    NDT_PROF_T(4)
+#ifdef NDT_MATCH_PROF
+    if (tid == 0) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&g_prof[k], (unsigned long long)w.prof[k]); atomicAdd((unsigned long long *)&g_prof[5 + (WITH_H ? 1 : 0)], 1ull); }
+#endif
 }
 
 }  // namespace
@@ -359,12 +418,15 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     const double *__restrict__ Q36 /* per pair Tcov^-1 (matchFusion soft constraint) or NULL */,
     unsigned n_pairs, int park_iters, char *__restrict__ work_mem)
 {
-    __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
-    __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
-    __shared__ double s_part[NDT_MATCH_WAVES * 32];
-    __shared__ double s_sums[32];
+    __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     __shared__ MatchState st;
     __shared__ int s_job, s_next;
+    // per-registration state that outlives an evaluation sits in LDS, not in registers: the evaluation needs ~220
+    // VGPRs, and what is live across it would be spilled to scratch memory
+    __shared__ MapView s_tg, s_sv;
+    __shared__ long long s_cnt[4];      // thread 0: shader clocks in evaluations / in the solver, pair terms g / h
+    __shared__ NdtMatchParamsDev s_prm; // the solver takes the parameters by reference: LDS, not a scratch copy
+    if (threadIdx.x == 0) s_prm = prm;
 
     NdtMatchWork *work = reinterpret_cast<NdtMatchWork *>(work_mem);
     unsigned *ids = reinterpret_cast<unsigned *>(work_mem + sizeof(NdtMatchWork));
@@ -400,35 +462,34 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
         const bool resumed = job <= -2;
         const unsigned pair = resumed ? (unsigned)(-2 - job) : (unsigned)job;
 
-        const MapView tg = map_view(tset, tidx[pair]);
-        const MapView sv = map_view(sset, sidx[pair]);
-        double *Tio = T16 + (size_t)pair * 16;
-        long long cyc_eval = 0, cyc_solver = 0, terms_g = 0, terms_h = 0;
         if (threadIdx.x == 0) {
+            s_tg = map_view(tset, tidx[pair]);
+            s_sv = map_view(sset, sidx[pair]);
             if (resumed) {
                 const NdtParkedState &ps = parked[pair];
                 st = ps.st;
-                cyc_eval = ps.cyc_eval; cyc_solver = ps.cyc_solver; terms_g = ps.terms_g; terms_h = ps.terms_h;
+                s_cnt[0] = ps.cyc_eval; s_cnt[1] = ps.cyc_solver; s_cnt[2] = ps.terms_g; s_cnt[3] = ps.terms_h;
             } else {
-                match_state_init(st, Tio, prm, Q36 ? Q36 + (size_t)pair * 36 : nullptr);
+                match_state_init(st, T16 + (size_t)pair * 16, s_prm, Q36 ? Q36 + (size_t)pair * 36 : nullptr);
+                s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0;
             }
         }
         __syncthreads();
 
         bool parked_now = false;
         while (!st.done) {
-            const rigid Te = st.Teval;
+            // the request (pose, with / without Hessian) is read from LDS where the solver left it: thread 0 rewrites
+            // it only after the evaluation's closing barrier, when nobody reads it any more
             const int with_h = st.with_h;
-            __syncthreads();   // everyone has read the request before thread 0 may rewrite it
             long long c0 = __builtin_readcyclecounter();
-            if (with_h) eval_derivs<NN, true>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
-            else eval_derivs<NN, false>(tg, sv.cells, sv.n_cells, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
+            if (with_h) eval_derivs<NN, true>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh);
+            else eval_derivs<NN, false>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh);
             long long c1 = __builtin_readcyclecounter();
             if (threadIdx.x == 0) {
-                if (with_h) terms_h += (long long)s_sums[28]; else terms_g += (long long)s_sums[28];
-                match_state_step(st, s_sums, prm);
-                cyc_eval += c1 - c0;
-                cyc_solver += (long long)__builtin_readcyclecounter() - c1;
+                s_cnt[with_h ? 3 : 2] += (long long)sh.sums[28];
+                s_cnt[0] += c1 - c0;
+                match_state_step(st, sh.sums, s_prm);
+                s_cnt[1] += (long long)__builtin_readcyclecounter() - c1;
                 // about to start another Newton iteration of a long registration: hand the CU to a pair that has
                 // not started yet, if there is one
                 s_job = 0;
@@ -439,7 +500,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
                     if (f < n_pairs) {
                         NdtParkedState &ps = parked[pair];
                         ps.st = st;
-                        ps.cyc_eval = cyc_eval; ps.cyc_solver = cyc_solver; ps.terms_g = terms_g; ps.terms_h = terms_h;
+                        ps.cyc_eval = s_cnt[0]; ps.cyc_solver = s_cnt[1]; ps.terms_g = s_cnt[2]; ps.terms_h = s_cnt[3];
                         __hip_atomic_store(&ids[slot], pair + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         s_next = (int)f;
                         s_job = 1;
@@ -454,13 +515,13 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
 
         if (threadIdx.x == 0 && !parked_now) {
             NdtMatchResultDev o;
-            match_state_result(st, Tio, o);
-            o.n_source = sv.n_cells;
-            o.n_target = tg.n_cells;
-            o.cycles_eval = cyc_eval;
-            o.cycles_solver = cyc_solver;
-            o.pair_terms_g = terms_g;
-            o.pair_terms_h = terms_h;
+            match_state_result(st, T16 + (size_t)pair * 16, o);
+            o.n_source = s_sv.n_cells;
+            o.n_target = s_tg.n_cells;
+            o.cycles_eval = s_cnt[0];
+            o.cycles_solver = s_cnt[1];
+            o.pair_terms_g = s_cnt[2];
+            o.pair_terms_h = s_cnt[3];
             res[pair] = o;
         }
         __syncthreads();
@@ -473,19 +534,16 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_kernel(
     NdtSetView tset, unsigned tmap, const NdtCell *__restrict__ src, unsigned m, int with_h, double lfd1,
     double lfd2, double *__restrict__ out28)
 {
-    __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
-    __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
-    __shared__ double s_part[NDT_MATCH_WAVES * 32];
-    __shared__ double s_sums[32];
+    __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     const MapView tg = map_view(tset, tmap);
     rigid I;
     for (int k = 0; k < 9; k++) I.r[k] = (k % 4 == 0) ? 1.0 : 0.0;
     I.t[0] = I.t[1] = I.t[2] = 0.0;
-    if (threadIdx.x < 28) s_sums[threadIdx.x] = 0.0;
+    if (threadIdx.x < 28) sh.sums[threadIdx.x] = 0.0;
     __syncthreads();
-    if (with_h) eval_derivs<NN, true>(tg, src, (int)m, I, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
-    else eval_derivs<NN, false>(tg, src, (int)m, I, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
-    if (threadIdx.x < 28) out28[threadIdx.x] = s_sums[threadIdx.x];
+    if (with_h) eval_derivs<NN, true>(tg, src, (int)m, I, lfd1, lfd2, sh);
+    else eval_derivs<NN, false>(tg, src, (int)m, I, lfd1, lfd2, sh);
+    if (threadIdx.x < 28) out28[threadIdx.x] = sh.sums[threadIdx.x];
 }
 
 // One evaluation of derivativesNDT for ONE pair spread over many workgroups (host-driven matcher for
@@ -497,19 +555,16 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_eval_kernel(
     NdtSetView tset, unsigned tmap, NdtSetView sset, unsigned smap, rigid T, int with_h, double lfd1, double lfd2,
     double *__restrict__ partials)
 {
-    __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
-    __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
-    __shared__ double s_part[NDT_MATCH_WAVES * 32];
-    __shared__ double s_sums[32];
+    __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     const MapView tg = map_view(tset, tmap);
     const MapView sv = map_view(sset, smap);
     const int per = (sv.n_cells + (int)gridDim.x - 1) / (int)gridDim.x;
     const int begin = min(sv.n_cells, (int)blockIdx.x * per), count = min(sv.n_cells - begin, per);
-    if (threadIdx.x < 32) s_sums[threadIdx.x] = 0.0;
+    if (threadIdx.x < 32) sh.sums[threadIdx.x] = 0.0;
     __syncthreads();
-    if (with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
-    else eval_derivs<NN, false>(tg, sv.cells + begin, count, T, lfd1, lfd2, s_src, s_queue, s_part, s_sums);
-    if (threadIdx.x < 32) partials[blockIdx.x * 32 + threadIdx.x] = s_sums[threadIdx.x];
+    if (with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, T, lfd1, lfd2, sh);
+    else eval_derivs<NN, false>(tg, sv.cells + begin, count, T, lfd1, lfd2, sh);
+    if (threadIdx.x < 32) partials[blockIdx.x * 32 + threadIdx.x] = sh.sums[threadIdx.x];
 }
 
 // ONE registration spread over the whole launch grid (small batches / large maps: the reference's
@@ -558,10 +613,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     double *__restrict__ T16_all, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res_all,
     const double *__restrict__ Q36_all, char *__restrict__ work_all, size_t work_stride, unsigned cells_per_group)
 {
-    __shared__ double s_src[NDT_MATCH_WAVES * 9 * 64];
-    __shared__ uint32_t s_queue[NDT_MATCH_WAVES * NDT_QN];
-    __shared__ double s_part[NDT_MATCH_WAVES * 32];
-    __shared__ double s_sums[32];
+    __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     __shared__ MatchState st;       // workgroup 0 only
     __shared__ rigid s_T;
     __shared__ int s_with_h, s_done;
@@ -602,9 +654,9 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         if (s_done) break;
         const rigid Te = s_T;
         long long c0 = __builtin_readcyclecounter();
-        if (s_with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
-        else eval_derivs<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, s_src, s_queue, s_part, s_sums);
-        if (threadIdx.x < 32) { partials[g * 32 + threadIdx.x] = s_sums[threadIdx.x]; __threadfence(); }
+        if (s_with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
+        else eval_derivs<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
+        if (threadIdx.x < 32) { partials[g * 32 + threadIdx.x] = sh.sums[threadIdx.x]; __threadfence(); }
         long long c1 = __builtin_readcyclecounter();
         cyc_eval += c1 - c0;
         if (!coop_barrier(ctrl, target, G)) return;               // all partials are in memory
@@ -617,19 +669,19 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
                 const unsigned k = threadIdx.x & 31u, r = threadIdx.x >> 5;
                 double a = 0;
                 for (unsigned w = r; w < G; w += 16u) a += partials[w * 32 + k];
-                s_src[r * 32 + k] = a;                     // the source tile buffer is free between evaluations
+                sh.src[r * 32 + k] = a;                    // the source tile buffer is free between evaluations
             }
             __syncthreads();
             if (threadIdx.x < 29) {
                 double a = 0;
-                for (unsigned r = 0; r < 16u; r++) a += s_src[r * 32 + threadIdx.x];
-                s_sums[threadIdx.x] = a;
+                for (unsigned r = 0; r < 16u; r++) a += sh.src[r * 32 + threadIdx.x];
+                sh.sums[threadIdx.x] = a;
             }
             __syncthreads();
             if (threadIdx.x == 0) {
                 long long d0 = __builtin_readcyclecounter();
-                if (s_with_h) terms_h += (long long)s_sums[28]; else terms_g += (long long)s_sums[28];
-                match_state_step(st, s_sums, prm);
+                if (s_with_h) terms_h += (long long)sh.sums[28]; else terms_g += (long long)sh.sums[28];
+                match_state_step(st, sh.sums, prm);
                 ctrl->Teval = st.Teval; ctrl->with_h = st.with_h; ctrl->done = st.done;
                 cyc_solver += (long long)__builtin_readcyclecounter() - d0;
             }
@@ -734,3 +786,16 @@ hipError_t ndt_launch_derivatives(const NdtSetView &tset, size_t tmap, const Ndt
 #undef NDT_LAUNCH_DERIV
     return hipGetLastError();
 }
+
+#ifdef NDT_MATCH_PROF
+extern "C" int ndtgpu_debug_prof(long long out[8], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 8 * sizeof(long long)) != hipSuccess) return -1;
+    if (reset) {
+        long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -71,12 +71,35 @@ NDT_HD sym3 rotate_cov(const double *R, sym3 c)
     return o;
 }
 
+// sin and cos of a pose-increment angle.  Newton / line-search increments are small: for |x| <= pi/4 the minimax
+// kernels of fdlibm (k_sin.c / k_cos.c in the msun form, error < 1 ulp) need no argument reduction -- ~25
+// instructions against ~300 for the general library pair, and the serial solver composes three of them per trial
+// pose.  Larger angles take the library functions.
+NDT_HD void sincos_pose(double x, double &sn, double &cs)
+{
+    if (fabs(x) <= 0.78539816339744830962) {
+        const double z = x * x, w = z * z;
+        const double rs = 8.33333333332248946124e-03 +
+                          z * (-1.98412698298579493134e-04 +
+                               z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+        sn = x + (z * x) * (-1.66666666666666324348e-01 + z * rs);
+        const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
+                          (w * w) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+        const double hz = 0.5 * z, c1 = 1.0 - hz;
+        cs = c1 + (((1.0 - c1) - hz) + z * rc);
+    } else {
+        sn = sin(x);
+        cs = cos(x);
+    }
+}
+
 // TR = Translation(p0,p1,p2) * Rx(p3) * Ry(p4) * Rz(p5)   (ndt_matcher_d2d_fusion.h:1036-1039)
 NDT_HD void pose_to_rigid(const double *p, rigid &T)
 {
-    double cx = cos(p[3]), sx = sin(p[3]);
-    double cy = cos(p[4]), sy = sin(p[4]);
-    double cz = cos(p[5]), sz = sin(p[5]);
+    double cx, sx, cy, sy, cz, sz;
+    sincos_pose(p[3], sx, cx);
+    sincos_pose(p[4], sy, cy);
+    sincos_pose(p[5], sz, cz);
     // Rx*Ry*Rz
     T.r[0] = cy * cz;                  T.r[1] = -cy * sz;                 T.r[2] = sy;
     T.r[3] = cx * sz + sx * sy * cz;   T.r[4] = cx * cz - sx * sy * sz;   T.r[5] = -sx * cy;
@@ -214,6 +237,132 @@ NDT_HD void jacobi_static(double (&a)[N][N], double (&v)[N][N])
             }
         }
     }
+}
+
+// lambda_min and lambda_max of a symmetric 6x6 matrix (what the Newton loop's regulariser needs from
+// Eigen::SelfAdjointEigenSolver, fusion.h:922-940) without a full eigen-decomposition: Householder
+// tridiagonalisation (4 reflectors, static indices: registers only) and Laguerre's iteration on the
+// characteristic polynomial of the tridiagonal matrix, started outside the spectrum at the Gershgorin bounds.
+// For a polynomial with only real roots Laguerre converges monotonically (and cubically) to the nearest root from
+// outside, i.e. to lambda_min from the left and lambda_max from the right.  The three-term recurrence is the
+// Sturm sequence (backward stable): the results carry an error of a few eps * ||A||, like the cyclic Jacobi
+// sweeps this replaces (~60 k shader cycles on one lane against ~6 k).
+namespace ndt_eig6 {
+// p, p', p'' of det(T - x I) for the tridiagonal T = (d, e) by the three-term recurrence
+NDT_HD void charpoly(const double (&d)[6], const double (&e2)[5], double x, double &p, double &dp, double &ddp)
+{
+    double p0 = 1.0, q0 = 0.0, r0 = 0.0;                     // p_{k-2}, derivatives
+    double p1 = d[0] - x, q1 = -1.0, r1 = 0.0;               // p_{k-1}
+#pragma unroll
+    for (int k = 1; k < 6; k++) {
+        const double a = d[k] - x, b = e2[k - 1];
+        const double p2 = a * p1 - b * p0;
+        const double q2 = a * q1 - p1 - b * q0;
+        const double r2 = a * r1 - 2.0 * q1 - b * r0;
+        p0 = p1; q0 = q1; r0 = r1;
+        p1 = p2; q1 = q2; r1 = r2;
+    }
+    p = p1; dp = q1; ddp = r1;
+}
+// one extreme root: dir = -1 starts left of the spectrum (lambda_min), +1 right of it (lambda_max)
+NDT_HD double laguerre_extreme(const double (&d)[6], const double (&e2)[5], double x, int dir)
+{
+    for (int it = 0; it < 48; it++) {
+        double p, dp, ddp;
+        charpoly(d, e2, x, p, dp, ddp);
+        if (p == 0.0) break;
+        const double G = dp / p;
+        const double Hh = G * G - ddp / p;
+        double disc = 5.0 * (6.0 * Hh - G * G);
+        if (!(disc > 0.0)) disc = 0.0;
+        const double sq = sqrt(disc);
+        const double den = (G >= 0.0) ? G + sq : G - sq;
+        if (den == 0.0) break;
+        const double a = 6.0 / den;
+        // from outside the spectrum the step points inwards (a < 0 on the left, a > 0 on the right); a step the
+        // other way is rounding noise at the root
+        if ((dir < 0) ? !(a < 0.0) : !(a > 0.0)) break;
+        const double xn = x - a;
+        if (xn == x) break;
+        const bool small = fabs(a) <= 4.0e-16 * (fabs(xn) > 1.0 ? fabs(xn) : 1.0);
+        x = xn;
+        if (small) break;
+    }
+    return x;
+}
+}  // namespace ndt_eig6
+
+NDT_HD void sym6_extreme_eigs(const double (&H)[6][6], double &lmin, double &lmax)
+{
+    double a[6][6];
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            a[i][j] = 0.5 * (H[i][j] + H[j][i]);
+            scale = fmax(scale, fabs(a[i][j]));
+        }
+    if (!(scale > 0.0) || !(scale < 1.0e300)) { lmin = 0.0; lmax = 0.0; return; }   // zero (or non-finite) matrix
+    const double inv = 1.0 / scale;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) a[i][j] *= inv;
+    // Householder: after step k column k is zero below the sub-diagonal
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double sig = 0.0;
+#pragma unroll
+        for (int i = k + 2; i < 6; i++) sig += a[i][k] * a[i][k];
+        if (sig > 0.0) {
+            const double x0 = a[k + 1][k];
+            const double nrm = sqrt(x0 * x0 + sig);
+            const double alpha = (x0 > 0.0) ? -nrm : nrm;
+            double v[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) v[i] = (i > k + 1) ? a[i][k] : 0.0;
+            v[k + 1] = x0 - alpha;
+            const double vtv = v[k + 1] * v[k + 1] + sig;
+            const double beta = 2.0 / vtv;
+            double pv[6], w[6];
+            double ptv = 0.0;
+#pragma unroll
+            for (int i = k + 1; i < 6; i++) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = k + 1; j < 6; j++) s += a[i][j] * v[j];
+                pv[i] = beta * s;
+                ptv += pv[i] * v[i];
+            }
+            const double kk = 0.5 * beta * ptv;
+#pragma unroll
+            for (int i = k + 1; i < 6; i++) w[i] = pv[i] - kk * v[i];
+#pragma unroll
+            for (int i = k + 1; i < 6; i++)
+#pragma unroll
+                for (int j = k + 1; j < 6; j++) a[i][j] -= v[i] * w[j] + w[i] * v[j];
+            a[k + 1][k] = alpha;
+            a[k][k + 1] = alpha;
+#pragma unroll
+            for (int i = k + 2; i < 6; i++) { a[i][k] = 0.0; a[k][i] = 0.0; }
+        }
+    }
+    double d[6], e2[5];
+    double lo = 1.0e300, hi = -1.0e300;
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = a[i][i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) e2[i] = a[i + 1][i] * a[i + 1][i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double r = ((i > 0) ? fabs(a[i][i - 1]) : 0.0) + ((i < 5) ? fabs(a[i + 1][i]) : 0.0);
+        lo = fmin(lo, d[i] - r);
+        hi = fmax(hi, d[i] + r);
+    }
+    const double margin = 1.0e-3 * (hi - lo) + 1.0e-12;       // strictly outside the spectrum
+    lmin = scale * ndt_eig6::laguerre_extreme(d, e2, lo - margin, -1);
+    lmax = scale * ndt_eig6::laguerre_extreme(d, e2, hi + margin, +1);
 }
 
 // true when the symmetric matrix is positive definite (unpivoted Cholesky, registers only).  The factor is

@@ -245,21 +245,14 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     for (int a = 0; a < 6; a++) gnorm += g[a] * g[a];
     gnorm = sqrt(gnorm);
     // fusion.h:922-940.  evals += regularizer with the same regularizer for every eigenvalue, then
-    // H = V diag(evals) V^T, i.e. H + regularizer*I: only lambda_min and lambda_max are needed.  A
-    // positive definite H (the usual case near the optimum) is certified by an unpivoted Cholesky
-    // and skips the eigen-decomposition altogether.
+    // H = V diag(evals) V^T, i.e. H + regularizer*I: only lambda_min and lambda_max are needed
+    // (sym6_extreme_eigs: tridiagonalisation + Laguerre, no eigenvectors).  A positive definite H (the
+    // usual case near the optimum) is certified by an unpivoted Cholesky and skips even that.
     double Lf[6][6], Ldinv[6];
     const bool is_pd = chol_is_pd<6>(H, Lf, Ldinv);
     if (!is_pd) {
-        double A[6][6], V[6][6];
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = 0; b < 6; b++) A[a][b] = H[a][b];
-        jacobi_static<6, false>(A, V);
-        double minC = A[0][0], maxC = A[0][0];
-#pragma unroll
-        for (int a = 1; a < 6; a++) { minC = dmin(minC, A[a][a]); maxC = dmax(maxC, A[a][a]); }
+        double minC, maxC;
+        sym6_extreme_eigs(H, minC, maxC);
         if (minC < 0) {
             double regularizer = gnorm;
             regularizer = (regularizer + minC > 0) ? regularizer : 0.001 * maxC - minC;

@@ -396,7 +396,7 @@ def test_persistent_cooperative_and_host_driven_paths_agree(N, O, monkeypatch):
         T3, r3 = N.match_d2d(tg, b, sr, b, T0[b])
         monkeypatch.delenv("NDTGPU_COOP_CELLS")
         dt, dr = pose_close(T3, Tb[b])
-        assert dt < 1e-9 and dr < 1e-9 and r3["fevals"] == rs["fevals"]
+        assert dt < 1e-9 and dr < 1e-9 and abs(int(r3["fevals"]) - int(rs["fevals"])) <= 2   # a line-search trial more or less
         To, ro = O.match_d2d(om[b][0], om[b][1], T0[b])
         dt, dr = pose_close(Ts, To)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
