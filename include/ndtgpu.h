@@ -144,6 +144,52 @@ ndtgpu_status ndtgpu_mapset_export_cells(ndtgpu_mapset *set, size_t map, double 
 ndtgpu_status ndtgpu_mapset_set_cells(ndtgpu_mapset *set, size_t map, const double *mean3, const double *cov9,
                                       size_t n_cells);
 
+/* ---- incremental (fused) node maps ------------------------------------------------------------- */
+/* NDTMap::initialize(cx,cy,cz,sx,sy,sz) on every map of the set (fuser_hmt.cpp:89): every cell of the grid exists
+ * and carries an occupancy (log-odds, 0 = no reading).  Allocates the per-slot occupancy arrays and the second cell
+ * array an incremental update needs (12 bytes per slot + 80 bytes per cell and map).  Idempotent.  Plain builds
+ * (ndtgpu_mapset_build*) on such a set also leave the occupancies NDTCell::computeGaussian would. */
+ndtgpu_status ndtgpu_mapset_enable_occupancy(ndtgpu_mapset *set);
+
+/* NDTMap::addPointCloud(origin, cloud, classifierTh, maxz, sensor_noise, occupancy_limit) immediately followed by
+ * NDTMap::computeNDTCells(CELL_UPDATE_MODE_SAMPLE_VARIANCE, maxnumpoints, occupancy_limit, origin, noise): the two
+ * calls the reference always makes together (fuser_hmt.cpp:92-94: (.., 0.1, 100.0, 0.1) + (.., 1e5, 255, ..);
+ * :485-486: (.., 0.06, 25) + (.., 1e5, 255, ..)).  classifierTh, and origin / noise of computeNDTCells, are unused
+ * upstream on this path and have no counterpart here. */
+typedef struct {
+    double maxz;            /* addPointCloud: points above it are dropped (100.0 / 25) */
+    double sensor_noise;    /* addPointCloud: 0.1 / 0.06 */
+    double maxnumpoints;    /* computeNDTCells: N saturates here ("sliding average"; 1e5); <= 0: never */
+    double occupancy_limit; /* both: occupancy is clamped to +-limit (255) */
+    int32_t n_min;          /* see ndtgpu_cell_params */
+    double eval_factor;
+} ndtgpu_fuse_params;
+void ndtgpu_default_fuse_params(ndtgpu_fuse_params *p);   /* the values of fuser_hmt.cpp:485-486 */
+/* Maps [first, first+count) each receive one cloud (map k: n_points records at xyz + k*map_stride_bytes, in the map's
+ * frame) taken from sensor position origins[3*k..] (HOST).  Per beam the cells between sensor and hit receive
+ * emptiness evidence, the hit joins its cell; cells merge the new points into their Gaussian (N, mean, covariance),
+ * Gaussians whose occupancy falls to <= 0 disappear.  Needs ndtgpu_mapset_enable_occupancy.  xyz_dev: DEVICE pointer;
+ * asynchronous on `stream`. */
+ndtgpu_status ndtgpu_mapset_add_cloud(ndtgpu_mapset *set, size_t first, size_t count, const void *xyz_dev,
+                                      size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                      const double *origins, const ndtgpu_fuse_params *prm, ndtgpu_stream stream);
+/* same, points in HOST memory; synchronous */
+ndtgpu_status ndtgpu_mapset_add_cloud_host(ndtgpu_mapset *set, size_t first, size_t count, const void *xyz_host,
+                                           size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                           const double *origins, const ndtgpu_fuse_params *prm);
+/* a fresh NDTMap in slots [first, first+count): no Gaussians, occupancy 0 (a new graph node, graph.cpp:87-101) */
+ndtgpu_status ndtgpu_mapset_clear(ndtgpu_mapset *set, size_t first, size_t count);
+/* NDTCell::getOccupancy of every cell of one map, slot order (x-major, y, z): cells_per_axis[0]*[1]*[2] floats */
+ndtgpu_status ndtgpu_mapset_export_occupancy(ndtgpu_mapset *set, size_t map, float *occ_out);
+
+/* ndt_feature::overlapNDTOccupancyScore(ref, mov, T) (ndt_feature_node.h:213-252; used at ndt_feature_graph.cpp:175,
+ * 338-340) for n_links (ref, mov, T) triples.  Both sets need ndtgpu_mapset_enable_occupancy.  T16: HOST, n_links x 16
+ * column-major.  score: HOST n_links doubles (1.0 when no cell pair overlaps); nb_sum (may be NULL): HOST, the number
+ * of compared cell pairs.  Synchronous. */
+ndtgpu_status ndtgpu_overlap_score_batch(ndtgpu_mapset *ref_set, const uint32_t *ref_idx, ndtgpu_mapset *mov_set,
+                                         const uint32_t *mov_idx, const double *T16, size_t n_links, double *score,
+                                         int64_t *nb_sum, ndtgpu_stream stream);
+
 /* ---- matcher ---------------------------------------------------------------------------- */
 /* NDTMatcherD2D::derivativesNDT(sourceCells, targetMap, g, H, computeHessian)
  * (ndt_matcher_d2d_fusion.h:80, 238, 444, 617, 856, 1085): lets the in-repo matchFusion host

@@ -9,4 +9,4 @@ There is no CPU fallback: importing works anywhere (the build check runs without
 every compute call raises NdtGpuError when the HIP library or a device is missing.
 """
 from .binding import (MapSet, MatchParams, NdtGpuError, build_library, derivatives, device_count, lib,  # noqa: F401
-                      library_path, match_batch, match_d2d, match_fusion_batch)
+                      library_path, match_batch, match_d2d, match_fusion_batch, overlap_score)

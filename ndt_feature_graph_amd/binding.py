@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_HERE, "libndtgpu.so")
-_SOURCES = ["ndt_build.hip", "ndt_match.hip", "ndtgpu_api.hip"]
+_SOURCES = ["ndt_build.hip", "ndt_match.hip", "ndt_fuse.hip", "ndtgpu_api.hip"]
 
 STATUS = {0: "OK", -1: "ERR_INVALID", -2: "ERR_HIP", -3: "ERR_NO_DEVICE", -4: "ERR_CAPACITY", -5: "ERR_ALLOC"}
 
@@ -52,6 +52,11 @@ class CellParams(C.Structure):
     _fields_ = [("n_min", C.c_int32), ("eval_factor", C.c_double)]
 
 
+class FuseParams(C.Structure):
+    _fields_ = [("maxz", C.c_double), ("sensor_noise", C.c_double), ("maxnumpoints", C.c_double),
+                ("occupancy_limit", C.c_double), ("n_min", C.c_int32), ("eval_factor", C.c_double)]
+
+
 class MatchParams(C.Structure):
     _fields_ = [("n_neighbours", C.c_int32), ("itr_max", C.c_int32), ("delta_score", C.c_double),
                 ("step_control", C.c_int32), ("lfd1", C.c_double), ("lfd2", C.c_double), ("dof_mask", C.c_int32),
@@ -76,7 +81,10 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_info", "ndtgpu_mapset_build", "ndtgpu_mapset_build_host", "ndtgpu_mapset_num_cells",
            "ndtgpu_mapset_export_cells", "ndtgpu_mapset_set_cells", "ndtgpu_derivatives", "ndtgpu_match_batch",
            "ndtgpu_match_batch_device", "ndtgpu_match_d2d", "ndtgpu_kernel_name", "ndtgpu_profiling_enable",
-           "ndtgpu_last_kernel_ms", "ndtgpu_mapset_counters", "ndtgpu_match_fusion_batch"]
+           "ndtgpu_last_kernel_ms", "ndtgpu_mapset_counters", "ndtgpu_match_fusion_batch",
+           "ndtgpu_mapset_enable_occupancy", "ndtgpu_default_fuse_params", "ndtgpu_mapset_add_cloud",
+           "ndtgpu_mapset_add_cloud_host", "ndtgpu_mapset_clear", "ndtgpu_mapset_export_occupancy",
+           "ndtgpu_overlap_score_batch"]
 
 _lib = None
 
@@ -123,6 +131,15 @@ def lib():
     L.ndtgpu_profiling_enable.argtypes = [vp, C.c_int]
     L.ndtgpu_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.ndtgpu_mapset_counters.argtypes = [vp, C.c_size_t, u32p]
+    L.ndtgpu_mapset_enable_occupancy.argtypes = [vp]
+    L.ndtgpu_default_fuse_params.argtypes = [C.POINTER(FuseParams)]
+    L.ndtgpu_mapset_add_cloud.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, dp,
+                                          C.POINTER(FuseParams), vp]
+    L.ndtgpu_mapset_add_cloud_host.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, dp,
+                                               C.POINTER(FuseParams)]
+    L.ndtgpu_mapset_clear.argtypes = [vp, C.c_size_t, C.c_size_t]
+    L.ndtgpu_mapset_export_occupancy.argtypes = [vp, C.c_size_t, C.POINTER(C.c_float)]
+    L.ndtgpu_overlap_score_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, dp, C.POINTER(C.c_int64), vp]
     _lib = L
     return L
 
@@ -225,6 +242,48 @@ class MapSet:
             _check(lib().ndtgpu_mapset_build_host(self.h, int(first), B, C.c_void_p(a.ctypes.data), N, 4 * W,
                                                   4 * W * N, float(range_limit), rop, C.byref(cp)))
 
+    def enable_occupancy(self):
+        """NDTMap::initialize: every cell exists and carries an occupancy; needed by add_cloud / overlap_score."""
+        _check(lib().ndtgpu_mapset_enable_occupancy(self.h))
+
+    def add_cloud(self, xyz, origins, first=0, stream=None, **params):
+        """NDTMap::addPointCloud(origin, cloud, ., maxz, sensor_noise) + computeNDTCells(SAMPLE_VARIANCE, maxnumpoints,
+        occupancy_limit, ..) for maps [first, first+B): xyz [B,N,3|4] float32 (torch CUDA tensor: asynchronous; NumPy:
+        host path), origins [B,3] sensor positions in the map frame."""
+        fp = FuseParams()
+        lib().ndtgpu_default_fuse_params(C.byref(fp))
+        for k, v in params.items():
+            if not hasattr(fp, k):
+                raise TypeError("unknown fuse parameter %r" % k)
+            setattr(fp, k, v)
+        is_torch = hasattr(xyz, "data_ptr")
+        if xyz.ndim == 2:
+            xyz = xyz[None]
+        B, N, W = int(xyz.shape[0]), int(xyz.shape[1]), int(xyz.shape[2])
+        assert W in (3, 4)
+        org = _f64(origins).reshape(B, 3)
+        if is_torch:
+            import torch
+            assert xyz.dtype == torch.float32 and xyz.is_cuda and xyz.is_contiguous()
+            if stream is None:
+                stream = torch.cuda.current_stream()
+            _check(lib().ndtgpu_mapset_add_cloud(self.h, int(first), B, C.c_void_p(xyz.data_ptr()), N, 4 * W, 4 * W * N,
+                                                 _dp(org), C.byref(fp), _stream_ptr(stream)))
+        else:
+            a = np.ascontiguousarray(xyz, dtype=np.float32)
+            _check(lib().ndtgpu_mapset_add_cloud_host(self.h, int(first), B, C.c_void_p(a.ctypes.data), N, 4 * W, 4 * W * N,
+                                                      _dp(org), C.byref(fp)))
+
+    def clear(self, first=0, count=None):
+        _check(lib().ndtgpu_mapset_clear(self.h, int(first), int(self.n_maps - first if count is None else count)))
+
+    def occupancy(self, i=0):
+        """NDTCell::occ of every cell of map i, shape (sx, sy, sz)."""
+        shape = tuple(self.info()["cells_per_axis"])
+        out = np.zeros(shape, dtype=np.float32)
+        _check(lib().ndtgpu_mapset_export_occupancy(self.h, int(i), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def profiling(self, on=True):
         _check(lib().ndtgpu_profiling_enable(self.h, int(bool(on))))
 
@@ -318,3 +377,17 @@ def match_batch_device(target_set, tidx_dev, source_set, sidx_dev, T16_dev, resu
 def match_d2d(target_set, tmap, source_set, smap, T, **params):
     To, res = match_batch(target_set, [tmap], source_set, [smap], np.asarray(T)[None], **params)
     return To[0], res[0]
+
+
+def overlap_score(ref_set, ref_idx, mov_set, mov_idx, T, stream=None):
+    """ndt_feature::overlapNDTOccupancyScore(ref, mov, T) for every link -> (scores [n], nb_sum [n])."""
+    ri = np.ascontiguousarray(ref_idx, dtype=np.uint32)
+    mi = np.ascontiguousarray(mov_idx, dtype=np.uint32)
+    n = ri.shape[0]
+    Tc = np.ascontiguousarray(np.transpose(np.asarray(T, dtype=np.float64).reshape(n, 4, 4), (0, 2, 1))).copy()
+    score = np.zeros(n)
+    nb = np.zeros(n, dtype=np.int64)
+    _check(lib().ndtgpu_overlap_score_batch(ref_set.h, ri.ctypes.data_as(C.POINTER(C.c_uint32)), mov_set.h,
+                                            mi.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), n, _dp(score),
+                                            nb.ctypes.data_as(C.POINTER(C.c_int64)), _stream_ptr(stream)))
+    return score, nb

@@ -164,7 +164,7 @@ template <int STRIDE_DW, int MODE>
 __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) void ndt_build_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
     size_t map_stride_bytes, double range_limit, const double *__restrict__ range_origins, int n_min,
-    double eval_factor, int s1_shift, int s2_shift, int dbg)
+    double eval_factor, int s1_shift, int s2_shift, int dbg, float z_max32)
 {
     constexpr int SD = STRIDE_DW ? STRIDE_DW : 3;
     constexpr int LANE_DW = NDT_PPL * SD + 1;          // +1: odd stride -> conflict-free per-lane walks
@@ -190,7 +190,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     int32_t *table = set.table + (size_t)map * g.slots;
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     const unsigned bm_words = (unsigned)((g.slots + 31) >> 5);
-    NdtCell *cells = set.cells + (size_t)map * cap;
+    NdtCell *cells = set.cells + (size_t)map * cap;          // a (re)build always lands in the first cell array
+    // ... the previous content may sit in the second one (after an incremental update, csrc/ndt_fuse.hip)
+    const NdtCell *cells_prev = ndt_cells_of(set, map, set.cell_sel ? set.cell_sel[map] : 0u);
     NdtMapCounters *ctr = set.counters + map;
     const double cx = set.centres[map * 3 + 0], cy = set.centres[map * 3 + 1], cz = set.centres[map * 3 + 2];
     const double res = g.res, inv_res = 1.0 / g.res;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         unsigned old = ctr->n_cells;
         if (old > cap) old = cap;
         for (unsigned i = fin_part * nthreads + tid; i < old; i += nthreads * fin_parts) {
-            const uint32_t sl = cells[i].slot;
+            const uint32_t sl = cells_prev[i].slot;
             table[sl] = NDT_EMPTY;
             rankmap[sl >> 5].x = 0u;
         }
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             // Inf passes the range test when no range is set and is then out of the grid.
             const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
             const float dd = dx * dx + dy * dy + dz * dz;
-            const bool okr = dd <= r2eff;                                   // r2eff = +inf without a range limit
+            const bool okz = fz <= z_max32;                                 // addPointCloud's maxz (+inf otherwise)
+            const bool okr = dd <= r2eff && okz;                            // r2eff = +inf without a range limit
             const bool near_r = fabsf(dd - r2) < r2band;                    // r2band < 0 without a range limit
             // v = (p - c)/res + 0.5 + size/2 in one fma per axis; the integer part is the cell index
             const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
@@ -383,14 +386,14 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
                         (unsigned)iz < (unsigned)g.size[2]) ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
             // ... and the reference's fp64 formulas for the few points near a cell face / the range sphere
             // (frac_lim < 0 sends every point here: odd grid sizes, absurd centres)
-            const bool need_exact = (okr || near_r) && (near_r || !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim));
+            const bool need_exact = (okr || (near_r && okz)) && (near_r || !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim));
             if (__ballot(need_exact)) {
                 if (need_exact) {
                     bool ok = okr;
                     if (near_r) {
 #pragma clang fp contract(off)
                         double ex = (double)fx - ox, ey = (double)fy - oy, ez = (double)fz - oz;
-                        ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit);
+                        ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit) && okz;
                     }
                     if (!(tx <= frac_lim)) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
                     if (!(ty <= frac_lim)) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
@@ -585,6 +588,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         for (int k = 0; k < 6; k++) c.cov[k] = 0;
         unsigned long long n = (unsigned long long)a.n;
         binned += (unsigned)n;               // points that reached a cell (the others were NaN, out of range / grid)
+        if (set.occ && n > 0) {
+            // NDTCell::computeGaussian on a fresh cell: occ = n log(0.6 / 0.4), clamped to the default limit 255
+            // (the launcher zeroed the map's occupancies)
+            const float o = (float)((double)n * NDT_LOGODD_OCC);
+            set.occ[(size_t)map * g.slots + bc.acc_slot[id]] = o > 255.0f ? 255.0f : o;
+        }
         if (n >= 2 && n >= (unsigned long long)n_min) {
             unsigned slot = bc.acc_slot[id];
             int iz = slot % g.size[2];
@@ -799,6 +808,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     }
     if (tid == 0) {
         ctr->n_cells = s_base;
+        if (set.cell_sel) set.cell_sel[map] = 0u;
         ctr->n_alloc = 0;
         ctr->n_dropped = n_points - s_dropped;          // s_dropped holds the number of binned points here
         ctr->cyc[0] = (uint32_t)(t1 - t0);
@@ -832,6 +842,7 @@ extern "C" __global__ void ndt_install_cells_kernel(NdtSetView set, unsigned map
         if (i == 0 || (src[i - 1].slot >> 5) != (c.slot >> 5)) rankmap[c.slot >> 5].y = i;   // sorted by slot
     }
     if (i == 0) {
+        if (set.cell_sel) set.cell_sel[map] = 0u;
         set.counters[map].n_cells = n_cells;
         set.counters[map].n_alloc = 0;
         set.counters[map].overflow = 0;
@@ -875,7 +886,7 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
 #define NDT_LAUNCH_BUILD(SDW, MODE, GRID)                                                                            \
     hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set, (unsigned)first, \
                        (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes, map_stride_bytes,          \
-                       range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg)
+                       range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg, __builtin_inff())
 #define NDT_LAUNCH_BUILD_SD(MODE, GRID)                                                                              \
     do {                                                                                                             \
         if (sdw == 3) NDT_LAUNCH_BUILD(3, MODE, GRID);                                                               \
@@ -896,10 +907,49 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         if (fin_parts < 1u) fin_parts = 1u;
         hipLaunchKernelGGL((ndt_build_kernel<0, 2>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
                            (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
-                           map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg);
+                           map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg,
+                           __builtin_inff());
     }
 #undef NDT_LAUNCH_BUILD_SD
 #undef NDT_LAUNCH_BUILD
+    return hipGetLastError();
+}
+
+// Phase A only (MODE 1) for the incremental update of csrc/ndt_fuse.hip: the points of one cloud per map are added
+// to the moment accumulators of their cells; nothing is finalised.  z_max: NDTMap::addPointCloud's maxz.
+hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                                 size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                 const double *range_origins_dev, double z_max, int *s1_shift_out, int *s2_shift_out,
+                                 hipStream_t stream)
+{
+    int lg = 1;
+    while ((1ull << lg) < (unsigned long long)(n_points ? n_points : 1)) lg++;
+    const bool odd = (set.grid.size[0] | set.grid.size[1] | set.grid.size[2]) & 1;
+    int s1_shift = (odd ? 51 : 53) - lg, s2_shift = (odd ? 50 : 54) - lg;
+    if (s1_shift > 44) s1_shift = 44;
+    if (s2_shift > 44) s2_shift = 44;
+    *s1_shift_out = s1_shift;
+    *s2_shift_out = s2_shift;
+    if (count == 0 || n_points == 0) return hipSuccess;
+    // the largest float that does not exceed z_max: `z <= zf` in float == `(double) z <= z_max`
+    float zf = (float)z_max;
+    if ((double)zf > z_max) zf = nextafterf(zf, -__builtin_inff());
+    const bool aligned4 = (((uintptr_t)xyz_dev | map_stride_bytes) & 3u) == 0;
+    const int sdw = (stride_bytes == 12 && aligned4) ? 3 : (stride_bytes == 16 && aligned4) ? 4 : 0;
+    const unsigned n_tiles = (unsigned)((n_points + NDT_TILE - 1) / NDT_TILE);
+    unsigned parts = (unsigned)(1024 / count);
+    if (parts > n_tiles / 4) parts = n_tiles / 4;
+    if (parts < 1) parts = 1;
+    hipError_t e = hipMemset2DAsync(&set.counters[first].overflow, sizeof(NdtMapCounters), 0, 2 * sizeof(uint32_t), count, stream);
+    if (e != hipSuccess) return e;
+#define NDT_LAUNCH_ACC(SDW)                                                                                           \
+    hipLaunchKernelGGL((ndt_build_kernel<SDW, 1>), dim3(parts, (unsigned)count), dim3(NDT_BUILD_THREADS), 0, stream, set, \
+                       (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,           \
+                       map_stride_bytes, range_limit, range_origins_dev, 0, 0.0, s1_shift, s2_shift, 0, zf)
+    if (sdw == 3) NDT_LAUNCH_ACC(3);
+    else if (sdw == 4) NDT_LAUNCH_ACC(4);
+    else NDT_LAUNCH_ACC(0);
+#undef NDT_LAUNCH_ACC
     return hipGetLastError();
 }
 

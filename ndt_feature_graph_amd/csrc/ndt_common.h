@@ -18,6 +18,9 @@
 // lambda_min <= NDT_DEGENERATE_REL * lambda_max counts as "eigenvalue <= 0" in
 // NDTCell::rescaleCovariance (rank-deficient sample covariance; see DESIGN.md "Deviations").
 #define NDT_DEGENERATE_REL 1e-9
+// log(0.6 / (1.0 - 0.6)) as the reference's double arithmetic yields it (0.6 / 0.4 is 1.4999999999999998): the
+// occupancy log-odds one point adds to its cell (NDTCell::computeGaussian)
+#define NDT_LOGODD_OCC 0x1.9f323ecbf9849p-2
 // Eigen computeInverseAndDetWithCheck default threshold on |det(CSum)|
 #define NDT_DET_EPS 1e-12
 
@@ -72,7 +75,20 @@ struct NdtSetView {            // what kernels see of a mapset
     uint32_t *acc_slot;        // [n_maps][max_cells] slot of each accumulator id
     NdtMapCounters *counters;  // [n_maps]
     double *centres;           // [n_maps][3]
+    // incremental (fused) node maps -- allocated by ndtgpu_mapset_enable_occupancy, NULL otherwise:
+    float *occ;                // [n_maps][slots]      NDTCell::occ of every cell (NDTMap::initialize: all cells exist)
+    long long *occ_delta;      // [n_maps][slots]      beam evidence of one addPointCloud, exact sums in units of 2^-32
+                               //                      (all 0 between calls)
+    NdtCell *cells_alt;        // [n_maps][max_cells]  second cell array: an incremental update reads the old cells
+                               //                      while it writes the new ranking
+    uint32_t *cell_sel;        // [n_maps]             0: the map's cells are in `cells`, 1: in `cells_alt`
 };
+
+// the cell array a map currently lives in
+static inline __host__ __device__ NdtCell *ndt_cells_of(const NdtSetView &s, size_t map, uint32_t sel)
+{
+    return (sel ? s.cells_alt : s.cells) + map * (size_t)s.grid.max_cells;
+}
 
 // Lanes of one wave that hand data to each other through LDS (queues, lists, tables): the hardware runs a wave's
 // LDS operations in program order, but the COMPILER only knows about one thread -- without a fence it may hoist a
@@ -106,6 +122,21 @@ struct NdtMatchResultDev {     // mirrors ndtgpu_match_result
 hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                             size_t stride_bytes, size_t map_stride_bytes, double range_limit,
                             const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream);
+// accumulate only (phase A of the build: points -> per-cell moment accumulators), z_max: points above it are dropped
+hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                                 size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                 const double *range_origins_dev, double z_max, int *s1_shift_out, int *s2_shift_out,
+                                 hipStream_t stream);
+struct NdtFuseParams {         // NDTMap::addPointCloud + computeNDTCells arguments (fuser_hmt.cpp:92-94, 485-486)
+    double maxz, sensor_noise, maxnumpoints, occupancy_limit, eval_factor;
+    int n_min;
+};
+hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                           size_t stride_bytes, size_t map_stride_bytes, const double *origins_dev,
+                           const NdtFuseParams &prm, hipStream_t stream);
+hipError_t ndt_launch_overlap(const NdtSetView &rset, const uint32_t *ridx_dev, const NdtSetView &mset,
+                              const uint32_t *midx_dev, const double *T16_dev, size_t n_links, double *score_dev,
+                              long long *nb_dev, hipStream_t stream);
 hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const NdtCell *cells_dev, size_t n_cells,
                                     hipStream_t stream);
 size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups);

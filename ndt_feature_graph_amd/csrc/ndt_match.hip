@@ -48,7 +48,7 @@ NDT_D MapView map_view(const NdtSetView &s, unsigned map)
 {
     MapView v;
     v.rankmap = s.rankmap + (size_t)map * ndt_rm_stride(s.grid);
-    v.cells = s.cells + (size_t)map * s.grid.max_cells;
+    v.cells = ndt_cells_of(s, map, s.cell_sel ? s.cell_sel[map] : 0u);   // (second array after an incremental update)
     v.n_cells = (int)s.counters[map].n_cells;
     v.sx = s.grid.size[0]; v.sy = s.grid.size[1]; v.sz = s.grid.size[2];
     v.cx = s.centres[map * 3]; v.cy = s.centres[map * 3 + 1]; v.cz = s.centres[map * 3 + 2];

@@ -191,6 +191,10 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (s->v.acc_slot) (void)hipFree(s->v.acc_slot);
     if (s->v.counters) (void)hipFree(s->v.counters);
     if (s->v.centres) (void)hipFree(s->v.centres);
+    if (s->v.occ) (void)hipFree(s->v.occ);
+    if (s->v.occ_delta) (void)hipFree(s->v.occ_delta);
+    if (s->v.cells_alt) (void)hipFree(s->v.cells_alt);
+    if (s->v.cell_sel) (void)hipFree(s->v.cell_sel);
     if (s->stage) (void)hipFree(s->stage);
     if (s->work) (void)hipFree(s->work);
     if (s->origins_dev) (void)hipFree(s->origins_dev);
@@ -242,6 +246,8 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
         orig_dev = s->origins_dev;
     }
     s->last_stream = st;
+    if (s->v.occ && count)   // a rebuilt map starts from cells without readings
+        HIP_TRY(hipMemsetAsync(s->v.occ + first * (size_t)s->v.grid.slots, 0, count * (size_t)s->v.grid.slots * sizeof(float), st));
     if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
     hipError_t e = ndt_launch_build(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit,
                          orig_dev, cp.n_min, cp.eval_factor, st);
@@ -323,9 +329,10 @@ ndtgpu_status ndtgpu_mapset_export_cells(ndtgpu_mapset *s, size_t map, double *m
     ndtgpu_status rc = read_counters(s, map, &c);
     if (rc != NDTGPU_OK) return rc;
     std::vector<NdtCell> host(c.n_cells);
+    uint32_t sel = 0;
+    if (s->v.cell_sel) HIP_TRY(hipMemcpy(&sel, s->v.cell_sel + map, sizeof sel, hipMemcpyDeviceToHost));
     if (c.n_cells)
-        HIP_TRY(hipMemcpy(host.data(), s->v.cells + map * (size_t)s->v.grid.max_cells, c.n_cells * sizeof(NdtCell),
-                          hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(host.data(), ndt_cells_of(s->v, map, sel), c.n_cells * sizeof(NdtCell), hipMemcpyDeviceToHost));
     const NdtGrid &g = s->v.grid;
     for (uint32_t i = 0; i < c.n_cells; i++) {
         const NdtCell &k = host[i];
@@ -430,6 +437,148 @@ ndtgpu_status ndtgpu_derivatives(ndtgpu_mapset *t, size_t tmap, const double *sr
         for (int a = 0; a < 6; a++)
             for (int b = a; b < 6; b++) { H[a * 6 + b] = out[o]; H[b * 6 + a] = out[o]; o++; }
     }
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_enable_occupancy(ndtgpu_mapset *s)
+{
+    if (!s) return fail(NDTGPU_ERR_INVALID, "enable_occupancy: null");
+    if (s->v.occ) return NDTGPU_OK;
+    const size_t slots = (size_t)s->v.grid.slots, cap = s->v.grid.max_cells, n = s->n_maps;
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    float *occ = nullptr;
+    long long *delta = nullptr;
+    NdtCell *alt = nullptr;
+    uint32_t *sel = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&occ, n * slots * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc((void **)&delta, n * slots * sizeof(long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&alt, n * cap * sizeof(NdtCell))) != hipSuccess ||
+        (e = hipMalloc((void **)&sel, n * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemset(occ, 0, n * slots * sizeof(float))) != hipSuccess ||
+        (e = hipMemset(delta, 0, n * slots * sizeof(long long))) != hipSuccess ||
+        (e = hipMemset(sel, 0, n * sizeof(uint32_t))) != hipSuccess) {
+        if (occ) (void)hipFree(occ);
+        if (delta) (void)hipFree(delta);
+        if (alt) (void)hipFree(alt);
+        if (sel) (void)hipFree(sel);
+        return fail(NDTGPU_ERR_ALLOC, "enable_occupancy: device memory", e);
+    }
+    s->v.occ = occ; s->v.occ_delta = delta; s->v.cells_alt = alt; s->v.cell_sel = sel;
+    return NDTGPU_OK;
+}
+
+void ndtgpu_default_fuse_params(ndtgpu_fuse_params *p)
+{
+    p->maxz = 25.0;             // fuser_hmt.cpp:485
+    p->sensor_noise = 0.06;
+    p->maxnumpoints = 1e5;      // fuser_hmt.cpp:486
+    p->occupancy_limit = 255.0;
+    p->n_min = 3;
+    p->eval_factor = 1000.0;
+}
+
+ndtgpu_status ndtgpu_mapset_add_cloud(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                                      size_t stride_bytes, size_t map_stride_bytes, const double *origins,
+                                      const ndtgpu_fuse_params *prm, ndtgpu_stream stream)
+{
+    if (!s || first + count > s->n_maps || (!xyz_dev && n_points) || stride_bytes < 12 || (stride_bytes & 3) ||
+        n_points > 0xFFFFFFFFull || (count && !origins))
+        return fail(NDTGPU_ERR_INVALID, "add_cloud: bad argument");
+    if (!s->v.occ) return fail(NDTGPU_ERR_INVALID, "add_cloud: call ndtgpu_mapset_enable_occupancy first (NDTMap::initialize)");
+    if (count == 0) return NDTGPU_OK;
+    ndtgpu_fuse_params fp;
+    ndtgpu_default_fuse_params(&fp);
+    if (prm) fp = *prm;
+    if (!(fp.occupancy_limit > 0)) return fail(NDTGPU_ERR_INVALID, "add_cloud: occupancy_limit must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    if (s->origins_cap < count * 3) {
+        if (s->origins_dev) (void)hipFree(s->origins_dev);
+        s->origins_dev = nullptr;
+        s->origins_cap = 0;
+        HIP_TRY(hipMalloc((void **)&s->origins_dev, count * 3 * sizeof(double)));
+        s->origins_cap = count * 3;
+    }
+    HIP_TRY(hipMemcpyAsync(s->origins_dev, origins, count * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    s->last_stream = st;
+    NdtFuseParams p;
+    p.maxz = fp.maxz; p.sensor_noise = fp.sensor_noise; p.maxnumpoints = fp.maxnumpoints;
+    p.occupancy_limit = fp.occupancy_limit; p.eval_factor = fp.eval_factor; p.n_min = fp.n_min;
+    hipError_t e = ndt_launch_fuse(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, s->origins_dev, p, st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "add_cloud: launch", e);
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_add_cloud_host(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,
+                                           size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                           const double *origins, const ndtgpu_fuse_params *prm)
+{
+    if (!s || (!xyz_host && n_points) || count == 0) return fail(NDTGPU_ERR_INVALID, "add_cloud_host: bad argument");
+    size_t bytes = (count - 1) * map_stride_bytes + n_points * stride_bytes;
+    if (bytes == 0) bytes = 16;
+    ndtgpu_status rc = s->ensure_stage(bytes);
+    if (rc != NDTGPU_OK) return rc;
+    if (n_points) HIP_TRY(hipMemcpy(s->stage, xyz_host, bytes, hipMemcpyHostToDevice));
+    rc = ndtgpu_mapset_add_cloud(s, first, count, s->stage, n_points, stride_bytes, map_stride_bytes, origins, prm, nullptr);
+    if (rc != NDTGPU_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_clear(ndtgpu_mapset *s, size_t first, size_t count)
+{
+    if (!s || first + count > s->n_maps) return fail(NDTGPU_ERR_INVALID, "mapset_clear: bad argument");
+    if (count == 0) return NDTGPU_OK;
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    const NdtGrid &g = s->v.grid;
+    const size_t slots = (size_t)g.slots;
+    HIP_TRY(hipMemset(s->v.table + first * slots, 0xFF, count * slots * sizeof(int32_t)));
+    HIP_TRY(hipMemset(s->v.rankmap + first * ndt_rm_stride(g), 0, count * ndt_rm_stride(g) * sizeof(uint2)));
+    HIP_TRY(hipMemset(s->v.counters + first, 0, count * sizeof(NdtMapCounters)));
+    if (s->v.occ) {
+        HIP_TRY(hipMemset(s->v.occ + first * slots, 0, count * slots * sizeof(float)));
+        HIP_TRY(hipMemset(s->v.cell_sel + first, 0, count * sizeof(uint32_t)));
+    }
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_export_occupancy(ndtgpu_mapset *s, size_t map, float *occ_out)
+{
+    if (!s || map >= s->n_maps || !occ_out) return fail(NDTGPU_ERR_INVALID, "export_occupancy: bad argument");
+    if (!s->v.occ) return fail(NDTGPU_ERR_INVALID, "export_occupancy: occupancy not enabled on this set");
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    HIP_TRY(hipMemcpy(occ_out, s->v.occ + map * (size_t)s->v.grid.slots, (size_t)s->v.grid.slots * sizeof(float), hipMemcpyDeviceToHost));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_overlap_score_batch(ndtgpu_mapset *rs, const uint32_t *ridx, ndtgpu_mapset *ms, const uint32_t *midx,
+                                         const double *T16, size_t n_links, double *score, int64_t *nb_sum,
+                                         ndtgpu_stream stream)
+{
+    if (!rs || !ms || (n_links && (!ridx || !midx || !T16 || !score)))
+        return fail(NDTGPU_ERR_INVALID, "overlap_score: bad argument");
+    if (!rs->v.occ || !ms->v.occ) return fail(NDTGPU_ERR_INVALID, "overlap_score: occupancy not enabled on both sets");
+    if (n_links == 0) return NDTGPU_OK;
+    for (size_t k = 0; k < n_links; k++)
+        if (ridx[k] >= rs->n_maps || midx[k] >= ms->n_maps) return fail(NDTGPU_ERR_INVALID, "overlap_score: map index");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(rs->last_stream));
+    HIP_TRY(hipStreamSynchronize(ms->last_stream));
+    const size_t bT = n_links * 16 * sizeof(double), bI = n_links * sizeof(uint32_t), bS = n_links * sizeof(double);
+    const size_t off_r = (bT + 255) & ~(size_t)255, off_m = (off_r + bI + 255) & ~(size_t)255,
+                 off_s = (off_m + bI + 255) & ~(size_t)255, off_n = (off_s + bS + 255) & ~(size_t)255;
+    ndtgpu_status rc = rs->ensure_stage(off_n + n_links * sizeof(long long));
+    if (rc != NDTGPU_OK) return rc;
+    char *base = (char *)rs->stage;
+    HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_r, ridx, bI, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_m, midx, bI, hipMemcpyHostToDevice, st));
+    hipError_t e = ndt_launch_overlap(rs->v, (const uint32_t *)(base + off_r), ms->v, (const uint32_t *)(base + off_m),
+                                      (const double *)base, n_links, (double *)(base + off_s), (long long *)(base + off_n), st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "overlap_score: launch", e);
+    HIP_TRY(hipMemcpyAsync(score, base + off_s, bS, hipMemcpyDeviceToHost, st));
+    if (nb_sum) HIP_TRY(hipMemcpyAsync(nb_sum, base + off_n, n_links * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return NDTGPU_OK;
 }
 

@@ -51,6 +51,16 @@ def lib():
     L.oracle_map_index_for_point.argtypes = [C.c_void_p, dp, ip]
     L.oracle_map_load_points.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, dp]
     L.oracle_map_compute_cells.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.oracle_map_compute_cells_full.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.oracle_map_add_point_cloud.argtypes = [C.c_void_p, dp, C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
+                                             C.c_double, C.c_int]
+    L.oracle_beam_evidence.argtypes = [dp, dp, dp, C.POINTER(C.c_float), C.c_double, C.POINTER(C.c_float)]
+    L.oracle_map_occupancy.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.oracle_map_size.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.oracle_occupancy_rescaled.restype = C.c_float
+    L.oracle_occupancy_rescaled.argtypes = [C.c_float]
+    L.oracle_overlap_score.restype = C.c_double
+    L.oracle_overlap_score.argtypes = [C.c_void_p, C.c_void_p, dp, C.POINTER(C.c_longlong)]
     L.oracle_map_num_cells.argtypes = [C.c_void_p]
     L.oracle_map_export_cells.argtypes = [C.c_void_p, dp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.oracle_map_set_cells.argtypes = [C.c_void_p, dp, dp, C.c_size_t]
@@ -118,6 +128,28 @@ class OracleMap:
 
     def compute_cells(self, n_min=3, eval_factor=1000.0):
         self._L.oracle_map_compute_cells(self.h, int(n_min), float(eval_factor))
+
+    def compute_cells_full(self, n_min=3, eval_factor=1000.0, maxnumpoints=1e5, occupancy_limit=255.0):
+        """computeNDTCells(SAMPLE_VARIANCE, maxnumpoints, occupancy_limit, origin, noise) (fuser_hmt.cpp:94, 486)."""
+        self._L.oracle_map_compute_cells_full(self.h, int(n_min), float(eval_factor), float(maxnumpoints),
+                                              float(occupancy_limit))
+
+    def add_point_cloud(self, origin, xyz, maxz=100.0, sensor_noise=0.1, occupancy_limit=255.0, order_free=False):
+        """NDTMap::addPointCloud(origin, cloud, classifierTh, maxz, sensor_noise, occupancy_limit) (fuser_hmt.cpp:92, 485)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        o = _f64(origin)
+        rc = self._L.oracle_map_add_point_cloud(self.h, _dp(o), xyz.ctypes.data, xyz.shape[0], xyz.shape[1], float(maxz),
+                                                float(sensor_noise), float(occupancy_limit), int(bool(order_free)))
+        if rc:
+            raise RuntimeError("oracle_map_add_point_cloud")
+
+    def occupancy(self):
+        """NDTCell::occ of every slot, shape (sx, sy, sz)."""
+        size = (C.c_int * 3)()
+        self._L.oracle_map_size(self.h, size)
+        out = np.zeros(tuple(size), dtype=np.float32)
+        self._L.oracle_map_occupancy(self.h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
 
     def num_cells(self):
         return self._L.oracle_map_num_cells(self.h)
@@ -235,3 +267,25 @@ def mt_linesearch(phi, finit, dginit):
     info = C.c_int(0)
     stp = lib().oracle_mt_linesearch(cb, None, finit, dginit, C.byref(nfev), C.byref(info))
     return stp, nfev.value, info.value
+
+
+def overlap_score(ref, mov, T):
+    """ndt_feature::overlapNDTOccupancyScore(ref, mov, T) -> (score, nb_sum)."""
+    Tc = _f64(np.asarray(T, dtype=np.float64).T.reshape(-1))
+    nb = C.c_longlong(0)
+    s = lib().oracle_overlap_score(ref.h, mov.h, _dp(Tc), C.byref(nb))
+    return s, nb.value
+
+
+def beam_evidence(mean, cov, origin, end, sensor_noise=0.1):
+    """One beam through one Gaussian cell: float log-odds update, or None when the cell is left alone."""
+    mean, cov, origin = _f64(mean), _f64(cov), _f64(origin)
+    pe = np.ascontiguousarray(end, dtype=np.float32)
+    out = C.c_float(0)
+    ok = lib().oracle_beam_evidence(_dp(mean), _dp(cov), _dp(origin), pe.ctypes.data_as(C.POINTER(C.c_float)),
+                                    float(sensor_noise), C.byref(out))
+    return out.value if ok else None
+
+
+def occupancy_rescaled(occ):
+    return float(lib().oracle_occupancy_rescaled(float(occ)))

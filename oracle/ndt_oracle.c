@@ -256,12 +256,17 @@ struct oracle_map {
     double centre[3];
     int size[3];
     size_t nslots;
-    int32_t *cell_of_slot; /* -1 = NULL pointer in dataArray */
+    int32_t *cell_of_slot; /* -1 = no points / no Gaussian ever (the NDTCell may still exist: see occ) */
     ocell *cells;
     size_t ncells, capcells;
-    /* points waiting for computeNDTCells, grouped per cell (NDTCell::points_) */
-    float *pts;       /* xyz packed, sorted by cell, insertion order kept */
-    size_t *pt_begin; /* ncells+1 */
+    /* NDTCell::occ of every slot (float, like upstream).  NDTMap::initialize allocates every cell with occ = 0;
+     * a lazily allocated map has occ = 0 in the cells that do not exist, which nobody can tell apart (every reader
+     * skips occ == 0: ndt_feature_node.h:224, 237). */
+    float *occ;
+    /* points waiting for computeNDTCells (NDTCell::points_ of the cells in update_set), in insertion order */
+    float *pend_xyz;
+    int32_t *pend_cell;
+    size_t npend, cappend;
 };
 
 oracle_map *oracle_map_create(double res, const double centre[3], const double size_m[3])
@@ -279,15 +284,18 @@ oracle_map *oracle_map_create(double res, const double centre[3], const double s
     m->cell_of_slot = (int32_t *)malloc(m->nslots * sizeof(int32_t));
     if (!m->cell_of_slot) { free(m); return NULL; }
     for (size_t i = 0; i < m->nslots; i++) m->cell_of_slot[i] = -1;
+    m->occ = (float *)calloc(m->nslots, sizeof(float));
+    if (!m->occ) { free(m->cell_of_slot); free(m); return NULL; }
     return m;
 }
 
 static void map_clear(oracle_map *m)
 {
-    for (size_t i = 0; i < m->nslots; i++) m->cell_of_slot[i] = -1;
+    for (size_t i = 0; i < m->nslots; i++) { m->cell_of_slot[i] = -1; m->occ[i] = 0.0f; }
     free(m->cells); m->cells = NULL; m->ncells = m->capcells = 0;
-    free(m->pts); m->pts = NULL;
-    free(m->pt_begin); m->pt_begin = NULL;
+    free(m->pend_xyz); m->pend_xyz = NULL;
+    free(m->pend_cell); m->pend_cell = NULL;
+    m->npend = m->cappend = 0;
 }
 
 void oracle_map_destroy(oracle_map *m)
@@ -295,6 +303,7 @@ void oracle_map_destroy(oracle_map *m)
     if (!m) return;
     map_clear(m);
     free(m->cell_of_slot);
+    free(m->occ);
     free(m);
 }
 
@@ -340,47 +349,47 @@ static int cell_for_slot_create(oracle_map *m, size_t slot, const int idx[3])
     return (int)m->ncells++;
 }
 
+/* LazyGrid::addPoint: the point joins points_ of its cell (created on demand) and the cell joins update_set */
+static int pend_point(oracle_map *m, const float *q)
+{
+    double p[3] = {q[0], q[1], q[2]};
+    int idx[3];
+    index_for_point(m, p, idx);
+    if (!idx_inside(m, idx)) return 0;
+    int c = cell_for_slot_create(m, slot_of(m, idx), idx);
+    if (c < 0) return -1;
+    if (m->npend == m->cappend) {
+        size_t nc = m->cappend ? 2 * m->cappend : 4096;
+        float *px = (float *)realloc(m->pend_xyz, nc * 3 * sizeof(float));
+        if (!px) return -1;
+        m->pend_xyz = px;
+        int32_t *pc = (int32_t *)realloc(m->pend_cell, nc * sizeof(int32_t));
+        if (!pc) return -1;
+        m->pend_cell = pc;
+        m->cappend = nc;
+    }
+    m->pend_xyz[3 * m->npend] = q[0]; m->pend_xyz[3 * m->npend + 1] = q[1]; m->pend_xyz[3 * m->npend + 2] = q[2];
+    m->pend_cell[m->npend++] = c;
+    return 0;
+}
+
 int oracle_map_load_points(oracle_map *m, const float *xyz, size_t n, size_t stride, double range_limit,
                            const double *range_origin)
 {
     map_clear(m);
-    int32_t *cell_of_pt = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
-    if (!cell_of_pt) return -1;
     /* NDTMap::loadPointCloud: skip NaN, skip ||p|| > range_limit, LazyGrid::addPoint drops
      * points whose index falls outside the grid. */
     for (size_t i = 0; i < n; i++) {
         const float *q = xyz + i * stride;
-        cell_of_pt[i] = -1;
         if (isnan(q[0]) || isnan(q[1]) || isnan(q[2])) continue;
-        double p[3] = {q[0], q[1], q[2]};
         if (range_limit > 0) {
-            double d[3] = {p[0], p[1], p[2]};
+            double d[3] = {q[0], q[1], q[2]};
             if (range_origin)
                 for (int a = 0; a < 3; a++) d[a] -= range_origin[a];
             if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > range_limit) continue;
         }
-        int idx[3];
-        index_for_point(m, p, idx);
-        if (!idx_inside(m, idx)) continue;
-        int c = cell_for_slot_create(m, slot_of(m, idx), idx);
-        if (c < 0) { free(cell_of_pt); return -1; }
-        cell_of_pt[i] = c;
-        m->cells[c].n++;
+        if (pend_point(m, q) < 0) return -1;
     }
-    m->pt_begin = (size_t *)calloc(m->ncells + 1, sizeof(size_t));
-    for (size_t c = 0; c < m->ncells; c++) m->pt_begin[c + 1] = m->pt_begin[c] + (size_t)m->cells[c].n;
-    size_t tot = m->pt_begin[m->ncells];
-    m->pts = (float *)malloc((tot ? tot : 1) * 3 * sizeof(float));
-    size_t *fill = (size_t *)calloc(m->ncells ? m->ncells : 1, sizeof(size_t));
-    for (size_t i = 0; i < n; i++) {
-        int c = cell_of_pt[i];
-        if (c < 0) continue;
-        size_t o = (m->pt_begin[c] + fill[c]++) * 3;
-        const float *q = xyz + i * stride;
-        m->pts[o] = q[0]; m->pts[o + 1] = q[1]; m->pts[o + 2] = q[2];
-    }
-    free(fill);
-    free(cell_of_pt);
     return 0;
 }
 
@@ -415,37 +424,109 @@ static void rescale_covariance(ocell *ce, double eval_factor)
             }
 }
 
-/* NDTCell::computeGaussian, first-Gaussian branch:
- * occupancy: logodd = n*log(0.6/0.4) > 0 for any cell that holds points, so
- * occ > 0; points_.size() < n_min -> no Gaussian; mean = sum/n;
- * cov = sum (p-mean)(p-mean)^T / (n-1); rescaleCovariance. */
-int oracle_map_compute_cells(oracle_map *m, int n_min, double eval_factor)
+/* NDTCell::updateOccupancy(occ_val, max_occu): float arithmetic, clamped to +-max_occu */
+static void update_occupancy(oracle_map *m, size_t slot, float occ_val, float max_occu)
 {
-    if (!m->pt_begin) return 0;
+    float o = m->occ[slot] + occ_val;
+    if (o > max_occu) o = max_occu;
+    if (o < -max_occu) o = -max_occu;
+    m->occ[slot] = o;
+}
+
+/* NDTMap::computeNDTCells(mode = SAMPLE_VARIANCE, maxnumpoints, occupancy_limit, origin, sensor_noise)
+ * (fuser_hmt.cpp:94, 486; :227 and ndt_odom_debug.cpp:179 with the defaults 1e9 / 255) over update_set ->
+ * NDTCell::computeGaussian (perception_oru; origin and sensor_noise are unused on this branch):
+ *   occupancy += n * log(0.6 / 0.4), clamped;  occ <= 0 -> hasGaussian_ = false, points dropped;
+ *   no Gaussian yet and n < n_min -> points dropped;
+ *   no Gaussian yet: mean, cov = sum (p - mean)(p - mean)^T / (n - 1), N = n;
+ *   Gaussian already: Chan's pairwise update of (N, N mean, (N - 1) cov) with the new batch, N saturating at
+ *   maxnumpoints ("sliding average");
+ *   rescaleCovariance. */
+int oracle_map_compute_cells_full(oracle_map *m, int n_min, double eval_factor, double maxnumpoints, double occupancy_limit)
+{
+    if (!m->npend) return 0;
+    /* group the pending points by cell, insertion order kept */
+    size_t *begin = (size_t *)calloc(m->ncells + 1, sizeof(size_t));
+    size_t *fill = (size_t *)calloc(m->ncells ? m->ncells : 1, sizeof(size_t));
+    float *pts = (float *)malloc(m->npend * 3 * sizeof(float));
+    if (!begin || !fill || !pts) { free(begin); free(fill); free(pts); return -1; }
+    for (size_t i = 0; i < m->npend; i++) begin[m->pend_cell[i] + 1]++;
+    for (size_t c = 0; c < m->ncells; c++) begin[c + 1] += begin[c];
+    for (size_t i = 0; i < m->npend; i++) {
+        int c = m->pend_cell[i];
+        size_t o = (begin[c] + fill[c]++) * 3;
+        pts[o] = m->pend_xyz[3 * i]; pts[o + 1] = m->pend_xyz[3 * i + 1]; pts[o + 2] = m->pend_xyz[3 * i + 2];
+    }
     for (size_t c = 0; c < m->ncells; c++) {
         ocell *ce = &m->cells[c];
-        size_t b = m->pt_begin[c], e = m->pt_begin[c + 1], n = e - b;
-        ce->has_gaussian = 0;
-        if ((int)n < n_min || n == 0) continue;
-        double mean[3] = {0, 0, 0};
-        for (size_t i = b; i < e; i++)
-            for (int a = 0; a < 3; a++) mean[a] += (double)m->pts[i * 3 + a];
-        for (int a = 0; a < 3; a++) mean[a] /= (double)n;
-        mat3 S = m3_zero();
-        for (size_t i = b; i < e; i++) {
-            double d[3];
-            for (int a = 0; a < 3; a++) d[a] = (double)m->pts[i * 3 + a] - mean[a];
+        size_t b = begin[c], e = begin[c + 1], n = e - b;
+        if (n == 0) continue;                                   /* not in update_set */
+        size_t slot = slot_of(m, ce->idx);
+        double logoddlikoccu = (double)n * log(0.6 / (1.0 - 0.6));
+        update_occupancy(m, slot, (float)logoddlikoccu, (float)occupancy_limit);   /* > 0.4 for every n >= 1 */
+        if (m->occ[slot] <= 0) { ce->has_gaussian = 0; continue; }
+        if (!ce->has_gaussian && (int)n < n_min) continue;
+        if (!ce->has_gaussian) {
+            double mean[3] = {0, 0, 0};
+            for (size_t i = b; i < e; i++)
+                for (int a = 0; a < 3; a++) mean[a] += (double)pts[i * 3 + a];
+            for (int a = 0; a < 3; a++) mean[a] /= (double)n;
+            mat3 S = m3_zero();
+            for (size_t i = b; i < e; i++) {
+                double d[3];
+                for (int a = 0; a < 3; a++) d[a] = (double)pts[i * 3 + a] - mean[a];
+                for (int r = 0; r < 3; r++)
+                    for (int q = 0; q < 3; q++) S.m[r][q] += d[r] * d[q];
+            }
             for (int r = 0; r < 3; r++)
-                for (int q = 0; q < 3; q++) S.m[r][q] += d[r] * d[q];
+                for (int q = 0; q < 3; q++) ce->cov.m[r][q] = S.m[r][q] / (double)(n - 1);
+            for (int a = 0; a < 3; a++) ce->mean[a] = mean[a];
+            ce->n = (int)n;
+            rescale_covariance(ce, eval_factor);
+        } else {
+            double N = (double)ce->n, dn = (double)n;
+            double meanSum[3], T2[3] = {0, 0, 0}, m2[3];
+            mat3 covSum, c2 = m3_zero();
+            for (int a = 0; a < 3; a++) meanSum[a] = ce->mean[a] * N;
+            for (int r = 0; r < 3; r++)
+                for (int q = 0; q < 3; q++) covSum.m[r][q] = ce->cov.m[r][q] * (N - 1.0);
+            for (size_t i = b; i < e; i++)
+                for (int a = 0; a < 3; a++) T2[a] += (double)pts[i * 3 + a];
+            for (int a = 0; a < 3; a++) m2[a] = T2[a] / dn;
+            for (size_t i = b; i < e; i++) {
+                double d[3];
+                for (int a = 0; a < 3; a++) d[a] = (double)pts[i * 3 + a] - m2[a];
+                for (int r = 0; r < 3; r++)
+                    for (int q = 0; q < 3; q++) c2.m[r][q] += d[r] * d[q];
+            }
+            double w1 = N / (dn * (N + dn)), w2 = dn / N, c3[3];
+            for (int a = 0; a < 3; a++) c3[a] = meanSum[a] * w2 - T2[a];
+            for (int r = 0; r < 3; r++)
+                for (int q = 0; q < 3; q++) covSum.m[r][q] += c2.m[r][q] + w1 * (c3[r] * c3[q]);
+            for (int a = 0; a < 3; a++) meanSum[a] += T2[a];
+            N += dn;
+            if (maxnumpoints > 0 && maxnumpoints < N) {
+                for (int a = 0; a < 3; a++) meanSum[a] *= maxnumpoints / N;
+                for (int r = 0; r < 3; r++)
+                    for (int q = 0; q < 3; q++) covSum.m[r][q] *= (maxnumpoints - 1.0) / (N - 1.0);
+                N = maxnumpoints;
+            }
+            for (int a = 0; a < 3; a++) ce->mean[a] = meanSum[a] / N;
+            for (int r = 0; r < 3; r++)
+                for (int q = 0; q < 3; q++) ce->cov.m[r][q] = covSum.m[r][q] / (N - 1.0);
+            ce->n = (int)N;
+            rescale_covariance(ce, eval_factor);
         }
-        for (int r = 0; r < 3; r++)
-            for (int q = 0; q < 3; q++) ce->cov.m[r][q] = S.m[r][q] / (double)(n - 1);
-        for (int a = 0; a < 3; a++) ce->mean[a] = mean[a];
-        rescale_covariance(ce, eval_factor);
     }
-    free(m->pts); m->pts = NULL;
-    free(m->pt_begin); m->pt_begin = NULL;
+    free(begin); free(fill); free(pts);
+    m->npend = 0;
     return 0;
+}
+
+/* NDTMap::computeNDTCells(CELL_UPDATE_MODE_SAMPLE_VARIANCE) with its default arguments */
+int oracle_map_compute_cells(oracle_map *m, int n_min, double eval_factor)
+{
+    return oracle_map_compute_cells_full(m, n_min, eval_factor, 1e9, 255.0);
 }
 
 int oracle_map_num_cells(const oracle_map *m)
@@ -492,6 +573,248 @@ int oracle_map_set_cells(oracle_map *m, const double *mean3, const double *cov9,
         ce->has_gaussian = 1;
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* NDTMap::addPointCloud (ray-traced insert) and the occupancy readers    */
+/* ------------------------------------------------------------------ */
+
+/* 3x3 inverse by cofactors (NDTCell::icov_; upstream builds it from the eigen-decomposition of
+ * rescaleCovariance: the same matrix up to rounding) */
+static int m3_inverse_plain(mat3 a, mat3 *inv)
+{
+    mat3 t;
+    double c00 = a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1];
+    double c01 = a.m[1][2] * a.m[2][0] - a.m[1][0] * a.m[2][2];
+    double c02 = a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0];
+    double det = a.m[0][0] * c00 + a.m[0][1] * c01 + a.m[0][2] * c02;
+    if (det == 0.0 || det != det) return 0;
+    double id = 1.0 / det;
+    t.m[0][0] = c00 * id; t.m[1][0] = c01 * id; t.m[2][0] = c02 * id;
+    t.m[0][1] = (a.m[0][2] * a.m[2][1] - a.m[0][1] * a.m[2][2]) * id;
+    t.m[1][1] = (a.m[0][0] * a.m[2][2] - a.m[0][2] * a.m[2][0]) * id;
+    t.m[2][1] = (a.m[0][1] * a.m[2][0] - a.m[0][0] * a.m[2][1]) * id;
+    t.m[0][2] = (a.m[0][1] * a.m[1][2] - a.m[0][2] * a.m[1][1]) * id;
+    t.m[1][2] = (a.m[0][2] * a.m[1][0] - a.m[0][0] * a.m[1][2]) * id;
+    t.m[2][2] = (a.m[0][0] * a.m[1][1] - a.m[0][1] * a.m[1][0]) * id;
+    *inv = t;
+    return 1;
+}
+
+/* The emptiness evidence ONE beam leaves in ONE traversed cell that holds a Gaussian
+ * (NDTMap::addPointCloud + NDTCell::computeMaximumLikelihoodAlongLine + getLikelihood, perception_oru; SURVEY
+ * App. A): X = the point of maximum likelihood on the beam, lik = exp(-(X - mean)^T icov (X - mean) / 2); a maximum
+ * behind the measured end is ignored; the closer X is to the end point the less the beam says about the cell
+ * being empty (distance-dependent sensor noise).  origin: the sensor (double, and its float copy `po` as the
+ * pcl::PointXYZ upstream builds); end point pe (float).  Returns 0 when the beam leaves the cell untouched, else
+ * writes the (negative) log-odds update as the float NDTCell::updateOccupancy receives. */
+int oracle_beam_evidence(const double mean[3], const double cov9[9], const double origin[3], const float pe[3],
+                         double sensor_noise, float *logodd)
+{
+    mat3 C, ic;
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) C.m[a][b] = cov9[3 * a + b];
+    if (!m3_inverse_plain(C, &ic)) return 0;
+    float po[3] = {(float)origin[0], (float)origin[1], (float)origin[2]};
+    double v1[3] = {po[0], po[1], po[2]}, v2[3] = {pe[0], pe[1], pe[2]};
+    double d[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+    double nl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    vec3 L = {{d[0] / nl, d[1] / nl, d[2] / nl}};
+    vec3 A = m3_v(ic, L);
+    vec3 B = {{v2[0] - mean[0], v2[1] - mean[1], v2[2] - mean[2]}};
+    double sigma = A.v[0] * L.v[0] + A.v[1] * L.v[1] + A.v[2] * L.v[2];
+    if (sigma == 0) return 0; /* upstream returns 1.0 without setting `out` and then reads it: unreachable for a regular Gaussian */
+    double t = -(A.v[0] * B.v[0] + A.v[1] * B.v[1] + A.v[2] * B.v[2]) / sigma;
+    double X[3], lik;
+    for (int a = 0; a < 3; a++) X[a] = L.v[a] * t + v2[a];
+    {   /* getLikelihood(pcl::PointXYZ): the point is rounded to float first */
+        float xf[3] = {(float)X[0], (float)X[1], (float)X[2]};
+        vec3 w = {{(double)xf[0] - mean[0], (double)xf[1] - mean[1], (double)xf[2] - mean[2]}};
+        double q = v3_dot(w, m3_v(ic, w));
+        lik = (q != q) ? -1.0 : exp(-q / 2);
+    }
+    /* l = |end - origin| and dist = |origin - X| use the DOUBLE origin */
+    double e[3] = {v2[0] - origin[0], v2[1] - origin[1], v2[2] - origin[2]};
+    double l = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    double o[3] = {origin[0] - X[0], origin[1] - X[1], origin[2] - X[2]};
+    double dist = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    if (dist > l) return 0;
+    double g[3] = {X[0] - v2[0], X[1] - v2[1], X[2] - v2[2]};
+    double l2target = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    double sigma_dist = 0.5 * (dist / 30.0);
+    double snoise = sigma_dist + sensor_noise;
+    double thr = exp(-0.5 * (l2target * l2target) / (snoise * snoise));
+    lik *= (1.0 - thr);
+    if (lik < 0.3) return 0;
+    lik = 0.1 * lik + 0.5;
+    *logodd = (float)log((1.0 - lik) / lik);
+    return 1;
+}
+
+/* LazyGrid::traceLine: the cells a beam crosses, SAMPLED every `res` along the beam (N = (int)(l / res) steps,
+ * samples i = 1 .. N - 2: the walk stops about two cells short of the end point), sample coordinates rounded to
+ * float (pcl::PointXYZ), consecutive samples in the same cell visited once.  visit(slot) for every in-grid cell. */
+typedef void (*visit_fn)(void *ctx, size_t slot);
+static void trace_line(const oracle_map *m, const double origin[3], const float pe[3], visit_fn visit, void *ctx)
+{
+    double diff[3] = {(double)pe[0] - origin[0], (double)pe[1] - origin[1], (double)pe[2] - origin[2]};
+    double l = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+    int N = (int)(l / m->res);
+    if (N <= 2) return;
+    double step[3] = {diff[0] / (float)N, diff[1] / (float)N, diff[2] / (float)N};
+    int io[3] = {0, 0, 0};   /* idxo = idyo = idzo = 0: a first sample in cell (0,0,0) is skipped like upstream */
+    for (int i = 0; i < N - 2; i++) {
+        float pt[3];
+        for (int a = 0; a < 3; a++) pt[a] = (float)(origin[a] + ((float)(i + 1)) * step[a]);
+        double p[3] = {pt[0], pt[1], pt[2]};
+        int idx[3];
+        index_for_point(m, p, idx);
+        if (idx[0] == io[0] && idx[1] == io[1] && idx[2] == io[2]) continue;
+        io[0] = idx[0]; io[1] = idx[1]; io[2] = idx[2];
+        if (!idx_inside(m, idx)) continue;
+        visit(ctx, slot_of(m, idx));
+    }
+}
+
+typedef struct {
+    oracle_map *m;
+    const double *origin;
+    const float *pe;
+    double sensor_noise;
+    float occupancy_limit;
+    int order_free;
+    const unsigned char *had_gaussian; /* order_free: hasGaussian_ of every cell when the call started */
+    long long *delta;                  /* order_free: exact sum of the float updates, in units of 2^-32 */
+} beam_ctx;
+
+static void visit_cell(void *vctx, size_t slot)
+{
+    beam_ctx *b = (beam_ctx *)vctx;
+    oracle_map *m = b->m;
+    int32_t c = m->cell_of_slot[slot];
+    int gauss = b->order_free ? (int)b->had_gaussian[slot] : (c >= 0 && m->cells[c].has_gaussian);
+    float upd;
+    if (gauss) {
+        const ocell *ce = &m->cells[c];
+        double cov9[9];
+        for (int a = 0; a < 3; a++)
+            for (int q = 0; q < 3; q++) cov9[3 * a + q] = ce->cov.m[a][q];
+        if (!oracle_beam_evidence(ce->mean, cov9, b->origin, b->pe, b->sensor_noise, &upd)) return;
+    } else {
+        upd = -0.2f;   /* seen empty, no Gaussian to argue with */
+    }
+    if (b->order_free) {
+        b->delta[slot] += llrint((double)upd * 4294967296.0);   /* exact: a float below 1 in magnitude */
+        return;
+    }
+    update_occupancy(m, slot, upd, b->occupancy_limit);
+    if (m->occ[slot] <= 0 && c >= 0) m->cells[c].has_gaussian = 0;
+}
+
+/* NDTMap::addPointCloud(origin, pc, classifierTh, maxz, sensor_noise, occupancy_limit)
+ * (fuser_hmt.cpp:92: (Tnow_sensor, cloud, 0.1, 100.0, 0.1); :485: (spose, cloud_orig, 0.06, 25)) on a map that went
+ * through NDTMap::initialize (isFirstLoad_ == false, every cell allocated).  classifierTh is unused upstream.
+ * order_free == 0: the reference's sequential semantics (beam after beam; a cell that loses its Gaussian half way
+ *                  through the cloud is treated as empty by the remaining beams; float accumulation);
+ * order_free == 1: what the HIP path implements (DESIGN.md "Deviations"): every beam sees the cells as they were
+ *                  when the call started, the updates of a cell are summed exactly and applied once. */
+int oracle_map_add_point_cloud(oracle_map *m, const double origin[3], const float *xyz, size_t n, size_t stride,
+                               double maxz, double sensor_noise, double occupancy_limit, int order_free)
+{
+    const double max_range = 200.0;
+    beam_ctx b = {m, origin, NULL, sensor_noise, (float)occupancy_limit, order_free, NULL, NULL};
+    unsigned char *had = NULL;
+    long long *delta = NULL;
+    if (order_free) {
+        had = (unsigned char *)calloc(m->nslots, 1);
+        delta = (long long *)calloc(m->nslots, sizeof(long long));
+        if (!had || !delta) { free(had); free(delta); return -1; }
+        for (size_t s = 0; s < m->nslots; s++) {
+            int32_t c = m->cell_of_slot[s];
+            had[s] = (c >= 0 && m->cells[c].has_gaussian) ? 1 : 0;
+        }
+        b.had_gaussian = had;
+        b.delta = delta;
+    }
+    for (size_t i = 0; i < n; i++) {
+        const float *q = xyz + i * stride;
+        if (isnan(q[0]) || isnan(q[1]) || isnan(q[2])) continue;
+        double d[3] = {(double)q[0] - origin[0], (double)q[1] - origin[1], (double)q[2] - origin[2]};
+        if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) > max_range) continue;
+        if ((double)q[2] > maxz) continue;                    /* traceLine returns false: the point is dropped */
+        b.pe = q;
+        trace_line(m, origin, q, visit_cell, &b);
+        if (pend_point(m, q) < 0) { free(had); free(delta); return -1; }
+    }
+    if (order_free) {
+        for (size_t s = 0; s < m->nslots; s++) {
+            if (!delta[s]) continue;
+            float o = (float)((double)m->occ[s] + (double)delta[s] * (1.0 / 4294967296.0));
+            if (o > (float)occupancy_limit) o = (float)occupancy_limit;
+            if (o < -(float)occupancy_limit) o = -(float)occupancy_limit;
+            m->occ[s] = o;
+            int32_t c = m->cell_of_slot[s];
+            if (o <= 0 && c >= 0) m->cells[c].has_gaussian = 0;
+        }
+        free(had);
+        free(delta);
+    }
+    return 0;
+}
+
+void oracle_map_size(const oracle_map *m, int size[3])
+{
+    for (int a = 0; a < 3; a++) size[a] = m->size[a];
+}
+
+void oracle_map_occupancy(const oracle_map *m, float *occ_out)
+{
+    memcpy(occ_out, m->occ, m->nslots * sizeof(float));
+}
+
+/* NDTCell::getOccupancyRescaled: 1 - 1 / (1 + exp(occ)) in FLOAT arithmetic.  expf is restated as the correctly
+ * rounded value float(exp(double)) (glibc's expf is correctly rounded for all but a handful of inputs), so that the
+ * HIP path can reproduce it bit for bit. */
+float oracle_occupancy_rescaled(float occ)
+{
+    float e = (float)exp((double)occ);
+    float o = 1.0f - 1.0f / (1.0f + e);
+    return o > 1 ? 1 : (o < 0 ? 0 : o);
+}
+
+/* ndt_feature::overlapNDTOccupancyScore(ref, mov, T)  (ndt_feature_node.h:213-252; used at
+ * ndt_feature_graph.cpp:175, 338-340): over the cells of `mov` that carry a reading, the squared difference of the
+ * rescaled occupancies with the `ref` cell their transformed centre falls into. */
+double oracle_overlap_score(const oracle_map *ref, const oracle_map *mov, const double T[16], long long *nb_sum_out)
+{
+    double diff_sum = 0;
+    long long nb_sum = 0;
+    for (size_t s = 0; s < mov->nslots; s++) {
+        double mov_occ = oracle_occupancy_rescaled(mov->occ[s]);
+        if (mov_occ == 0.5) continue;
+        size_t iz = s % (size_t)mov->size[2], iy = (s / (size_t)mov->size[2]) % (size_t)mov->size[1],
+               ix = s / ((size_t)mov->size[2] * (size_t)mov->size[1]);
+        /* NDTCell::getCenter(): pcl::PointXYZ (float) of the cell centre */
+        float cf[3] = {(float)(mov->centre[0] + ((double)ix - mov->size[0] / 2) * mov->res),
+                       (float)(mov->centre[1] + ((double)iy - mov->size[1] / 2) * mov->res),
+                       (float)(mov->centre[2] + ((double)iz - mov->size[2] / 2) * mov->res)};
+        double e[3] = {cf[0], cf[1], cf[2]}, t[3];
+        for (int r = 0; r < 3; r++) t[r] = T[0 * 4 + r] * e[0] + T[1 * 4 + r] * e[1] + T[2 * 4 + r] * e[2] + T[12 + r];
+        float pf[3] = {(float)t[0], (float)t[1], (float)t[2]};
+        double p[3] = {pf[0], pf[1], pf[2]};
+        int idx[3];
+        index_for_point(ref, p, idx);
+        if (!idx_inside(ref, idx)) continue;
+        double ref_occ = oracle_occupancy_rescaled(ref->occ[slot_of(ref, idx)]);
+        if (ref_occ != 0.5) {
+            nb_sum++;
+            double diff = mov_occ - ref_occ;
+            diff_sum += diff * diff;
+        }
+    }
+    if (nb_sum_out) *nb_sum_out = nb_sum;
+    if (nb_sum == 0) return 1.;
+    return diff_sum / (1. * nb_sum);
 }
 
 /* ------------------------------------------------------------------ */

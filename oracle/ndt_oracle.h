@@ -51,6 +51,32 @@ int oracle_map_load_points(oracle_map *m, const float *xyz, size_t n, size_t str
  * (ndt_feature_fuser_hmt.cpp:227; ndt_odom_debug.cpp:179). */
 int oracle_map_compute_cells(oracle_map *m, int n_min, double eval_factor);
 
+/* NDTMap::computeNDTCells(SAMPLE_VARIANCE, maxnumpoints, occupancy_limit, origin, sensor_noise)
+ * (ndt_feature_fuser_hmt.cpp:94, 486): occupancy log-odds, first Gaussian or recursive (N, mean, cov) merge with
+ * the `maxnumpoints` saturation, occ <= 0 => no Gaussian, rescaleCovariance (perception_oru). */
+int oracle_map_compute_cells_full(oracle_map *m, int n_min, double eval_factor, double maxnumpoints,
+                                  double occupancy_limit);
+
+/* NDTMap::addPointCloud(origin, cloud, classifierTh, maxz, sensor_noise, occupancy_limit)
+ * (ndt_feature_fuser_hmt.cpp:92, 485) on an initialize()d map: per beam, the cells between sensor and hit get
+ * emptiness evidence, the hit joins its cell.  order_free: 0 = the reference's beam-after-beam semantics,
+ * 1 = the order-independent semantics of the HIP path (see ndt_oracle.c). */
+int oracle_map_add_point_cloud(oracle_map *m, const double origin[3], const float *xyz, size_t n,
+                               size_t stride_floats, double maxz, double sensor_noise, double occupancy_limit,
+                               int order_free);
+/* one beam x one Gaussian cell: the log-odds update (float) or 0 = cell untouched */
+int oracle_beam_evidence(const double mean[3], const double cov9[9], const double origin[3], const float pe[3],
+                         double sensor_noise, float *logodd);
+/* cells per axis */
+void oracle_map_size(const oracle_map *m, int size[3]);
+/* NDTCell::occ of every slot (x-major, y, z) */
+void oracle_map_occupancy(const oracle_map *m, float *occ_out);
+/* NDTCell::getOccupancyRescaled */
+float oracle_occupancy_rescaled(float occ);
+/* ndt_feature::overlapNDTOccupancyScore(ref, mov, T) (ndt_feature_node.h:213-252); T column-major 4x4.
+ * *nb_sum = number of cell pairs compared. */
+double oracle_overlap_score(const oracle_map *ref, const oracle_map *mov, const double T[16], long long *nb_sum);
+
 /* number of cells with hasGaussian_, in slot order (x-major, then y, then z) */
 int oracle_map_num_cells(const oracle_map *m);
 /* export gaussian cells in slot order: mean3[3*i], cov9[9*i] (row-major), idx3, npts */
