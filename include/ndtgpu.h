@@ -231,6 +231,18 @@ ndtgpu_status ndtgpu_match_fusion_batch(ndtgpu_mapset *target_set, const uint32_
                                         ndtgpu_mapset *source_set, const uint32_t *source_idx, double *T16,
                                         const double *Tcov36, size_t n_pairs, const ndtgpu_match_params *prm,
                                         int use_soft_constraints, ndtgpu_match_result *results, ndtgpu_stream stream);
+/* NDTMatcherD2D::covariance(target, source, T, cov) for n_links registered links (ndt_feature_graph.cpp:296-298;
+ * ndt_feature_fuser_hmt.cpp:403-405): cov = H^-1 (0.03^2 J^T J) H^-1, H = D2D Hessian at T (prm->n_neighbours, lfd1,
+ * lfd2), one row of J per source cell that falls into a Gaussian target cell.  PROVENANCE: perception_oru, restated from
+ * memory (the least certain part of the path); `mode` selects what the row formula uses for the
+ * pose Jacobians: 0 = those of the source cell itself (computeDerivativesLocal), 1 = the matcher's constructor values
+ * (j = [I 0], Z = 0), which is what revisions whose derivativesNDT works on thread-local copies effectively compute.
+ * T16: HOST n_links x 16 column-major (the registered poses); cov36: HOST n_links x 36 row-major.  A singular Hessian
+ * gives an all-zero matrix for that link and NDTGPU_ERR_INVALID is NOT raised: singular[k] (may be NULL) is set to 1. */
+ndtgpu_status ndtgpu_covariance_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx, ndtgpu_mapset *source_set,
+                                      const uint32_t *source_idx, const double *T16, size_t n_links,
+                                      const ndtgpu_match_params *prm, int mode, double *cov36, int32_t *singular,
+                                      ndtgpu_stream stream);
 /* single pair convenience == graph.cpp:273 */
 ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *target_set, size_t target_map, ndtgpu_mapset *source_set,
                                size_t source_map, double T16[16], const ndtgpu_match_params *prm,

@@ -84,7 +84,7 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_last_kernel_ms", "ndtgpu_mapset_counters", "ndtgpu_match_fusion_batch",
            "ndtgpu_mapset_enable_occupancy", "ndtgpu_default_fuse_params", "ndtgpu_mapset_add_cloud",
            "ndtgpu_mapset_add_cloud_host", "ndtgpu_mapset_clear", "ndtgpu_mapset_export_occupancy",
-           "ndtgpu_overlap_score_batch"]
+           "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch"]
 
 _lib = None
 
@@ -140,6 +140,7 @@ def lib():
     L.ndtgpu_mapset_clear.argtypes = [vp, C.c_size_t, C.c_size_t]
     L.ndtgpu_mapset_export_occupancy.argtypes = [vp, C.c_size_t, C.POINTER(C.c_float)]
     L.ndtgpu_overlap_score_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, dp, C.POINTER(C.c_int64), vp]
+    L.ndtgpu_covariance_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, C.POINTER(MatchParams), C.c_int, dp, i32p, vp]
     _lib = L
     return L
 
@@ -391,3 +392,18 @@ def overlap_score(ref_set, ref_idx, mov_set, mov_idx, T, stream=None):
                                             mi.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), n, _dp(score),
                                             nb.ctypes.data_as(C.POINTER(C.c_int64)), _stream_ptr(stream)))
     return score, nb
+
+
+def covariance(target_set, target_idx, source_set, source_idx, T, mode=0, stream=None, **params):
+    """NDTMatcherD2D::covariance(target, source, T, cov) for every link -> (cov [n,6,6], singular [n])."""
+    ti = np.ascontiguousarray(target_idx, dtype=np.uint32)
+    si = np.ascontiguousarray(source_idx, dtype=np.uint32)
+    n = ti.shape[0]
+    Tc = np.ascontiguousarray(np.transpose(np.asarray(T, dtype=np.float64).reshape(n, 4, 4), (0, 2, 1))).copy()
+    cov = np.zeros((n, 6, 6))
+    sing = np.zeros(n, dtype=np.int32)
+    p = match_params(**params)
+    _check(lib().ndtgpu_covariance_batch(target_set.h, ti.ctypes.data_as(C.POINTER(C.c_uint32)), source_set.h,
+                                         si.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), n, C.byref(p), int(mode), _dp(cov),
+                                         sing.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(stream)))
+    return cov, sing

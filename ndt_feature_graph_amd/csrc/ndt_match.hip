@@ -546,6 +546,140 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_kernel(
     if (threadIdx.x < 28) out28[threadIdx.x] = sh.sums[threadIdx.x];
 }
 
+// NDTMatcherD2D::covariance(target, source, T, cov) (ndt_feature_graph.cpp:296-298; fuser_hmt.cpp:403-405) for n
+// links, one workgroup per link: cov = H^-1 (sigma_S J^T J) H^-1 with H the D2D Hessian at T (the evaluation above)
+// and one row of J per source cell whose transformed mean falls into a target cell with a Gaussian (perception_oru,
+// SURVEY.md App. A.7; mode 0: the cell's own pose Jacobians, mode 1: the matcher's constructor values j = [I 0], Z = 0).
+template <int NN>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
+    NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
+    const double *__restrict__ T16, double lfd1, double lfd2, int mode, double *__restrict__ cov36,
+    int *__restrict__ status)
+{
+    __shared__ EvalShared<NDT_MATCH_WAVES> sh;
+    __shared__ rigid s_T;
+    const unsigned link = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const MapView tg = map_view(tset, tidx[link]);
+    const MapView sv = map_view(sset, sidx[link]);
+    const int32_t *table = tset.table + (size_t)tidx[link] * tset.grid.slots;
+    if (tid == 0) {
+        const double *Tm = T16 + (size_t)link * 16;
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) s_T.r[r * 3 + c] = Tm[c * 4 + r];
+            s_T.t[r] = Tm[12 + r];
+        }
+    }
+    __syncthreads();
+    eval_derivs<NN, true>(tg, sv.cells, sv.n_cells, s_T, lfd1, lfd2, sh);
+    double Hu[21];
+    if (tid == 0)
+        for (int k = 0; k < 21; k++) Hu[k] = sh.sums[7 + k];
+    __syncthreads();
+    // J^T J: 21 sums over the source cells
+    const double sigmaS = 0.03 * 0.03;
+    double jj[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) jj[k] = 0.0;
+    const rigid T = s_T;
+    for (int i = (int)tid; i < sv.n_cells; i += NDT_MATCH_THREADS) {
+        const NdtCell *sc = sv.cells + i;
+        const d3 m = apply(T, d3{sc->mean[0], sc->mean[1], sc->mean[2]});
+        const sym3 C = rotate_cov(T.r, sym3{sc->cov[0], sc->cov[1], sc->cov[2], sc->cov[3], sc->cov[4], sc->cov[5]});
+        const int ix = lazygrid_index(m.x, tg.cx, tg.res, tg.sx), iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy),
+                  iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
+        if ((unsigned)ix >= (unsigned)tg.sx || (unsigned)iy >= (unsigned)tg.sy || (unsigned)iz >= (unsigned)tg.sz) continue;
+        const int r = table[(ix * tg.sy + iy) * tg.sz + iz];
+        if (r < 0) continue;
+        const NdtCell *tc = tg.cells + r;
+        const d3 x = m - d3{tc->mean[0], tc->mean[1], tc->mean[2]};
+        sym3 B;
+        if (!inverse_check(C + sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]}, B)) continue;
+        const d3 Bx = mul(B, x);
+        double factor = -dot(x, Bx) / 2;
+        if (factor < -120) continue;
+        factor = exp(lfd2 * factor) / 2;
+        if (factor > 1 || factor < 0 || factor * 0 != 0) continue;
+        // Q = -sigma_S B B (symmetric): Q x = -sigma_S B (B x)
+        const d3 Qx = (-sigmaS) * mul(B, Bx);
+        const double f1 = dot(x, Qx);
+        double G[6] = {Qx.x, Qx.y, Qx.z, 0.0, 0.0, 0.0};     // x^T Q j_a, translations
+        if (mode == 0) {
+            // rotations: j_a = e_a x m;  Z_a = [e_a]x C + C [e_a]x^T  =>  Z_a v = e_a x (C v) - C (e_a x v)
+            const d3 CBx = mul(C, Bx), CQx = mul(C, Qx);
+            const d3 ja[3] = {ex_cross(m), ey_cross(m), ez_cross(m)};
+            const d3 zb[3] = {ex_cross(CBx) - mul(C, ex_cross(Bx)), ey_cross(CBx) - mul(C, ey_cross(Bx)), ez_cross(CBx) - mul(C, ez_cross(Bx))};
+            const d3 zq[3] = {ex_cross(CQx) - mul(C, ex_cross(Qx)), ey_cross(CQx) - mul(C, ey_cross(Qx)), ez_cross(CQx) - mul(C, ez_cross(Qx))};
+#pragma unroll
+            for (int a = 0; a < 3; a++) G[3 + a] = dot(Qx, ja[a]) - dot(Qx, zb[a]) - dot(Bx, zq[a]);
+        }
+        const double sc2 = factor * lfd1 * lfd2 / 2;
+#pragma unroll
+        for (int a = 0; a < 6; a++) G[a] = (G[a] + (-lfd2 / 2) * f1) * sc2;
+        int o = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) jj[o++] += G[a] * G[b];
+    }
+    {
+        const double tot = wave_sum_all<32>(jj);
+        if ((lane & 1u) == 0u && (lane >> 1) < 21u) sh.part[wave * 32 + (lane >> 1)] = tot;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double H[6][12], JK[6][6];
+        int o = 0;
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) {
+                double s2 = 0;
+                for (int k = 0; k < NDT_MATCH_WAVES; k++) s2 += sh.part[k * 32 + o];
+                JK[a][b] = JK[b][a] = sigmaS * s2;
+                H[a][b] = H[b][a] = Hu[o];
+                o++;
+            }
+        // H^-1 by Gauss-Jordan with partial pivoting (Eigen: cov.inverse())
+        bool ok = true;
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) H[a][6 + b] = (a == b) ? 1.0 : 0.0;
+        for (int c = 0; c < 6 && ok; c++) {
+            int piv = c;
+            for (int r = c + 1; r < 6; r++)
+                if (fabs(H[r][c]) > fabs(H[piv][c])) piv = r;
+            if (H[piv][c] == 0.0) { ok = false; break; }
+            if (piv != c)
+                for (int j = 0; j < 12; j++) { const double t = H[c][j]; H[c][j] = H[piv][j]; H[piv][j] = t; }
+            const double d = H[c][c];
+            for (int j = 0; j < 12; j++) H[c][j] /= d;
+            for (int r = 0; r < 6; r++) {
+                if (r == c) continue;
+                const double f = H[r][c];
+                if (f != 0.0)
+                    for (int j = 0; j < 12; j++) H[r][j] -= f * H[c][j];
+            }
+        }
+        double *out = cov36 + (size_t)link * 36;
+        if (!ok) {
+            for (int k = 0; k < 36; k++) out[k] = 0.0;
+            status[link] = 1;                      // singular Hessian
+        } else {
+            double tmp[6][6];
+            for (int a = 0; a < 6; a++)
+                for (int b = 0; b < 6; b++) {
+                    double s2 = 0;
+                    for (int k = 0; k < 6; k++) s2 += H[a][6 + k] * JK[k][b];
+                    tmp[a][b] = s2;
+                }
+            for (int a = 0; a < 6; a++)
+                for (int b = 0; b < 6; b++) {
+                    double s2 = 0;
+                    for (int k = 0; k < 6; k++) s2 += tmp[a][k] * H[k][6 + b];
+                    out[a * 6 + b] = s2;
+                }
+            status[link] = 0;
+        }
+    }
+}
+
 // One evaluation of derivativesNDT for ONE pair spread over many workgroups (host-driven matcher for
 // small batches / large maps: a single registration then uses the whole chip instead of one CU).
 // Workgroup g evaluates a contiguous share of the source cells and writes its 28 partial sums;
@@ -799,3 +933,22 @@ extern "C" int ndtgpu_debug_prof(long long out[8], int reset)
     return 0;
 }
 #endif
+
+hipError_t ndt_launch_covariance(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
+                                 const uint32_t *sidx_dev, const double *T16_dev, size_t n_links, int n_neighbours,
+                                 double lfd1, double lfd2, int mode, double *cov36_dev, int *status_dev, hipStream_t stream)
+{
+    if (n_links == 0) return hipSuccess;
+#define NDT_LAUNCH_COV(NN)                                                                                            \
+    hipLaunchKernelGGL(ndt_covariance_kernel<NN>, dim3((unsigned)n_links), dim3(NDT_MATCH_THREADS), 0, stream, tset,  \
+                       tidx_dev, sset, sidx_dev, T16_dev, lfd1, lfd2, mode, cov36_dev, status_dev)
+    switch (n_neighbours) {
+    case 0: NDT_LAUNCH_COV(0); break;
+    case 1: NDT_LAUNCH_COV(1); break;
+    case 2: NDT_LAUNCH_COV(2); break;
+    case 3: NDT_LAUNCH_COV(3); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef NDT_LAUNCH_COV
+    return hipGetLastError();
+}

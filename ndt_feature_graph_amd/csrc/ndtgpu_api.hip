@@ -861,6 +861,39 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
     return NDTGPU_OK;
 }
 
+ndtgpu_status ndtgpu_covariance_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                      const double *T16, size_t n_links, const ndtgpu_match_params *prm, int mode,
+                                      double *cov36, int32_t *singular, ndtgpu_stream stream)
+{
+    if (!ts || !ss || (n_links && (!tidx || !sidx || !T16 || !cov36)) || mode < 0 || mode > 1)
+        return fail(NDTGPU_ERR_INVALID, "covariance: bad argument");
+    if (n_links == 0) return NDTGPU_OK;
+    for (size_t k = 0; k < n_links; k++)
+        if (tidx[k] >= ts->n_maps || sidx[k] >= ss->n_maps) return fail(NDTGPU_ERR_INVALID, "covariance: map index");
+    NdtMatchParamsDev p = to_dev(prm);
+    if (p.n_neighbours < 0 || p.n_neighbours > 3) return fail(NDTGPU_ERR_INVALID, "covariance: n_neighbours must be 0..3");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(ts->last_stream));
+    HIP_TRY(hipStreamSynchronize(ss->last_stream));
+    const size_t bT = n_links * 16 * sizeof(double), bI = n_links * sizeof(uint32_t), bC = n_links * 36 * sizeof(double);
+    const size_t off_t = (bT + 255) & ~(size_t)255, off_s = (off_t + bI + 255) & ~(size_t)255,
+                 off_c = (off_s + bI + 255) & ~(size_t)255, off_f = (off_c + bC + 255) & ~(size_t)255;
+    ndtgpu_status rc = ts->ensure_stage(off_f + n_links * sizeof(int));
+    if (rc != NDTGPU_OK) return rc;
+    char *base = (char *)ts->stage;
+    HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_t, tidx, bI, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_s, sidx, bI, hipMemcpyHostToDevice, st));
+    hipError_t e = ndt_launch_covariance(ts->v, (const uint32_t *)(base + off_t), ss->v, (const uint32_t *)(base + off_s),
+                                         (const double *)base, n_links, p.n_neighbours, p.lfd1, p.lfd2, mode,
+                                         (double *)(base + off_c), (int *)(base + off_f), st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "covariance: launch", e);
+    HIP_TRY(hipMemcpyAsync(cov36, base + off_c, bC, hipMemcpyDeviceToHost, st));
+    if (singular) HIP_TRY(hipMemcpyAsync(singular, base + off_f, n_links * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NDTGPU_OK;
+}
+
 ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *ts, size_t tmap, ndtgpu_mapset *ss, size_t smap, double T16[16],
                                const ndtgpu_match_params *prm, ndtgpu_match_result *result)
 {

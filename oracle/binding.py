@@ -71,6 +71,7 @@ def lib():
     L.oracle_score_at.argtypes = [C.c_void_p, C.c_void_p, dp, dp, C.c_int, C.c_double, C.c_double]
     L.oracle_match_d2d.argtypes = [C.c_void_p, C.c_void_p, dp, C.POINTER(MatchParams), C.POINTER(MatchResult)]
     L.oracle_match_fusion.argtypes = [C.c_void_p, C.c_void_p, dp, C.POINTER(MatchParams), dp, C.c_int, C.POINTER(MatchResult)]
+    L.oracle_covariance.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_int, C.c_double, C.c_double, C.c_int, dp]
     L.oracle_mt_cstep.argtypes = [dp, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, ip, C.c_double, C.c_double]
     L.oracle_mt_linesearch.restype = C.c_double
     L.oracle_mt_linesearch.argtypes = [PHI_FN, C.c_void_p, C.c_double, C.c_double, ip, ip]
@@ -289,3 +290,13 @@ def beam_evidence(mean, cov, origin, end, sensor_noise=0.1):
 
 def occupancy_rescaled(occ):
     return float(lib().oracle_occupancy_rescaled(float(occ)))
+
+
+def covariance(target, source, T, n_neighbours=2, lfd1=1.0, lfd2=0.05, mode=0):
+    """NDTMatcherD2D::covariance(target, source, T, cov) -> 6x6."""
+    Tc = _f64(np.asarray(T, dtype=np.float64).T.reshape(-1))
+    cov = np.zeros((6, 6))
+    rc = lib().oracle_covariance(target.h, source.h, _dp(Tc), int(n_neighbours), lfd1, lfd2, int(mode), _dp(cov))
+    if rc:
+        raise RuntimeError("oracle_covariance rc=%d" % rc)
+    return cov

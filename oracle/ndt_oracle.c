@@ -990,6 +990,88 @@ double oracle_score_at(const oracle_map *target, const oracle_map *source, const
     return s;
 }
 
+static int invert6(const double *A, double *inv);
+
+/* NDTMatcherD2D::covariance(target, source, T, cov)  (ndt_feature_graph.cpp:296-298; fuser_hmt.cpp:403-405).
+ * perception_oru, restated from memory (SURVEY App. A.7 -- the least certain part of the path):
+ *   cov = H^-1 (sigma_S J^T J) H^-1,  sigma_S = 0.03^2,
+ * H = the D2D Hessian of derivativesNDT at T, J = one row per source cell whose (transformed) mean falls into a
+ * target cell with a Gaussian:
+ *   x = m_src - m_tgt,  B = (C_tgt + C_src)^-1,  f = exp(lfd2 * (-x^T B x / 2)) / 2  (skipped when x^T B x / 2 > 120
+ *   or f outside [0, 1]),  Q = -sigma_S B B,
+ *   G_a = x^T Q j_a  [- x^T Q Z_a B x - x^T B Z_a Q x for the rotations]  + (-lfd2 / 2) x^T Q x,
+ *   row = G * f * lfd1 * lfd2 / 2.
+ * mode 0: j_a, Z_a are the derivatives of THIS source cell (computeDerivativesLocal); mode 1: the matcher's member
+ * copies as its constructor leaves them (j = [I 0], Z = 0) -- what the OpenMP revisions, whose derivativesNDT works on
+ * thread-local copies, effectively use.  The reference's extra rows for target cells whose transformed mean equals
+ * the matched mean only exist when T is the identity and are not reproduced. */
+int oracle_covariance(const oracle_map *target, const oracle_map *source, const double T[16], int n_neighbours,
+                      double lfd1, double lfd2, int mode, double cov36[36])
+{
+    const double sigmaS = 0.03 * 0.03;
+    size_t n;
+    ocell *src = pseudo_transform(source, T, &n);
+    double g6[6], H[36], JK[36];
+    derivatives_cells(target, src, n, n_neighbours, 1, lfd1, lfd2, g6, H);
+    memset(JK, 0, sizeof JK);
+    for (size_t i = 0; i < n; i++) {
+        int idx[3];
+        index_for_point(target, src[i].mean, idx);
+        if (!idx_inside(target, idx)) continue;
+        int32_t c = target->cell_of_slot[slot_of(target, idx)];
+        if (c < 0 || !target->cells[c].has_gaussian) continue;
+        const ocell *tc = &target->cells[c];
+        vec3 x = {{src[i].mean[0] - tc->mean[0], src[i].mean[1] - tc->mean[1], src[i].mean[2] - tc->mean[2]}};
+        mat3 B;
+        double det;
+        if (!m3_inverse_check(m3_add(tc->cov, src[i].cov), &B, &det)) continue;
+        double factor = -v3_dot(x, m3_v(B, x)) / 2;
+        if (factor < -120) continue;
+        factor = exp(lfd2 * factor) / 2;
+        if (factor > 1 || factor < 0 || factor * 0 != 0) continue;
+        mat3 Q = m3_mul(B, B);
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) Q.m[r][q] *= -sigmaS;
+        local_derivs L;
+        if (mode == 0) {
+            vec3 mm = {{src[i].mean[0], src[i].mean[1], src[i].mean[2]}};
+            compute_derivatives_local(mm, src[i].cov, 0, &L);
+        } else {
+            memset(&L, 0, sizeof L);
+            for (int a = 0; a < 3; a++) L.J[a].v[a] = 1.0;
+        }
+        vec3 xQ = m3_v(m3_T(Q), x), xB = m3_v(m3_T(B), x), Bx = m3_v(B, x), Qx = m3_v(Q, x);
+        double f1 = v3_dot(xQ, x), G[6];
+        for (int a = 0; a < 6; a++) {
+            double ga = 0;
+            if (a >= 3) {
+                ga = -v3_dot(xQ, m3_v(L.Z[a], Bx));
+                ga = ga - v3_dot(xB, m3_v(L.Z[a], Qx));
+            }
+            G[a] = (ga + v3_dot(xQ, L.J[a]) + (-lfd2 / 2) * f1) * factor * lfd1 * lfd2 / 2;
+        }
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) JK[a * 6 + b] += G[a] * G[b];
+    }
+    free(src);
+    for (int a = 0; a < 36; a++) JK[a] *= sigmaS;
+    double Hinv[36], tmp[36];
+    if (!invert6(H, Hinv)) return -2;
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) {
+            double s2 = 0;
+            for (int k = 0; k < 6; k++) s2 += Hinv[a * 6 + k] * JK[k * 6 + b];
+            tmp[a * 6 + b] = s2;
+        }
+    for (int a = 0; a < 6; a++)
+        for (int b = 0; b < 6; b++) {
+            double s2 = 0;
+            for (int k = 0; k < 6; k++) s2 += tmp[a * 6 + k] * Hinv[k * 6 + b];
+            cov36[a * 6 + b] = s2;
+        }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* More-Thuente                                                         */
 /* ------------------------------------------------------------------ */

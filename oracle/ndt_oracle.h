@@ -127,6 +127,12 @@ int oracle_match_fusion(const oracle_map *target, const oracle_map *source, doub
                         const oracle_match_params *prm, const double Tcov[36], int use_soft_constraints,
                         oracle_match_result *res);
 
+/* NDTMatcherD2D::covariance(target, source, T, cov) (ndt_feature_graph.cpp:296-298): cov = H^-1 (0.03^2 J^T J) H^-1;
+ * mode 0 = per-cell Jacobians, 1 = the matcher's constructor values (see ndt_oracle.c).  cov36 row-major.
+ * Returns -2 when the Hessian is singular. */
+int oracle_covariance(const oracle_map *target, const oracle_map *source, const double T[16], int n_neighbours,
+                      double lfd1, double lfd2, int mode, double cov36[36]);
+
 /* MoreThuente::cstep (MINPACK-2 dcstep; called at ndt_matcher_d2d_fusion.h:756,775). */
 int oracle_mt_cstep(double *stx, double *fx, double *dx, double *sty, double *fy, double *dy,
                     double *stp, double fp, double dp, int *brackt, double stmin, double stmax);
