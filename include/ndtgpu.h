@@ -225,8 +225,10 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *target_set, const uint32_
  * ndt_feature_fuser_hmt.cpp:356-357): the D2D matcher plus the odometry soft constraint
  * x^T Tcov^-1 x on the accumulated pose increment (fusion.h:875-890, 1098-1110).
  * Tcov36: HOST, n_pairs x 36 doubles, row-major 6x6 covariance of (x,y,z,roll,pitch,yaw).
- * use_soft_constraints == 0 degenerates to ndtgpu_match_batch.  Feature terms (FLIRT) and the Tikhonov
- * variant are not part of the path (disabled in every shipped configuration). */
+ * use_soft_constraints is a bit set: bit 0 = useSoftConstraints, bit 1 = useTikhonovRegularization (fusion.h:894-911,
+ * 1113-1115: g <- H^T g + Q x0, H <- H^T H + Q, score += x0^T Q x0 with x0 the 2D pose vector of T Tinit^-1 and
+ * Q = Tcov^-1); 0 degenerates to ndtgpu_match_batch.  Feature terms (FLIRT) are not part of the path (disabled in
+ * every shipped configuration). */
 ndtgpu_status ndtgpu_match_fusion_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx,
                                         ndtgpu_mapset *source_set, const uint32_t *source_idx, double *T16,
                                         const double *Tcov36, size_t n_pairs, const ndtgpu_match_params *prm,

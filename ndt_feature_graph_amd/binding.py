@@ -351,8 +351,9 @@ def match_batch(target_set, target_idx, source_set, source_idx, T, stream=None, 
 
 
 def match_fusion_batch(target_set, target_idx, source_set, source_idx, T, Tcov, use_soft_constraints=True, stream=None,
-                       **params):
-    """ndt_feature::matchFusion (NDT term + odometry soft constraint) for every pair.  Tcov: [n,6,6]."""
+                       tikhonov=False, **params):
+    """ndt_feature::matchFusion (NDT term + odometry soft constraint and / or Tikhonov regularisation) for every pair.
+    Tcov: [n,6,6]."""
     ti = np.ascontiguousarray(target_idx, dtype=np.uint32)
     si = np.ascontiguousarray(source_idx, dtype=np.uint32)
     n = ti.shape[0]
@@ -362,7 +363,8 @@ def match_fusion_batch(target_set, target_idx, source_set, source_idx, T, Tcov, 
     p = match_params(**params)
     _check(lib().ndtgpu_match_fusion_batch(target_set.h, ti.ctypes.data_as(C.POINTER(C.c_uint32)), source_set.h,
                                            si.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), _dp(cov), n, C.byref(p),
-                                           int(bool(use_soft_constraints)), C.c_void_p(res.ctypes.data), _stream_ptr(stream)))
+                                           int(bool(use_soft_constraints)) | (2 if tikhonov else 0), C.c_void_p(res.ctypes.data),
+                                           _stream_ptr(stream)))
     return np.transpose(Tc, (0, 2, 1)).copy(), res
 
 

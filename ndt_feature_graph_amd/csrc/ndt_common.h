@@ -107,6 +107,7 @@ static inline __host__ __device__ size_t ndt_rm_stride(const NdtGrid &g) { retur
 
 struct NdtMatchParamsDev {
     int n_neighbours, itr_max, step_control, dof_mask, use_initial_guess;
+    int fusion_flags;          // matchFusion with a Tcov: bit 0 soft constraint, bit 1 Tikhonov regularisation
     double delta_score, lfd1, lfd2;
 };
 

@@ -31,6 +31,10 @@ struct MatchState {
     int use_prior;
     double pose_local[6];
     double Q[36];
+    // matchFusion generalised Tikhonov regularisation (fusion.h:894-911): x0 = 2D pose vector of T Tinit^-1
+    int use_tikhonov;
+    rigid Tinit_inv;
+    double x0[6];
 };
 
 // computeScoreMahalanobis (fusion.h:24-27): x^T Q x
@@ -40,6 +44,29 @@ NDT_HD double prior_score(const MatchState &st)
     for (int i = 0; i < 6; i++)
         for (int j = 0; j < 6; j++) s += st.pose_local[i] * st.Q[i * 6 + j] * st.pose_local[j];
     return s;
+}
+
+// x0^T Q x0 (fusion.h:910, 1113-1115)
+NDT_HD double tikhonov_score(const MatchState &st)
+{
+    double s = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) s += st.x0[i] * st.Q[i * 6 + j] * st.x0[j];
+    return s;
+}
+
+// x0: convertAffineToVector(forceEigenAffine3dTo2d(T Tinit^-1)) (fusion.h:903-907; utils.h:30-68, 161-169) =
+// (tx, ty, 0, 0, 0, yaw), yaw by getRobustYawFromAffine3d: acos of the rotated x axis' x component, signed by its y
+// component (the argument is clamped to [-1, 1]: one ulp above 1 would be a NaN in the reference)
+NDT_HD void tikhonov_x0(MatchState &st)
+{
+    rigid D;
+    rigid_mul(st.T, st.Tinit_inv, D);
+    double c = D.r[0];
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    const double ang = acos(c);
+    st.x0[0] = D.t[0]; st.x0[1] = D.t[1]; st.x0[2] = 0.0;
+    st.x0[3] = 0.0; st.x0[4] = 0.0; st.x0[5] = (D.r[3] > 0) ? ang : -ang;
 }
 
 NDT_HD double dmin(double a, double b) { return a < b ? a : b; }
@@ -197,7 +224,7 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     st.fevals++;
     st.score_here = sums[0];
     if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:875-890
-    if (st.score_here < st.score_best) {   // fusion.h:914-920
+    if (!st.use_tikhonov && st.score_here < st.score_best) {   // fusion.h:914-920 (with Tikhonov: after its term, below)
         st.Tbest = st.T;
         st.score_best = st.score_here;
     }
@@ -223,13 +250,41 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     double gnorm = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
-        bool on = (prm.dof_mask >> a) & 1;
-        g[a] = on ? sums[1 + a] : 0.0;
-        if (st.use_prior && on) {          // + computeGradientMahalanobis = (Q + Q^T) X   (fusion.h:29-32)
+        g[a] = sums[1 + a];
+        if (st.use_prior) {                // + computeGradientMahalanobis = (Q + Q^T) X   (fusion.h:29-32)
             double gp = 0;
             for (int j = 0; j < 6; j++) gp += (st.Q[a * 6 + j] + st.Q[j * 6 + a]) * st.pose_local[j];
             g[a] += gp;
         }
+    }
+    if (st.use_tikhonov) {
+        // fusion.h:894-911 with P = I:  g <- H^T g + Q x0,  H <- H^T H + Q,  score += x0^T Q x0
+        tikhonov_x0(st);
+        double g2[6], H2[6][6];
+        for (int a = 0; a < 6; a++) {
+            double s1 = 0;
+            for (int k = 0; k < 6; k++) s1 += H[k][a] * g[k] + st.Q[a * 6 + k] * st.x0[k];
+            g2[a] = s1;
+            for (int b = 0; b < 6; b++) {
+                double s2 = st.Q[a * 6 + b];
+                for (int k = 0; k < 6; k++) s2 += H[k][a] * H[k][b];
+                H2[a][b] = s2;
+            }
+        }
+        for (int a = 0; a < 6; a++) {
+            g[a] = g2[a];
+            for (int b = 0; b < 6; b++) H[a][b] = H2[a][b];
+        }
+        st.score_here += tikhonov_score(st);
+        if (st.score_here < st.score_best) {   // fusion.h:914-920
+            st.Tbest = st.T;
+            st.score_best = st.score_here;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        bool on = (prm.dof_mask >> a) & 1;
+        if (!on) g[a] = 0.0;
         if (on && !havepad) { pad = H[a][a]; havepad = true; }
     }
 #pragma unroll
@@ -301,7 +356,7 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     st.dginit = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) st.dginit += st.incr[a] * sums[1 + a];
-    if (!st.use_prior) st.dginit = dginit;
+    if (!st.use_prior && !st.use_tikhonov) st.dginit = dginit;
     if (st.dginit >= 0.0) {                // fusion.h:456-479
         for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
         st.dginit = -st.dginit;
@@ -327,6 +382,7 @@ NDT_HD void match_state_final(MatchState &st, const double *sums)
     st.fevals++;
     st.score_here = sums[0];
     if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:1098-1110
+    if (st.use_tikhonov) st.score_here += tikhonov_score(st);   // fusion.h:1113-1115: x0 of the LAST Newton evaluation
     if (st.score_here > st.score_best) st.T = st.Tbest;
     st.done = 1;
 }
@@ -383,10 +439,12 @@ NDT_HDN void linesearch_step(MatchState &st, const double *sums, const NdtMatchP
 
 
 // T0: column-major 4x4 (Eigen::Affine3d storage) or NULL for identity
-// Q36: Tcov^-1 row-major, or NULL for NDTMatcherD2D::match (no soft constraint)
+// Q36: Tcov^-1 row-major, or NULL for NDTMatcherD2D::match; prm.fusion_flags says what it is used for
 NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchParamsDev &prm, const double *Q36 = nullptr)
 {
-    st.use_prior = Q36 != nullptr;
+    st.use_prior = Q36 != nullptr && (prm.fusion_flags & 1);
+    st.use_tikhonov = Q36 != nullptr && (prm.fusion_flags & 2);
+    for (int a = 0; a < 6; a++) st.x0[a] = 0.0;
     for (int a = 0; a < 6; a++) st.pose_local[a] = 0.0;
     for (int a = 0; a < 36; a++) st.Q[a] = Q36 ? Q36[a] : 0.0;
     rigid T0;
@@ -400,6 +458,10 @@ NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchPa
         T0.t[0] = T0.t[1] = T0.t[2] = 0.0;
     }
     st.T = T0; st.Tbest = T0; st.Teval = T0;
+    for (int r = 0; r < 3; r++) {          // Tinit^-1 (rigid)
+        for (int c = 0; c < 3; c++) st.Tinit_inv.r[r * 3 + c] = T0.r[c * 3 + r];
+        st.Tinit_inv.t[r] = -(T0.r[0 * 3 + r] * T0.t[0] + T0.r[1 * 3 + r] * T0.t[1] + T0.r[2 * 3 + r] * T0.t[2]);
+    }
     st.score_best = DBL_MAX; st.score_here = 0;
     st.itr_ctr = 0; st.fevals = 0; st.ret = 1; st.exit_code = 0;
     st.phase = PH_NEWTON; st.with_h = 1; st.done = 0;

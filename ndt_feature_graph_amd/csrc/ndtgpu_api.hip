@@ -596,6 +596,7 @@ static NdtMatchParamsDev to_dev(const ndtgpu_match_params *p)
     o.delta_score = d.delta_score;
     o.lfd1 = d.lfd1;
     o.lfd2 = d.lfd2;
+    o.fusion_flags = 1;
     return o;
 }
 
@@ -604,24 +605,25 @@ static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result 
 static ndtgpu_status match_device_q(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
                                     const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
                                     const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
-                                    const double *Q36_dev, ndtgpu_stream stream);
+                                    const double *Q36_dev, int fusion_flags, ndtgpu_stream stream);
 
 ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
                                         const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
                                         const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
                                         ndtgpu_stream stream)
 {
-    return match_device_q(ts, tidx_dev, ss, sidx_dev, T16_dev, n_pairs, prm, results_dev, nullptr, stream);
+    return match_device_q(ts, tidx_dev, ss, sidx_dev, T16_dev, n_pairs, prm, results_dev, nullptr, 0, stream);
 }
 
 static ndtgpu_status match_device_q(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
                                     const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
                                     const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
-                                    const double *Q36_dev, ndtgpu_stream stream)
+                                    const double *Q36_dev, int fusion_flags, ndtgpu_stream stream)
 {
     if (!ts || !ss || (n_pairs && (!tidx_dev || !sidx_dev || !T16_dev || !results_dev)))
         return fail(NDTGPU_ERR_INVALID, "match_batch_device: bad argument");
     NdtMatchParamsDev p = to_dev(prm);
+    p.fusion_flags = fusion_flags;
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
     if (n_pairs == 0) return NDTGPU_OK;
@@ -766,13 +768,13 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
 
 static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                         double *T16, size_t n_pairs, const ndtgpu_match_params *prm, const double *Q36,
-                                        ndtgpu_match_result *results, ndtgpu_stream stream);
+                                        int fusion_flags, ndtgpu_match_result *results, ndtgpu_stream stream);
 
 ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                  double *T16, size_t n_pairs, const ndtgpu_match_params *prm,
                                  ndtgpu_match_result *results, ndtgpu_stream stream)
 {
-    return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, nullptr, results, stream);
+    return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, nullptr, 0, results, stream);
 }
 
 // 6x6 inverse by Gauss-Jordan with partial pivoting (Eigen: Tcov.inverse(), fusion.h:845)
@@ -807,17 +809,18 @@ ndtgpu_status ndtgpu_match_fusion_batch(ndtgpu_mapset *ts, const uint32_t *tidx,
                                         const ndtgpu_match_params *prm, int use_soft_constraints,
                                         ndtgpu_match_result *results, ndtgpu_stream stream)
 {
-    if (!use_soft_constraints) return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, nullptr, results, stream);
+    const int flags = use_soft_constraints & 3;   // bit 0 useSoftConstraints, bit 1 useTikhonovRegularization
+    if (!flags) return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, nullptr, 0, results, stream);
     if (!Tcov36) return fail(NDTGPU_ERR_INVALID, "match_fusion: Tcov missing");
     std::vector<double> Q(36 * n_pairs);
     for (size_t k = 0; k < n_pairs; k++)
         if (!invert6(Tcov36 + 36 * k, Q.data() + 36 * k)) return fail(NDTGPU_ERR_INVALID, "match_fusion: singular Tcov");
-    return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, Q.data(), results, stream);
+    return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, Q.data(), flags, results, stream);
 }
 
 static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                         double *T16, size_t n_pairs, const ndtgpu_match_params *prm, const double *Q36,
-                                        ndtgpu_match_result *results, ndtgpu_stream stream)
+                                        int fusion_flags, ndtgpu_match_result *results, ndtgpu_stream stream)
 {
     if (!ts || !ss || (n_pairs && (!tidx || !sidx || !T16 || !results)))
         return fail(NDTGPU_ERR_INVALID, "match_batch: bad argument");
@@ -830,6 +833,7 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
     HIP_TRY(hipStreamSynchronize(ss->last_stream));
     {
         NdtMatchParamsDev p = to_dev(prm);
+        p.fusion_flags = fusion_flags;
         if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
             return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
         // NDTGPU_HOST_LOOP=1: the host runs the state machine, one launch per evaluation (A/B, debugging)
@@ -853,7 +857,7 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
     if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
     rc = match_device_q(ts, (const uint32_t *)(base + off_ti), ss, (const uint32_t *)(base + off_si), (double *)base,
                         n_pairs, prm, (ndtgpu_match_result *)(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr,
-                        stream);
+                        fusion_flags, stream);
     if (rc != NDTGPU_OK) return rc;
     HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));

@@ -202,15 +202,16 @@ def match_d2d(target, source, T0, **kw):
                    exit_code=R.exit_code)
 
 
-def match_fusion(target, source, T0, Tcov, use_soft_constraints=True, **kw):
-    """ndt_feature::matchFusion with empty feature maps (NDT + odometry soft constraint)."""
+def match_fusion(target, source, T0, Tcov, use_soft_constraints=True, tikhonov=False, **kw):
+    """ndt_feature::matchFusion with empty feature maps (NDT + odometry soft constraint and / or Tikhonov)."""
     prm = dict(DEFAULT_PARAMS)
     prm.update(kw)
     P = MatchParams(**prm)
     R = MatchResult()
     Tc = _f64(np.asarray(T0, dtype=np.float64).T.reshape(-1)).copy()
     cov = _f64(np.asarray(Tcov, dtype=np.float64).reshape(-1))
-    rc = lib().oracle_match_fusion(target.h, source.h, _dp(Tc), C.byref(P), _dp(cov), int(bool(use_soft_constraints)), C.byref(R))
+    rc = lib().oracle_match_fusion(target.h, source.h, _dp(Tc), C.byref(P), _dp(cov),
+                                   int(bool(use_soft_constraints)) | (2 if tikhonov else 0), C.byref(R))
     if rc:
         raise RuntimeError("oracle_match_fusion rc=%d" % rc)
     return Tc.reshape(4, 4).T.copy(), dict(converged=bool(R.converged), iterations=R.iterations, fevals=R.fevals,

@@ -1350,12 +1350,13 @@ static int invert6(const double *A, double *inv)
 }
 
 static int match_common(const oracle_map *target, const oracle_map *source, double T[16],
-                        const oracle_match_params *prm, const double *Q /* Tcov^-1 or NULL */, oracle_match_result *res);
+                        const oracle_match_params *prm, const double *Q /* Tcov^-1 or NULL */, int flags,
+                        oracle_match_result *res);
 
 int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double T[16],
                      const oracle_match_params *prm, oracle_match_result *res)
 {
-    return match_common(target, source, T, prm, NULL, res);
+    return match_common(target, source, T, prm, NULL, 0, res);
 }
 
 /* ndt_feature::matchFusion ([fusion.h]:797-1155) with useNDT = true, useFeat = false (empty feature
@@ -1369,15 +1370,36 @@ int oracle_match_fusion(const oracle_map *target, const oracle_map *source, doub
                         const oracle_match_params *prm, const double Tcov[36], int use_soft_constraints,
                         oracle_match_result *res)
 {
+    /* use_soft_constraints: bit 0 = useSoftConstraints, bit 1 = useTikhonovRegularization ([fusion.h]:894-911) */
     double Q[36];
-    if (!use_soft_constraints) return match_common(target, source, T, prm, NULL, res);
+    if (!(use_soft_constraints & 3)) return match_common(target, source, T, prm, NULL, 0, res);
     if (!invert6(Tcov, Q)) return -2;
-    return match_common(target, source, T, prm, Q, res);
+    return match_common(target, source, T, prm, Q, use_soft_constraints & 3, res);
+}
+
+/* x0 = convertAffineToVector(forceEigenAffine3dTo2d(T * Tinit^-1))  ([fusion.h]:903-907, utils.h:30-68, 161-169) */
+static void tikhonov_x0(const double T[16], const double Tinit[16], double x0[6])
+{
+    double Ti[16], D[16];
+    memset(Ti, 0, sizeof Ti);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) Ti[c * 4 + r] = Tinit[r * 4 + c];
+        Ti[12 + r] = -(Tinit[r * 4 + 0] * Tinit[12] + Tinit[r * 4 + 1] * Tinit[13] + Tinit[r * 4 + 2] * Tinit[14]);
+    }
+    Ti[15] = 1.0;
+    T_mul(T, Ti, D);
+    double c = D[0];
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);      /* getRobustYawFromAffine3d: acos(dot), sign from the cross product */
+    double ang = acos(c);
+    x0[0] = D[12]; x0[1] = D[13]; x0[2] = 0;
+    x0[3] = 0; x0[4] = 0; x0[5] = (D[1] > 0) ? ang : -ang;
 }
 
 static int match_common(const oracle_map *target, const oracle_map *source, double T[16],
-                        const oracle_match_params *prm, const double *Q, oracle_match_result *res)
+                        const oracle_match_params *prm, const double *Q, int flags, oracle_match_result *res)
 {
+    const int soft = Q && (flags & 1), tikhonov = Q && (flags & 2);
+    double Tinit[16], x0[6] = {0, 0, 0, 0, 0, 0};
     int dofs[6], nd = 0;
     for (int a = 0; a < 6; a++)
         if (prm->dof_mask & (1 << a)) dofs[nd++] = a;
@@ -1391,6 +1413,7 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
         oracle_pose_to_T(z, T);
     }
     memcpy(Tbest, T, sizeof Tbest);
+    memcpy(Tinit, T, sizeof Tinit);
 
     size_t n;
     double pose_local[6] = {0, 0, 0, 0, 0, 0};
@@ -1401,11 +1424,29 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
     while (!convergence) {
         score_here = derivatives_cells(target, next, n, prm->n_neighbours, 1, prm->lfd1, prm->lfd2, g6, H36);
         fevals++;
-        if (Q) { /* [fusion.h]:875-890 */
+        if (soft) { /* [fusion.h]:875-890 */
             double gq[6], Hq[36];
             score_here += oracle_mahalanobis(pose_local, Q, gq, Hq);
             for (int i = 0; i < 6; i++) g6[i] += gq[i];
             for (int i = 0; i < 36; i++) H36[i] += Hq[i];
+        }
+        if (tikhonov) { /* [fusion.h]:894-911, P = I */
+            double g2[6], H2[36];
+            tikhonov_x0(T, Tinit, x0);
+            for (int a = 0; a < 6; a++) {
+                double s1 = 0;
+                for (int k = 0; k < 6; k++) s1 += H36[k * 6 + a] * g6[k] + Q[a * 6 + k] * x0[k];
+                g2[a] = s1;
+                for (int b = 0; b < 6; b++) {
+                    double s2 = Q[a * 6 + b];
+                    for (int k = 0; k < 6; k++) s2 += H36[k * 6 + a] * H36[k * 6 + b];
+                    H2[a * 6 + b] = s2;
+                }
+            }
+            memcpy(g6, g2, sizeof g2);
+            memcpy(H36, H2, sizeof H2);
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) score_here += x0[i] * Q[i * 6 + j] * x0[j];
         }
         /* restrict to the active dofs (6-DoF: identity) */
         double g[6], H[36];
@@ -1485,10 +1526,13 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
     /* [fusion.h]:1085-1121 */
     score_here = derivatives_cells(target, next, n, prm->n_neighbours, 0, prm->lfd1, prm->lfd2, g6, H36);
     fevals++;
-    if (Q) { /* [fusion.h]:1098-1110 */
+    if (soft) { /* [fusion.h]:1098-1110 */
         double gq[6], Hq[36];
         score_here += oracle_mahalanobis(pose_local, Q, gq, Hq);
     }
+    if (tikhonov) /* [fusion.h]:1113-1115: the x0 of the last loop pass */
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) score_here += x0[i] * Q[i * 6 + j] * x0[j];
     if (score_here > score_best) memcpy(T, Tbest, sizeof Tbest);
 
 done_early:

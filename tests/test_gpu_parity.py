@@ -558,6 +558,27 @@ def test_match_fusion_soft_constraint_parity(N, O):
     assert np.array_equal(Tn, Tp)
 
 
+def test_match_fusion_tikhonov_parity(N, O):
+    """matchFusion with useTikhonovRegularization (fusion.h:894-911, 1113-1115), alone and together with the soft
+    constraint (the offline tool's defaults, ndt_feature_fuser_hmt.h:91-94): g <- H^T g + Q x0, H <- H^T H + Q."""
+    pr, tg, sr, om = _pair_maps(N, O, list(range(21, 29)), 20000, 0.5)
+    T0 = pr["T_init"].numpy()
+    B = len(T0)
+    rng = np.random.default_rng(8)
+    covs = np.stack([np.diag([2e-3, 2e-3, 1.0, 1.0, 1.0, 4e-4]) * (1 + rng.uniform(0, 1)) for _ in range(B)])
+    idx = np.arange(B)
+    Tp, _ = N.match_batch(tg, idx, sr, idx, T0)
+    for soft in (False, True):
+        Tb, rb = N.match_fusion_batch(tg, idx, sr, idx, T0, covs, use_soft_constraints=soft, tikhonov=True)
+        for b in range(B):
+            To, ro = O.match_fusion(om[b][0], om[b][1], T0[b], covs[b], use_soft_constraints=soft, tikhonov=True)
+            dt, dr = pose_close(Tb[b], To)
+            assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (soft, b, dt, dr)
+            assert bool(rb["converged"][b]) == ro["converged"] and rb["iterations"][b] == ro["iterations"], (soft, b)
+            assert abs(rb["score"][b] - ro["score"]) < 1e-6 * abs(ro["score"])
+        assert max(pose_close(Tp[b], Tb[b])[0] for b in range(B)) > 1e-6        # the regulariser changes the result
+
+
 def test_config4_replay_small(N, O):
     """configs[3] at CI size: a short trajectory of nodes in one building, one NDT map per node, ALL node
     pairs as candidate edges (NDTFeatureGraph::computeAllPossibleLinks order), edges dealt block-cyclically
