@@ -1,8 +1,14 @@
-// host_demo.cpp -- the reference's offline edge-refinement flow (ndt_feature_graph_opt.cpp:131-160:
-// all possible links -> NDT registration -> gates) written against the host mirror, with the
-// synthetic corridor of ndt_odom_debug.cpp:94-119 as input.  Exit code 0 = every check passed.
-//   no GPU : checks that the library loads and fails loudly (NDTGPU_ERR_NO_DEVICE), exit 0
-//   GPU    : builds N node maps, registers all pairs in one batch, checks the recovered poses
+// host_demo.cpp -- the reference's call sites, written against the host mirror and run through the C-ABI:
+//   A. the graph front door: NDTFeatureGraph::initialize / update (ndt_feature_graph.cpp:24-144) driving
+//      NDTFeatureFuserHMT::initialize / update (ndt_feature_fuser_hmt.cpp:65-512) over a synthetic trajectory
+//      (the corridor of ndt_odom_debug.cpp:94-119, closed by end walls), with the shipped parameter set;
+//   B. the offline edge refinement (ndt_feature_graph_opt.cpp:131-160): all possible links -> NDT registration
+//      (+ covariance + occupancy overlap score) -> gates;
+//   C. the Newton loop of ndt_matcher_d2d_fusion.h:847-1121 RE-TYPED on the host against the mirror
+//      (pseudoTransformNDT -> NDTCell* vector, derivativesNDT with MatrixXd, lineSearchMT, in-place cell transform,
+//      delete) -- one ndtgpu_derivatives call per evaluation -- and compared with the device-resident matchFusion;
+//   D. loadPointCloudCentroid, NDTMatcherD2D_2D, and the arguments the mirror must reject.
+// Exit code 0 = every check passed.  Without a GPU: checks that the library fails loudly (NDTGPU_ERR_NO_DEVICE).
 #include "ndt_feature_graph_gpu.h"
 
 #include <cstdio>
@@ -10,34 +16,239 @@
 
 using namespace ndt_feature;
 
-static PointCloud<PointXYZ> corridor_scan(const Affine3d &sensor_pose_world, unsigned seed, int n_per_wall = 4000)
+static int g_fails = 0;
+#define CHECK(cond, ...)                                                     \
+    do {                                                                     \
+        if (!(cond)) { std::printf("FAIL (%s:%d): ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); g_fails++; } \
+    } while (0)
+
+// a closed corridor (two wavy walls + two end walls) seen from `sensor_pose_world`; points in the sensor frame,
+// ordered by bearing like a laser sweep
+static pcl::PointCloud<pcl::PointXYZ> corridor_scan(const Eigen::Affine3d &sensor_pose_world, unsigned seed, int n_beams = 6000)
 {
-    // two walls y = +-2 and an end wall x = 12, seen from `sensor_pose_world`; points in the sensor frame
     std::mt19937 rng(seed);
     std::normal_distribution<double> nd(0.0, 0.03);
     std::uniform_real_distribution<double> uz(0.0, 0.02);
-    PointCloud<PointXYZ> pc;
-    Affine3d inv = sensor_pose_world.inverse();
-    auto add = [&](double wx, double wy) {
-        double x = inv(0, 0) * wx + inv(0, 1) * wy + inv(0, 3), y = inv(1, 0) * wx + inv(1, 1) * wy + inv(1, 3);
-        pc.push_back(PointXYZ((float)(x + nd(rng)), (float)(y + nd(rng)), (float)uz(rng)));
-    };
-    for (int j = 0; j < n_per_wall; j++) {
-        double t = -8.0 + 20.0 * j / n_per_wall;
-        add(t, 2.0 + 0.3 * std::sin(0.9 * t));
-        add(t, -2.0 - 0.2 * std::cos(0.7 * t));
+    pcl::PointCloud<pcl::PointXYZ> pc;
+    const double ox = sensor_pose_world(0, 3), oy = sensor_pose_world(1, 3);
+    const double yaw = std::atan2(sensor_pose_world(1, 0), sensor_pose_world(0, 0));
+    for (int j = 0; j < n_beams; j++) {
+        const double phi = -M_PI + 2.0 * M_PI * (j + 0.5) / n_beams, a = phi + yaw;
+        const double dx = std::cos(a), dy = std::sin(a);
+        // march along the beam until a wall is crossed (walls: y = +-(2 + 0.3 sin(0.9 x)), x = -9, x = 13)
+        double r = 0.0, step = 0.02;
+        for (; r < 40.0; r += step) {
+            const double x = ox + r * dx, y = oy + r * dy;
+            if (x < -9.0 || x > 13.0 || y > 2.0 + 0.3 * std::sin(0.9 * x) || y < -2.0 - 0.2 * std::cos(0.7 * x)) break;
+        }
+        r += nd(rng);
+        if (r < 0.3 || r > 30.0) continue;
+        pc.push_back(pcl::PointXYZ((float)(r * std::cos(phi)), (float)(r * std::sin(phi)), (float)uz(rng)));
     }
-    for (int j = 0; j < n_per_wall / 4; j++) add(12.0, -2.0 + 4.0 * j / (n_per_wall / 4.0));
     return pc;
+}
+
+static void pose_error(const Eigen::Affine3d &a, const Eigen::Affine3d &b, double &d, double &ang) { distanceBetweenAffine3d(a, b, d, ang); }
+
+// ---- C: the reference's host loop, re-typed ------------------------------------------------------------------
+namespace retyped {
+// computeHessianMahalanobis / computeScoreMahalanobis / computeGradientMahalanobis (fusion.h:11-32)
+static Eigen::MatrixXd computeHessianMahalanobis(const Eigen::MatrixXd &Q)
+{
+    Eigen::MatrixXd H(6, 6);
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) H(i, j) = Q(j, i) + Q(i, j);
+    return H;
+}
+static double computeScoreMahalanobis(const double X[6], const Eigen::MatrixXd &Q)
+{
+    double s = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) s += X[i] * Q(i, j) * X[j];
+    return s;
+}
+static Eigen::MatrixXd computeGradientMahalanobis(const double X[6], const Eigen::MatrixXd &Q)
+{
+    Eigen::MatrixXd g(6, 1);
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) g(i, 0) += (Q(i, j) + Q(j, i)) * X[j];
+    return g;
+}
+// Eigen::SelfAdjointEigenSolver<6x6> eigenvalues + vectors (cyclic Jacobi) and Hessian.ldlt().solve: only here, for the
+// re-typed loop (the product does this on the device)
+static void eig6(const Eigen::MatrixXd &A, double ev[6], double V[6][6])
+{
+    double a[6][6];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) { a[i][j] = 0.5 * (A(i, j) + A(j, i)); V[i][j] = (i == j); }
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i + 1; j < 6; j++) off += a[i][j] * a[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 6; p++)
+            for (int q = p + 1; q < 6; q++) {
+                if (a[p][q] == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 6; k++) { double x = a[k][p], y = a[k][q]; a[k][p] = c * x - s * y; a[k][q] = s * x + c * y; }
+                for (int k = 0; k < 6; k++) { double x = a[p][k], y = a[q][k]; a[p][k] = c * x - s * y; a[q][k] = s * x + c * y; }
+                for (int k = 0; k < 6; k++) { double x = V[k][p], y = V[k][q]; V[k][p] = c * x - s * y; V[k][q] = s * x + c * y; }
+            }
+    }
+    for (int i = 0; i < 6; i++) ev[i] = a[i][i];
+}
+static void solve6(const Eigen::MatrixXd &A, const Eigen::MatrixXd &b, double x[6])   // Gaussian elimination, partial pivoting
+{
+    double a[6][7];
+    for (int i = 0; i < 6; i++) { for (int j = 0; j < 6; j++) a[i][j] = A(i, j); a[i][6] = b(i, 0); }
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        for (int j = 0; j < 7; j++) std::swap(a[c][j], a[piv][j]);
+        for (int r = c + 1; r < 6; r++) { double f = a[r][c] / a[c][c]; for (int j = c; j < 7; j++) a[r][j] -= f * a[c][j]; }
+    }
+    for (int i = 5; i >= 0; i--) { double s = a[i][6]; for (int j = i + 1; j < 6; j++) s -= a[i][j] * x[j]; x[i] = s / a[i][i]; }
+}
+
+static int g_evals = 0;
+
+// ndt_feature::matchFusion, fusion.h:797-1155, with useNDT = true, useFeat = false (the feature maps are empty),
+// useTikhonovRegularization = false -- statement by statement against the mirror's lslgeneric:: API.
+static bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, Eigen::Affine3d &T, const Eigen::MatrixXd &Tcov,
+                        bool useInitialGuess, bool step_control, int ITR_MAX, int n_neighbours, double DELTA_SCORE, bool useSoftConstraints)
+{
+    lslgeneric::NDTMatcherD2D matcher_d2d;
+    matcher_d2d.n_neighbours = n_neighbours;
+    bool convergence = false;
+    double score_best = 1.7976931348623157e308;
+    int itr_ctr = 0;
+    double step_size = 1;
+    double pose_increment_v[6], pose_local_v[6] = {0, 0, 0, 0, 0, 0};
+    Eigen::MatrixXd Hessian(6, 6), score_gradient(6, 1), Hessian_ndt(6, 6), score_gradient_ndt(6, 1);
+    Eigen::Affine3d TR, Tbest;
+    bool ret = true;
+    if (!useInitialGuess) T.setIdentity();
+    Tbest = T;
+    std::vector<lslgeneric::NDTCell *> nextNDT = sourceNDT.pseudoTransformNDT(T);
+    Eigen::MatrixXd Q(6, 6);
+    {   // Q = Tcov.inverse()
+        for (int c = 0; c < 6; c++) {
+            Eigen::MatrixXd e(6, 1);
+            e(c, 0) = 1.0;
+            double col[6];
+            solve6(Tcov, e, col);
+            for (int r = 0; r < 6; r++) Q(r, c) = col[r];
+        }
+    }
+    auto free_cells = [&]() { for (unsigned int i = 0; i < nextNDT.size(); i++) if (nextNDT[i] != NULL) delete nextNDT[i]; };
+    while (!convergence) {
+        TR.setIdentity();
+        Hessian.setZero();
+        score_gradient.setZero();
+        double score_here = 0.;
+        double score_here_ndt = matcher_d2d.derivativesNDT(nextNDT, targetNDT, score_gradient_ndt, Hessian_ndt, true);
+        g_evals++;
+        score_here += score_here_ndt;
+        Hessian += Hessian_ndt;
+        score_gradient += score_gradient_ndt;
+        if (useSoftConstraints) {
+            score_here += computeScoreMahalanobis(pose_local_v, Q);
+            Hessian += computeHessianMahalanobis(Q);
+            score_gradient += computeGradientMahalanobis(pose_local_v, Q);
+        }
+        Eigen::MatrixXd scg = score_gradient;
+        if (score_here < score_best) { Tbest = T; score_best = score_here; }
+        double evals[6], evecs[6][6];
+        eig6(Hessian, evals, evecs);
+        double minCoeff = evals[0], maxCoeff = evals[0];
+        for (int i = 1; i < 6; i++) { minCoeff = std::fmin(minCoeff, evals[i]); maxCoeff = std::fmax(maxCoeff, evals[i]); }
+        if (minCoeff < 0) {
+            double regularizer = score_gradient.norm();
+            regularizer = regularizer + minCoeff > 0 ? regularizer : 0.001 * maxCoeff - minCoeff;
+            for (int i = 0; i < 6; i++) evals[i] += regularizer;
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) {
+                    double s = 0;
+                    for (int k = 0; k < 6; k++) s += evecs[i][k] * evals[k] * evecs[j][k];
+                    Hessian(i, j) = s;
+                }
+        }
+        if (score_gradient.norm() <= DELTA_SCORE) {
+            if (score_here > score_best) T = Tbest;
+            free_cells();
+            return true;
+        }
+        solve6(Hessian, score_gradient, pose_increment_v);
+        for (int i = 0; i < 6; i++) pose_increment_v[i] = -pose_increment_v[i];
+        double dginit = 0;
+        for (int i = 0; i < 6; i++) dginit += pose_increment_v[i] * scg(i, 0);
+        if (dginit > 0) {
+            if (score_here > score_best) T = Tbest;
+            free_cells();
+            return true;
+        }
+        if (step_control) {
+            struct V6 { double *p; double &operator()(int i) { return p[i]; } } incr{pose_increment_v};
+            double step_size_ndt = matcher_d2d.lineSearchMT(incr, nextNDT, targetNDT);
+            step_size = std::fmax(step_size_ndt, 0.);   // step_size_feat == 0 (fusion.h:1018-1023)
+        } else {
+            step_size = 1;
+        }
+        double inorm = 0;
+        for (int i = 0; i < 6; i++) { pose_increment_v[i] *= step_size; inorm += pose_increment_v[i] * pose_increment_v[i]; }
+        inorm = std::sqrt(inorm);
+        TR = ndtgpu_host::affine_from_pose(pose_increment_v[0], pose_increment_v[1], pose_increment_v[2], pose_increment_v[3],
+                                          pose_increment_v[4], pose_increment_v[5]);
+        T = TR * T;
+        for (int i = 0; i < 6; i++) pose_local_v[i] += pose_increment_v[i];
+        for (unsigned int i = 0; i < nextNDT.size(); i++) {
+            Eigen::Vector3d meanC = nextNDT[i]->getMean();
+            Eigen::Matrix3d covC = nextNDT[i]->getCov();
+            meanC = TR * meanC;
+            covC = TR.rotation() * covC * TR.rotation().transpose();
+            nextNDT[i]->setMean(meanC);
+            nextNDT[i]->setCov(covC);
+        }
+        if (itr_ctr > 0) convergence = (inorm < DELTA_SCORE);
+        if (itr_ctr > ITR_MAX) { convergence = true; ret = false; }
+        itr_ctr++;
+    }
+    double score_here = matcher_d2d.derivativesNDT(nextNDT, targetNDT, score_gradient_ndt, Hessian_ndt, false);
+    g_evals++;
+    if (useSoftConstraints) score_here += computeScoreMahalanobis(pose_local_v, Q);
+    if (score_here > score_best) T = Tbest;
+    free_cells();
+    return ret;
+}
+}  // namespace retyped
+
+template <class F> static bool throws_invalid(F f)
+{
+    try { f(); } catch (const ndtgpu_host::Error &e) { return e.status == NDTGPU_ERR_INVALID; }
+    return false;
 }
 
 int main()
 {
+    NDTFeatureFuserHMT::Params fp;       // the shipped parameter set (gustav_laser_tf.launch:8-88; ndt_graph_offline.cpp:265-330)
+    fp.resolution = 0.5; fp.map_size_x = 60; fp.map_size_y = 60; fp.map_size_z = 1.0; fp.sensor_range = 30;
+    fp.useNDT = true; fp.useFeat = false; fp.useOdom = false;
+    fp.neighbours = 2; fp.stepcontrol = true; fp.ITR_MAX = 30; fp.DELTA_SCORE = 1e-6;
+    fp.globalTransf = false; fp.loadCentroid = false; fp.fusion2d = false;
+    fp.useSoftConstraints = true; fp.useTikhonovRegularization = false; fp.computeCov = true;
+    NDTFeatureGraph::Params gp;
+    gp.newNodeTranslDist = 1.0;
+    gp.maxNodes = 8;
+    InterestPointVec no_pts;
+
     if (ndtgpu_device_count() < 1) {
-        NDTFeatureGraph::Params p;
         try {
-            NDTFeatureGraph g(p);
-            std::printf("FAIL: graph construction succeeded without a device\n");
+            NDTFeatureGraph g(gp, fp);
+            pcl::PointCloud<pcl::PointXYZ> pc = corridor_scan(Eigen::Affine3d::Identity(), 1, 200);
+            g.initialize(Eigen::Affine3d::Identity(), pc, no_pts);
+            std::printf("FAIL: graph initialisation succeeded without a device\n");
             return 1;
         } catch (const ndtgpu_host::Error &e) {
             if (e.status != NDTGPU_ERR_NO_DEVICE) { std::printf("FAIL: wrong status %d\n", e.status); return 1; }
@@ -45,69 +256,128 @@ int main()
             return 0;
         }
     }
-    NDTFeatureGraph::Params p;
-    p.resolution = 0.5; p.map_size_x = 60; p.map_size_y = 60; p.map_size_z = 1; p.sensor_range = 30; p.max_nodes = 8;
-    NDTFeatureGraph graph(p);
-    const int N = 5;
-    std::vector<Affine3d> gt;
-    for (int k = 0; k < N; k++) {
-        Affine3d T = Affine3d::fromPose(0.35 * k, 0.05 * k, 0, 0, 0, 0.02 * k);
-        gt.push_back(T);
-        // odometry-like node pose: ground truth perturbed
-        Affine3d odo = Affine3d::fromPose(0.35 * k + 0.03 * (k % 2 ? 1 : -1), 0.05 * k - 0.02, 0, 0, 0, 0.02 * k + 0.004);
-        graph.addNode(odo, corridor_scan(T, 100 + k));
-    }
-    int fails = 0;
-    for (int k = 0; k < N; k++)
-        if (graph.getMap(k)->numberOfActiveCells() < 20) { std::printf("FAIL: node %d has too few cells\n", k); fails++; }
 
-    std::vector<NDTFeatureLink> links = graph.computeAllPossibleLinks();
-    std::vector<NDTFeatureLink> serial = links;
-    graph.updateLinksUsingNDTRegistration(links, 2, true);                 // one batched call
-    for (auto &l : serial) graph.updateLinkUsingNDTRegistration(l, 2, true);   // the reference's loop shape
-    for (size_t k = 0; k < links.size(); k++) {
-        Affine3d want = gt[links[k].ref_idx].inverse() * gt[links[k].mov_idx];
-        double d, a;
-        distanceBetweenAffine3d(want, links[k].T, d, a);
-        // the batched call runs the persistent kernel, a single link the host-driven multi-workgroup path:
-        // same algorithm, different summation order
-        bool same = true;
-        for (int q = 0; q < 16; q++) same = same && std::fabs(links[k].T.m[q] - serial[k].T.m[q]) < 1e-9;
-        std::printf("link %zu-%zu: |dt| %.4f m  |dyaw| %.5f rad  iters %d  converged %d  batch==single %d\n", links[k].ref_idx,
-                    links[k].mov_idx, d, a, links[k].iterations, (int)links[k].converged, (int)same);
-        if (d > 0.06 || a > 0.01 || !same) fails++;   // grid-limited accuracy with the edge preset (DELTA_SCORE 1e-3)
-    }
-    std::vector<NDTFeatureLink> valid = graph.getValidLinks(links, 1e9, 1.0, 0.2, 2);
-    std::printf("%zu links, %zu valid after the gates, %d failures\n", links.size(), valid.size(), fails);
-    // single-map API used by the fuser call sites
-    lslgeneric::NDTMap ndglobal(new lslgeneric::LazyGrid(0.5), true);
-    ndglobal.guessSize(0, 0, 0, 60, 60, 1);
-    PointCloud<PointXYZ> pc = corridor_scan(gt[0], 100);
-    ndglobal.loadPointCloud(pc, 30.0);
-    ndglobal.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE);
-    if (ndglobal.numberOfActiveCells() != graph.getMap(0)->numberOfActiveCells()) { std::printf("FAIL: stand-alone map differs\n"); fails++; }
-    lslgeneric::NDTMatcherD2D m;
-    m.n_neighbours = 2;
-    Affine3d T = Affine3d::Identity();
-    bool conv = m.match(*graph.getMap(0), ndglobal, T, true);
-    double d, a;
-    distanceBetweenAffine3d(Affine3d::Identity(), T, d, a);
-    if (!conv || d > 1e-6) { std::printf("FAIL: self match moved by %g\n", d); fails++; }
-    // matchFusion with a tight odometry prior stays at the initial guess, with a loose one it equals match()
+    // ---- A. NDTFeatureGraph::initialize / update over a trajectory -----------------------------------------------
+    NDTFeatureGraph graph(gp, fp);
+    const int K = 14;
+    std::vector<Eigen::Affine3d> gt;
+    for (int k = 0; k < K; k++) gt.push_back(ndtgpu_host::affine_from_pose(-6.0 + 0.3 * k, 0.05 * std::sin(0.7 * k), 0, 0, 0, 0.015 * k));
+    std::mt19937 rng(5);
+    std::normal_distribution<double> odo_t(0.0, 0.01), odo_r(0.0, 0.002);
     {
-        Affine3d Tg = Affine3d::fromPose(0.05, -0.02, 0, 0, 0, 0.003), Ta = Tg, Tb = Tg, Tc = Tg;
-        double tight[36] = {0}, loose[36] = {0};
-        for (int q = 0; q < 6; q++) { tight[q * 7] = 1e-12; loose[q * 7] = 1e12; }
-        matchFusion(*graph.getMap(0), ndglobal, Ta, tight, true, true, 30, 2, 1e-6, true);
-        matchFusion(*graph.getMap(0), ndglobal, Tb, loose, true, true, 30, 2, 1e-6, true);
-        lslgeneric::NDTMatcherD2D m2; m2.n_neighbours = 2; m2.ITR_MAX = 30; m2.DELTA_SCORE = 1e-6;
-        m2.match(*graph.getMap(0), ndglobal, Tc, true);
-        double d1, a1, d2, a2;
-        distanceBetweenAffine3d(Tg, Ta, d1, a1);
-        distanceBetweenAffine3d(Tc, Tb, d2, a2);
-        std::printf("matchFusion: tight prior moved %.2e m, loose prior differs from match() by %.2e m\n", d1, d2);
-        if (d1 > 1e-6 || d2 > 1e-6) fails++;
+        pcl::PointCloud<pcl::PointXYZ> pc = corridor_scan(gt[0], 100);
+        graph.initialize(gt[0], pc, no_pts);
     }
-    std::printf("%d failures in total\n", fails);
-    return fails ? 1 : 0;
+    double worst_d = 0, worst_a = 0;
+    for (int k = 1; k < K; k++) {
+        Eigen::Affine3d inc = gt[k - 1].inverse() * gt[k];
+        Eigen::Affine3d Tmotion = ndtgpu_host::affine_from_pose(inc(0, 3) + odo_t(rng), inc(1, 3) + odo_t(rng), 0, 0, 0,
+                                                                std::atan2(inc(1, 0), inc(0, 0)) + odo_r(rng));
+        pcl::PointCloud<pcl::PointXYZ> pc = corridor_scan(gt[k], 100 + k);
+        Eigen::Affine3d Tnow = graph.update(Tmotion, pc, no_pts);
+        double d, a;
+        pose_error(gt[k], Tnow, d, a);
+        worst_d = std::fmax(worst_d, d); worst_a = std::fmax(worst_a, a);
+    }
+    std::printf("A: %d scans -> %zu nodes; worst pose error along the trajectory %.4f m / %.5f rad\n", K, graph.getNbNodes(), worst_d, worst_a);
+    CHECK(graph.getNbNodes() >= 3 && graph.getNbNodes() <= gp.maxNodes, "node count %zu", graph.getNbNodes());
+    CHECK(worst_d < 0.05 && worst_a < 0.01, "trajectory drifted: %.4f m / %.5f rad", worst_d, worst_a);
+    CHECK(graph.fullInit(), "a node is not initialised");
+    for (size_t n = 0; n < graph.getNbNodes(); n++) {
+        CHECK(graph.getMap((int)n)->numberOfActiveCells() > 30, "node %zu has %d cells", n, graph.getMap((int)n)->numberOfActiveCells());
+        std::vector<float> occ = graph.getMap((int)n)->getOccupancy();
+        size_t neg = 0, pos = 0;
+        for (float o : occ) { neg += o < 0; pos += o > 0; }
+        CHECK(neg > 200 && pos > 30, "node %zu: occupancy not carved (%zu free, %zu occupied cells)", n, neg, pos);
+    }
+    CHECK(graph.getNode(0).nbUpdates >= 2 && graph.getNode(0).getFuser().last_match.iterations > 0, "node 0 was not updated through matchFusion");
+
+    // ---- B. all possible links -> NDT registration + covariance + overlap score -> gates -------------------------------------
+    std::vector<NDTFeatureLink> links = graph.computeAllPossibleLinks();
+    for (auto &l : links) CHECK(l.score >= 0.0 && l.score <= 1.0, "overlap score %g out of range", l.score);
+    std::vector<NDTFeatureLink> serial = links;
+    graph.updateLinksUsingNDTRegistration(links, 2, false);                   // three batched device calls
+    for (auto &l : serial) graph.updateLinkUsingNDTRegistration(l, 2, false);    // the reference's loop shape
+    for (size_t k = 0; k < links.size(); k++) {
+        bool same = true;
+        for (int q = 0; q < 16; q++) same = same && std::fabs(links[k].T.data()[q] - serial[k].T.data()[q]) < 1e-9;
+        double asym = 0, tr = 0;
+        for (int a = 0; a < 6; a++) { tr += links[k].cov_3d(a, a); for (int b = 0; b < 6; b++) asym = std::fmax(asym, std::fabs(links[k].cov_3d(a, b) - links[k].cov_3d(b, a))); }
+        std::printf("B: link %zu-%zu iters %d converged %d score %.4f trace(cov) %.3e batch==single %d\n", links[k].ref_idx, links[k].mov_idx,
+                    links[k].iterations, (int)links[k].converged, links[k].score, tr, (int)same);
+        CHECK(same, "batched and single-link registration differ");
+        CHECK(tr > 0 && asym < 1e-9 * tr, "covariance: trace %g asymmetry %g", tr, asym);
+        CHECK(std::fabs(links[k].score - serial[k].score) < 1e-12, "scores differ");
+    }
+    std::vector<NDTFeatureLink> valid = graph.getValidLinks(links, 1.0, 3.0, 0.5, 1);
+    CHECK(!valid.empty(), "no link survives the gates");
+
+    // ---- C. the re-typed host loop vs the device-resident matchFusion -----------------------------------------------------
+    {
+        lslgeneric::NDTMap &target = *graph.getMap(0);
+        lslgeneric::NDTMap src(new lslgeneric::LazyGrid(0.5), true);
+        pcl::PointCloud<pcl::PointXYZ> pc = corridor_scan(gt[2], 777);
+        src.guessSize(0, 0, 0, 30, 30, 1.0);
+        src.loadPointCloud(pc, 30.0);
+        src.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE);
+        Eigen::Affine3d guess = graph.getNode(0).T.inverse() * gt[2];
+        guess = ndtgpu_host::affine_from_pose(guess(0, 3) + 0.06, guess(1, 3) - 0.04, 0, 0, 0, std::atan2(guess(1, 0), guess(0, 0)) + 0.01);
+        MotionModel2d mm;
+        Eigen::MatrixXd Tcov = mm.getCovMatrix6(Pose2d(0.6, 0.05, 0.03));
+        Tcov(2, 2) = 1; Tcov(3, 3) = 1; Tcov(4, 4) = 1;
+        std::vector<std::pair<int, int> > corr;
+        for (int soft = 0; soft < 2; soft++) {
+            Eigen::Affine3d Th = guess, Td = guess;
+            retyped::g_evals = 0;
+            bool rh = retyped::matchFusion(target, src, Th, Tcov, true, true, 30, 2, 1e-6, soft != 0);
+            ndtgpu_match_result res;
+            bool rd = matchFusion(target, src, nullptr, nullptr, corr, Td, Tcov, true, true, false, true, 30, 2, 1e-6, soft != 0, true, false, &res);
+            double d, a;
+            pose_error(Th, Td, d, a);
+            std::printf("C: soft=%d  host loop (%d Hessian evaluations) vs device loop (%d iterations): |dt| %.2e m |dyaw| %.2e rad  ret %d/%d\n", soft,
+                        retyped::g_evals, res.iterations, d, a, (int)rh, (int)rd);
+            CHECK(d < 1e-6 && a < 1e-6 && rh == rd, "re-typed host loop and device loop disagree");
+            CHECK(retyped::g_evals == res.iterations + 1 || retyped::g_evals == res.iterations, "evaluation count %d vs iterations %d", retyped::g_evals, res.iterations);
+            double dg, ag;
+            pose_error(graph.getNode(0).T.inverse() * gt[2], Td, dg, ag);
+            CHECK(dg < 0.05, "matchFusion is %.3f m from the true pose", dg);
+        }
+    }
+
+    // ---- D. loadPointCloudCentroid, NDTMatcherD2D_2D, rejected arguments ---------------------------------------------------
+    {
+        lslgeneric::NDTMap &node0 = *graph.getMap(0);
+        Eigen::Vector3d map_centroid;
+        node0.getCentroid(map_centroid[0], map_centroid[1], map_centroid[2]);
+        pcl::PointCloud<pcl::PointXYZ> pc = corridor_scan(gt[1], 901);
+        ndtgpu_host::transformPointCloudInPlace(graph.getNode(0).T.inverse() * gt[1], pc);
+        Eigen::Vector3d origin = (graph.getNode(0).T.inverse() * gt[1]).translation();
+        lslgeneric::NDTMap local(new lslgeneric::LazyGrid(0.5), true);
+        local.loadPointCloudCentroid(pc, origin, map_centroid, Eigen::Vector3d(31.5, 31.5, 1.0), 30.0);
+        local.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE);
+        double cx, cy, cz;
+        local.getCentroid(cx, cy, cz);
+        const double kx = (cx - map_centroid[0]) / 0.5, ky = (cy - map_centroid[1]) / 0.5;
+        CHECK(std::fabs(kx - std::round(kx)) < 1e-12 && std::fabs(ky - std::round(ky)) < 1e-12, "centroid not on the node map's lattice");
+        CHECK(local.numberOfActiveCells() > 30, "centroid-loaded map has %d cells", local.numberOfActiveCells());
+        // cell faces coincide: every Gaussian cell of the local map has its centre on the node map's lattice too
+        std::vector<lslgeneric::NDTCell *> cells = local.getAllCells();
+        for (auto *c : cells) delete c;
+        lslgeneric::NDTMatcherD2D_2D m2;
+        m2.n_neighbours = 2; m2.ITR_MAX = 30; m2.DELTA_SCORE = 1e-6;
+        Eigen::Affine3d T2 = ndtgpu_host::affine_from_pose(0.02, -0.01, 0, 0, 0, 0.0);
+        m2.match(node0, local, T2, true);
+        CHECK(T2(2, 3) == 0.0 && T2(2, 2) == 1.0 && std::sqrt(T2(0, 3) * T2(0, 3) + T2(1, 3) * T2(1, 3)) < 0.05, "2D matcher left the plane or diverged");
+        CHECK(throws_invalid([&] { local.loadPointCloud(pc, 30.0); local.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_COVARIANCE_INTERSECTION); }),
+              "unsupported cell update mode accepted");
+        CHECK(throws_invalid([&] { local.loadPointCloud(pc, 30.0); local.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE, 1e5, 100.f); }),
+              "occupancy_limit the plain build cannot honour accepted");
+        NDTFeatureFuserHMT::Params bad = fp;
+        bad.useFeat = true;
+        NDTFeatureFuserHMT fuser(bad);
+        fuser.initialize(Eigen::Affine3d::Identity(), pc, no_pts);
+        CHECK(throws_invalid([&] { fuser.update(Eigen::Affine3d::Identity(), pc, no_pts); }), "useFeat accepted");
+    }
+    std::printf("%d failures in total\n", g_fails);
+    return g_fails ? 1 : 0;
 }

@@ -1,41 +1,135 @@
-// ndt_feature_graph_gpu.h -- host mirror of the graph-layer entry points that drive the hot path:
-// ndt_feature::NDTFeatureLink / NDTFeatureNode / NDTFeatureGraph (ndt_feature_link.h:9-56,
-// ndt_feature_node.h:38-209, ndt_feature_graph.h:20-280), restricted to what the NDT path needs:
-// node maps, candidate links, the registration of links (ndt_feature_graph.cpp:260-353) and the
-// link gates (:527-556).  The ROS / iSAM / FLIRT members of the reference classes stay where they
-// are (out of scope); the incremental fuser update is a "next" row (8f-1).
+// ndt_feature_graph_gpu.h -- host mirror of the ndt_feature classes that drive the hot path:
+//   ndt_feature::MotionModel2d        motion_model.hpp:123-163, motion_model.cpp:166-207
+//   ndt_feature::matchFusion / matchFusion2d   ndt_matcher_d2d_fusion.h:797-1155, 1159-1176
+//   ndt_feature::NDTFeatureFuserHMT   ndt_feature_fuser_hmt.h:36-334, ndt_feature_fuser_hmt.cpp:65-102 (initialize), 108-512 (update)
+//   ndt_feature::NDTFeatureLink / NDTFeatureNode / overlapNDTOccupancyScore   ndt_feature_link.h:9-56, ndt_feature_node.h:38-252
+//   ndt_feature::NDTFeatureGraph      ndt_feature_graph.h:20-280, ndt_feature_graph.cpp:24-144 (initialize, update),
+//                                     :260-353 (updateLink[s]UsingNDTRegistration), :395-405, :527-556
+// Same class, member and parameter names and the same control flow as the reference; the lslgeneric:: calls go to the
+// GPU through lslgeneric_gpu.h.  The ROS / iSAM / FLIRT members stay where they are (out of scope):
+// InterestPointVec is an empty placeholder, and a configuration that asks for the feature or odometry-cell terms
+// (Params::useFeat / useOdom) is rejected loudly instead of being silently ignored.
 //
-// What changes against the reference: updateLinksUsingNDTRegistration registers ALL links in one
-// batched GPU call instead of a serial loop, never blocks on stdin (graph.cpp:318-328) and reports
-// non-convergence in NDTFeatureLink::converged.
+// What changes against the reference: updateLinksUsingNDTRegistration registers ALL links in one batched GPU call
+// (matcher, covariance and overlap score: three calls per batch instead of three per link), never blocks on stdin
+// (graph.cpp:318-328) and reports non-convergence in NDTFeatureLink::converged; node maps live in one device pool.
 #pragma once
 #include "lslgeneric_gpu.h"
 
 #include <cstdlib>
+#include <iostream>
+#include <sstream>
 
 namespace ndt_feature {
 
-using ndtgpu_host::Affine3d;
-using ndtgpu_host::PointCloud;
-using ndtgpu_host::PointXYZ;
+struct InterestPointVec {};   // flirtlib's InterestPoint container: the feature front-end is out of scope (useFeat = false)
 
-// getRobustYawFromAffine3d (utils.h:30-40) for rigid transforms
-inline double getRobustYawFromAffine3d(const Affine3d &a) { return std::atan2(a(1, 0), a(0, 0)); }
-// distanceBetweenAffine3d (utils.h:42-47)
-inline void distanceBetweenAffine3d(const Affine3d &p1, const Affine3d &p2, double &dist, double &angularDist)
+typedef Eigen::Vector3d Pose2d;
+struct Pose2dCov {
+    Pose2d mean;
+    Eigen::Matrix3d cov;
+};
+
+// getRobustYawFromAffine3d (utils.h:30-41)
+inline double getRobustYawFromAffine3d(const Eigen::Affine3d &a)
 {
-    Affine3d tmp = p1.inverse() * p2;
-    dist = std::sqrt(tmp(0, 3) * tmp(0, 3) + tmp(1, 3) * tmp(1, 3) + tmp(2, 3) * tmp(2, 3));
+    const double dot = a(0, 0);                       // v1 = (1,0,0), v2 = R v1: v1.v2 in the xy plane
+    const double angle = std::acos(std::fmax(-1.0, std::fmin(1.0, dot)));
+    return (a(1, 0) > 0) ? angle : -angle;
+}
+// distanceBetweenAffine3d (utils.h:43-48)
+inline void distanceBetweenAffine3d(const Eigen::Affine3d &p1, const Eigen::Affine3d &p2, double &dist, double &angularDist)
+{
+    Eigen::Affine3d tmp = p1.inverse() * p2;
+    dist = tmp.translation().norm();
     angularDist = std::fabs(getRobustYawFromAffine3d(tmp));
 }
-
-// ndt_feature::matchFusion (ndt_matcher_d2d_fusion.h:797-1155) for the shipped configurations
-// (useNDT, no FLIRT features, no Tikhonov): D2D-NDT + the odometry soft constraint.  The feature-map
-// arguments of the reference signature are dropped (they are empty maps there).
-inline bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, Affine3d &T, const double Tcov[36],
-                        bool useInitialGuess, bool step_control, int ITR_MAX = 30, int n_neighbours = 2,
-                        double DELTA_SCORE = 10e-4, bool useSoftConstraints = true)
+// forceEigenAffine3dTo2dInPlace (utils.h:50-72)
+inline void forceEigenAffine3dTo2dInPlace(Eigen::Affine3d &a3d)
 {
+    const double yaw = getRobustYawFromAffine3d(a3d);
+    const Eigen::Vector3d t = a3d.translation();
+    a3d = ndtgpu_host::affine_from_pose(t(0), t(1), 0., 0., 0., yaw);
+}
+// pose2dFromAffine3d, cov6toCov3, pose2dClearDependence (motion_model.cpp:128-165)
+inline Pose2d pose2dFromAffine3d(const Eigen::Affine3d &T)
+{
+    return Pose2d(T.translation()(0), T.translation()(1), T.rotation().eulerAngles(0, 1, 2)(2));
+}
+inline Eigen::Matrix3d cov6toCov3(const Eigen::MatrixXd &cov6)
+{
+    Eigen::Matrix3d c;
+    c(0, 0) = cov6(0, 0); c(1, 1) = cov6(1, 1); c(2, 2) = cov6(5, 5);
+    c(0, 1) = cov6(0, 1); c(1, 0) = cov6(1, 0);
+    c(0, 2) = cov6(0, 5); c(1, 2) = cov6(1, 5); c(2, 0) = cov6(5, 0); c(2, 1) = cov6(5, 1);
+    return c;
+}
+inline void pose2dClearDependence(Pose2dCov &p)
+{
+    p.cov(0, 1) = p.cov(1, 0) = p.cov(0, 2) = p.cov(1, 2) = p.cov(2, 0) = p.cov(2, 1) = 0.;
+}
+// computeLocalCentroid (utils.h:213-227)
+inline Eigen::Vector3d computeLocalCentroid(const Eigen::Vector3d &map_centroid, const Eigen::Vector3d &local_pos, double resolution)
+{
+    Eigen::Vector3d diff = map_centroid - local_pos, local_centroid;
+    for (int i = 0; i < 3; i++) local_centroid(i) = diff(i) - std::floor(diff(i) / resolution) * resolution;
+    return local_centroid;
+}
+
+// Eliazar-style odometry covariance (motion_model.hpp:123-163; motion_model.cpp:166-207)
+class MotionModel2d {
+public:
+    class Params {
+    public:
+        Params() { Cd = 0.001; Ct = 0.001; Dd = 0.005; Dt = 0.005; Td = 0.001; Tt = 0.001; }
+        double Cd, Ct, Dd, Dt, Td, Tt;
+    };
+    MotionModel2d() {}
+    MotionModel2d(const MotionModel2d::Params &p) : params(p) {}
+    void setParams(const MotionModel2d::Params &p) { params = p; }
+    Pose2dCov getPose2dCov(const Pose2d &rel) const
+    {
+        Pose2dCov ret;
+        ret.mean = rel;
+        ret.cov = getMeasurementCov(rel);
+        return ret;
+    }
+    Eigen::MatrixXd getCovMatrix6(const Pose2d &rel) const
+    {
+        Eigen::MatrixXd cov(6, 6);
+        cov.setIdentity();
+        Eigen::Matrix3d c2 = getMeasurementCov(rel);
+        cov(0, 0) = c2(0, 0); cov(1, 0) = c2(1, 0); cov(0, 1) = c2(0, 1); cov(1, 1) = c2(1, 1);
+        cov(0, 5) = c2(0, 2); cov(1, 5) = c2(1, 2);
+        cov(5, 0) = c2(2, 0); cov(5, 1) = c2(2, 1); cov(5, 5) = c2(2, 2);
+        return cov;
+    }
+    MotionModel2d::Params params;
+
+private:
+    Eigen::Matrix3d getMeasurementCov(const Eigen::Vector3d &rel) const
+    {
+        const double dist = std::sqrt(rel[0] * rel[0] + rel[1] * rel[1]), rot = rel[2];
+        Eigen::Matrix3d R;
+        R(0, 0) = params.Dd * dist * dist + params.Dt * rot * rot;
+        R(1, 1) = params.Cd * dist * dist + params.Ct * rot * rot;
+        R(2, 2) = params.Td * dist * dist + params.Tt * rot * rot;
+        return R;
+    }
+};
+
+// ndt_feature::matchFusion (ndt_matcher_d2d_fusion.h:797-1155) -- the reference's full signature.  The whole Newton /
+// More-Thuente loop runs on the device (ndtgpu_match_fusion_batch).  The feature maps must be empty (useFeat == false).
+inline bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, lslgeneric::NDTMap * /*targetNDT_feat*/,
+                        lslgeneric::NDTMap * /*sourceNDT_feat*/, const std::vector<std::pair<int, int> > &corr_feat,
+                        Eigen::Affine3d &T, const Eigen::MatrixXd &Tcov, bool useInitialGuess, bool useNDT, bool useFeat,
+                        bool step_control, int ITR_MAX = 30, int n_neighbours = 2, double DELTA_SCORE = 10e-4,
+                        bool useSoftConstraints = true, bool /*step_control_fusion*/ = true, bool useTikhonovRegularization = false,
+                        ndtgpu_match_result *result = nullptr)
+{
+    if (useFeat || !corr_feat.empty())
+        throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "matchFusion: feature / odometry-cell terms (useFeat) are not implemented");
+    if (!useNDT) throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "matchFusion: useNDT == false leaves nothing to match");
     lslgeneric::NDTMatcherD2D m;
     m.n_neighbours = n_neighbours;
     m.ITR_MAX = ITR_MAX;
@@ -44,81 +138,443 @@ inline bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourc
     ndtgpu_match_params p = m.params(0x3f, useInitialGuess);
     ndtgpu_match_result r;
     uint32_t ti = (uint32_t)targetNDT.slot(), si = (uint32_t)sourceNDT.slot();
-    ndtgpu_host::check(ndtgpu_match_fusion_batch(targetNDT.handle(), &ti, sourceNDT.handle(), &si, ndtgpu_host::affine_data(T),
-                                                 Tcov, 1, &p, useSoftConstraints ? 1 : 0, &r, nullptr), "ndtgpu_match_fusion_batch");
+    double c36[36];
+    const int flags = (useSoftConstraints ? 1 : 0) | (useTikhonovRegularization ? 2 : 0);
+    if (flags) {
+        if (Tcov.rows() != 6 || Tcov.cols() != 6) throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "matchFusion: Tcov must be 6x6");
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) c36[a * 6 + b] = Tcov(a, b);
+    }
+    ndtgpu_host::check(ndtgpu_match_fusion_batch(targetNDT.handle(), &ti, sourceNDT.handle(), &si, T.data(), flags ? c36 : nullptr, 1,
+                                                 &p, flags, &r, nullptr), "ndtgpu_match_fusion_batch");
+    if (result) *result = r;
     return r.converged != 0;
 }
+// ndt_feature::matchFusion2d (ndt_matcher_d2d_fusion.h:1159-1176): NDTMatcherD2D_2D on the NDT maps
+inline bool matchFusion2d(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, lslgeneric::NDTMap * /*targetNDT_feat*/,
+                          lslgeneric::NDTMap * /*sourceNDT_feat*/, const std::vector<std::pair<int, int> > & /*corr_feat*/,
+                          Eigen::Affine3d &T, bool useInitialGuess, bool /*useNDT*/, bool /*useFeat*/, bool step_control, int ITR_MAX = 30,
+                          int n_neighbours = 2, double DELTA_SCORE = 10e-4)
+{
+    lslgeneric::NDTMatcherD2D_2D matcher_d2d_2d;
+    matcher_d2d_2d.n_neighbours = n_neighbours;
+    matcher_d2d_2d.step_control = step_control;
+    matcher_d2d_2d.ITR_MAX = ITR_MAX;
+    matcher_d2d_2d.DELTA_SCORE = DELTA_SCORE;
+    return matcher_d2d_2d.match(targetNDT, sourceNDT, T, useInitialGuess);
+}
+
+class NDTFeatureFuserHMT {
+public:
+    Eigen::Affine3d Tnow, Tlast_fuse, Todom;   ///< current pose
+    lslgeneric::NDTMap *map;                   ///< da map
+
+    //! ndt_feature_fuser_hmt.h:58-207: all 30 fields, the reference's defaults
+    class Params {
+    public:
+        Params()
+        {
+            checkConsistency = false;
+            resolution = 1.;
+            map_size_x = 40.; map_size_y = 40.; map_size_z = 10.;
+            sensor_range = 3.;
+            max_translation_norm = 1;
+            max_rotation_norm = M_PI / 4.;
+            fuseIncomplete = false;
+            beHMT = true;
+            prefix = "";
+            hmt_map_dir = "map";
+            useNDT = true; useFeat = true; useOdom = true;
+            neighbours = 0;
+            stepcontrol = true;
+            ITR_MAX = 30;
+            DELTA_SCORE = 10e-4;
+            globalTransf = true;
+            loadCentroid = true;
+            forceOdomAsEst = false;
+            visualizeLocalCloud = false;
+            fusion2d = false;
+            allMatchesValid = false;
+            discardCells = false;
+            useSoftConstraints = true;
+            computeCov = true;
+            stepControlFusion = true;
+            useTikhonovRegularization = true;
+        }
+        bool checkConsistency;
+        double resolution, map_size_x, map_size_y, map_size_z, sensor_range, max_translation_norm, max_rotation_norm;
+        bool fuseIncomplete, beHMT;
+        std::string prefix, hmt_map_dir;
+        bool useNDT, useFeat, useOdom;
+        int neighbours;
+        bool stepcontrol;
+        int ITR_MAX;
+        double DELTA_SCORE;
+        bool globalTransf, loadCentroid, forceOdomAsEst, visualizeLocalCloud, fusion2d, allMatchesValid, discardCells,
+            useSoftConstraints, computeCov, stepControlFusion, useTikhonovRegularization;
+        std::string getDescString() const
+        {
+            std::ostringstream os;
+            os << "resolution" << resolution << "loadCentroid" << loadCentroid << "discardCells" << discardCells << "neighbours" << neighbours
+               << "forceOdomAsEst" << forceOdomAsEst << "useSoftConstraints" << useSoftConstraints;
+            return os.str();
+        }
+    };
+
+    Params params_;
+    MotionModel2d::Params motion_params_;
+    ndtgpu_match_result last_match{};        // (added) what the device matcher reported for the last update
+
+    NDTFeatureFuserHMT(const NDTFeatureFuserHMT::Params &params) : map(NULL), params_(params)
+    {
+        isInit = false;
+        translation_fuse_delta = 0.05;
+        rotation_fuse_delta = 0.01;
+        localMapSize = Eigen::Vector3d(params.sensor_range + 3 * params.resolution, params.sensor_range + 3 * params.resolution, params.map_size_z);
+    }
+    // the node map lives in a device pool shared with the other nodes of a graph (batched edge registration)
+    NDTFeatureFuserHMT(const NDTFeatureFuserHMT::Params &params, std::shared_ptr<ndtgpu_host::MapPool> pool, size_t slot)
+        : NDTFeatureFuserHMT(params)
+    {
+        pool_ = std::move(pool);
+        pool_slot_ = slot;
+    }
+    ~NDTFeatureFuserHMT()
+    {
+        if (map != NULL) delete map;
+    }
+    NDTFeatureFuserHMT(const NDTFeatureFuserHMT &) = delete;
+    NDTFeatureFuserHMT &operator=(const NDTFeatureFuserHMT &) = delete;
+
+    void setMotionParams(const MotionModel2d::Params &params) { motion_params_ = params; }
+    void setSensorPose(Eigen::Affine3d spose) { sensor_pose = spose; }
+    bool wasInit() { return isInit; }
+    const NDTFeatureFuserHMT::Params &getParam() const { return params_; }
+    Eigen::Matrix3d &getCov() { return current_posecov.cov; }
+
+    /** Set the initial position and set the first scan to the map (ndt_feature_fuser_hmt.cpp:65-102) */
+    void initialize(Eigen::Affine3d initPos, const pcl::PointCloud<pcl::PointXYZ> &cloudOrig, const InterestPointVec & /*pts*/, bool /*preLoad*/ = false)
+    {
+        pcl::PointCloud<pcl::PointXYZ> cloud(cloudOrig);
+        ndtgpu_host::transformPointCloudInPlace(sensor_pose, cloud);
+        ndtgpu_host::transformPointCloudInPlace(initPos, cloud);
+        Tnow = initPos;
+        if (map != NULL) delete map;
+        map = pool_ ? new lslgeneric::NDTMap(pool_, pool_slot_) : new lslgeneric::NDTMap(new lslgeneric::LazyGrid(params_.resolution));
+        map->initialize(Tnow.translation()(0), Tnow.translation()(1), 0., params_.map_size_x, params_.map_size_y, params_.map_size_z);
+        Eigen::Affine3d Tnow_sensor = Tnow * sensor_pose;   // the origin from where the sensor readings occured
+        map->addPointCloud(Tnow_sensor.translation(), cloud, 0.1, 100.0, 0.1);
+        map->computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE, 1e5, 255, Tnow_sensor.translation(), 0.1);
+        isInit = true;
+        Tlast_fuse = Tnow;
+        Todom = Tnow;
+    }
+
+    /** ndt_feature_fuser_hmt.cpp:108-512 */
+    Eigen::Affine3d update(Eigen::Affine3d Tmotion, const pcl::PointCloud<pcl::PointXYZ> &cloudOrig, const InterestPointVec & /*pts*/,
+                           bool /*updateFeatureMap*/ = true, bool updateNDTMap = true)
+    {
+        if (!isInit) {
+            fprintf(stderr, "NDT-FuserHMT: Call Initialize first!!\n");
+            return Tnow;
+        }
+        if (params_.useFeat || params_.useOdom)
+            throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: the FLIRT feature (useFeat) and odometry-cell (useOdom) terms are not "
+                                                         "implemented; every shipped configuration sets both to false");
+        if (params_.discardCells)
+            throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: discardCells is not implemented (false in every shipped configuration)");
+        pcl::PointCloud<pcl::PointXYZ> cloud(cloudOrig);
+        pcl::PointCloud<pcl::PointXYZ> cloud_orig(cloudOrig);
+
+        Eigen::Vector3d map_centroid;
+        map->getCentroid(map_centroid[0], map_centroid[1], map_centroid[2]);
+
+        // Odometry 'constraints'
+        MotionModel2d motion(motion_params_);
+        Pose2d relpose(Tmotion.translation()[0], Tmotion.translation()[1], Tmotion.rotation().eulerAngles(0, 1, 2)[2]);
+        Eigen::MatrixXd TmotionCov = motion.getCovMatrix6(relpose);
+        TmotionCov(2, 2) = 1;   // z
+        TmotionCov(3, 3) = 1;   // roll
+        TmotionCov(4, 4) = 1;   // pitch
+
+        Todom = Todom * Tmotion;   // we track this only for display purposes!
+
+        Eigen::Affine3d Tinit;
+        if (params_.globalTransf) Tinit = Tnow;
+        else Tinit.setIdentity();
+        Eigen::Affine3d Tmotion_est;
+        if (params_.globalTransf) Tmotion_est = Tmotion;
+        else Tmotion_est = Tnow * Tmotion;
+
+        Eigen::Affine3d global_rotation;
+        Eigen::Affine3d Tinit_sensor_pose = Tinit * sensor_pose;
+        ndtgpu_host::transformPointCloudInPlace(Tinit_sensor_pose, cloud);   // Cloud -> transformed in to the vehicle origin!
+
+        // the map of the current scan ("ndglobal"); the device arena is kept between updates
+        const double lsx = params_.loadCentroid ? localMapSize(0) : params_.sensor_range;
+        const double lsy = params_.loadCentroid ? localMapSize(1) : params_.sensor_range;
+        const double lsz = params_.loadCentroid ? localMapSize(2) : params_.map_size_z;
+        if (!scan_pool_) {
+            const double c[3] = {0, 0, 0}, s[3] = {lsx, lsy, lsz};
+            scan_pool_ = std::make_shared<ndtgpu_host::MapPool>(params_.resolution, c, s, 1);
+        }
+        lslgeneric::NDTMap ndglobal(scan_pool_, 0);
+
+        if (params_.loadCentroid) {
+            if (params_.globalTransf) {
+                ndglobal.loadPointCloudCentroid(cloud, Tinit_sensor_pose.translation(), map_centroid, localMapSize, params_.sensor_range);
+            } else {
+                // 1) rotate the cloud to be aligned with a global frame (Tmotion_est)
+                // 2) a translation (new map_centroid) that aligns the current local map
+                global_rotation = Tmotion_est;
+                Tmotion_est = ndtgpu_host::affine_from_pose(global_rotation.translation()(0), global_rotation.translation()(1),
+                                                            global_rotation.translation()(2), 0, 0, 0);
+                global_rotation.data()[12] = 0.; global_rotation.data()[13] = 0.; global_rotation.data()[14] = 0.;
+                ndtgpu_host::transformPointCloudInPlace(global_rotation, cloud);
+                Eigen::Vector3d local_centroid = computeLocalCentroid(map_centroid, Tmotion_est.translation(), params_.resolution);
+                ndglobal.loadPointCloudCentroid(cloud, Tinit_sensor_pose.translation(), local_centroid, localMapSize, params_.sensor_range);
+            }
+        } else {
+            if (!params_.globalTransf) ndglobal.guessSize(0, 0, 0, params_.sensor_range, params_.sensor_range, params_.map_size_z);
+            else throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: globalTransf without loadCentroid sizes the scan map from "
+                                                             "the cloud (4 x its radius): not implemented for the reusable scan arena");
+            ndglobal.loadPointCloud(cloud, params_.sensor_range);
+        }
+        ndglobal.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE);
+
+        std::vector<std::pair<int, int> > corr;
+        bool match_ok = true;
+        if (params_.fusion2d) {
+            match_ok = matchFusion2d(*map, ndglobal, nullptr, nullptr, corr, Tmotion_est, true, params_.useNDT, false, params_.stepcontrol,
+                                     params_.ITR_MAX, params_.neighbours, params_.DELTA_SCORE) || params_.fuseIncomplete;
+        } else {
+            match_ok = matchFusion(*map, ndglobal, nullptr, nullptr, corr, Tmotion_est, TmotionCov, true, params_.useNDT, false, params_.stepcontrol,
+                                   params_.ITR_MAX, params_.neighbours, params_.DELTA_SCORE, params_.useSoftConstraints, params_.stepControlFusion,
+                                   params_.useTikhonovRegularization, &last_match) || params_.fuseIncomplete;
+        }
+        if (params_.allMatchesValid) match_ok = true;
+
+        if (match_ok) {
+            if (params_.computeCov) {   // recompute the covariance (based on the matching)
+                lslgeneric::NDTMatcherD2D matcher_d2d;
+                Eigen::MatrixXd matching_cov(6, 6);
+                matcher_d2d.covariance(*map, ndglobal, Tmotion_est, matching_cov);
+                Pose2dCov posecov;
+                posecov.mean = pose2dFromAffine3d(Tmotion_est);
+                posecov.cov = cov6toCov3(matching_cov);
+                pose2dClearDependence(posecov);
+                current_posecov.mean = pose2dFromAffine3d(Tmotion_est);
+                Eigen::Matrix3d prev_cov = current_posecov.cov;
+                current_posecov.cov = prev_cov + posecov.cov;
+            }
+            Eigen::Affine3d diff = (Tmotion_est).inverse() * Tmotion;
+            if ((diff.translation().norm() > params_.max_translation_norm ||
+                 diff.rotation().eulerAngles(0, 1, 2).norm() > params_.max_rotation_norm) && params_.checkConsistency) {
+                fprintf(stderr, "****  NDTFuserHMT -- ALMOST DEFINATELY A REGISTRATION FAILURE *****\n");
+                Tnow = Tnow * Tmotion;
+            } else {
+                if (params_.forceOdomAsEst) Tnow = Tnow * Tmotion;
+                else if (params_.globalTransf) Tnow = Tnow * Tmotion_est;
+                else if (params_.loadCentroid) Tnow = Tmotion_est * global_rotation;   // global_rotation, used with centroids
+                else Tnow = Tmotion_est;
+                Eigen::Affine3d diff_fuse = Tlast_fuse.inverse() * Tnow;
+                if (diff_fuse.translation().norm() > translation_fuse_delta ||
+                    diff_fuse.rotation().eulerAngles(0, 1, 2).norm() > rotation_fuse_delta)
+                    Tlast_fuse = Tnow;
+            }
+        } else {
+            Tnow = Tnow * Tmotion;
+        }
+
+        Eigen::Affine3d spose = Tnow * sensor_pose;
+        ndtgpu_host::transformPointCloudInPlace(spose, cloud_orig);
+        if (updateNDTMap) {
+            map->addPointCloud(spose.translation(), cloud_orig, 0.06, 25);   // keep the raw cloud and add it here
+            map->computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE, 1e5, 255, spose.translation(), 0.1);
+        }
+        return Tnow;
+    }
+
+private:
+    bool isInit;
+    double translation_fuse_delta, rotation_fuse_delta;
+    Eigen::Affine3d sensor_pose;
+    Eigen::Vector3d localMapSize;
+    Pose2dCov current_posecov;
+    std::shared_ptr<ndtgpu_host::MapPool> pool_, scan_pool_;
+    size_t pool_slot_ = 0;
+};
 
 class NDTFeatureLink {
 public:
-    NDTFeatureLink() : ref_idx(0), mov_idx(0), score(0.) {}
-    NDTFeatureLink(size_t ref, size_t mov) : ref_idx(ref), mov_idx(mov), score(0.) {}
-    size_t ref_idx, mov_idx;
-    Affine3d T;                 // from ref -> mov
-    double cov_3d[36] = {0};    // NDTMatcherD2D::covariance is a "next" row; 0.02*I fallback of graph.cpp:300-310
+    NDTFeatureLink() : ref_idx(0), mov_idx(0), cov_3d(6, 6), score(0.) {}
+    NDTFeatureLink(size_t ref, size_t mov) : ref_idx(ref), mov_idx(mov), cov_3d(6, 6), score(0.) {}
+    size_t ref_idx, mov_idx;   // Vector idx...
+    Eigen::Affine3d T;         // From ref->mov.
+    Eigen::Matrix3d cov;
+    Eigen::MatrixXd cov_3d;    // the covariance returned by NDTMatcherD2D::covariance (graph.cpp:296-310, 330)
     double score;
-    bool converged = true;      // replaces the stdin pause of graph.cpp:318-323
+    bool converged = true;     // (added) replaces the stdin pause of graph.cpp:318-323
     int iterations = 0;
-    const Affine3d &getRelPose() const { return T; }
+    const Eigen::Affine3d &getRelPose() const { return T; }
+    const Eigen::Matrix3d &getRelCov() const { return cov; }
     double getScore() const { return score; }
     size_t getRefIdx() const { return ref_idx; }
     size_t getMovIdx() const { return mov_idx; }
+    void force2D() { forceEigenAffine3dTo2dInPlace(this->T); }
 };
 
 class NDTFeatureNode {
 public:
-    std::shared_ptr<lslgeneric::NDTMap> map;   // reference: NDTFeatureFuserHMT* map; map->map is the NDTMap
-    Affine3d T, Tlocal_odom, Tlocal_fuse;
-    int nbUpdates = 0;
-    lslgeneric::NDTMap &getNDTMap() { return *map; }
-    const Affine3d &getPose() const { return T; }
+    NDTFeatureNode() : map(NULL), nbUpdates(0), time_last_update(0) {}
+    NDTFeatureFuserHMT *map;   // owned by the graph (ndt_feature_graph.h:78-88); node copies are shallow like the reference's
+    Eigen::Affine3d T;
+    Eigen::Matrix3d cov;
+    Eigen::Affine3d Tlocal_odom;   // Incremental odometry between successive local maps.
+    Eigen::Affine3d Tlocal_fuse;   // Incremental fuse estimates between sucessive local maps.
+    int nbUpdates;
+    double time_last_update;
+    lslgeneric::NDTMap &getNDTMap() { return *(map->map); }
+    NDTFeatureFuserHMT &getFuser() { return *map; }
+    const Eigen::Affine3d &getPose() const { return T; }
+    void setPose(const Eigen::Affine3d &pose) { T = pose; }
+    const Eigen::Matrix3d &getCov() const { return cov; }
+    void setCov(const Eigen::Matrix3d &c) { cov = c; }
+    void force2D()
+    {
+        forceEigenAffine3dTo2dInPlace(this->T);
+        forceEigenAffine3dTo2dInPlace(this->Tlocal_odom);
+        forceEigenAffine3dTo2dInPlace(this->Tlocal_fuse);
+    }
 };
+
+// ndt_feature::overlapNDTOccupancyScore(ref, mov, T)  (ndt_feature_node.h:213-252), on the device
+inline double overlapNDTOccupancyScore(NDTFeatureNode &ref, NDTFeatureNode &mov, const Eigen::Affine3d &T)
+{
+    uint32_t ri = (uint32_t)ref.getNDTMap().slot(), mi = (uint32_t)mov.getNDTMap().slot();
+    double score = 1.;
+    ndtgpu_host::check(ndtgpu_overlap_score_batch(ref.getNDTMap().handle(), &ri, mov.getNDTMap().handle(), &mi, T.data(), 1, &score, nullptr, nullptr),
+                       "ndtgpu_overlap_score_batch");
+    return score;
+}
 
 class NDTFeatureGraph {
 public:
-    struct Params {
-        double newNodeTranslDist = 1.;   // ndt_feature_graph.h:28
-        double resolution = 1.;          // fuser params (ndt_feature_fuser_hmt.h:63-67)
-        double map_size_x = 40., map_size_y = 40., map_size_z = 10.;
-        double sensor_range = 3.;
-        size_t max_nodes = 64;
-        uint32_t max_cells = 0;
+    class Params {   // ndt_feature_graph.h:24-56
+    public:
+        Params()
+        {
+            newNodeNumberOfFrames = 20;
+            newNodeTranslDist = 1.;
+            storePtsInNodes = false;
+            storePtsInNodesIncr = 8;
+            popNodes = false;
+            maxNodes = 256;
+        }
+        int newNodeNumberOfFrames;
+        double newNodeTranslDist;
+        bool storePtsInNodes;
+        int storePtsInNodesIncr;
+        bool popNodes;
+        size_t maxNodes;   // (added) capacity of the device pool the node maps live in
     };
 
-    explicit NDTFeatureGraph(const Params &p) : params_(p)
+    NDTFeatureGraph() : distance_moved_in_last_node_(0.) {}
+    NDTFeatureGraph(const NDTFeatureGraph::Params &params, const NDTFeatureFuserHMT::Params &fuserParams)
+        : params_(params), fuser_params_(fuserParams), distance_moved_in_last_node_(0.) {}
+    virtual ~NDTFeatureGraph()
     {
-        double c[3] = {0, 0, 0}, s[3] = {p.map_size_x, p.map_size_y, p.map_size_z};
-        pool_ = std::make_shared<ndtgpu_host::MapPool>(p.resolution, c, s, p.max_nodes, p.max_cells);
+        for (auto it = nodes_.begin(); it != nodes_.end(); ++it)
+            if (it->map != NULL) delete it->map;
     }
+    NDTFeatureGraph(const NDTFeatureGraph &) = delete;
+    NDTFeatureGraph &operator=(const NDTFeatureGraph &) = delete;
 
     size_t getNbNodes() const { return nodes_.size(); }
     size_t getNbLinks() const { return links_.size(); }
     NDTFeatureNode &getNode(size_t i) { return nodes_[i]; }
     NDTFeatureLink &getLink(size_t i) { return links_[i]; }
-    lslgeneric::NDTMap *getMap(int i) { return nodes_[i].map.get(); }
-    Affine3d getT() { return nodes_.back().T; }
+    lslgeneric::NDTMap *getMap(int i) { return nodes_[i].map->map; }
+    Eigen::Affine3d getT() { return Tnow; }
+    void setFuserParams(const NDTFeatureFuserHMT::Params &p) { fuser_params_ = p; }
+    void setMotionParams(const MotionModel2d::Params &p) { motion_params_ = p; }
+    void setSensorPose(const Eigen::Affine3d &p) { sensor_pose_ = p; }
     void clearAllLinks() { links_.clear(); }
     void setLinks(const std::vector<NDTFeatureLink> &l) { links_ = l; }
     void appendLinks(const std::vector<NDTFeatureLink> &l) { links_.insert(links_.end(), l.begin(), l.end()); }
     const std::vector<NDTFeatureLink> &getCurrentLinks() { return links_; }
-
-    // New node whose map is built from one cloud in the node frame (the per-scan local map of
-    // NDTFeatureFuserHMT::update, fuser_hmt.cpp:195-227: guessSize + loadPointCloud + computeNDTCells).
-    size_t addNode(const Affine3d &pose, const PointCloud<PointXYZ> &cloud)
+    void force2D()
     {
-        NDTFeatureNode n;
-        n.T = pose;
-        n.map = std::make_shared<lslgeneric::NDTMap>(pool_, pool_->allocate());
-        n.map->guessSize(0, 0, 0, params_.map_size_x, params_.map_size_y, params_.map_size_z);
-        n.map->loadPointCloud(cloud, params_.sensor_range);
-        n.map->computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE);
-        n.nbUpdates = 1;
-        nodes_.push_back(n);
-        return nodes_.size() - 1;
+        for (auto &n : nodes_) n.force2D();
+        for (auto &l : links_) l.force2D();
+    }
+    bool fullInit()
+    {
+        for (size_t i = 0; i < getNbNodes(); ++i)
+            if (nodes_[i].map->wasInit() == false) return false;
+        return true;
     }
 
-    // computeAllPossibleLinks (graph.cpp:395-405) with the odometry-predicted relative pose as link.T
-    // (the reference seeds it from the FLIRT feature match, computeLink :162-177 -- out of scope)
+    // Initialize the first entry of the map (graph.cpp:24-55)
+    void initialize(Eigen::Affine3d initPose, pcl::PointCloud<pcl::PointXYZ> &cloud, const InterestPointVec &pts, bool preLoad = false)
+    {
+        NDTFeatureNode node;
+        node.map = new_fuser();
+        node.T = initPose;
+        node.map->setMotionParams(motion_params_);
+        node.map->setSensorPose(sensor_pose_);
+        initPose.setIdentity();   // keep each map in it's own ref frame (that is node.T)
+        node.map->initialize(initPose, cloud, pts, preLoad);
+        nodes_.push_back(node);
+        Tnow = node.T;
+    }
+
+    // Update the map with new readings, return the current pose in global coordinates (graph.cpp:60-144)
+    Eigen::Affine3d update(Eigen::Affine3d Tmotion, pcl::PointCloud<pcl::PointXYZ> &cloud, const InterestPointVec &pts)
+    {
+        NDTFeatureNode &node = nodes_.back();
+        distance_moved_in_last_node_ += Tmotion.translation().norm();
+        if (distance_moved_in_last_node_ > params_.newNodeTranslDist) {   // start on a new map
+            distance_moved_in_last_node_ = 0.;
+            // the returned pose is the local map coord; do not update the maps in this step
+            Eigen::Affine3d Tnow_local = node.map->update(Tmotion, cloud, pts, false, false);
+            Tnow = node.T * Tnow_local;
+            node.Tlocal_odom = node.Tlocal_odom * Tmotion;
+            node.Tlocal_fuse = Tnow_local;
+            NDTFeatureNode new_node;
+            if (params_.popNodes) {
+                delete nodes_.back().map;
+                nodes_.pop_back();
+                pool_->release_last();
+            }
+            new_node.map = new_fuser();
+            new_node.map->setMotionParams(motion_params_);
+            new_node.map->setSensorPose(sensor_pose_);
+            new_node.T = Tnow;
+            Eigen::Affine3d init_pose;
+            init_pose.setIdentity();
+            new_node.map->initialize(init_pose, cloud, pts, false);   // add the first data
+            nodes_.push_back(new_node);
+            return Tnow;
+        }
+        Eigen::Affine3d Tnow_local = node.map->update(Tmotion, cloud, pts);
+        Tnow = node.T * Tnow_local;
+        node.Tlocal_odom = node.Tlocal_odom * Tmotion;
+        node.Tlocal_fuse = Tnow_local;
+        node.nbUpdates++;
+        return Tnow;
+    }
+
+    // computeLink (graph.cpp:162-177) without the FLIRT feature match that seeds link.T upstream (out of scope): the
+    // relative pose of the node estimates, scored by the occupancy overlap like the reference
+    NDTFeatureLink computeLink(size_t idx_ref, size_t idx_mov)
+    {
+        NDTFeatureLink m(idx_ref, idx_mov);
+        m.T = nodes_[idx_ref].T.inverse() * nodes_[idx_mov].T;
+        m.score = overlapNDTOccupancyScore(nodes_[idx_ref], nodes_[idx_mov], m.T);
+        return m;
+    }
+    // computeAllPossibleLinks (graph.cpp:395-405); the overlap scores of all links in ONE device call
     std::vector<NDTFeatureLink> computeAllPossibleLinks()
     {
         std::vector<NDTFeatureLink> ret;
@@ -126,51 +582,72 @@ public:
             for (size_t j = i + 1; j < nodes_.size(); j++) {
                 NDTFeatureLink m(i, j);
                 m.T = nodes_[i].T.inverse() * nodes_[j].T;
-                m.score = -1.;
                 ret.push_back(m);
             }
+        score_links(ret);
+        return ret;
+    }
+    std::vector<NDTFeatureLink> getIncrementalLinks() const   // graph.cpp:180-204
+    {
+        std::vector<NDTFeatureLink> ret;
+        for (size_t i = 0; i + 1 < nodes_.size(); i++) {
+            NDTFeatureLink m(i, i + 1);
+            m.T = nodes_[i].T.inverse() * nodes_[i + 1].T;
+            m.score = -1.;
+            ret.push_back(m);
+        }
         return ret;
     }
 
     // updateLinkUsingNDTRegistration (graph.cpp:260-345): one link
-    void updateLinkUsingNDTRegistration(NDTFeatureLink &link, int nb_neighbours, bool /*keepScore*/)
+    void updateLinkUsingNDTRegistration(NDTFeatureLink &link, int nb_neighbours, bool keepScore)
     {
         std::vector<NDTFeatureLink> one(1, link);
-        updateLinksUsingNDTRegistration(one, nb_neighbours, true);
+        updateLinksUsingNDTRegistration(one, nb_neighbours, keepScore);
         link = one[0];
     }
-
-    // updateLinksUsingNDTRegistration (graph.cpp:347-353): every link in ONE batched GPU call
-    void updateLinksUsingNDTRegistration(std::vector<NDTFeatureLink> &links, int nb_neighbours, bool /*keepScore*/)
+    // updateLinksUsingNDTRegistration (graph.cpp:347-353): every link's match, covariance and overlap score in three
+    // batched device calls
+    void updateLinksUsingNDTRegistration(std::vector<NDTFeatureLink> &links, int nb_neighbours, bool keepScore)
     {
         const size_t n = links.size();
         if (!n) return;
         std::vector<uint32_t> ti(n), si(n);
-        std::vector<double> T(16 * n);
+        std::vector<double> T(16 * n), before(16 * n), cov(36 * n);
         std::vector<ndtgpu_match_result> res(n);
+        std::vector<int32_t> singular(n);
         for (size_t k = 0; k < n; k++) {
-            ti[k] = (uint32_t)nodes_[links[k].ref_idx].map->slot();
-            si[k] = (uint32_t)nodes_[links[k].mov_idx].map->slot();
-            const double *m = ndtgpu_host::affine_data(links[k].T);
-            for (int q = 0; q < 16; q++) T[16 * k + q] = m[q];
+            ti[k] = (uint32_t)nodes_[links[k].ref_idx].getNDTMap().slot();
+            si[k] = (uint32_t)nodes_[links[k].mov_idx].getNDTMap().slot();
+            const double *m = links[k].T.data();
+            for (int q = 0; q < 16; q++) T[16 * k + q] = before[16 * k + q] = m[q];
         }
         lslgeneric::NDTMatcherD2D matcher_d2d;          // default-constructed, graph.cpp:261
         matcher_d2d.n_neighbours = nb_neighbours;       // graph.cpp:262
         ndtgpu_match_params p = matcher_d2d.params(0x3f, true);
-        ndtgpu_host::check(ndtgpu_match_batch(pool_->handle(), ti.data(), pool_->handle(), si.data(), T.data(), n, &p,
-                                              res.data(), nullptr), "ndtgpu_match_batch");
+        ndtgpu_mapset *pool = pool_->handle();
+        ndtgpu_host::check(ndtgpu_match_batch(pool, ti.data(), pool, si.data(), T.data(), n, &p, res.data(), nullptr), "ndtgpu_match_batch");
+        ndtgpu_host::check(ndtgpu_covariance_batch(pool, ti.data(), pool, si.data(), T.data(), n, &p, matcher_d2d.covariance_mode, cov.data(),
+                                                   singular.data(), nullptr), "ndtgpu_covariance_batch");
         for (size_t k = 0; k < n; k++) {
-            double *m = ndtgpu_host::affine_data(links[k].T);
+            double *m = links[k].T.data();
             bool same = true;
-            for (int q = 0; q < 16; q++) { same = same && (m[q] == T[16 * k + q]); m[q] = T[16 * k + q]; }
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) same = same && (before[16 * k + c * 4 + r] == T[16 * k + c * 4 + r]);
+            for (int q = 0; q < 16; q++) m[q] = T[16 * k + q];
             links[k].converged = res[k].converged != 0;
             links[k].iterations = res[k].iterations;
-            if (same)   // "NOTHING HAPPENED": identity-scaled covariance, graph.cpp:300-310
-                for (int q = 0; q < 36; q++) links[k].cov_3d[q] = (q % 7 == 0) ? 0.02 : 0.0;
+            if (links[k].cov_3d.rows() != 6) links[k].cov_3d.resize(6, 6);
+            for (int a = 0; a < 6; a++)
+                for (int b = 0; b < 6; b++)   // "NOTHING HAPPENED": 0.02 * identity, graph.cpp:300-310
+                    links[k].cov_3d(a, b) = same ? ((a == b) ? 0.02 : 0.0) : cov[36 * k + a * 6 + b];
         }
+        if (!keepScore) score_links(links);             // graph.cpp:335-341
     }
     void updateAllGraphLinksUsingNDTRegistration(int nb_neighbours, bool keepScore)
     {
+        // (the reference updates COPIES of its links here, graph.cpp:249-258: the results are lost; the stored links are
+        //  updated instead)
         updateLinksUsingNDTRegistration(links_, nb_neighbours, keepScore);
     }
 
@@ -184,7 +661,7 @@ public:
             if (std::abs((int)links[i].getMovIdx() - (int)links[i].getRefIdx()) < minIdxDist) continue;
             const NDTFeatureNode &ref_node = nodes_[links[i].getRefIdx()];
             const NDTFeatureNode &mov_node = nodes_[links[i].getMovIdx()];
-            Affine3d Tlink = ref_node.T * links[i].T;
+            Eigen::Affine3d Tlink = ref_node.T * links[i].T;
             double dist, angular_dist;
             distanceBetweenAffine3d(mov_node.T, Tlink, dist, angular_dist);
             if (dist < maxDist && angular_dist < maxAngularDist) ret.push_back(links[i]);
@@ -193,11 +670,40 @@ public:
     }
 
     Params params_;
+    NDTFeatureFuserHMT::Params fuser_params_;
+    MotionModel2d::Params motion_params_;
 
 protected:
+    NDTFeatureFuserHMT *new_fuser()
+    {
+        if (!pool_) {
+            const double c[3] = {0, 0, 0}, s[3] = {fuser_params_.map_size_x, fuser_params_.map_size_y, fuser_params_.map_size_z};
+            pool_ = std::make_shared<ndtgpu_host::MapPool>(fuser_params_.resolution, c, s, params_.maxNodes);
+        }
+        return new NDTFeatureFuserHMT(fuser_params_, pool_, pool_->allocate());
+    }
+    void score_links(std::vector<NDTFeatureLink> &links)
+    {
+        const size_t n = links.size();
+        if (!n) return;
+        std::vector<uint32_t> ri(n), mi(n);
+        std::vector<double> T(16 * n), score(n);
+        for (size_t k = 0; k < n; k++) {
+            ri[k] = (uint32_t)nodes_[links[k].ref_idx].getNDTMap().slot();
+            mi[k] = (uint32_t)nodes_[links[k].mov_idx].getNDTMap().slot();
+            const double *m = links[k].T.data();
+            for (int q = 0; q < 16; q++) T[16 * k + q] = m[q];
+        }
+        ndtgpu_host::check(ndtgpu_overlap_score_batch(pool_->handle(), ri.data(), pool_->handle(), mi.data(), T.data(), n, score.data(), nullptr, nullptr),
+                           "ndtgpu_overlap_score_batch");
+        for (size_t k = 0; k < n; k++) links[k].score = score[k];
+    }
+
     std::shared_ptr<ndtgpu_host::MapPool> pool_;
     std::vector<NDTFeatureNode> nodes_;
     std::vector<NDTFeatureLink> links_;
+    Eigen::Affine3d sensor_pose_, Tnow;
+    double distance_moved_in_last_node_;
 };
 
 }  // namespace ndt_feature

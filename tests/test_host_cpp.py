@@ -1,6 +1,8 @@
-"""The C++ host mirror (ndt_feature_graph_amd/host/*.h: lslgeneric::NDTMap / NDTMatcherD2D and
-ndt_feature::NDTFeatureGraph over the C-ABI) compiles with plain g++ and behaves: without a GPU it
-fails loudly, with a GPU it registers all node pairs in one batch and recovers the known poses."""
+"""The C++ host mirror (ndt_feature_graph_amd/host/*.h: lslgeneric::NDTMap / NDTMatcherD2D[_2D] and
+ndt_feature::NDTFeatureFuserHMT / NDTFeatureGraph over the C-ABI) compiles with plain g++ and behaves: without a GPU it
+fails loudly; with a GPU host_demo.cpp drives the graph front door over a trajectory, refines all links in batched
+calls, and runs the reference's Newton loop (ndt_matcher_d2d_fusion.h:847-1121) RE-TYPED against the mirror -- one
+ndtgpu_derivatives call per evaluation -- landing on the device-resident matchFusion's pose."""
 import os
 import subprocess
 
@@ -33,4 +35,5 @@ def test_host_demo_on_gpu():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "0 failures" in out.stdout and "batch==single 1" in out.stdout
+    assert "0 failures in total" in out.stdout and "batch==single 1" in out.stdout
+    assert "A: " in out.stdout and "C: soft=1" in out.stdout
