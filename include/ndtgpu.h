@@ -86,7 +86,8 @@ typedef struct {
     int32_t converged;  /* return value of match(): 0 = iteration cap hit */
     int32_t iterations; /* itr_ctr at exit */
     int32_t fevals;     /* derivativesNDT evaluations */
-    int32_t exit_code;  /* 0 step<delta, 1 gradient vanished, 2 wrong direction, 3 iteration cap */
+    int32_t exit_code;  /* 0 step<delta, 1 gradient vanished, 2 wrong direction, 3 iteration cap;
+                         * not run (device-pointer batches): -2 map index out of range, -3 a map overflowed max_cells */
     double score;       /* score at the returned pose */
     int32_t n_source;   /* Gaussian cells in the source map */
     int32_t n_target;
@@ -213,8 +214,12 @@ ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *targ
                                  const ndtgpu_match_params *prm, ndtgpu_match_result *results,
                                  ndtgpu_stream stream);
 /* device-resident variant for pipelines: T16_dev / results_dev are DEVICE buffers, idx arrays
- * DEVICE uint32; asynchronous on `stream`, no host synchronisation (the set's work area -- ticket counters,
- * parked solver states -- is allocated by the first call of a given batch size).  Always the persistent kernel. */
+ * DEVICE uint32; asynchronous on `stream`, no host synchronisation.  Always the persistent kernel (a batch of a few
+ * very large maps is better served by ndtgpu_match_batch, which spreads a registration over several CUs).
+ * The indices are range-checked on the device and a map whose build overflowed max_cells is refused: such a pair gets
+ * converged = 0 and exit_code -2 / -3, its pose stays untouched.  The work area (ticket counters, parked solver
+ * states) belongs to the TARGET set: calls on different streams with the same target set are ordered by an event;
+ * builds of the involved maps must be ordered before the call by the caller (same stream, or an event). */
 ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *target_set, const uint32_t *target_idx_dev,
                                         ndtgpu_mapset *source_set, const uint32_t *source_idx_dev,
                                         double *T16_dev, size_t n_pairs, const ndtgpu_match_params *prm,

@@ -65,6 +65,7 @@ struct NdtMapCounters {        // per map, device resident
 
 struct NdtSetView {            // what kernels see of a mapset
     NdtGrid grid;
+    uint32_t n_maps;
     int32_t *table;            // [n_maps][slots]      slot -> cell rank, -1 = no Gaussian
     uint2 *rankmap;            // [n_maps][rm_stride]  per 32 slots: {.x = Gaussian-cell bits, .y = rank of the word's
                                //                      first Gaussian cell (valid when .x != 0)}: what the matcher probes
@@ -142,10 +143,11 @@ hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const Ndt
                                     hipStream_t stream);
 size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups);
 size_t ndt_match_coop_work_bytes(size_t n_groups);
+unsigned ndt_match_coop_capacity(int n_neighbours);
 hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
-                                 const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                                 NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups,
-                                 unsigned cells_per_group, void *work_dev, hipStream_t stream);
+                                 const uint32_t *sidx_dev, double *T16_dev, size_t pair_begin, size_t pair_count,
+                                 const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
+                                 unsigned n_groups, unsigned cells_per_group, void *work_dev, hipStream_t stream);
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
                             NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters,

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
 {
     __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     __shared__ MatchState st;
-    __shared__ int s_job, s_next;
+    __shared__ int s_job, s_next, s_skip;
     // per-registration state that outlives an evaluation sits in LDS, not in registers: the evaluation needs ~220
     // VGPRs, and what is live across it would be spilled to scratch memory
     __shared__ MapView s_tg, s_sv;
@@ -462,6 +462,21 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
         const bool resumed = job <= -2;
         const unsigned pair = resumed ? (unsigned)(-2 - job) : (unsigned)job;
 
+        if (threadIdx.x == 0) {
+            // the indices and the maps come from device memory the host never saw: check them here
+            const uint32_t ti = tidx[pair], si = sidx[pair];
+            const bool bad_index = ti >= tset.n_maps || si >= sset.n_maps;
+            const bool truncated = !bad_index && (tset.counters[ti].overflow != 0u || sset.counters[si].overflow != 0u);
+            s_skip = 0;
+            if (bad_index || truncated) {
+                NdtMatchResultDev o = {};
+                o.exit_code = bad_index ? -2 : -3;     // -2 map index out of range, -3 a map needed more cells than max_cells
+                res[pair] = o;                         // (converged = 0; the pose is left untouched)
+                s_skip = 1;
+            }
+        }
+        __syncthreads();
+        if (s_skip) { __syncthreads(); continue; }
         if (threadIdx.x == 0) {
             s_tg = map_view(tset, tidx[pair]);
             s_sv = map_view(sset, sidx[pair]);
@@ -745,17 +760,18 @@ template <int NN>
 __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
     double *__restrict__ T16_all, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res_all,
-    const double *__restrict__ Q36_all, char *__restrict__ work_all, size_t work_stride, unsigned cells_per_group)
+    const double *__restrict__ Q36_all, char *__restrict__ work_all, size_t work_stride, unsigned cells_per_group,
+    unsigned pair_begin)
 {
     __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     __shared__ MatchState st;       // workgroup 0 only
     __shared__ rigid s_T;
     __shared__ int s_with_h, s_done;
 
-    // blockIdx.y = registration: its gridDim.x workgroups have their own control block and barrier.  Workgroups
-    // are dispatched x-fastest, so the workgroups of one registration become resident together; registrations
-    // whose workgroups are all resident always finish and free their CUs for the next ones.
-    const unsigned pair = blockIdx.y;
+    // blockIdx.y = registration: its gridDim.x workgroups have their own control block and barrier.  The launch is a
+    // cooperative one sized by the occupancy query: every workgroup of the grid is resident, so no barrier can wait
+    // for a workgroup that has not started.
+    const unsigned pair = pair_begin + blockIdx.y;
     char *work_mem = work_all + (size_t)pair * work_stride;
     double *T16 = T16_all + (size_t)pair * 16;
     NdtMatchResultDev *res = res_all + pair;
@@ -839,27 +855,47 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     }
 }
 
-hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
-                                 const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                                 NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups,
-                                 unsigned cells_per_group, void *work_dev, hipStream_t stream)
+// Workgroups of the cooperative matcher that can be resident at once (occupancy query x CUs): the grid barrier of a
+// launch is only safe when the whole grid is co-resident.
+unsigned ndt_match_coop_capacity(int n_neighbours)
 {
-    const size_t stride = ndt_match_coop_work_bytes(n_groups);
-    hipError_t e = hipMemset2DAsync(work_dev, stride, 0, sizeof(NdtCoopCtrl), n_pairs, stream);
-    if (e != hipSuccess) return e;
-#define NDT_LAUNCH_COOP(NN)                                                                                           \
-    hipLaunchKernelGGL(ndt_match_coop_kernel<NN>, dim3(n_groups, (unsigned)n_pairs), dim3(NDT_MATCH_THREADS), 0, stream, \
-                       tset, tidx_dev, sset, sidx_dev, T16_dev, prm, res_dev, Q36_dev, (char *)work_dev, stride,       \
-                       cells_per_group)
+    int dev = 0, n_cu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        return 0;
+    hipError_t e;
+    switch (n_neighbours) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ndt_match_coop_kernel<0>, NDT_MATCH_THREADS, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ndt_match_coop_kernel<1>, NDT_MATCH_THREADS, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ndt_match_coop_kernel<2>, NDT_MATCH_THREADS, 0); break;
+    case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ndt_match_coop_kernel<3>, NDT_MATCH_THREADS, 0); break;
+    default: return 0;
+    }
+    if (e != hipSuccess || per_cu <= 0) return 0;
+    if (per_cu > 1) per_cu = 1;     // 85 KB of LDS and 8 x 256 VGPRs: one workgroup per CU, whatever the query says at an edge
+    return (unsigned)(per_cu * n_cu);
+}
+
+// ONE cooperative launch (hipLaunchCooperativeKernel: the runtime checks the grid against the occupancy and refuses
+// what cannot be co-resident) for pairs [pair_begin, pair_begin + pair_count).  The caller has cleared the control blocks.
+hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
+                                 const uint32_t *sidx_dev, double *T16_dev, size_t pair_begin, size_t pair_count,
+                                 const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
+                                 unsigned n_groups, unsigned cells_per_group, void *work_dev, hipStream_t stream)
+{
+    size_t stride = ndt_match_coop_work_bytes(n_groups);
+    NdtSetView ts = tset, ss = sset;
+    NdtMatchParamsDev p = prm;
+    char *work = (char *)work_dev;
+    unsigned pb = (unsigned)pair_begin;
+    void *args[] = {&ts, &tidx_dev, &ss, &sidx_dev, &T16_dev, &p, &res_dev, &Q36_dev, &work, &stride, &cells_per_group, &pb};
+    const dim3 grid(n_groups, (unsigned)pair_count), block(NDT_MATCH_THREADS);
     switch (prm.n_neighbours) {
-    case 0: NDT_LAUNCH_COOP(0); break;
-    case 1: NDT_LAUNCH_COOP(1); break;
-    case 2: NDT_LAUNCH_COOP(2); break;
-    case 3: NDT_LAUNCH_COOP(3); break;
+    case 0: return hipLaunchCooperativeKernel((const void *)ndt_match_coop_kernel<0>, grid, block, args, 0, stream);
+    case 1: return hipLaunchCooperativeKernel((const void *)ndt_match_coop_kernel<1>, grid, block, args, 0, stream);
+    case 2: return hipLaunchCooperativeKernel((const void *)ndt_match_coop_kernel<2>, grid, block, args, 0, stream);
+    case 3: return hipLaunchCooperativeKernel((const void *)ndt_match_coop_kernel<3>, grid, block, args, 0, stream);
     default: return hipErrorInvalidValue;
     }
-#undef NDT_LAUNCH_COOP
-    return hipGetLastError();
 }
 
 hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,

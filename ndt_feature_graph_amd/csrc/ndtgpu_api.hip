@@ -54,6 +54,9 @@ struct ndtgpu_mapset {
     // matcher work area: ticket counters, parked list, parked solver states
     void *work = nullptr;
     size_t work_bytes = 0;
+    hipEvent_t work_ev = nullptr;      // recorded after the last launch that uses `work`
+    bool work_ev_valid = false;
+    hipStream_t work_stream = nullptr;
     // profiling hooks: [0,1] bracket the build kernel, [2,3] the match kernel
     bool profiling = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -129,6 +132,7 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
     ndtgpu_mapset *s = new (std::nothrow) ndtgpu_mapset();
     if (!s) return fail(NDTGPU_ERR_ALLOC, "mapset_create: host alloc");
     s->n_maps = n_maps;
+    s->v.n_maps = (uint32_t)n_maps;
     NdtGrid &g = s->v.grid;
     g.res = grid->res;
     long long slots = 1;
@@ -197,6 +201,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (s->v.cell_sel) (void)hipFree(s->v.cell_sel);
     if (s->stage) (void)hipFree(s->stage);
     if (s->work) (void)hipFree(s->work);
+    if (s->work_ev) (void)hipEventDestroy(s->work_ev);
     if (s->origins_dev) (void)hipFree(s->origins_dev);
     for (int k = 0; k < 4; k++)
         if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
@@ -602,49 +607,76 @@ static NdtMatchParamsDev to_dev(const ndtgpu_match_params *p)
 
 static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result layouts must agree");
 
-static ndtgpu_status match_device_q(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
-                                    const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
-                                    const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
-                                    const double *Q36_dev, int fusion_flags, ndtgpu_stream stream);
+// The persistent matcher on device-resident arguments: asynchronous on `stream`.
+static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss, const uint32_t *sidx_dev,
+                                       double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &p,
+                                       ndtgpu_match_result *results_dev, const double *Q36_dev, hipStream_t st)
+{
+    if (n_pairs == 0) return NDTGPU_OK;
+    // one persistent workgroup per CU (the kernel's registers and LDS allow exactly one); pairs are pulled from
+    // a ticket counter.  NDTGPU_PARK_ITERS: iterations after which a long registration yields to a fresh pair.
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    const char *park_env = getenv("NDTGPU_PARK_ITERS");       // read per call: tests switch it
+    const int park_iters = park_env ? atoi(park_env) : 6;
+    const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
+    // The work area (ticket counters, parked solver states) belongs to the target set: a launch on another stream
+    // waits for the previous one, and growing the area waits for everything that may still use the old one.
+    if (ts->work_ev_valid && ts->work_stream != st) HIP_TRY(hipStreamWaitEvent(st, ts->work_ev, 0));
+    const size_t need = ndt_match_work_bytes(n_pairs, n_groups);
+    if (need > ts->work_bytes && ts->work_ev_valid) HIP_TRY(hipEventSynchronize(ts->work_ev));
+    ndtgpu_status wrc = ts->ensure_work(need);
+    if (wrc != NDTGPU_OK) return wrc;
+    if (ts->profiling) HIP_TRY(hipEventRecord(ts->ev[2], st));
+    hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
+                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, n_groups, park_iters,
+                                    ts->work, st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
+    if (ts->profiling) { HIP_TRY(hipEventRecord(ts->ev[3], st)); ts->ev_valid[1] = true; }
+    if (!ts->work_ev) HIP_TRY(hipEventCreateWithFlags(&ts->work_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ts->work_ev, st));
+    ts->work_ev_valid = true;
+    ts->work_stream = st;
+    return NDTGPU_OK;
+}
 
 ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
                                         const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
                                         const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
                                         ndtgpu_stream stream)
 {
-    return match_device_q(ts, tidx_dev, ss, sidx_dev, T16_dev, n_pairs, prm, results_dev, nullptr, 0, stream);
-}
-
-static ndtgpu_status match_device_q(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
-                                    const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
-                                    const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
-                                    const double *Q36_dev, int fusion_flags, ndtgpu_stream stream)
-{
     if (!ts || !ss || (n_pairs && (!tidx_dev || !sidx_dev || !T16_dev || !results_dev)))
         return fail(NDTGPU_ERR_INVALID, "match_batch_device: bad argument");
     NdtMatchParamsDev p = to_dev(prm);
-    p.fusion_flags = fusion_flags;
+    p.fusion_flags = 0;
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
-    if (n_pairs == 0) return NDTGPU_OK;
-    // one persistent workgroup per CU (the kernel's registers and LDS allow exactly one); pairs are pulled from
-    // a ticket counter.  NDTGPU_PARK_ITERS: iterations after which a long registration yields to a fresh pair.
-    static const int n_cu = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    const char *park_env = getenv("NDTGPU_PARK_ITERS");       // read per call: tests switch it
-    const int park_iters = park_env ? atoi(park_env) : 6;
-    const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
-    ndtgpu_status wrc = ts->ensure_work(ndt_match_work_bytes(n_pairs, n_groups));
-    if (wrc != NDTGPU_OK) return wrc;
-    if (ts->profiling) HIP_TRY(hipEventRecord(ts->ev[2], (hipStream_t)stream));
-    hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
-                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, n_groups, park_iters,
-                                    ts->work, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
-    if (ts->profiling) { HIP_TRY(hipEventRecord(ts->ev[3], (hipStream_t)stream)); ts->ev_valid[1] = true; }
+    return match_device_core(ts, tidx_dev, ss, sidx_dev, T16_dev, n_pairs, p, results_dev, nullptr, (hipStream_t)stream);
+}
+
+// host arrays -> staging -> persistent matcher -> host arrays; synchronous
+static ndtgpu_status match_persistent_host(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                           double *T16, size_t n_pairs, const NdtMatchParamsDev &p, const double *Q36,
+                                           ndtgpu_match_result *results, hipStream_t st)
+{
+    size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
+    size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
+           off_si = (off_ti + bI + 255) & ~(size_t)255, off_Q = (off_si + bI + 255) & ~(size_t)255,
+           total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
+    ndtgpu_status rc = ts->ensure_stage(total);
+    if (rc != NDTGPU_OK) return rc;
+    char *base = (char *)ts->stage;
+    HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
+    if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
+    rc = match_device_core(ts, (const uint32_t *)(base + off_ti), ss, (const uint32_t *)(base + off_si), (double *)base, n_pairs, p,
+                           (ndtgpu_match_result *)(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr, st);
+    if (rc != NDTGPU_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return NDTGPU_OK;
 }
 
@@ -699,7 +731,7 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
     return NDTGPU_OK;
 }
 
-// Batches that cannot fill the chip with one workgroup per registration: ONE cooperative launch, n_groups workgroups
+// Batches that cannot fill the chip with one workgroup per registration: cooperative launches, n_groups workgroups
 // per registration (csrc/ndt_match.hip ndt_match_coop_kernel): the group evaluates, its workgroup 0 solves, no
 // host round trip per evaluation.  Returns NDTGPU_OK with *done = false when one workgroup per registration is
 // the better shape (the caller then uses the persistent kernel).
@@ -747,21 +779,57 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
     if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
-    // Two cooperative launches in flight at once (two host threads, two streams) could each hold part of the chip
-    // and wait for the rest: one at a time per process; the call is synchronous anyway.
+    // Cooperative launches sized by the occupancy query: as many registrations per launch as fit on the chip together
+    // (`groups` workgroups each), launch after launch on the same stream.  One cooperative launch at a time per
+    // process: two of them (two host threads, two streams) could each hold part of the chip and wait for the rest.
+    const unsigned capacity = ndt_match_coop_capacity(p.n_neighbours);
+    if (capacity == 0) return NDTGPU_OK;                                          // no occupancy figure: persistent kernel instead
+    if (groups > capacity) groups = capacity;
+    const size_t per_launch = std::max<size_t>(1, capacity / groups);
+    HIP_TRY(hipMemset2DAsync(ts->work, stride, 0, 64 + 16 * 16 * sizeof(unsigned), n_pairs, st));   // control blocks (NdtCoopCtrl)
     static std::mutex coop_mutex;
-    std::lock_guard<std::mutex> coop_lock(coop_mutex);
-    hipError_t e = ndt_launch_match_coop(ts->v, (const uint32_t *)(base + off_ti), ss->v, (const uint32_t *)(base + off_si),
-                                         (double *)base, n_pairs, p, reinterpret_cast<NdtMatchResultDev *>(base + off_R),
-                                         Q36 ? (const double *)(base + off_Q) : nullptr, groups, per_group, ts->work, st);
-    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: cooperative launch", e);
     std::vector<unsigned> ctrl(n_pairs * 4);
-    HIP_TRY(hipMemcpy2DAsync(ctrl.data(), 16, ts->work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
+    {
+        std::lock_guard<std::mutex> coop_lock(coop_mutex);
+        for (size_t b0 = 0; b0 < n_pairs; b0 += per_launch) {
+            hipError_t e = ndt_launch_match_coop(ts->v, (const uint32_t *)(base + off_ti), ss->v, (const uint32_t *)(base + off_si),
+                                                 (double *)base, b0, std::min(per_launch, n_pairs - b0), p,
+                                                 reinterpret_cast<NdtMatchResultDev *>(base + off_R),
+                                                 Q36 ? (const double *)(base + off_Q) : nullptr, groups, per_group, ts->work, st);
+            if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: cooperative launch", e);
+        }
+        HIP_TRY(hipMemcpy2DAsync(ctrl.data(), 16, ts->work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    // A registration whose grid barrier gave up (it cannot with a co-resident grid; the bounded spin stays as a guard
+    // against a foreign kernel holding CUs) is run again on the persistent kernel: the call does not fail.
+    std::vector<size_t> bad;
+    for (size_t k = 0; k < n_pairs; k++)
+        if (ctrl[4 * k + 1]) bad.push_back(k);
+    std::vector<double> Tin;
+    if (!bad.empty()) {
+        Tin.resize(16 * bad.size());
+        for (size_t j = 0; j < bad.size(); j++) memcpy(&Tin[16 * j], T16 + 16 * bad[j], 16 * sizeof(double));
+    }
     HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    for (size_t k = 0; k < n_pairs; k++)
-        if (ctrl[4 * k + 1]) return fail(NDTGPU_ERR_HIP, "match: cooperative kernel gave up waiting at a grid barrier");
+    if (!bad.empty()) {
+        std::vector<uint32_t> bt(bad.size()), bs(bad.size());
+        std::vector<double> bQ;
+        std::vector<ndtgpu_match_result> br(bad.size());
+        for (size_t j = 0; j < bad.size(); j++) { bt[j] = tidx[bad[j]]; bs[j] = sidx[bad[j]]; }
+        if (Q36) {
+            bQ.resize(36 * bad.size());
+            for (size_t j = 0; j < bad.size(); j++) memcpy(&bQ[36 * j], Q36 + 36 * bad[j], 36 * sizeof(double));
+        }
+        rc = match_persistent_host(ts, bt.data(), ss, bs.data(), Tin.data(), bad.size(), p, Q36 ? bQ.data() : nullptr, br.data(), st);
+        if (rc != NDTGPU_OK) return rc;
+        for (size_t j = 0; j < bad.size(); j++) {
+            memcpy(T16 + 16 * bad[j], &Tin[16 * j], 16 * sizeof(double));
+            results[bad[j]] = br[j];
+        }
+    }
     *done = true;
     return NDTGPU_OK;
 }
@@ -844,25 +912,9 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
         ndtgpu_status crc = match_coop(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st, &done);
         if (crc != NDTGPU_OK || done) return crc;
     }
-    size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
-    size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
-           off_si = (off_ti + bI + 255) & ~(size_t)255, off_Q = (off_si + bI + 255) & ~(size_t)255,
-           total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
-    ndtgpu_status rc = ts->ensure_stage(total);
-    if (rc != NDTGPU_OK) return rc;
-    char *base = (char *)ts->stage;
-    HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
-    if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
-    rc = match_device_q(ts, (const uint32_t *)(base + off_ti), ss, (const uint32_t *)(base + off_si), (double *)base,
-                        n_pairs, prm, (ndtgpu_match_result *)(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr,
-                        fusion_flags, stream);
-    if (rc != NDTGPU_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return NDTGPU_OK;
+    NdtMatchParamsDev pp = to_dev(prm);
+    pp.fusion_flags = fusion_flags;
+    return match_persistent_host(ts, tidx, ss, sidx, T16, n_pairs, pp, Q36, results, st);
 }
 
 ndtgpu_status ndtgpu_covariance_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,

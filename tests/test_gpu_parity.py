@@ -579,6 +579,39 @@ def test_match_fusion_tikhonov_parity(N, O):
         assert max(pose_close(Tp[b], Tb[b])[0] for b in range(B)) > 1e-6        # the regulariser changes the result
 
 
+def test_device_pointer_batch_checks_indices_and_overflow(N):
+    """ndtgpu_match_batch_device takes its indices from device memory: an index out of range and a map whose build
+    overflowed max_cells are refused per pair (exit codes -2 / -3, pose untouched), the other pairs are registered."""
+    import torch
+    from ndt_feature_graph_amd import binding, synth
+    pr = synth.pair_2d([1, 2, 3], 20000)
+    dev = torch.device("cuda", 0)
+    tg = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=3)
+    sr = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=3)
+    small = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=3, max_cells=16)
+    tg.build(pr["fixed"].numpy(), range_limit=30.0)
+    sr.build(pr["moving"].numpy(), range_limit=30.0)
+    small.build(pr["moving"].numpy(), range_limit=30.0)          # overflows: 16 cells are not enough
+    T0 = pr["T_init"].transpose(1, 2).contiguous().reshape(3, 16).to(dev)
+    st = torch.cuda.current_stream()
+
+    def run(sset, tidx, sidx):
+        T16 = T0.clone()
+        res = torch.zeros((3, 64), dtype=torch.uint8, device=dev)
+        binding.match_batch_device(tg, torch.tensor(tidx, dtype=torch.int32, device=dev), sset,
+                                   torch.tensor(sidx, dtype=torch.int32, device=dev), T16, res, 3, stream=st)
+        torch.cuda.synchronize()
+        return T16.cpu().numpy(), res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(3)
+    Tg, rg = run(sr, [0, 1, 2], [0, 1, 2])
+    assert np.all(rg["exit_code"] >= 0) and np.all(rg["iterations"] > 0)
+    Tb, rb = run(sr, [0, 7, 2], [0, 1, 99])                      # pair 1: target index, pair 2: source index out of range
+    assert rb["exit_code"][1] == -2 and rb["exit_code"][2] == -2 and rb["converged"][1] == 0
+    assert np.array_equal(Tb[1], T0[1].cpu().numpy()) and np.array_equal(Tb[2], T0[2].cpu().numpy())
+    assert np.array_equal(Tb[0], Tg[0]) and rb["exit_code"][0] == rg["exit_code"][0]
+    To, ro = run(small, [0, 1, 2], [0, 1, 2])
+    assert np.all(ro["exit_code"] == -3) and np.array_equal(To, T0.cpu().numpy())
+
+
 def test_config4_replay_small(N, O):
     """configs[3] at CI size: a short trajectory of nodes in one building, one NDT map per node, ALL node
     pairs as candidate edges (NDTFeatureGraph::computeAllPossibleLinks order), edges dealt block-cyclically
