@@ -860,8 +860,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
 unsigned ndt_match_coop_capacity(int n_neighbours)
 {
     int dev = 0, n_cu = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-        return 0;
+    if (n_neighbours < 0 || n_neighbours > 3 || hipGetDevice(&dev) != hipSuccess) return 0;
+    static unsigned cache[16][4];      // the query costs tens of microseconds: once per device and kernel
+    if (dev >= 0 && dev < 16 && cache[dev][n_neighbours]) return cache[dev][n_neighbours];
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) return 0;
     hipError_t e;
     switch (n_neighbours) {
     case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ndt_match_coop_kernel<0>, NDT_MATCH_THREADS, 0); break;
@@ -872,6 +874,7 @@ unsigned ndt_match_coop_capacity(int n_neighbours)
     }
     if (e != hipSuccess || per_cu <= 0) return 0;
     if (per_cu > 1) per_cu = 1;     // 85 KB of LDS and 8 x 256 VGPRs: one workgroup per CU, whatever the query says at an edge
+    if (dev >= 0 && dev < 16) cache[dev][n_neighbours] = (unsigned)(per_cu * n_cu);
     return (unsigned)(per_cu * n_cu);
 }
 

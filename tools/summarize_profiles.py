@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/prof_* (rocprofv3 CSV) into the committed profiles/rNN_* summaries.
-usage: python tools/summarize_profiles.py r01"""
+usage: python tools/summarize_profiles.py r02"""
 import collections, csv, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 # kernel stats
@@ -31,7 +31,10 @@ def pmc(dirname):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 fetch, write, sq = pmc("prof_fetch"), pmc("prof_write"), pmc("prof_sq")
-out = {"command": "python bench.py --steps 10 --warmup 2 --no-cpu (1024 pairs x 100k pts, two-buffer pipeline; *_serial: same with --no-pipeline)",
+sys.path.insert(0, root)
+from ndt_feature_graph_amd import binding
+out = {"round": tag, "lib_version": binding.lib().ndtgpu_version().decode(),   # bench.py refuses a summary of another binary
+       "command": "python bench.py --steps 10 --warmup 2 --no-cpu (1024 pairs x 100k pts, two-buffer pipeline; *_serial: same with --no-pipeline)",
        "note": "FETCH_SIZE / WRITE_SIZE are in KB per dispatch (rocprofv3, separate --pmc passes, --kernel-include-regex ndt_). "
                "On gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM): "
                "hbm_read_bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken at face value (uncalibrated).",
