@@ -160,11 +160,13 @@ NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int s
 // MODE 1: accumulate only, gridDim.x workgroups share one map (gridDim.y maps): a single scan or a small
 //         batch then streams on many CUs; the atomics are memory-side, hence coherent across XCDs
 // MODE 2: finalise only (phases 0, B, C, D), one workgroup per map, after a MODE 1 launch
+// (no minimum-waves hint: __launch_bounds__(256, 2) halves the speed of phase A although the register count stays at
+//  250 -- measured 1.79 vs 0.94 ms -- and 3 / 4 waves per SIMD spill: 2.53 / 1.92 ms)
 template <int STRIDE_DW, int MODE>
 __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) void ndt_build_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
     size_t map_stride_bytes, double range_limit, const double *__restrict__ range_origins, int n_min,
-    double eval_factor, int s1_shift, int s2_shift, int dbg, float z_max32)
+    double eval_factor, int s1_shift, int s2_shift, int dbg, float z_max32, int nice)
 {
     constexpr int SD = STRIDE_DW ? STRIDE_DW : 3;
     constexpr int LANE_DW = NDT_PPL * SD + 1;          // +1: odd stride -> conflict-free per-lane walks
@@ -220,6 +222,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     const float kx32 = (float)(0.5 + hx - cx * inv_res), ky32 = (float)(0.5 + hy - cy * inv_res),
                 kz32 = (float)(0.5 + hz - cz * inv_res);
     const float ox32 = (float)ox, oy32 = (float)oy, oz32 = (float)oz;
+    // `nice` grids (the launcher checked it for every map of the launch): res and every cell origin c + (k - size/2) res
+    // are fp32 numbers.  Then origin32 = fma(k, res32, c0) is exact, and so is the fp32 difference p - origin32 (the point
+    // lies within a cell of its origin, and |origin| >= res or origin == 0: the difference needs no more bits than p has):
+    // the offset of a point from its cell origin costs three fp32 operations instead of five fp64 ones per axis.
+    const float res32 = (float)res;
+    const float c0x32 = (float)(cx - hx * res), c0y32 = (float)(cy - hy * res), c0z32 = (float)(cz - hz * res);
     const float r2 = (float)(range_limit * range_limit);
     const float r2eff = range_limit > 0 ? r2 : __builtin_inff();
     const float r2band = range_limit > 0 ? 1e-3f * r2 : -1.0f;
@@ -469,9 +477,16 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             }
             NDT_QS(0)
             // offset from the point's own cell origin: |d| <= one cell, no cancellation later on
-            const double x = (double)fx - (cx + ((double)ix - hx) * res);
-            const double y = (double)fy - (cy + ((double)iy - hy) * res);
-            const double z = (double)fz - (cz + ((double)iz - hz) * res);
+            double x, y, z;
+            if (nice) {
+                x = (double)(fx - fmaf((float)ix, res32, c0x32));
+                y = (double)(fy - fmaf((float)iy, res32, c0y32));
+                z = (double)(fz - fmaf((float)iz, res32, c0z32));
+            } else {
+                x = (double)fx - (cx + ((double)ix - hx) * res);
+                y = (double)fy - (cy + ((double)iy - hy) * res);
+                z = (double)fz - (cz + ((double)iz - hz) * res);
+            }
             const bool in0 = slot == cs0, in1 = slot == cs1;          // cs0 / cs1 are never -1
             if (in0) {
                 rn += 1.0;
@@ -850,9 +865,27 @@ extern "C" __global__ void ndt_install_cells_kernel(NdtSetView set, unsigned map
     }
 }
 
+bool ndt_grid_is_nice(const NdtGrid &g, const double centre[3])
+{
+    const double res = g.res;
+    if ((double)(float)res != res || !(res > 0)) return false;
+    // res = odd * 2^e: (m + k) * res is an fp32 number when |m + k| * odd < 2^24
+    int e = 0;
+    double mant = frexp(res, &e);                 // res = mant * 2^e, mant in [0.5, 1)
+    double odd = mant * 16777216.0;               // a 24-bit integer (res is an fp32 number)
+    while (odd != 0.0 && fmod(odd, 2.0) == 0.0) odd /= 2.0;
+    for (int a = 0; a < 3; a++) {
+        const double c0 = centre[a] - (g.size[a] / 2.0) * res;
+        const double q = c0 / res;
+        if (q != rint(q) || q * res != c0) return false;          // the lattice of cell origins passes through c0 = q res
+        if ((fabs(q) + (double)g.size[a] + 1.0) * odd >= 16777216.0) return false;
+    }
+    return true;
+}
+
 hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                             size_t stride_bytes, size_t map_stride_bytes, double range_limit,
-                            const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream)
+                            const double *range_origins_dev, int n_min, double eval_factor, int nice, hipStream_t stream)
 {
     if (count == 0) return hipSuccess;
     // scales that keep every accumulator an exact integer below 2^53.  Even grid sizes: |u| <= 1/2
@@ -886,7 +919,7 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
 #define NDT_LAUNCH_BUILD(SDW, MODE, GRID)                                                                            \
     hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set, (unsigned)first, \
                        (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes, map_stride_bytes,          \
-                       range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg, __builtin_inff())
+                       range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg, __builtin_inff(), nice)
 #define NDT_LAUNCH_BUILD_SD(MODE, GRID)                                                                              \
     do {                                                                                                             \
         if (sdw == 3) NDT_LAUNCH_BUILD(3, MODE, GRID);                                                               \
@@ -908,7 +941,7 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         hipLaunchKernelGGL((ndt_build_kernel<0, 2>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
                            (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
                            map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg,
-                           __builtin_inff());
+                           __builtin_inff(), nice);
     }
 #undef NDT_LAUNCH_BUILD_SD
 #undef NDT_LAUNCH_BUILD
@@ -919,7 +952,7 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
 // to the moment accumulators of their cells; nothing is finalised.  z_max: NDTMap::addPointCloud's maxz.
 hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                                  size_t stride_bytes, size_t map_stride_bytes, double range_limit,
-                                 const double *range_origins_dev, double z_max, int *s1_shift_out, int *s2_shift_out,
+                                 const double *range_origins_dev, double z_max, int nice, int *s1_shift_out, int *s2_shift_out,
                                  hipStream_t stream)
 {
     int lg = 1;
@@ -945,7 +978,7 @@ hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t cou
 #define NDT_LAUNCH_ACC(SDW)                                                                                           \
     hipLaunchKernelGGL((ndt_build_kernel<SDW, 1>), dim3(parts, (unsigned)count), dim3(NDT_BUILD_THREADS), 0, stream, set, \
                        (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,           \
-                       map_stride_bytes, range_limit, range_origins_dev, 0, 0.0, s1_shift, s2_shift, 0, zf)
+                       map_stride_bytes, range_limit, range_origins_dev, 0, 0.0, s1_shift, s2_shift, 0, zf, nice)
     if (sdw == 3) NDT_LAUNCH_ACC(3);
     else if (sdw == 4) NDT_LAUNCH_ACC(4);
     else NDT_LAUNCH_ACC(0);

@@ -123,11 +123,11 @@ struct NdtMatchResultDev {     // mirrors ndtgpu_match_result
 // host launchers (defined next to their kernels)
 hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                             size_t stride_bytes, size_t map_stride_bytes, double range_limit,
-                            const double *range_origins_dev, int n_min, double eval_factor, hipStream_t stream);
+                            const double *range_origins_dev, int n_min, double eval_factor, int nice, hipStream_t stream);
 // accumulate only (phase A of the build: points -> per-cell moment accumulators), z_max: points above it are dropped
 hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                                  size_t stride_bytes, size_t map_stride_bytes, double range_limit,
-                                 const double *range_origins_dev, double z_max, int *s1_shift_out, int *s2_shift_out,
+                                 const double *range_origins_dev, double z_max, int nice, int *s1_shift_out, int *s2_shift_out,
                                  hipStream_t stream);
 struct NdtFuseParams {         // NDTMap::addPointCloud + computeNDTCells arguments (fuser_hmt.cpp:92-94, 485-486)
     double maxz, sensor_noise, maxnumpoints, occupancy_limit, eval_factor;
@@ -135,7 +135,10 @@ struct NdtFuseParams {         // NDTMap::addPointCloud + computeNDTCells argume
 };
 hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                            size_t stride_bytes, size_t map_stride_bytes, const double *origins_dev,
-                           const NdtFuseParams &prm, hipStream_t stream);
+                           const NdtFuseParams &prm, int nice, hipStream_t stream);
+// true when res and every cell origin centre + (k - size/2) res of the grid are fp32 numbers (fp32 cell offsets are
+// then exact, csrc/ndt_build.hip)
+bool ndt_grid_is_nice(const NdtGrid &g, const double centre[3]);
 hipError_t ndt_launch_overlap(const NdtSetView &rset, const uint32_t *ridx_dev, const NdtSetView &mset,
                               const uint32_t *midx_dev, const double *T16_dev, size_t n_links, double *score_dev,
                               long long *nb_dev, hipStream_t stream);

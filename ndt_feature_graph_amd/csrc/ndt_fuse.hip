@@ -465,7 +465,7 @@ extern "C" __global__ __launch_bounds__(256) void ndt_overlap_kernel(
 
 hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                            size_t stride_bytes, size_t map_stride_bytes, const double *origins_dev,
-                           const NdtFuseParams &prm, hipStream_t stream)
+                           const NdtFuseParams &prm, int nice, hipStream_t stream)
 {
     if (count == 0) return hipSuccess;
     if (n_points) {
@@ -479,7 +479,7 @@ hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, co
     int s1 = 0, s2 = 0;
     // the hits: NaN dropped, |p - origin| > 200 dropped (addPointCloud's max_range), z > maxz dropped, outside the grid dropped
     hipError_t e = ndt_launch_accumulate(set, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, 200.0,
-                                         origins_dev, prm.maxz, &s1, &s2, stream);
+                                         origins_dev, prm.maxz, nice, &s1, &s2, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(ndt_fuse_finalize_kernel, dim3((unsigned)count), dim3(NDT_FUSE_THREADS), 0, stream, set,
                        (unsigned)first, (unsigned)n_points, prm.n_min, prm.eval_factor, prm.maxnumpoints,

@@ -469,9 +469,11 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
             const bool truncated = !bad_index && (tset.counters[ti].overflow != 0u || sset.counters[si].overflow != 0u);
             s_skip = 0;
             if (bad_index || truncated) {
-                NdtMatchResultDev o = {};
-                o.exit_code = bad_index ? -2 : -3;     // -2 map index out of range, -3 a map needed more cells than max_cells
-                res[pair] = o;                         // (converged = 0; the pose is left untouched)
+                NdtMatchResultDev *o = res + pair;      // (converged = 0; the pose is left untouched)
+                o->converged = 0; o->iterations = 0; o->fevals = 0;
+                o->exit_code = bad_index ? -2 : -3;     // -2 map index out of range, -3 a map needed more cells than max_cells
+                o->score = 0.0; o->n_source = 0; o->n_target = 0;
+                o->cycles_eval = 0; o->cycles_solver = 0; o->pair_terms_g = 0; o->pair_terms_h = 0;
                 s_skip = 1;
             }
         }
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
         }
 
         if (threadIdx.x == 0 && !parked_now) {
-            NdtMatchResultDev o;
+            NdtMatchResultDev &o = res[pair];
             match_state_result(st, T16 + (size_t)pair * 16, o);
             o.n_source = s_sv.n_cells;
             o.n_target = s_tg.n_cells;
@@ -537,7 +539,6 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
             o.cycles_solver = s_cnt[1];
             o.pair_terms_g = s_cnt[2];
             o.pair_terms_h = s_cnt[3];
-            res[pair] = o;
         }
         __syncthreads();
     }

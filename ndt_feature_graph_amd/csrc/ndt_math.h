@@ -290,6 +290,45 @@ NDT_HD double laguerre_extreme(const double (&d)[6], const double (&e2)[5], doub
     }
     return x;
 }
+template <int K>
+NDT_HD void householder_step(double (&a)[6][6])
+{
+    double sig = 0.0;
+#pragma unroll
+    for (int i = K + 2; i < 6; i++) sig += a[i][K] * a[i][K];
+    if (sig > 0.0) {
+        const double x0 = a[K + 1][K];
+        const double nrm = sqrt(x0 * x0 + sig);
+        const double alpha = (x0 > 0.0) ? -nrm : nrm;
+        double v[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = (i > K + 1) ? a[i][K] : 0.0;
+        v[K + 1] = x0 - alpha;
+        const double vtv = v[K + 1] * v[K + 1] + sig;
+        const double beta = 2.0 / vtv;
+        double pv[6], w[6];
+        double ptv = 0.0;
+#pragma unroll
+        for (int i = K + 1; i < 6; i++) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = K + 1; j < 6; j++) s += a[i][j] * v[j];
+            pv[i] = beta * s;
+            ptv += pv[i] * v[i];
+        }
+        const double kk = 0.5 * beta * ptv;
+#pragma unroll
+        for (int i = K + 1; i < 6; i++) w[i] = pv[i] - kk * v[i];
+#pragma unroll
+        for (int i = K + 1; i < 6; i++)
+#pragma unroll
+            for (int j = K + 1; j < 6; j++) a[i][j] -= v[i] * w[j] + w[i] * v[j];
+        a[K + 1][K] = alpha;
+        a[K][K + 1] = alpha;
+#pragma unroll
+        for (int i = K + 2; i < 6; i++) { a[i][K] = 0.0; a[K][i] = 0.0; }
+    }
+}
 }  // namespace ndt_eig6
 
 NDT_HD void sym6_extreme_eigs(const double (&H)[6][6], double &lmin, double &lmax)
@@ -309,45 +348,11 @@ NDT_HD void sym6_extreme_eigs(const double (&H)[6][6], double &lmin, double &lma
     for (int i = 0; i < 6; i++)
 #pragma unroll
         for (int j = 0; j < 6; j++) a[i][j] *= inv;
-    // Householder: after step k column k is zero below the sub-diagonal
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        double sig = 0.0;
-#pragma unroll
-        for (int i = k + 2; i < 6; i++) sig += a[i][k] * a[i][k];
-        if (sig > 0.0) {
-            const double x0 = a[k + 1][k];
-            const double nrm = sqrt(x0 * x0 + sig);
-            const double alpha = (x0 > 0.0) ? -nrm : nrm;
-            double v[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) v[i] = (i > k + 1) ? a[i][k] : 0.0;
-            v[k + 1] = x0 - alpha;
-            const double vtv = v[k + 1] * v[k + 1] + sig;
-            const double beta = 2.0 / vtv;
-            double pv[6], w[6];
-            double ptv = 0.0;
-#pragma unroll
-            for (int i = k + 1; i < 6; i++) {
-                double s = 0.0;
-#pragma unroll
-                for (int j = k + 1; j < 6; j++) s += a[i][j] * v[j];
-                pv[i] = beta * s;
-                ptv += pv[i] * v[i];
-            }
-            const double kk = 0.5 * beta * ptv;
-#pragma unroll
-            for (int i = k + 1; i < 6; i++) w[i] = pv[i] - kk * v[i];
-#pragma unroll
-            for (int i = k + 1; i < 6; i++)
-#pragma unroll
-                for (int j = k + 1; j < 6; j++) a[i][j] -= v[i] * w[j] + w[i] * v[j];
-            a[k + 1][k] = alpha;
-            a[k][k + 1] = alpha;
-#pragma unroll
-            for (int i = k + 2; i < 6; i++) { a[i][k] = 0.0; a[k][i] = 0.0; }
-        }
-    }
+    // Householder: after step K column K is zero below the sub-diagonal (template steps: every index is a constant)
+    ndt_eig6::householder_step<0>(a);
+    ndt_eig6::householder_step<1>(a);
+    ndt_eig6::householder_step<2>(a);
+    ndt_eig6::householder_step<3>(a);
     double d[6], e2[5];
     double lo = 1.0e300, hi = -1.0e300;
 #pragma unroll

@@ -253,6 +253,7 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
         g[a] = sums[1 + a];
         if (st.use_prior) {                // + computeGradientMahalanobis = (Q + Q^T) X   (fusion.h:29-32)
             double gp = 0;
+#pragma unroll
             for (int j = 0; j < 6; j++) gp += (st.Q[a * 6 + j] + st.Q[j * 6 + a]) * st.pose_local[j];
             g[a] += gp;
         }
@@ -261,18 +262,24 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
         // fusion.h:894-911 with P = I:  g <- H^T g + Q x0,  H <- H^T H + Q,  score += x0^T Q x0
         tikhonov_x0(st);
         double g2[6], H2[6][6];
+#pragma unroll
         for (int a = 0; a < 6; a++) {
             double s1 = 0;
+#pragma unroll
             for (int k = 0; k < 6; k++) s1 += H[k][a] * g[k] + st.Q[a * 6 + k] * st.x0[k];
             g2[a] = s1;
+#pragma unroll
             for (int b = 0; b < 6; b++) {
                 double s2 = st.Q[a * 6 + b];
+#pragma unroll
                 for (int k = 0; k < 6; k++) s2 += H[k][a] * H[k][b];
                 H2[a][b] = s2;
             }
         }
+#pragma unroll
         for (int a = 0; a < 6; a++) {
             g[a] = g2[a];
+#pragma unroll
             for (int b = 0; b < 6; b++) H[a][b] = H2[a][b];
         }
         st.score_here += tikhonov_score(st);

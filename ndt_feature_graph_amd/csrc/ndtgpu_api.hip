@@ -45,6 +45,13 @@ struct ndtgpu_mapset {
     NdtSetView v{};
     size_t n_maps = 0;
     std::vector<double> centres_host;
+    std::vector<unsigned char> nice_host;   // per map: fp32 cell offsets are exact (ndt_grid_is_nice)
+    int nice_range(size_t first, size_t count) const
+    {
+        for (size_t m = first; m < first + count; m++)
+            if (!nice_host[m]) return 0;
+        return 1;
+    }
     hipStream_t last_stream = nullptr;
     // staging buffers reused across calls
     void *stage = nullptr;
@@ -150,6 +157,7 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
     s->centres_host.resize(n_maps * 3);
     for (size_t m = 0; m < n_maps; m++)
         for (int a = 0; a < 3; a++) s->centres_host[m * 3 + a] = grid->centre[a];
+    s->nice_host.assign(n_maps, ndt_grid_is_nice(g, grid->centre) ? 1 : 0);
 
     hipError_t e;
 #define ALLOC(ptr, bytes)                                                          \
@@ -213,6 +221,7 @@ ndtgpu_status ndtgpu_mapset_set_centre(ndtgpu_mapset *s, size_t map, const doubl
 {
     if (!s || !centre || map >= s->n_maps) return fail(NDTGPU_ERR_INVALID, "set_centre: bad argument");
     for (int a = 0; a < 3; a++) s->centres_host[map * 3 + a] = centre[a];
+    s->nice_host[map] = ndt_grid_is_nice(s->v.grid, centre) ? 1 : 0;
     HIP_TRY(hipMemcpy(s->v.centres + map * 3, centre, 3 * sizeof(double), hipMemcpyHostToDevice));
     return NDTGPU_OK;
 }
@@ -255,7 +264,7 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
         HIP_TRY(hipMemsetAsync(s->v.occ + first * (size_t)s->v.grid.slots, 0, count * (size_t)s->v.grid.slots * sizeof(float), st));
     if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
     hipError_t e = ndt_launch_build(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit,
-                         orig_dev, cp.n_min, cp.eval_factor, st);
+                         orig_dev, cp.n_min, cp.eval_factor, s->nice_range(first, count), st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: launch", e);
     if (s->profiling) { HIP_TRY(hipEventRecord(s->ev[1], st)); s->ev_valid[0] = true; }
     return NDTGPU_OK;
@@ -509,7 +518,8 @@ ndtgpu_status ndtgpu_mapset_add_cloud(ndtgpu_mapset *s, size_t first, size_t cou
     NdtFuseParams p;
     p.maxz = fp.maxz; p.sensor_noise = fp.sensor_noise; p.maxnumpoints = fp.maxnumpoints;
     p.occupancy_limit = fp.occupancy_limit; p.eval_factor = fp.eval_factor; p.n_min = fp.n_min;
-    hipError_t e = ndt_launch_fuse(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, s->origins_dev, p, st);
+    hipError_t e = ndt_launch_fuse(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, s->origins_dev, p,
+                                   s->nice_range(first, count), st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "add_cloud: launch", e);
     return NDTGPU_OK;
 }
