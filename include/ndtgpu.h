@@ -145,6 +145,10 @@ ndtgpu_status ndtgpu_mapset_export_cells(ndtgpu_mapset *set, size_t map, double 
 ndtgpu_status ndtgpu_mapset_set_cells(ndtgpu_mapset *set, size_t map, const double *mean3, const double *cov9,
                                       size_t n_cells);
 
+/* ndt_feature::discardCell(map, pt) (utils.h:229-236; ndt_feature_fuser_hmt.cpp:229-232, ndt_odom_debug.cpp:194-198): the cells that
+ * hold the given points (HOST, n x packed float xyz) lose their Gaussian (hasGaussian_ = false).  Synchronous. */
+ndtgpu_status ndtgpu_mapset_discard_cells(ndtgpu_mapset *set, size_t map, const float *xyz, size_t n_points);
+
 /* ---- incremental (fused) node maps ------------------------------------------------------------- */
 /* NDTMap::initialize(cx,cy,cz,sx,sy,sz) on every map of the set (fuser_hmt.cpp:89): every cell of the grid exists
  * and carries an occupancy (log-odds, 0 = no reading).  Allocates the per-slot occupancy arrays and the second cell
@@ -182,6 +186,10 @@ ndtgpu_status ndtgpu_mapset_add_cloud_host(ndtgpu_mapset *set, size_t first, siz
 ndtgpu_status ndtgpu_mapset_clear(ndtgpu_mapset *set, size_t first, size_t count);
 /* NDTCell::getOccupancy of every cell of one map, slot order (x-major, y, z): cells_per_axis[0]*[1]*[2] floats */
 ndtgpu_status ndtgpu_mapset_export_occupancy(ndtgpu_mapset *set, size_t map, float *occ_out);
+
+/* the inverse of export_occupancy: installs NDTCell::occ of every cell of one map (a map received as a message,
+ * ndtgraph_conversion.h:129-158).  Needs ndtgpu_mapset_enable_occupancy. */
+ndtgpu_status ndtgpu_mapset_import_occupancy(ndtgpu_mapset *set, size_t map, const float *occ);
 
 /* ndt_feature::overlapNDTOccupancyScore(ref, mov, T) (ndt_feature_node.h:213-252; used at ndt_feature_graph.cpp:175,
  * 338-340) for n_links (ref, mov, T) triples.  Both sets need ndtgpu_mapset_enable_occupancy.  T16: HOST, n_links x 16

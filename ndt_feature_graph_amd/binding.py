@@ -84,7 +84,7 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_last_kernel_ms", "ndtgpu_mapset_counters", "ndtgpu_match_fusion_batch",
            "ndtgpu_mapset_enable_occupancy", "ndtgpu_default_fuse_params", "ndtgpu_mapset_add_cloud",
            "ndtgpu_mapset_add_cloud_host", "ndtgpu_mapset_clear", "ndtgpu_mapset_export_occupancy",
-           "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch"]
+           "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch", "ndtgpu_mapset_discard_cells", "ndtgpu_mapset_import_occupancy"]
 
 _lib = None
 
@@ -140,6 +140,8 @@ def lib():
     L.ndtgpu_mapset_clear.argtypes = [vp, C.c_size_t, C.c_size_t]
     L.ndtgpu_mapset_export_occupancy.argtypes = [vp, C.c_size_t, C.POINTER(C.c_float)]
     L.ndtgpu_overlap_score_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, dp, C.POINTER(C.c_int64), vp]
+    L.ndtgpu_mapset_import_occupancy.argtypes = [vp, C.c_size_t, C.POINTER(C.c_float)]
+    L.ndtgpu_mapset_discard_cells.argtypes = [vp, C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
     L.ndtgpu_covariance_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, C.POINTER(MatchParams), C.c_int, dp, i32p, vp]
     _lib = L
     return L
@@ -274,6 +276,11 @@ class MapSet:
             a = np.ascontiguousarray(xyz, dtype=np.float32)
             _check(lib().ndtgpu_mapset_add_cloud_host(self.h, int(first), B, C.c_void_p(a.ctypes.data), N, 4 * W, 4 * W * N,
                                                       _dp(org), C.byref(fp)))
+
+    def discard_cells(self, i, xyz):
+        """ndt_feature::discardCell for every point: the cells that hold them lose their Gaussian."""
+        a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        _check(lib().ndtgpu_mapset_discard_cells(self.h, int(i), a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0]))
 
     def clear(self, first=0, count=None):
         _check(lib().ndtgpu_mapset_clear(self.h, int(first), int(self.n_maps - first if count is None else count)))

@@ -139,6 +139,7 @@ hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, co
 // true when res and every cell origin centre + (k - size/2) res of the grid are fp32 numbers (fp32 cell offsets are
 // then exact, csrc/ndt_build.hip)
 bool ndt_grid_is_nice(const NdtGrid &g, const double centre[3]);
+hipError_t ndt_launch_discard(const NdtSetView &set, size_t map, const float *xyz_dev, size_t n_pts, hipStream_t stream);
 hipError_t ndt_launch_overlap(const NdtSetView &rset, const uint32_t *ridx_dev, const NdtSetView &mset,
                               const uint32_t *midx_dev, const double *T16_dev, size_t n_links, double *score_dev,
                               long long *nb_dev, hipStream_t stream);

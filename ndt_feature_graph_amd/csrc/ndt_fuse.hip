@@ -463,6 +463,79 @@ extern "C" __global__ __launch_bounds__(256) void ndt_overlap_kernel(
     }
 }
 
+// ndt_feature::discardCell(map, pt) (utils.h:229-236; fuser_hmt.cpp:229-232): the cells that hold the given points lose
+// their Gaussian.  One workgroup; the surviving cells are compacted in place in rank order (a cell never moves up, and a
+// chunk of 1024 records is read completely before any of it is rewritten), then the rank table and the rank bitmap are
+// rebuilt for the map.
+extern "C" __global__ __launch_bounds__(NDT_FUSE_THREADS) void ndt_discard_kernel(NdtSetView set, unsigned map,
+                                                                                  const float *__restrict__ xyz, unsigned n_pts)
+{
+    __shared__ unsigned s_wave[NDT_FUSE_THREADS / 64];
+    __shared__ unsigned s_base;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const NdtGrid g = set.grid;
+    int32_t *table = set.table + (size_t)map * g.slots;
+    uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
+    NdtCell *cells = ndt_cells_of(set, map, set.cell_sel ? set.cell_sel[map] : 0u);
+    NdtMapCounters *ctr = set.counters + map;
+    const unsigned n_old = ctr->n_cells > g.max_cells ? g.max_cells : ctr->n_cells;
+    const double cx = set.centres[map * 3], cy = set.centres[map * 3 + 1], cz = set.centres[map * 3 + 2];
+    // 1. mark: table[slot] = -2 for the cells that hold a point (NDTMap::getCellAtPoint)
+    for (unsigned i = tid; i < n_pts; i += NDT_FUSE_THREADS) {
+        const int ix = lazygrid_index((double)xyz[3 * i], cx, g.res, g.size[0]);
+        const int iy = lazygrid_index((double)xyz[3 * i + 1], cy, g.res, g.size[1]);
+        const int iz = lazygrid_index((double)xyz[3 * i + 2], cz, g.res, g.size[2]);
+        if ((unsigned)ix >= (unsigned)g.size[0] || (unsigned)iy >= (unsigned)g.size[1] || (unsigned)iz >= (unsigned)g.size[2]) continue;
+        const int slot = (ix * g.size[1] + iy) * g.size[2] + iz;
+        if (table[slot] >= 0) table[slot] = -2;
+    }
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    // 2. compact in rank order, 1024 records at a time
+    for (unsigned c0 = 0; c0 < n_old; c0 += NDT_FUSE_THREADS) {
+        const unsigned r = c0 + tid;
+        NdtCell c;
+        bool keep = false;
+        if (r < n_old) {
+            c = cells[r];
+            rankmap[c.slot >> 5].x = 0u;                    // rebuilt below
+            keep = table[c.slot] != -2;
+            if (!keep) table[c.slot] = NDT_EMPTY;
+        }
+        const unsigned long long m = __ballot(keep);
+        const unsigned before = (unsigned)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64u - lane))));
+        if (lane == 0) s_wave[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned off = s_base;
+        for (unsigned k = 0; k < wave; k++) off += s_wave[k];
+        if (keep) {
+            cells[off + before] = c;
+            table[c.slot] = (int)(off + before);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned t = 0;
+            for (unsigned k = 0; k < NDT_FUSE_THREADS / 64; k++) t += s_wave[k];
+            s_base += t;
+        }
+        __syncthreads();
+    }
+    const unsigned n_new = s_base;
+    // 3. rank bitmap: a bit per Gaussian cell, the rank of the first one of every 32-slot word
+    for (unsigned r = tid; r < n_new; r += NDT_FUSE_THREADS) {
+        const unsigned slot = cells[r].slot;
+        atomicOr(&rankmap[slot >> 5].x, 1u << (slot & 31u));
+        if (r == 0 || (cells[r - 1].slot >> 5) != (slot >> 5)) rankmap[slot >> 5].y = r;
+    }
+    if (tid == 0) ctr->n_cells = n_new;
+}
+
+hipError_t ndt_launch_discard(const NdtSetView &set, size_t map, const float *xyz_dev, size_t n_pts, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ndt_discard_kernel, dim3(1), dim3(NDT_FUSE_THREADS), 0, stream, set, (unsigned)map, xyz_dev, (unsigned)n_pts);
+    return hipGetLastError();
+}
+
 hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                            size_t stride_bytes, size_t map_stride_bytes, const double *origins_dev,
                            const NdtFuseParams &prm, int nice, hipStream_t stream)

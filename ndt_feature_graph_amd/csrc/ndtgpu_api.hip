@@ -454,6 +454,20 @@ ndtgpu_status ndtgpu_derivatives(ndtgpu_mapset *t, size_t tmap, const double *sr
     return NDTGPU_OK;
 }
 
+ndtgpu_status ndtgpu_mapset_discard_cells(ndtgpu_mapset *s, size_t map, const float *xyz, size_t n_points)
+{
+    if (!s || map >= s->n_maps || (n_points && !xyz)) return fail(NDTGPU_ERR_INVALID, "discard_cells: bad argument");
+    if (n_points == 0) return NDTGPU_OK;
+    ndtgpu_status rc = s->ensure_stage(n_points * 3 * sizeof(float));
+    if (rc != NDTGPU_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    HIP_TRY(hipMemcpy(s->stage, xyz, n_points * 3 * sizeof(float), hipMemcpyHostToDevice));
+    hipError_t e = ndt_launch_discard(s->v, map, (const float *)s->stage, n_points, nullptr);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "discard_cells: launch", e);
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NDTGPU_OK;
+}
+
 ndtgpu_status ndtgpu_mapset_enable_occupancy(ndtgpu_mapset *s)
 {
     if (!s) return fail(NDTGPU_ERR_INVALID, "enable_occupancy: null");
@@ -563,6 +577,15 @@ ndtgpu_status ndtgpu_mapset_export_occupancy(ndtgpu_mapset *s, size_t map, float
     if (!s->v.occ) return fail(NDTGPU_ERR_INVALID, "export_occupancy: occupancy not enabled on this set");
     HIP_TRY(hipStreamSynchronize(s->last_stream));
     HIP_TRY(hipMemcpy(occ_out, s->v.occ + map * (size_t)s->v.grid.slots, (size_t)s->v.grid.slots * sizeof(float), hipMemcpyDeviceToHost));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_import_occupancy(ndtgpu_mapset *s, size_t map, const float *occ)
+{
+    if (!s || map >= s->n_maps || !occ) return fail(NDTGPU_ERR_INVALID, "import_occupancy: bad argument");
+    if (!s->v.occ) return fail(NDTGPU_ERR_INVALID, "import_occupancy: occupancy not enabled on this set");
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    HIP_TRY(hipMemcpy(s->v.occ + map * (size_t)s->v.grid.slots, occ, (size_t)s->v.grid.slots * sizeof(float), hipMemcpyHostToDevice));
     return NDTGPU_OK;
 }
 

@@ -10,6 +10,7 @@
 //   D. loadPointCloudCentroid, NDTMatcherD2D_2D, and the arguments the mirror must reject.
 // Exit code 0 = every check passed.  Without a GPU: checks that the library fails loudly (NDTGPU_ERR_NO_DEVICE).
 #include "ndt_feature_graph_gpu.h"
+#include "ndt_map_msg_gpu.h"
 
 #include <cstdio>
 #include <random>
@@ -377,6 +378,36 @@ int main()
         NDTFeatureFuserHMT fuser(bad);
         fuser.initialize(Eigen::Affine3d::Identity(), pc, no_pts);
         CHECK(throws_invalid([&] { fuser.update(Eigen::Affine3d::Identity(), pc, no_pts); }), "useFeat accepted");
+    }
+    // ---- E. the map wire format: toMessage / fromMessage round trip (ndtgraph_conversion.h:34-43, 129-158) -----------------
+    {
+        ndt_map::NDTMapMsg msg;
+        CHECK(lslgeneric::toMessage(graph.getMap(1), msg, "/world"), "toMessage failed");
+        CHECK(msg.header.frame_id == "/world" && msg.x_cell_size == 0.5 && msg.x_size == 60.0 && msg.z_size == 1.0, "message geometry");
+        size_t n_gauss = 0;
+        for (const auto &c : msg.cells) n_gauss += c.hasGaussian_;
+        CHECK((int)n_gauss == graph.getMap(1)->numberOfActiveCells() && msg.cells.size() > n_gauss, "message cells: %zu Gaussians of %zu", n_gauss, msg.cells.size());
+        lslgeneric::LazyGrid *lz = nullptr;
+        lslgeneric::NDTMap *back = nullptr;
+        std::string frame;
+        CHECK(lslgeneric::fromMessage(lz, back, msg, frame, true) && back != nullptr, "fromMessage failed");
+        CHECK(frame == "/world" && back->numberOfActiveCells() == (int)n_gauss, "round trip lost cells: %d vs %zu", back->numberOfActiveCells(), n_gauss);
+        // the map that came back registers like the original
+        lslgeneric::NDTMatcherD2D m;
+        m.n_neighbours = 2; m.ITR_MAX = 30; m.DELTA_SCORE = 1e-6;
+        Eigen::Affine3d Ta = ndtgpu_host::affine_from_pose(0.03, -0.02, 0, 0, 0, 0.004), Tb = Ta;
+        m.match(*graph.getMap(0), *graph.getMap(1), Ta, true);
+        m.match(*graph.getMap(0), *back, Tb, true);
+        double d, a;
+        pose_error(Ta, Tb, d, a);
+        std::printf("E: message with %zu cells (%zu Gaussians); registration against the round-tripped map differs by %.2e m\n", msg.cells.size(), n_gauss, d);
+        CHECK(d < 1e-9 && a < 1e-7, "round-tripped map registers differently: %g m %g rad", d, a);   // acos near 1: 1e-16 in R(0,0) is 1.5e-8 rad
+        std::vector<float> o1 = graph.getMap(1)->getOccupancy(), o2 = back->getOccupancy();
+        double worst = 0;
+        for (size_t k = 0; k < o1.size(); k++)
+            if (std::fabs(o1[k]) < 10.f) worst = std::fmax(worst, std::fabs(o1[k] - o2[k]));
+        CHECK(worst < 1e-3, "occupancy round trip off by %g", worst);
+        delete back;
     }
     std::printf("%d failures in total\n", g_fails);
     return g_fails ? 1 : 0;

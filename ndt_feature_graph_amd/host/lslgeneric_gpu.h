@@ -8,7 +8,7 @@
 //   ndt_feature/src/ndt_odom_debug.cpp:163-206
 // so that a maintainer can point those translation units at this header instead of
 // <ndt_map/ndt_map.h>, <ndt_map/lazy_grid.h>, <ndt_registration/ndt_matcher_d2d.h>, <ndt_registration/ndt_matcher_d2d_2d.h>.
-// tests/native/host_loop_test.cpp re-types the Newton loop of ndt_matcher_d2d_fusion.h:847-1121 against it.
+// host/host_demo.cpp (part C) re-types the Newton loop of ndt_matcher_d2d_fusion.h:847-1121 against it.
 // Everything that computes lives on the GPU; there is no CPU fallback: a failed C-ABI call throws
 // ndtgpu_host::Error (the reference has no error channel here besides bool returns).  Arguments the reference passes
 // but this implementation cannot honour are REJECTED (Error, NDTGPU_ERR_INVALID), never ignored.
@@ -235,6 +235,14 @@ public:
     // NDTMap::pseudoTransformNDT(T) (fusion.h:840-841): transformed heap copies of the Gaussian cells, the caller deletes
     // (fusion.h:953-962, 1122-1131)
     std::vector<NDTCell *> pseudoTransformNDT(const Eigen::Affine3d &T) { return cells_transformed(&T); }
+    // what ndt_feature::discardCell does through NDTMap::getCellAtPoint + hasGaussian_ = false (utils.h:229-236)
+    bool discardCellAtPoint(const pcl::PointXYZ &pt)
+    {
+        const int before = numberOfActiveCells();
+        const float xyz[3] = {pt.x, pt.y, pt.z};
+        ndtgpu_host::check(ndtgpu_mapset_discard_cells(handle(), slot_, xyz, 1), "ndtgpu_mapset_discard_cells");
+        return numberOfActiveCells() < before;
+    }
     bool getCentroid(double &cx, double &cy, double &cz) const { cx = centre_[0]; cy = centre_[1]; cz = centre_[2]; return true; }
     // NDTCell::getOccupancy of every cell, slot order (x-major, y, z) -- needs initialize()
     std::vector<float> getOccupancy()

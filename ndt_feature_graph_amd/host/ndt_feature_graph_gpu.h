@@ -68,6 +68,8 @@ inline void pose2dClearDependence(Pose2dCov &p)
 {
     p.cov(0, 1) = p.cov(1, 0) = p.cov(0, 2) = p.cov(1, 2) = p.cov(2, 0) = p.cov(2, 1) = 0.;
 }
+// discardCell (utils.h:229-236)
+inline bool discardCell(lslgeneric::NDTMap &map, const pcl::PointXYZ &pt) { return map.discardCellAtPoint(pt); }
 // computeLocalCentroid (utils.h:213-227)
 inline Eigen::Vector3d computeLocalCentroid(const Eigen::Vector3d &map_centroid, const Eigen::Vector3d &local_pos, double resolution)
 {
@@ -281,8 +283,6 @@ public:
         if (params_.useFeat || params_.useOdom)
             throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: the FLIRT feature (useFeat) and odometry-cell (useOdom) terms are not "
                                                          "implemented; every shipped configuration sets both to false");
-        if (params_.discardCells)
-            throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: discardCells is not implemented (false in every shipped configuration)");
         pcl::PointCloud<pcl::PointXYZ> cloud(cloudOrig);
         pcl::PointCloud<pcl::PointXYZ> cloud_orig(cloudOrig);
 
@@ -341,6 +341,10 @@ public:
             ndglobal.loadPointCloud(cloud, params_.sensor_range);
         }
         ndglobal.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE);
+        if (params_.discardCells && cloud.size() > 0) {   // fuser_hmt.cpp:229-232
+            discardCell(ndglobal, cloud.front());
+            discardCell(ndglobal, cloud.back());
+        }
 
         std::vector<std::pair<int, int> > corr;
         bool match_ok = true;

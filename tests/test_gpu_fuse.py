@@ -373,3 +373,34 @@ def test_fuse_3d_parity(N, O):
         origins.append(Ts[k][:3, 3])
     ms, om = fuse_both(N, O, clouds, np.array(origins), 0.5, [100, 100, 10], max_cells=60000)
     assert om.num_cells() > 500
+
+
+def test_discard_cells(N, O):
+    """ndt_feature::discardCell (utils.h:229-236): the cells holding the given points lose their Gaussian, everything else
+    (cell order, records, the matcher's rank structures) stays consistent."""
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_2d([6], 30000)
+    f, m = pr["fixed"][0].numpy(), pr["moving"][0].numpy()
+    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2)
+    ms.build(np.stack([f, m]), range_limit=30.0)
+    before = ms.export_cells(0)
+    ok = ~np.isnan(f[:, 0])
+    pts = f[ok][[0, -1, 1234, 1235, 20000]]
+    pts = np.concatenate([pts, [[1e3, 0, 0], before[0][7] + 0.01]]).astype(np.float32)     # one outside the grid, one by cell mean
+    ms.discard_cells(0, pts)
+    after = ms.export_cells(0)
+    idx_of = lambda p: tuple((np.floor(p.astype(np.float64) / 0.5 + 0.5) + np.array([100, 100, 1])).astype(int))
+    gone = {idx_of(p) for p in pts}
+    keep = np.array([tuple(i) not in gone for i in before[2]])
+    assert 1 <= (~keep).sum() <= len(pts) and len(after[3]) == keep.sum()
+    for x, y in zip(after, before):
+        assert np.array_equal(x, y[keep])
+    # the matcher sees exactly the remaining cells: derivatives equal the oracle's on a map with the same cells
+    om = O.OracleMap(0.5, [0, 0, 0], [100, 100, 1])
+    om.set_cells(after[0], after[1])
+    mean, cov, _, _ = ms.export_cells(1)
+    s1, g1, H1 = N.derivatives(ms, 0, mean, cov)
+    so, go, Ho = O.derivatives(om, mean, cov)
+    assert abs(s1 - so) < 1e-9 * abs(so) and np.max(np.abs(H1 - Ho)) < 1e-9 * np.max(np.abs(Ho))
+    T, r = N.match_d2d(ms, 0, ms, 1, pr["T_init"][0].numpy())
+    assert r["n_target"] == keep.sum() and np.all(np.isfinite(T))

@@ -36,4 +36,4 @@ def test_host_demo_on_gpu():
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failures in total" in out.stdout and "batch==single 1" in out.stdout
-    assert "A: " in out.stdout and "C: soft=1" in out.stdout
+    assert "A: " in out.stdout and "C: soft=1" in out.stdout and "E: message" in out.stdout
