@@ -181,7 +181,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     __shared__ unsigned s_dropped;
 
     const unsigned tid = threadIdx.x;
-    const unsigned lane = tid & 63u, wave = tid >> 6;
+    // the wave index through readfirstlane: everything derived from it (tile ranges, staging bases) is scalar
+    const unsigned lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned nthreads = (MODE == 2) ? NDT_FIN_THREADS : NDT_BUILD_THREADS, nwaves = nthreads / 64;
     const unsigned map_local = (MODE == 0) ? blockIdx.x : blockIdx.y;
     // MODE 2: gridDim.x workgroups share phases 0 and B of one map; the last one to finish runs phases C and D
@@ -342,24 +343,45 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             // (owner = d / (8*SD), e = d % (8*SD)): consecutive lanes read consecutive dwords of 96-byte pieces.
             const float *src = (const float *)pts + (size_t)p0 * SD;
             const bool full = (size_t)p0 + (size_t)NDT_TILE * R <= (size_t)n_points;
-            const unsigned lim_dw = (n_points - p0) * SD;                   // valid dwords from p0 on
-            constexpr int CH = 8;
-            static_assert((NDT_PPL * SD) % CH == 0, "staging chunk");
+            constexpr int ROW = NDT_PPL * SD;                                // dwords of one lane's 8 points
+            if (full) {
+                // d = lane + 64k walks (owner, e) = divmod(d, ROW) with period P in k (64 P = RS ROW): P lane constants
+                // per super-tile; everything else is a wave-uniform base (scalar) or an immediate LDS offset
+                constexpr int P = (ROW % 64 == 0) ? 1 : (ROW == 24 ? 3 : (64 % ROW == 0 ? 1 : ROW));
+                constexpr int RS = 64 * P / ROW;
+                static_assert((64 * P) % ROW == 0 && ROW % P == 0, "staging period");
+                unsigned goff[P], loff[P];
 #pragma unroll
-            for (int h = 0; h < NDT_PPL * SD / CH; h++) {
-                float tmp[CH];
-#pragma unroll
-                for (int k = 0; k < CH; k++) {
-                    const unsigned d = lane + 64u * (h * CH + k);
-                    const unsigned g = ((d / (NDT_PPL * SD)) * R + r) * (NDT_PPL * SD) + d % (NDT_PPL * SD);
-                    const bool have = full || g < lim_dw;
-                    const float v = src[have ? g : 0u];
-                    tmp[k] = have ? v : __builtin_nanf("");   // past the end of the scan: NaN points, skipped below
+                for (int c = 0; c < P; c++) {
+                    const unsigned d = lane + 64u * c, o = d / ROW, e = d % ROW;
+                    goff[c] = o * R * ROW + e;
+                    loff[c] = o * LANE_DW + e;
                 }
+                constexpr int CH = 8;
 #pragma unroll
-                for (int k = 0; k < CH; k++) {
-                    const unsigned d = lane + 64u * (h * CH + k);
-                    mytile[(d / (NDT_PPL * SD)) * LANE_DW + d % (NDT_PPL * SD)] = tmp[k];
+                for (int h = 0; h < ROW / CH; h++) {
+                    float tmp[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; k++) {
+                        const int kk = h * CH + k, c = kk % P, m = kk / P;
+                        const float *sb = src + (size_t)((unsigned)(RS * m) * R + r) * ROW;   // wave-uniform
+                        tmp[k] = sb[goff[c]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < CH; k++) {
+                        const int kk = h * CH + k, c = kk % P, m = kk / P;
+                        mytile[loff[c] + m * (RS * LANE_DW)] = tmp[k];
+                    }
+                }
+            } else {
+                const unsigned lim_dw = (n_points - p0) * SD;               // valid dwords from p0 on
+                for (int kk = 0; kk < ROW; kk++) {
+                    const unsigned d = lane + 64u * kk;
+                    const unsigned g = ((d / ROW) * R + r) * ROW + d % ROW;
+                    const bool have = g < lim_dw;
+                    const float v = src[have ? g : 0u];
+                    // past the end of the scan: NaN points, skipped below
+                    mytile[(d / ROW) * LANE_DW + d % ROW] = have ? v : __builtin_nanf("");
                 }
             }
         }
