@@ -40,35 +40,12 @@
 #define NDT_FIN_THREADS 1024  // finalise-only launch (MODE 2): more waves to hide the dependent table loads
 #define NDT_PPL 8            // consecutive points per lane per tile
 #define NDT_TILE (64 * NDT_PPL)
-#define NDT_ROUNDS 8         // sub-tiles per super-tile (one wavefront merge + flush per 2048 points)
+#ifndef NDT_ROUNDS
+#define NDT_ROUNDS 8
+#endif
+//        // sub-tiles per super-tile (one wavefront merge + flush per 2048 points)
 #define NDT_IDC 64           // entries of the per-wave slot -> id cache
 #define NDT_FLCAP 40         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 160 B)
-#ifdef NDT_BUILD_ABLATION
-#define NDT_DBGV dbg
-#else
-#define NDT_DBGV 0
-#endif
-#ifndef NDT_D1
-#define NDT_D1 NDT_DBGV
-#endif
-#ifndef NDT_D2
-#define NDT_D2 NDT_DBGV
-#endif
-#ifndef NDT_D3
-#define NDT_D3 NDT_DBGV
-#endif
-#ifndef NDT_D4
-#define NDT_D4 NDT_DBGV
-#endif
-#ifndef NDT_D5
-#define NDT_D5 NDT_DBGV
-#endif
-#ifndef NDT_D6
-#define NDT_D6 NDT_DBGV
-#endif
-#ifndef NDT_D7
-#define NDT_D7 NDT_DBGV
-#endif
 #define NDT_QRUNS 16         // per-wave table of replaced runs, keyed by cell (power of two)
 #define NDT_EMPTY (-1)
 
@@ -162,11 +139,14 @@ NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int s
 // MODE 2: finalise only (phases 0, B, C, D), one workgroup per map, after a MODE 1 launch
 // (no minimum-waves hint: __launch_bounds__(256, 2) halves the speed of phase A although the register count stays at
 //  250 -- measured 1.79 vs 0.94 ms -- and 3 / 4 waves per SIMD spill: 2.53 / 1.92 ms)
-template <int STRIDE_DW, int MODE>
-__global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) void ndt_build_kernel(
+template <int STRIDE_DW, int MODE, bool NICE>
+#ifndef NDT_BUILD_WPE
+#define NDT_BUILD_WPE
+#endif
+__global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) NDT_BUILD_WPE void ndt_build_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
     size_t map_stride_bytes, double range_limit, const double *__restrict__ range_origins, int n_min,
-    double eval_factor, int s1_shift, int s2_shift, int dbg, float z_max32, int nice)
+    double eval_factor, int s1_shift, int s2_shift, int dbg, float z_max32)
 {
     constexpr int SD = STRIDE_DW ? STRIDE_DW : 3;
     constexpr int LANE_DW = NDT_PPL * SD + 1;          // +1: odd stride -> conflict-free per-lane walks
@@ -264,15 +244,6 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
 
     // ---------------- phase A: key + accumulate ----------------------------------------------------
     long long t0 = __builtin_readcyclecounter();
-#ifdef NDT_PROFILE_SECTIONS
-    long long ps[4] = {0, 0, 0, 0}, pt = clock64();
-    long long qs[4] = {0, 0, 0, 0};
-#define NDT_QS(k) { long long now_ = clock64(); qs[k] += now_ - pt; ps[2] += now_ - pt; pt = now_; }
-#define NDT_PS(k) { long long now_ = clock64(); ps[k] += now_ - pt; pt = now_; }
-#else
-#define NDT_PS(k)
-#define NDT_QS(k)
-#endif
     // The scan is cut into sub-tiles of 512 points (64 lanes x 8 points).  A wave owns a contiguous range of
     // sub-tiles and walks it in SUPER-TILES of up to NDT_ROUNDS sub-tiles: lane l owns 8*R consecutive points of
     // the super-tile and visits them in R rounds through the same 8-point LDS row, so the wavefront merge and
@@ -303,7 +274,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         for (unsigned it = lane; it < items; it += 64u) {
             unsigned e = it / 20u, k = it % 20u;
             int id = fl_id[e];
-            if (k < 19u && id >= 0 && !(NDT_D1 & 1))
+            if (k < 19u && id >= 0)
                 unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + id) + k, fl_val[e * 20u + k]);
         }
         ndt_wave_sync();                                  // the list may be overwritten now
@@ -326,6 +297,45 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
     // parallel: nothing in the point loop waits for global memory
     double *q_val = s_qval + awave * (10 * NDT_QRUNS);
     int *q_slot = s_qslot + awave * NDT_QRUNS;
+    const unsigned gsx = (unsigned)g.size[0], gsy = (unsigned)g.size[1], gsz = (unsigned)g.size[2];
+    // fp32 fast path of one point -> cell index.  Every test is false for a NaN (NaN points are skipped, like padding);
+    // an Inf passes the range test when no range is set and is then out of the grid.  Returns true when the
+    // reference's fp64 formulas must decide (bin_exact): the point is within the fp32 error bound of a cell face or
+    // of the range sphere (frac_lim < 0 sends every point there: odd grid sizes, absurd centres).
+    auto bin_fast = [&](float fx, float fy, float fz, int &ix, int &iy, int &iz, int &slot) -> bool {
+        const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
+        const float dd = dx * dx + dy * dy + dz * dz;
+        const bool okz = fz <= z_max32;                                 // addPointCloud's maxz (+inf otherwise)
+        const bool okr = (dd <= r2eff) & okz;                           // r2eff = +inf without a range limit
+        const bool near_r = fabsf(dd - r2) < r2band;                    // r2band < 0 without a range limit
+        // v = (p - c)/res + 0.5 + size/2 in one fma per axis; the integer part is the cell index
+        const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
+        const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
+        const float tx = fabsf((vx - flx) - 0.5f), ty = fabsf((vy - fly) - 0.5f), tz = fabsf((vz - flz) - 0.5f);
+        ix = (int)flx; iy = (int)fly; iz = (int)flz;
+        const bool inb = ((unsigned)ix < gsx) & ((unsigned)iy < gsy) & ((unsigned)iz < gsz);
+        const int sl = (int)(((unsigned)ix * gsy + (unsigned)iy) * gsz + (unsigned)iz);
+        slot = (okr & inb) ? sl : -1;
+        return (okr | (near_r & okz)) & (near_r | !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim));
+    };
+    // ... and the reference's own formulas for those few points
+    auto bin_exact = [&](float fx, float fy, float fz, int &ix, int &iy, int &iz, int &slot) {
+        const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
+        const float dd = dx * dx + dy * dy + dz * dz;
+        const bool okz = fz <= z_max32;
+        bool ok = (dd <= r2eff) & okz;
+        if (fabsf(dd - r2) < r2band) {
+#pragma clang fp contract(off)
+            double ex = (double)fx - ox, ey = (double)fy - oy, ez = (double)fz - oz;
+            ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit) && okz;
+        }
+        const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
+        if (!(fabsf((vx - floorf(vx)) - 0.5f) <= frac_lim)) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
+        if (!(fabsf((vy - floorf(vy)) - 0.5f) <= frac_lim)) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
+        if (!(fabsf((vz - floorf(vz)) - 0.5f) <= frac_lim)) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
+        slot = (ok && (unsigned)ix < gsx && (unsigned)iy < gsy && (unsigned)iz < gsz)
+                   ? (int)(((unsigned)ix * gsy + (unsigned)iy) * gsz + (unsigned)iz) : -1;
+    };
     for (unsigned tile = tile_begin; tile < tile_end;) {
         const unsigned R = min((unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
         const unsigned p0 = tile * NDT_TILE;                              // its first point
@@ -335,6 +345,103 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         double rn = 0, rn1 = 0;
         double sd[3] = {0, 0, 0}, se[6] = {0, 0, 0, 0, 0, 0};
         double sd1[3] = {0, 0, 0}, se1[6] = {0, 0, 0, 0, 0, 0};
+        auto load_point = [&](unsigned r, int j, float &fx, float &fy, float &fz) {
+            if (STRIDE_DW) {
+                const tile_f32 *pf = mytile + lane * LANE_DW + j * SD;
+                fx = pf[0]; fy = pf[1]; fz = pf[2];
+            } else {
+                const unsigned i = p0 + (lane * R + r) * NDT_PPL + j;
+                const bool have = i < n_points;
+                const float *pf = (const float *)(pts + (size_t)(have ? i : 0u) * stride_bytes);
+                fx = have ? pf[0] : __builtin_nanf(""); fy = pf[1]; fz = pf[2];
+            }
+        };
+        // The replaced run is ADDED to the wave's LDS table entry of its cell (lanes that bounce between three or four
+        // cells at a cell corner replace a run at almost every point: the table keeps one record per cell however
+        // often that happens).  All additions to a wave's table come from that wave, in program order.
+        auto evict_run = [&](int victim, double vn, const double *v3, const double *v6) {
+            unsigned e = ((unsigned)victim * 0x9E3779B1u) >> 28;
+            bool placed = false;
+#pragma unroll 1
+            for (int probe = 0; probe < 4 && !placed; probe++) {
+                const int old = atomicCAS(&q_slot[e], -1, victim);
+                if (old == -1 || old == victim) {
+                    unsafeAtomicAdd(&q_val[0 * NDT_QRUNS + e], vn);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(&q_val[(1 + k) * NDT_QRUNS + e], v3[k]);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) unsafeAtomicAdd(&q_val[(4 + k) * NDT_QRUNS + e], v6[k]);
+                    placed = true;
+                } else {
+                    e = (e + 1u) & (NDT_QRUNS - 1u);
+                }
+            }
+            if (placed) {
+                s_qcnt[wave] = 1u;
+            } else {                             // table full (unordered cloud): add directly
+                double rec[20];
+                int rid;
+                write_flush_record(bc, rec, &rid, victim, vn, v3, v6);
+                if (rid >= 0)
+                    for (int k = 0; k < 19; k++)
+                        unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + rid) + k, rec[k]);
+            }
+        };
+        // A lane keeps the moments of TWO cells in registers (range noise on a wall that hugs a cell face makes its
+        // consecutive points alternate between two cells; a lane that walks into the next cell keeps the old one as
+        // well).  A third cell replaces the run that was used least recently; the replaced run goes to the wave's LDS
+        // table.  Nothing here touches LDS or memory on the common path.
+        auto add_point = [&](float fx, float fy, float fz, int ix, int iy, int iz, int slot) {
+            const bool newc = (slot >= 0) & (slot != cs0) & (slot != cs1);
+            if (__ballot(newc)) {
+                if (newc) {
+                    const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);   // an empty run first, else the older one
+                    // (one copy of the code per run: selecting the victim's ten sums first would cost twenty registers)
+                    if (to1) {
+                        if (cs1 >= 0) evict_run(cs1, rn1, sd1, se1);
+                        cs1 = slot; rn1 = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) sd1[k] = 0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) se1[k] = 0;
+                    } else {
+                        if (cs0 >= 0) evict_run(cs0, rn, sd, se);
+                        cs0 = slot; rn = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) sd[k] = 0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) se[k] = 0;
+                    }
+                }
+            }
+            // offset from the point's own cell origin: |d| <= one cell, no cancellation later on
+            double x, y, z;
+            if (NICE) {
+                x = (double)(fx - fmaf((float)ix, res32, c0x32));
+                y = (double)(fy - fmaf((float)iy, res32, c0y32));
+                z = (double)(fz - fmaf((float)iz, res32, c0z32));
+            } else {
+                x = (double)fx - (cx + ((double)ix - hx) * res);
+                y = (double)fy - (cy + ((double)iy - hy) * res);
+                z = (double)fz - (cz + ((double)iz - hz) * res);
+            }
+            const bool in0 = slot == cs0, in1 = slot == cs1;          // cs0 / cs1 are never -1
+            if (in0) {
+                rn += 1.0;
+                sd[0] += x; sd[1] += y; sd[2] += z;
+                se[0] = fma(x, x, se[0]); se[1] = fma(x, y, se[1]); se[2] = fma(x, z, se[2]);
+                se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
+            }
+            if (__ballot(in1)) {
+                if (in1) {
+                    rn1 += 1.0;
+                    sd1[0] += x; sd1[1] += y; sd1[2] += z;
+                    se1[0] = fma(x, x, se1[0]); se1[1] = fma(x, y, se1[1]); se1[2] = fma(x, z, se1[2]);
+                    se1[3] = fma(y, y, se1[3]); se1[4] = fma(y, z, se1[4]); se1[5] = fma(z, z, se1[5]);
+                }
+            }
+            mru1 = in1 ? 1 : (in0 ? 0 : mru1);
+        };
 #pragma unroll 1
         for (unsigned r = 0; r < R; r++) {
         if (STRIDE_DW) {
@@ -386,150 +493,25 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             }
         }
         ndt_wave_sync();   // a lane's row of the tile was written by other lanes
-        NDT_PS(0)
+        // Two points per trip: their index arithmetic is independent and interleaves (the loop is latency bound at the
+        // 3 waves per SIMD the register state allows); the run bookkeeping then takes them in scan order.
 #pragma unroll 1
-        for (int j = 0; j < NDT_PPL; j++) {
-            float fx, fy, fz;
-            if (STRIDE_DW) {
-                const tile_f32 *pf = mytile + lane * LANE_DW + j * SD;
-                fx = pf[0]; fy = pf[1]; fz = pf[2];
-            } else {
-                const unsigned i = p0 + (lane * R + r) * NDT_PPL + j;
-                const bool have = i < n_points;
-                const float *pf = (const float *)(pts + (size_t)(have ? i : 0u) * stride_bytes);
-                fx = have ? pf[0] : __builtin_nanf(""); fy = pf[1]; fz = pf[2];
+        for (int j = 0; j < NDT_PPL; j += 2) {
+            float ax, ay, az, bx, by, bz;
+            load_point(r, j, ax, ay, az);
+            load_point(r, j + 1, bx, by, bz);
+            int aix, aiy, aiz, aslot, bix, biy, biz, bslot;
+            const bool na = bin_fast(ax, ay, az, aix, aiy, aiz, aslot);
+            const bool nb = bin_fast(bx, by, bz, bix, biy, biz, bslot);
+            if (__ballot(na | nb)) {
+                if (na) bin_exact(ax, ay, az, aix, aiy, aiz, aslot);
+                if (nb) bin_exact(bx, by, bz, bix, biy, biz, bslot);
             }
-            if (NDT_D2 & 4) fx = __builtin_nanf("");
-            // fp32 fast paths.  Every test below is false for a NaN (NaN points are skipped, like padding); an
-            // Inf passes the range test when no range is set and is then out of the grid.
-            const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
-            const float dd = dx * dx + dy * dy + dz * dz;
-            const bool okz = fz <= z_max32;                                 // addPointCloud's maxz (+inf otherwise)
-            const bool okr = dd <= r2eff && okz;                            // r2eff = +inf without a range limit
-            const bool near_r = fabsf(dd - r2) < r2band;                    // r2band < 0 without a range limit
-            // v = (p - c)/res + 0.5 + size/2 in one fma per axis; the integer part is the cell index
-            const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
-            const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
-            const float tx = fabsf((vx - flx) - 0.5f), ty = fabsf((vy - fly) - 0.5f), tz = fabsf((vz - flz) - 0.5f);
-            int ix = (int)flx, iy = (int)fly, iz = (int)flz;
-            int slot = (okr && (unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] &&
-                        (unsigned)iz < (unsigned)g.size[2]) ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
-            // ... and the reference's fp64 formulas for the few points near a cell face / the range sphere
-            // (frac_lim < 0 sends every point here: odd grid sizes, absurd centres)
-            const bool need_exact = (okr || (near_r && okz)) && (near_r || !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim));
-            if (__ballot(need_exact)) {
-                if (need_exact) {
-                    bool ok = okr;
-                    if (near_r) {
-#pragma clang fp contract(off)
-                        double ex = (double)fx - ox, ey = (double)fy - oy, ez = (double)fz - oz;
-                        ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit) && okz;
-                    }
-                    if (!(tx <= frac_lim)) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
-                    if (!(ty <= frac_lim)) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
-                    if (!(tz <= frac_lim)) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
-                    slot = (ok && (unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] &&
-                            (unsigned)iz < (unsigned)g.size[2]) ? (ix * g.size[1] + iy) * g.size[2] + iz : -1;
-                }
-            }
-            NDT_PS(1)
-            if (NDT_D3 & 16) continue;
-            // A lane keeps the moments of TWO cells in registers (range noise on a wall that hugs a cell face makes
-            // its consecutive points alternate between two cells; a lane that walks into the next cell keeps the
-            // old one as well).  A third cell replaces the run that was used least recently; the replaced run goes
-            // to the wave's LDS queue.  Nothing in the loop touches LDS or memory on the common path.
-            bool newc = slot >= 0 && slot != cs0 && slot != cs1;
-            if (NDT_D4 & 32) { cs0 = slot >= 0 ? slot : cs0; newc = false; }
-            if (NDT_D5 & 64) { newc = newc && (cs0 < 0 || cs1 < 0); }
-            if (__ballot(newc)) {
-                if (newc) {
-                    const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);   // an empty run first, else the older one
-                    const int victim = to1 ? cs1 : cs0;
-                    if (victim >= 0 && !(NDT_D6 & 8)) {
-                        double vn = to1 ? rn1 : rn, v3[3], v6[6];
-#pragma unroll
-                        for (int k = 0; k < 3; k++) v3[k] = to1 ? sd1[k] : sd[k];
-#pragma unroll
-                        for (int k = 0; k < 6; k++) v6[k] = to1 ? se1[k] : se[k];
-                        // the replaced run is ADDED to the wave's LDS table entry of its cell (lanes that bounce
-                        // between three or four cells at a cell corner replace a run at almost every point: the
-                        // table keeps one record per cell however often that happens).  All additions to a
-                        // wave's table come from that wave, in program order.
-                        unsigned e = ((unsigned)victim * 0x9E3779B1u) >> 28;
-                        bool placed = false;
-#pragma unroll 1
-                        for (int probe = 0; probe < 4 && !placed; probe++) {
-                            const int old = atomicCAS(&q_slot[e], -1, victim);
-                            if (old == -1 || old == victim) {
-                                unsafeAtomicAdd(&q_val[0 * NDT_QRUNS + e], vn);
-#pragma unroll
-                                for (int k = 0; k < 3; k++) unsafeAtomicAdd(&q_val[(1 + k) * NDT_QRUNS + e], v3[k]);
-#pragma unroll
-                                for (int k = 0; k < 6; k++) unsafeAtomicAdd(&q_val[(4 + k) * NDT_QRUNS + e], v6[k]);
-                                placed = true;
-                            } else {
-                                e = (e + 1u) & (NDT_QRUNS - 1u);
-                            }
-                        }
-                        if (placed) {
-                            s_qcnt[wave] = 1u;
-                        } else {                             // table full (unordered cloud): add directly
-                            double rec[20];
-                            int rid;
-                            write_flush_record(bc, rec, &rid, victim, vn, v3, v6);
-                            if (rid >= 0)
-                                for (int k = 0; k < 19; k++)
-                                    unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + rid) + k, rec[k]);
-                        }
-                    }
-                    if (to1) {
-                        cs1 = slot; rn1 = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; k++) sd1[k] = 0;
-#pragma unroll
-                        for (int k = 0; k < 6; k++) se1[k] = 0;
-                    } else {
-                        cs0 = slot; rn = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; k++) sd[k] = 0;
-#pragma unroll
-                        for (int k = 0; k < 6; k++) se[k] = 0;
-                    }
-                }
-            }
-            NDT_QS(0)
-            // offset from the point's own cell origin: |d| <= one cell, no cancellation later on
-            double x, y, z;
-            if (nice) {
-                x = (double)(fx - fmaf((float)ix, res32, c0x32));
-                y = (double)(fy - fmaf((float)iy, res32, c0y32));
-                z = (double)(fz - fmaf((float)iz, res32, c0z32));
-            } else {
-                x = (double)fx - (cx + ((double)ix - hx) * res);
-                y = (double)fy - (cy + ((double)iy - hy) * res);
-                z = (double)fz - (cz + ((double)iz - hz) * res);
-            }
-            const bool in0 = slot == cs0, in1 = slot == cs1;          // cs0 / cs1 are never -1
-            if (in0) {
-                rn += 1.0;
-                sd[0] += x; sd[1] += y; sd[2] += z;
-                se[0] = fma(x, x, se[0]); se[1] = fma(x, y, se[1]); se[2] = fma(x, z, se[2]);
-                se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
-            }
-            NDT_QS(1)
-            if (__ballot(in1)) {
-                if (in1) {
-                    rn1 += 1.0;
-                    sd1[0] += x; sd1[1] += y; sd1[2] += z;
-                    se1[0] = fma(x, x, se1[0]); se1[1] = fma(x, y, se1[1]); se1[2] = fma(x, z, se1[2]);
-                    se1[3] = fma(y, y, se1[3]); se1[4] = fma(y, z, se1[4]); se1[5] = fma(z, z, se1[5]);
-                }
-            }
-            mru1 = in1 ? 1 : (in0 ? 0 : mru1);
-            NDT_QS(2)
+            add_point(ax, ay, az, aix, aiy, aiz, aslot);
+            add_point(bx, by, bz, bix, biy, biz, bslot);
         }
         }   // rounds
-        if (!(NDT_D7 & 2)) {
+        {
             ndt_wave_sync();   // table / flag written by other lanes during the rounds
             // Canonical order of a lane's two runs (run 0 = smaller slot): along a wall that hugs a cell
             // face neighbouring lanes then agree on which cell is run 0 and which is run 1, so both form
@@ -599,7 +581,6 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
             }
             drain_list();
         }
-        NDT_PS(3)
     }
     __syncthreads();
     if (MODE == 1) return;   // the finalise launch does the rest
@@ -852,12 +833,6 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) vo
         ctr->cyc[1] = (uint32_t)(t2 - t1);
         ctr->cyc[2] = (uint32_t)(t3 - t2);
         ctr->cyc[3] = 0u;                                  // reserved: ticket counter of the multi-workgroup finalise
-#ifdef NDT_PROFILE_SECTIONS
-        for (int k = 0; k < 4; k++) ctr->cyc[k] = (uint32_t)(ps[k] >> 4);   // wave 0: load, bin, accumulate, merge+flush (x16 cycles)
-#ifdef NDT_PROFILE_ACC
-        for (int k = 0; k < 4; k++) ctr->cyc[k] = (uint32_t)(qs[k] >> 4);   // cell bookkeeping, offsets + run 0, run 1, -
-#endif
-#endif
     }
 }
 
@@ -920,14 +895,7 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
     int s2_shift = (odd ? 50 : 54) - lg;
     if (s1_shift > 44) s1_shift = 44;
     if (s2_shift > 44) s2_shift = 44;
-#ifdef NDT_BUILD_ABLATION
-    // ablation build only (-DNDT_BUILD_ABLATION): NDT_BUILD_DBG switches parts of phase A off to time the rest
-    // (1 no flush atomics, 2 no merge / flush, 4 no points, 8 no run replacement, 16 no accumulation,
-    //  32 one cell per lane, 64 no third cell)
-    const int dbg = getenv("NDT_BUILD_DBG") ? atoi(getenv("NDT_BUILD_DBG")) : 0;
-#else
-    const int dbg = 0;
-#endif
+    const int dbg = 0;   // reserved kernel argument
     const bool aligned4 = (((uintptr_t)xyz_dev | map_stride_bytes) & 3u) == 0;
     const int sdw = (stride_bytes == 12 && aligned4) ? 3 : (stride_bytes == 16 && aligned4) ? 4 : 0;
     // Few maps: spread each scan over several workgroups (accumulate) and finalise in a second launch.
@@ -939,9 +907,18 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         if (parts < 1) parts = 1;
     }
 #define NDT_LAUNCH_BUILD(SDW, MODE, GRID)                                                                            \
-    hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set, (unsigned)first, \
-                       (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes, map_stride_bytes,          \
-                       range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg, __builtin_inff(), nice)
+    do {                                                                                                             \
+        if (nice)                                                                                                    \
+            hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE, true>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set,   \
+                               (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,   \
+                               map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift,       \
+                               s2_shift, dbg, __builtin_inff());                                                     \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE, false>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set,  \
+                               (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,   \
+                               map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift,       \
+                               s2_shift, dbg, __builtin_inff());                                                     \
+    } while (0)
 #define NDT_LAUNCH_BUILD_SD(MODE, GRID)                                                                              \
     do {                                                                                                             \
         if (sdw == 3) NDT_LAUNCH_BUILD(3, MODE, GRID);                                                               \
@@ -960,10 +937,10 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         unsigned fin_parts = (unsigned)(512 / count);
         if (fin_parts > 32u) fin_parts = 32u;
         if (fin_parts < 1u) fin_parts = 1u;
-        hipLaunchKernelGGL((ndt_build_kernel<0, 2>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
-                           (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
+        hipLaunchKernelGGL((ndt_build_kernel<0, 2, false>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream,
+                           set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
                            map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg,
-                           __builtin_inff(), nice);
+                           __builtin_inff());
     }
 #undef NDT_LAUNCH_BUILD_SD
 #undef NDT_LAUNCH_BUILD
@@ -998,9 +975,18 @@ hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t cou
     hipError_t e = hipMemset2DAsync(&set.counters[first].overflow, sizeof(NdtMapCounters), 0, 2 * sizeof(uint32_t), count, stream);
     if (e != hipSuccess) return e;
 #define NDT_LAUNCH_ACC(SDW)                                                                                           \
-    hipLaunchKernelGGL((ndt_build_kernel<SDW, 1>), dim3(parts, (unsigned)count), dim3(NDT_BUILD_THREADS), 0, stream, set, \
-                       (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,           \
-                       map_stride_bytes, range_limit, range_origins_dev, 0, 0.0, s1_shift, s2_shift, 0, zf, nice)
+    do {                                                                                                             \
+        if (nice)                                                                                                    \
+            hipLaunchKernelGGL((ndt_build_kernel<SDW, 1, true>), dim3(parts, (unsigned)count), dim3(NDT_BUILD_THREADS), 0, \
+                               stream, set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points,              \
+                               (unsigned)stride_bytes, map_stride_bytes, range_limit, range_origins_dev, 0, 0.0,     \
+                               s1_shift, s2_shift, 0, zf);                                                           \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ndt_build_kernel<SDW, 1, false>), dim3(parts, (unsigned)count), dim3(NDT_BUILD_THREADS), 0, \
+                               stream, set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points,              \
+                               (unsigned)stride_bytes, map_stride_bytes, range_limit, range_origins_dev, 0, 0.0,     \
+                               s1_shift, s2_shift, 0, zf);                                                           \
+    } while (0)
     if (sdw == 3) NDT_LAUNCH_ACC(3);
     else if (sdw == 4) NDT_LAUNCH_ACC(4);
     else NDT_LAUNCH_ACC(0);

@@ -330,7 +330,7 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, const NdtCell *__r
 template <int NW, bool WITH_H>
 NDT_D void wave_eval_init(WaveEval<WITH_H> &w, EvalShared<NW> &sh)
 {
-    const unsigned wave = threadIdx.x >> 6;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     w.mysrc = sh.src + wave * (9 * 64);
     w.myq = sh.queue + wave * NDT_QN;
     w.mywin = sh.win + wave * (7 * 64);
@@ -363,7 +363,7 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
                        double lfd2, EvalShared<NDT_MATCH_WAVES> &sh)
 {
     constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3;
-    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const unsigned tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
     WaveEval<WITH_H> w;
     wave_eval_init<NDT_MATCH_WAVES, WITH_H>(w, sh);
     const int per_wave = (msrc + NDT_MATCH_WAVES - 1) / NDT_MATCH_WAVES;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
 {
     __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     __shared__ rigid s_T;
-    const unsigned link = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const unsigned link = blockIdx.x, tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
     const MapView tg = map_view(tset, tidx[link]);
     const MapView sv = map_view(sset, sidx[link]);
     const int32_t *table = tset.table + (size_t)tidx[link] * tset.grid.slots;
