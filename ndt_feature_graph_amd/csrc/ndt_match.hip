@@ -36,9 +36,14 @@
 
 namespace {
 
+// cell records and rank bitmaps live in device (global) memory: said in the pointer types, so that pointers that went
+// through an LDS copy of a MapView are still dereferenced with global_load, not flat_load
+typedef const NdtCell __attribute__((address_space(1))) *gcell_ptr;
+typedef const unsigned long long __attribute__((address_space(1))) *grank_ptr;   // uint2 {bits, first rank} as one 8-byte word
+
 struct MapView {
-    const uint2 *rankmap;
-    const NdtCell *cells;
+    grank_ptr rankmap;
+    gcell_ptr cells;
     int n_cells;
     int sx, sy, sz;
     double cx, cy, cz, res;
@@ -47,8 +52,8 @@ struct MapView {
 NDT_D MapView map_view(const NdtSetView &s, unsigned map)
 {
     MapView v;
-    v.rankmap = s.rankmap + (size_t)map * ndt_rm_stride(s.grid);
-    v.cells = ndt_cells_of(s, map, s.cell_sel ? s.cell_sel[map] : 0u);   // (second array after an incremental update)
+    v.rankmap = (grank_ptr)(s.rankmap + (size_t)map * ndt_rm_stride(s.grid));
+    v.cells = (gcell_ptr)ndt_cells_of(s, map, s.cell_sel ? s.cell_sel[map] : 0u);   // (second array after an incremental update)
     v.n_cells = (int)s.counters[map].n_cells;
     v.sx = s.grid.size[0]; v.sy = s.grid.size[1]; v.sz = s.grid.size[2];
     v.cx = s.centres[map * 3]; v.cy = s.centres[map * 3 + 1]; v.cz = s.centres[map * 3 + 2];
@@ -190,7 +195,7 @@ struct EvalShared {
 
 // What a wave carries through an evaluation: its accumulators, its hit queue, its share of the LDS.
 #ifdef NDT_MATCH_PROF   // experiments: section clocks of wave 0 (src+transform, probe, pop, term, reduce)
-__device__ long long g_prof[8];
+__device__ long long g_prof[16];   // [0..5]: gradient-only evaluations (5 sections + count), [8..13]: with Hessian
 #define NDT_PROF_T(k) { if (threadIdx.x == 0) { long long n_ = clock64(); w.prof[k] += n_ - w.pt; w.pt = n_; } }
 #else
 #define NDT_PROF_T(k)
@@ -224,7 +229,7 @@ NDT_D void drain_queue(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, doub
             d3 m = {w.mysrc[0 * 64 + sl], w.mysrc[1 * 64 + sl], w.mysrc[2 * 64 + sl]};
             sym3 C = {w.mysrc[3 * 64 + sl], w.mysrc[4 * 64 + sl], w.mysrc[5 * 64 + sl],
                       w.mysrc[6 * 64 + sl], w.mysrc[7 * 64 + sl], w.mysrc[8 * 64 + sl]};
-            const NdtCell *tc = tg.cells + id;
+            gcell_ptr tc = tg.cells + id;
             d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
             sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
             pair_term<WITH_H>(m, C, mu, Cj, lfd1, lfd2, w.acc);
@@ -239,7 +244,7 @@ NDT_D void drain_queue(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, doub
 // One group of up to 64 consecutive source cells [base, end): transform (pseudoTransformNDT), PROBE, TERM.
 // On return every hit of the group has been summed into w.acc (the queue is empty).
 template <int NN, bool WITH_H>
-NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, const NdtCell *__restrict__ src, int base, int end,
+NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int base, int end,
                       const rigid &T, double lfd1, double lfd2)
 {
     constexpr int W = 2 * NN + 1;
@@ -250,7 +255,7 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, const NdtCell *__r
     int ix = 0, iy = 0, iz = 0;
     NDT_PROF_T(4)
     if (vi) {
-        const NdtCell *sc = src + i;
+        gcell_ptr sc = src + i;
         d3 m0 = {sc->mean[0], sc->mean[1], sc->mean[2]};
         sym3 C0 = {sc->cov[0], sc->cov[1], sc->cov[2], sc->cov[3], sc->cov[4], sc->cov[5]};
         d3 m = apply(T, m0);                    // pseudoTransformNDT: mean' = T mean
@@ -272,7 +277,7 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, const NdtCell *__r
     const bool flat = tg.sz <= NN + 1 && !__ballot(vi && !(iz - NN <= 0 && iz + NN >= tg.sz - 1));
     NDT_PROF_T(0)
     const int zlo = flat ? 0 : max(iz - NN, 0), zhi = flat ? tg.sz - 1 : min(iz + NN, tg.sz - 1);
-    const uint2 *rmw = tg.rankmap;
+    grank_ptr rmw = tg.rankmap;
     // The runs are fetched W at a time (flat map: the W runs of the W x-neighbours; otherwise, per x, the W
     // runs of the y-neighbours): all 2 W loads are in flight together, the decoded windows (bits, first cell)
     // wait in the wave's LDS staging rows, and a rolled loop pops them -- one L2 round trip per batch instead
@@ -294,8 +299,9 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, const NdtCell *__r
             const unsigned s0 = ok ? (unsigned)((xx * tg.sy + ylo) * tg.sz + zlo) : 0u;
             len[q] = ok ? (flat ? (yhi - ylo + 1) * tg.sz : zhi - zlo + 1) : 0;   // <= 28 bits
             sh[q] = s0 & 31u;
-            wa[q] = rmw[s0 >> 5];
-            wb[q] = rmw[(s0 >> 5) + 1u];
+            const unsigned long long ra = rmw[s0 >> 5], rb = rmw[(s0 >> 5) + 1u];
+            wa[q] = make_uint2((unsigned)ra, (unsigned)(ra >> 32));
+            wb[q] = make_uint2((unsigned)rb, (unsigned)(rb >> 32));
         }
 #pragma unroll
         for (int q = 0; q < W; q++) {
@@ -359,7 +365,7 @@ NDT_D double wave_totals(const WaveEval<WITH_H> &w)
 // workgroup: equal contiguous shares per wave (even a small range keeps all waves busy).  Result in sh.sums[0..6]
 // ([7..27] when WITH_H, [28] = pair terms).  Ends with a barrier.
 template <int NN, bool WITH_H>
-NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int msrc, const rigid &T, double lfd1,
+NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &T, double lfd1,
                        double lfd2, EvalShared<NDT_MATCH_WAVES> &sh)
 {
     constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3;
@@ -382,7 +388,7 @@ NDT_D void eval_derivs(const MapView &tg, const NdtCell *__restrict__ src, int m
     __syncthreads();
     NDT_PROF_T(4)
 #ifdef NDT_MATCH_PROF
-    if (tid == 0) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&g_prof[k], (unsigned long long)w.prof[k]); atomicAdd((unsigned long long *)&g_prof[5 + (WITH_H ? 1 : 0)], 1ull); }
+    if (tid == 0) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&g_prof[k + (WITH_H ? 8 : 0)], (unsigned long long)w.prof[k]); atomicAdd((unsigned long long *)&g_prof[5 + (WITH_H ? 8 : 0)], 1ull); }
 #endif
 }
 
@@ -557,8 +563,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_kernel(
     I.t[0] = I.t[1] = I.t[2] = 0.0;
     if (threadIdx.x < 28) sh.sums[threadIdx.x] = 0.0;
     __syncthreads();
-    if (with_h) eval_derivs<NN, true>(tg, src, (int)m, I, lfd1, lfd2, sh);
-    else eval_derivs<NN, false>(tg, src, (int)m, I, lfd1, lfd2, sh);
+    if (with_h) eval_derivs<NN, true>(tg, (gcell_ptr)src, (int)m, I, lfd1, lfd2, sh);
+    else eval_derivs<NN, false>(tg, (gcell_ptr)src, (int)m, I, lfd1, lfd2, sh);
     if (threadIdx.x < 28) out28[threadIdx.x] = sh.sums[threadIdx.x];
 }
 
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
     for (int k = 0; k < 32; k++) jj[k] = 0.0;
     const rigid T = s_T;
     for (int i = (int)tid; i < sv.n_cells; i += NDT_MATCH_THREADS) {
-        const NdtCell *sc = sv.cells + i;
+        gcell_ptr sc = sv.cells + i;
         const d3 m = apply(T, d3{sc->mean[0], sc->mean[1], sc->mean[2]});
         const sym3 C = rotate_cov(T.r, sym3{sc->cov[0], sc->cov[1], sc->cov[2], sc->cov[3], sc->cov[4], sc->cov[5]});
         const int ix = lazygrid_index(m.x, tg.cx, tg.res, tg.sx), iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy),
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
         if ((unsigned)ix >= (unsigned)tg.sx || (unsigned)iy >= (unsigned)tg.sy || (unsigned)iz >= (unsigned)tg.sz) continue;
         const int r = table[(ix * tg.sy + iy) * tg.sz + iz];
         if (r < 0) continue;
-        const NdtCell *tc = tg.cells + r;
+        gcell_ptr tc = tg.cells + r;
         const d3 x = m - d3{tc->mean[0], tc->mean[1], tc->mean[2]};
         sym3 B;
         if (!inverse_check(C + sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]}, B)) continue;
@@ -962,12 +968,12 @@ hipError_t ndt_launch_derivatives(const NdtSetView &tset, size_t tmap, const Ndt
 }
 
 #ifdef NDT_MATCH_PROF
-extern "C" int ndtgpu_debug_prof(long long out[8], int reset)
+extern "C" int ndtgpu_debug_prof(long long out[16], int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 8 * sizeof(long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 16 * sizeof(long long)) != hipSuccess) return -1;
     if (reset) {
-        long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess) return -1;
     }
     return 0;
