@@ -32,7 +32,7 @@
 
 #define NDT_MATCH_THREADS 512
 #define NDT_MATCH_WAVES (NDT_MATCH_THREADS / 64)
-#define NDT_QN 512
+#define NDT_QL 2048          // entries of a wave's hit list (source lane << 24 | target cell)
 
 namespace {
 
@@ -122,6 +122,41 @@ NDT_D unsigned long long lanemask_lt()
     return (lane == 0) ? 0ull : (~0ull >> (64u - lane));
 }
 
+// A constant that is (re)made in scalar registers where it is used: the pair term is inlined into loops whose vector
+// registers are all taken, and a loop-invariant constant hoisted into a vector register there is spilled to scratch
+// memory and reloaded, with a full memory wait, at every use.
+NDT_D double sgpr_const(double c)
+{
+    asm volatile("" : "+s"(c));
+    return c;
+}
+
+// exp(x) for x <= 0 (the exponent of a Gaussian): 2^k exp(r), k = rint(x log2 e), r = x - k ln 2 in two parts
+// (|r| <= 0.3466), exp(r) by its Taylor polynomial of degree 13 (truncation 4e-18), about one ulp like the library's;
+// 0 below the double range, NaN for NaN.
+NDT_D double exp_nonpos(double x)
+{
+    const double kf = rint(x * sgpr_const(1.4426950408889634));
+    double r = fma(kf, sgpr_const(-6.93147180369123816490e-01), x);
+    r = fma(kf, sgpr_const(-1.90821492927058770002e-10), r);
+    double p = sgpr_const(1.60590438368216133e-10);               // 1/13!
+    p = fma(p, r, sgpr_const(2.08767569878681002e-09));   // 1/12!
+    p = fma(p, r, sgpr_const(2.50521083854417202e-08));   // 1/11!
+    p = fma(p, r, sgpr_const(2.75573192239858883e-07));   // 1/10!
+    p = fma(p, r, sgpr_const(2.75573192239858925e-06));   // 1/9!
+    p = fma(p, r, sgpr_const(2.48015873015873016e-05));   // 1/8!
+    p = fma(p, r, sgpr_const(1.98412698412698413e-04));   // 1/7!
+    p = fma(p, r, sgpr_const(1.38888888888888894e-03));   // 1/6!
+    p = fma(p, r, sgpr_const(8.33333333333333322e-03));   // 1/5!
+    p = fma(p, r, sgpr_const(4.16666666666666644e-02));   // 1/4!
+    p = fma(p, r, sgpr_const(1.66666666666666657e-01));   // 1/3!
+    p = fma(p, r, sgpr_const(5.00000000000000000e-01));   // 1/2!
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double v = ldexp(p, (int)fmax(kf, -1100.0));
+    return x < -745.2 ? 0.0 : v;
+}
+
 // One (source cell, target cell) term of NDTMatcherD2D::derivativesNDT + updateGradientHessianLocal
 // (SURVEY.md App. A.4).  m, C: source mean / covariance already in the target frame.
 // acc: [0] score, [1..6] gradient, [7..27] upper triangle of the Hessian (row-major).
@@ -134,7 +169,7 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
     d3 xB = mul(B, x);
     double l = dot(x, xB);
     if (!(l * 0.0 == 0.0)) return;                   // if(l*0 != 0) continue;
-    double sh = -lfd1 * exp(-lfd2 * l * 0.5);
+    double sh = -lfd1 * exp_nonpos(-lfd2 * l * 0.5);
     double f = -(lfd2 * 0.5) * sh;
     d3 w = mul(C, xB);
     d3 c = cross(w, xB);                             // x^T B Z_k B x = 2 c_k
@@ -184,11 +219,19 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
 }
 
 // LDS of one workgroup's evaluation machinery (NW waves)
+struct HitCache {                   // what a wave remembers of its last evaluation (one group of source cells per wave)
+    unsigned key;                   // the caller's key of the registration (0: nothing cached)
+    int base;                       // first source cell of the group
+    unsigned count;                 // hits in the list
+    unsigned pad;
+};
 template <int NW>
 struct EvalShared {
     double src[NW * 9 * 64];        // per wave: the transformed source tile, one column per lane
-    uint32_t queue[NW * NDT_QN];    // per wave: hit queue (source lane << 24 | target cell)
+    uint32_t queue[NW * NDT_QL];    // per wave: the hit list of its group (source lane << 24 | target cell)
     uint2 win[NW * 7 * 64];         // per wave: decoded probe windows (up to 7 runs x 64 lanes)
+    int cell[NW * 3 * 64];          // per wave: the target-grid index of every lane's transformed mean, last evaluation
+    HitCache cache[NW];
     double part[NW * 32];           // wave partials (range-partitioned evaluations)
     double sums[32];                // the evaluation's result
 };
@@ -196,7 +239,10 @@ struct EvalShared {
 // What a wave carries through an evaluation: its accumulators, its hit queue, its share of the LDS.
 #ifdef NDT_MATCH_PROF   // experiments: section clocks of wave 0 (src+transform, probe, pop, term, reduce)
 __device__ long long g_prof[16];   // [0..5]: gradient-only evaluations (5 sections + count), [8..13]: with Hessian
-#define NDT_PROF_T(k) { if (threadIdx.x == 0) { long long n_ = clock64(); w.prof[k] += n_ - w.pt; w.pt = n_; } }
+#ifndef NDT_PROF_TID
+#define NDT_PROF_TID 0
+#endif
+#define NDT_PROF_T(k) { if (threadIdx.x == NDT_PROF_TID) { long long n_ = clock64(); w.prof[k] += n_ - w.pt; w.pt = n_; } }
 #else
 #define NDT_PROF_T(k)
 #endif
@@ -210,47 +256,92 @@ struct WaveEval {
     double *mysrc;
     uint32_t *myq;
     uint2 *mywin;
-    unsigned qhead, qcount, terms;   // wave-uniform
+    int *mycell;
+    HitCache *cache;
+    unsigned terms;                  // wave-uniform
 };
 
-// TERM stage: pops up to 64 (source lane, target cell) pairs; every lane does one dense pair term.
-// `min_fill` = 64 while probing (only full batches), 1 for the final flush of a source tile.
-template <bool WITH_H>
-NDT_D void drain_queue(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double lfd2, unsigned min_fill)
+NDT_D unsigned wave_incl_scan_u32(unsigned v)
 {
     const unsigned lane = threadIdx.x & 63u;
-    ndt_wave_sync();                 // queue entries and source tile columns were written by other lanes
-    NDT_PROF_T(2)
-    while (w.qcount >= min_fill && w.qcount > 0) {
-        unsigned n = w.qcount < 64u ? w.qcount : 64u;
-        if (lane < n) {
-            uint32_t e = w.myq[(w.qhead + lane) & (NDT_QN - 1)];
-            unsigned sl = e >> 24, id = e & 0xFFFFFFu;
-            d3 m = {w.mysrc[0 * 64 + sl], w.mysrc[1 * 64 + sl], w.mysrc[2 * 64 + sl]};
-            sym3 C = {w.mysrc[3 * 64 + sl], w.mysrc[4 * 64 + sl], w.mysrc[5 * 64 + sl],
-                      w.mysrc[6 * 64 + sl], w.mysrc[7 * 64 + sl], w.mysrc[8 * 64 + sl]};
-            gcell_ptr tc = tg.cells + id;
-            d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
-            sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
-            pair_term<WITH_H>(m, C, mu, Cj, lfd1, lfd2, w.acc);
-        }
-        w.qhead = (w.qhead + n) & (NDT_QN - 1);
-        w.qcount -= n;
-        w.terms += n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(v, o, 64);
+        if (lane >= (unsigned)o) v += t;
     }
-    NDT_PROF_T(3)
+    return v;
 }
 
-// One group of up to 64 consecutive source cells [base, end): transform (pseudoTransformNDT), PROBE, TERM.
-// On return every hit of the group has been summed into w.acc (the queue is empty).
+// TERM stage: the n (source lane, target cell) pairs at the head of the wave's list, 64 at a time; every lane does one
+// dense pair term.  Without a Hessian the target cells of the next batch are fetched while this one is computed.
+template <bool WITH_H>
+NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double lfd2, unsigned n)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    auto tile_m = [&](unsigned sl) { return d3{w.mysrc[0 * 64 + sl], w.mysrc[1 * 64 + sl], w.mysrc[2 * 64 + sl]}; };
+    auto tile_C = [&](unsigned sl) {
+        return sym3{w.mysrc[3 * 64 + sl], w.mysrc[4 * 64 + sl], w.mysrc[5 * 64 + sl],
+                    w.mysrc[6 * 64 + sl], w.mysrc[7 * 64 + sl], w.mysrc[8 * 64 + sl]};
+    };
+    if constexpr (WITH_H) {
+#pragma unroll 1
+        for (unsigned e0 = 0; e0 < n; e0 += 64u) {
+            if (e0 + lane < n) {
+                const uint32_t en = w.myq[e0 + lane];
+                gcell_ptr tc = tg.cells + (en & 0xFFFFFFu);
+                d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
+                sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
+                pair_term<true>(tile_m(en >> 24), tile_C(en >> 24), mu, Cj, lfd1, lfd2, w.acc);
+            }
+        }
+    } else {
+        bool v0 = lane < n;
+        uint32_t en0 = v0 ? w.myq[lane] : 0u;
+        d3 mu0 = {0, 0, 0};
+        sym3 Cj0 = {0, 0, 0, 0, 0, 0};
+        if (v0) {
+            gcell_ptr tc = tg.cells + (en0 & 0xFFFFFFu);
+            mu0 = d3{tc->mean[0], tc->mean[1], tc->mean[2]};
+            Cj0 = sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
+        }
+#pragma unroll 1
+        for (unsigned e0 = 0; e0 < n; e0 += 64u) {
+            const bool v1 = e0 + 64u + lane < n;
+            uint32_t en1 = 0u;
+            d3 mu1 = {0, 0, 0};
+            sym3 Cj1 = {0, 0, 0, 0, 0, 0};
+            if (v1) {
+                en1 = w.myq[e0 + 64u + lane];
+                gcell_ptr tc = tg.cells + (en1 & 0xFFFFFFu);
+                mu1 = d3{tc->mean[0], tc->mean[1], tc->mean[2]};
+                Cj1 = sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (the loads stay above the arithmetic)
+            if (v0) pair_term<false>(tile_m(en0 >> 24), tile_C(en0 >> 24), mu0, Cj0, lfd1, lfd2, w.acc);
+            v0 = v1; en0 = en1; mu0 = mu1; Cj0 = Cj1;
+        }
+    }
+    w.terms += n;
+}
+
+// One group of up to 64 source cells base + k stride < end: transform (pseudoTransformNDT), PROBE, TERM.
+//   PROBE reads the (2n+1)^3 slots around every lane's cell as bit windows of the map's rank bitmap (1 bit per slot +
+//   the rank of every 32-slot word's first Gaussian cell): slots are z-fastest, so the neighbours along z are one run
+//   of <= W bits, and in a flat map (sz <= n+1: every z-layer is a neighbour) the whole (y, z) block of one x is a
+//   single run of <= W*sz bits.  Cells are ranked in slot order, so the k-th set bit of a run is cell `first + k`: no
+//   per-slot lookups.  Every lane counts its hits, a scan over the wave gives it its place in the wave's hit list, and
+//   the lanes fill the list without talking to each other.
+//   The list only depends on the target-grid cells the transformed means fall into.  `cache_key` != 0 names the
+//   registration this evaluation belongs to: when the wave's last evaluation had the same key and group and no mean
+//   has left its cell since (the small steps of a line search), PROBE is skipped and the list is used again.
+// On return every hit of the group has been summed into w.acc.
 template <int NN, bool WITH_H>
-NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int base, int end,
-                      const rigid &T, double lfd1, double lfd2)
+NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int base, int stride, int end,
+                      const rigid &T, double lfd1, double lfd2, unsigned cache_key)
 {
     constexpr int W = 2 * NN + 1;
-    static_assert(63 + W * 64 <= NDT_QN, "per-wave hit queue too small for this neighbourhood");
     const unsigned lane = threadIdx.x & 63u;
-    const int i = base + (int)lane;
+    const int i = base + (int)lane * stride;
     const bool vi = i < end;
     int ix = 0, iy = 0, iz = 0;
     NDT_PROF_T(4)
@@ -267,24 +358,19 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
         iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy);
         iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
     }
-    // PROBE stage: the (2n+1)^3 slots around the lane's cell, read as bit windows of the map's rank bitmap
-    // (1 bit per slot + the rank of every 32-slot word's first Gaussian cell): slots are z-fastest, so the
-    // neighbours along z are one run of <= W bits, and in a flat map (sz <= n+1: every z-layer is a
-    // neighbour) the whole (y, z) block of one x is a single run of <= W*sz bits.  Cells are ranked in slot
-    // order, so the k-th set bit of a run is cell `first + k`: no per-slot lookups.
+    NDT_PROF_T(0)
+    const HitCache hc = *w.cache;
+    const bool moved = vi && (w.mycell[lane] != ix || w.mycell[64 + lane] != iy || w.mycell[128 + lane] != iz);
+    const bool reuse = cache_key != 0u && hc.key == cache_key && hc.base == base && !__ballot(moved);
+    if (vi && !reuse) { w.mycell[lane] = ix; w.mycell[64 + lane] = iy; w.mycell[128 + lane] = iz; }
     // flat form only when every lane's z-neighbourhood is the whole column (a source cell that lies two or
     // more cells above / below a thin map sees only part of it, or nothing): wave-uniform
     const bool flat = tg.sz <= NN + 1 && !__ballot(vi && !(iz - NN <= 0 && iz + NN >= tg.sz - 1));
-    NDT_PROF_T(0)
     const int zlo = flat ? 0 : max(iz - NN, 0), zhi = flat ? tg.sz - 1 : min(iz + NN, tg.sz - 1);
     grank_ptr rmw = tg.rankmap;
-    // The runs are fetched W at a time (flat map: the W runs of the W x-neighbours; otherwise, per x, the W
-    // runs of the y-neighbours): all 2 W loads are in flight together, the decoded windows (bits, first cell)
-    // wait in the wave's LDS staging rows, and a rolled loop pops them -- one L2 round trip per batch instead
-    // of one per run.
-    uint2 *win = w.mywin + lane;
-#pragma unroll 1
-    for (int outer = 0; outer < (flat ? 1 : W); outer++) {
+    // The runs are fetched W at a time (flat map: the W runs of the W x-neighbours; otherwise, per x, the W runs of the
+    // y-neighbours): all 2 W loads are in flight together.
+    auto windows = [&](int outer, unsigned (&bits)[W], unsigned (&id0)[W]) {
         uint2 wa[W], wb[W];
         unsigned sh[W];
         int len[W];
@@ -305,32 +391,74 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
         }
 #pragma unroll
         for (int q = 0; q < W; q++) {
-            const unsigned bits = __builtin_amdgcn_alignbit(wb[q].x, wa[q].x, sh[q]) & ((1u << len[q]) - 1u);
+            bits[q] = __builtin_amdgcn_alignbit(wb[q].x, wa[q].x, sh[q]) & ((1u << len[q]) - 1u);
             const unsigned lowa = wa[q].x >> sh[q];          // the window's part of the first word
-            const unsigned id0 = lowa ? wa[q].y + (unsigned)__popc(wa[q].x & ((1u << sh[q]) - 1u)) : wb[q].y;
-            win[q * 64] = make_uint2(bits, id0);
+            id0[q] = lowa ? wa[q].y + (unsigned)__popc(wa[q].x & ((1u << sh[q]) - 1u)) : wb[q].y;
         }
-        NDT_PROF_T(1)
+    };
+    uint2 *win = w.mywin + lane;
+    unsigned cnt = 0;
 #pragma unroll 1
+    for (int outer = 0; outer < (reuse ? 0 : flat ? 1 : W); outer++) {
+        unsigned bits[W], id0[W];
+        windows(outer, bits, id0);
+#pragma unroll
         for (int q = 0; q < W; q++) {
-            const uint2 v = win[q * 64];
-            unsigned bits = v.x, id = v.y;
-            // every lane pops its lowest remaining bit per round: ids count up from the run's first cell
-            while (true) {
-                const bool hit = bits != 0u;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                if (!mask) break;
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                if (hit) w.myq[(w.qhead + w.qcount + rank) & (NDT_QN - 1)] = (lane << 24) | id;
-                w.qcount += (unsigned)__popcll(mask);
-                id += 1u;
-                bits &= bits - 1u;
-                drain_queue<WITH_H>(w, tg, lfd1, lfd2, 64);
-            }
+            if (flat) win[q * 64] = make_uint2(bits[q], id0[q]);   // (the other form reads its windows again below)
+            cnt += (unsigned)__popc(bits[q]);
         }
     }
-    drain_queue<WITH_H>(w, tg, lfd1, lfd2, 1);   // the per-wave source tile is overwritten by the next group
-    ndt_wave_sync();
+    unsigned total = hc.count, my_off = 0u;
+    if (!reuse) {
+        const unsigned incl = wave_incl_scan_u32(cnt);
+        total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        my_off = incl - cnt;
+    }
+    NDT_PROF_T(1)
+    // the list is materialised NDT_QL hits at a time (one pass unless the neighbourhoods are dense 3D ones)
+#pragma unroll 1
+    for (unsigned p0 = 0; p0 < total; p0 += (unsigned)NDT_QL) {
+        const unsigned p1 = min(total, p0 + (unsigned)NDT_QL);
+        if (!reuse && my_off < p1 && my_off + cnt > p0) {
+            unsigned gi = my_off;
+            if (flat) {
+#pragma unroll 1
+                for (int q = 0; q < W; q++) {
+                    const uint2 v = win[q * 64];
+                    unsigned bits = v.x, id = v.y;
+                    while (bits) {
+                        if (gi >= p0 && gi < p1) w.myq[gi - p0] = (lane << 24) | id;
+                        gi += 1u; id += 1u; bits &= bits - 1u;
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int outer = 0; outer < W; outer++) {
+                    unsigned bits[W], id0[W];
+                    windows(outer, bits, id0);
+#pragma unroll
+                    for (int q = 0; q < W; q++) {
+                        unsigned b_ = bits[q], id = id0[q];
+                        while (b_) {
+                            if (gi >= p0 && gi < p1) w.myq[gi - p0] = (lane << 24) | id;
+                            gi += 1u; id += 1u; b_ &= b_ - 1u;
+                        }
+                    }
+                }
+            }
+        }
+        ndt_wave_sync();                             // list entries and tile columns were written by other lanes
+        NDT_PROF_T(2)
+        term_list<WITH_H>(w, tg, lfd1, lfd2, p1 - p0);
+        NDT_PROF_T(3)
+        ndt_wave_sync();                             // the next pass (or group) overwrites the list and the tile
+    }
+    if (lane == 0 && !reuse) {
+        HitCache nc;
+        nc.key = total <= (unsigned)NDT_QL ? cache_key : 0u;
+        nc.base = base; nc.count = total; nc.pad = 0u;
+        *w.cache = nc;
+    }
 }
 
 template <int NW, bool WITH_H>
@@ -338,9 +466,11 @@ NDT_D void wave_eval_init(WaveEval<WITH_H> &w, EvalShared<NW> &sh)
 {
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     w.mysrc = sh.src + wave * (9 * 64);
-    w.myq = sh.queue + wave * NDT_QN;
+    w.myq = sh.queue + wave * NDT_QL;
     w.mywin = sh.win + wave * (7 * 64);
-    w.qhead = 0; w.qcount = 0; w.terms = 0;
+    w.mycell = sh.cell + wave * (3 * 64);
+    w.cache = sh.cache + wave;
+    w.terms = 0;
 #pragma unroll
     for (int k = 0; k < WaveEval<WITH_H>::NACC; k++) w.acc[k] = 0.0;
 #ifdef NDT_MATCH_PROF
@@ -362,20 +492,21 @@ NDT_D double wave_totals(const WaveEval<WITH_H> &w)
 
 // ---- range-partitioned evaluation (cooperative / host-driven / stand-alone kernels) --------------------------
 // One evaluation of derivativesNDT over source cells [0, msrc), transformed by T, on the 8 waves of a wide
-// workgroup: equal contiguous shares per wave (even a small range keeps all waves busy).  Result in sh.sums[0..6]
+// workgroup: the cells are dealt to the waves in turn (even a small range keeps all waves busy).  Result in sh.sums[0..6]
 // ([7..27] when WITH_H, [28] = pair terms).  Ends with a barrier.
 template <int NN, bool WITH_H>
 NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &T, double lfd1,
-                       double lfd2, EvalShared<NDT_MATCH_WAVES> &sh)
+                       double lfd2, EvalShared<NDT_MATCH_WAVES> &sh, unsigned cache_key = 0u)
 {
     constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3;
     const unsigned tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
     WaveEval<WITH_H> w;
     wave_eval_init<NDT_MATCH_WAVES, WITH_H>(w, sh);
-    const int per_wave = (msrc + NDT_MATCH_WAVES - 1) / NDT_MATCH_WAVES;
-    const int w_begin = (int)wave * per_wave, w_end = min(msrc, w_begin + per_wave);
-    for (int base = w_begin; base < w_end; base += 64)
-        eval_group<NN, WITH_H>(w, tg, src, base, min(w_end, base + 64), T, lfd1, lfd2);
+    // cells are dealt to the waves in turn (cell i -> wave i mod 8): cells are ranked in slot order, so a contiguous
+    // share would be one strip of the map, and strips differ a lot in how many neighbours their cells have
+    const unsigned key = msrc <= 64 * NDT_MATCH_WAVES ? cache_key : 0u;   // a wave remembers the hit list of ONE group
+    for (int base = (int)wave; base < msrc; base += 64 * NDT_MATCH_WAVES)
+        eval_group<NN, WITH_H>(w, tg, src, base, NDT_MATCH_WAVES, msrc, T, lfd1, lfd2, key);
     const double tot = wave_totals<WITH_H>(w);
     if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) sh.part[wave * 32 + (lane >> SH)] = tot;
     if (lane == 0) sh.part[wave * 32 + 28] = (double)w.terms;
@@ -388,7 +519,7 @@ NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &
     __syncthreads();
     NDT_PROF_T(4)
 #ifdef NDT_MATCH_PROF
-    if (tid == 0) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&g_prof[k + (WITH_H ? 8 : 0)], (unsigned long long)w.prof[k]); atomicAdd((unsigned long long *)&g_prof[5 + (WITH_H ? 8 : 0)], 1ull); }
+    if (tid == NDT_PROF_TID) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&g_prof[k + (WITH_H ? 8 : 0)], (unsigned long long)w.prof[k]); atomicAdd((unsigned long long *)&g_prof[5 + (WITH_H ? 8 : 0)], 1ull); }
 #endif
 }
 
@@ -432,7 +563,9 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     __shared__ MapView s_tg, s_sv;
     __shared__ long long s_cnt[4];      // thread 0: shader clocks in evaluations / in the solver, pair terms g / h
     __shared__ NdtMatchParamsDev s_prm; // the solver takes the parameters by reference: LDS, not a scratch copy
-    if (threadIdx.x == 0) s_prm = prm;
+    __shared__ unsigned s_session;      // names the registration this workgroup is working on (key of the waves' hit lists)
+    if (threadIdx.x == 0) { s_prm = prm; s_session = 0u; }
+    if (threadIdx.x < NDT_MATCH_WAVES) sh.cache[threadIdx.x].key = 0u;
 
     NdtMatchWork *work = reinterpret_cast<NdtMatchWork *>(work_mem);
     unsigned *ids = reinterpret_cast<unsigned *>(work_mem + sizeof(NdtMatchWork));
@@ -461,6 +594,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
                 if (v >= 2u) job = -2 - (int)(v - 2u);
             }
             s_job = job;
+            s_session = s_session + 1u ? s_session + 1u : 1u;
         }
         __syncthreads();
         const int job = s_job;
@@ -505,14 +639,21 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
             // it only after the evaluation's closing barrier, when nobody reads it any more
             const int with_h = st.with_h;
             long long c0 = __builtin_readcyclecounter();
-            if (with_h) eval_derivs<NN, true>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh);
-            else eval_derivs<NN, false>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh);
+            if (with_h) eval_derivs<NN, true>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh, s_session);
+            else eval_derivs<NN, false>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh, s_session);
             long long c1 = __builtin_readcyclecounter();
             if (threadIdx.x == 0) {
                 s_cnt[with_h ? 3 : 2] += (long long)sh.sums[28];
                 s_cnt[0] += c1 - c0;
+#ifdef NDT_MATCH_PROF
+                const int ph_ = st.phase;
+#endif
                 match_state_step(st, sh.sums, s_prm);
                 s_cnt[1] += (long long)__builtin_readcyclecounter() - c1;
+#ifdef NDT_MATCH_PROF
+                atomicAdd((unsigned long long *)&g_prof[ph_ == PH_NEWTON ? 6 : 14], (unsigned long long)((long long)__builtin_readcyclecounter() - c1));
+                atomicAdd((unsigned long long *)&g_prof[ph_ == PH_NEWTON ? 7 : 15], 1ull);
+#endif
                 // about to start another Newton iteration of a long registration: hand the CU to a pair that has
                 // not started yet, if there is one
                 s_job = 0;
