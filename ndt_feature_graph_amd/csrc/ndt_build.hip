@@ -139,7 +139,9 @@ NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int s
 // MODE 2: finalise only (phases 0, B, C, D), one workgroup per map, after a MODE 1 launch
 // (no minimum-waves hint: __launch_bounds__(256, 2) halves the speed of phase A although the register count stays at
 //  250 -- measured 1.79 vs 0.94 ms -- and 3 / 4 waves per SIMD spill: 2.53 / 1.92 ms)
-template <int STRIDE_DW, int MODE, bool NICE>
+// SCAT: clouds whose consecutive points change cell every few points (3D sweeps): a replaced run goes straight to a
+//       flush list of its own (64 records per wave, 40 KB of LDS more) instead of the small per-wave table
+template <int STRIDE_DW, int MODE, bool NICE, bool SCAT>
 #ifndef NDT_BUILD_WPE
 #define NDT_BUILD_WPE
 #endif
@@ -151,7 +153,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     constexpr int SD = STRIDE_DW ? STRIDE_DW : 3;
     constexpr int LANE_DW = NDT_PPL * SD + 1;          // +1: odd stride -> conflict-free per-lane walks
     __shared__ __attribute__((aligned(16))) float s_tile[NDT_BUILD_WAVES * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1))];
-    __shared__ int s_flid[NDT_BUILD_WAVES * NDT_FLCAP];
+    constexpr int FLC = SCAT ? 64 : NDT_FLCAP;                       // records in a wave's flush list
+    __shared__ int s_flid[NDT_BUILD_WAVES * FLC];
+    __shared__ double s_list[SCAT ? NDT_BUILD_WAVES * 64 * 20 : 1];
     __shared__ double s_qval[NDT_BUILD_WAVES * 10 * NDT_QRUNS];
     __shared__ int s_qslot[NDT_BUILD_WAVES * NDT_QRUNS];
     __shared__ unsigned s_qcnt[NDT_BUILD_WAVES];
@@ -264,8 +268,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     // flush list: after the point loop the tile buffer is dead and holds the records of the partial
     // runs that must be added to their cells; ONE atomic instruction then serves up to 64 (record,
     // component) items, instead of 19 dependent single-lane atomics per run.
-    double *fl_val = reinterpret_cast<double *>(mytile);
-    int *fl_id = s_flid + awave * NDT_FLCAP;
+    double *fl_val = SCAT ? s_list + awave * (64 * 20) : reinterpret_cast<double *>(mytile);
+    int *fl_id = s_flid + awave * FLC;
     unsigned nfl = 0;   // wave-uniform
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
     auto drain_list = [&]() {
@@ -283,8 +287,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     auto push_runs = [&](bool mine, int slot, double n, const double *sd3, const double *se6) {
         unsigned long long m = __ballot(mine);
         while (m) {
-            if (nfl == NDT_FLCAP) drain_list();
-            const unsigned room = NDT_FLCAP - nfl;
+            if (nfl == (unsigned)FLC) drain_list();
+            const unsigned room = (unsigned)FLC - nfl;
             const unsigned rank = (unsigned)__popcll(m & lt_mask);
             const bool now = mine && ((m >> lane) & 1ull) && rank < room;
             if (now) write_flush_record(bc, fl_val + (nfl + rank) * 20u, fl_id + nfl + rank, slot, n, sd3, se6);
@@ -394,7 +398,33 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         auto add_point = [&](float fx, float fy, float fz, int ix, int iy, int iz, int slot) {
             const bool newc = (slot >= 0) & (slot != cs0) & (slot != cs1);
             if (__ballot(newc)) {
-                if (newc) {
+                if (SCAT) {
+                    // every lane with a replaced run appends one record to the wave's flush list (drained with wide
+                    // atomics whenever it is full)
+                    const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);
+                    const int victim = to1 ? cs1 : cs0;
+                    double vn = to1 ? rn1 : rn, v3[3], v6[6];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) v3[k] = to1 ? sd1[k] : sd[k];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v6[k] = to1 ? se1[k] : se[k];
+                    push_runs(newc && victim >= 0, victim, vn, v3, v6);
+                    if (newc) {
+                        if (to1) {
+                            cs1 = slot; rn1 = 0;
+#pragma unroll
+                            for (int k = 0; k < 3; k++) sd1[k] = 0;
+#pragma unroll
+                            for (int k = 0; k < 6; k++) se1[k] = 0;
+                        } else {
+                            cs0 = slot; rn = 0;
+#pragma unroll
+                            for (int k = 0; k < 3; k++) sd[k] = 0;
+#pragma unroll
+                            for (int k = 0; k < 6; k++) se[k] = 0;
+                        }
+                    }
+                } else if (newc) {
                     const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);   // an empty run first, else the older one
                     // (one copy of the code per run: selecting the victim's ten sums first would cost twenty registers)
                     if (to1) {
@@ -906,18 +936,20 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         if (parts > n_tiles / 4) parts = n_tiles / 4;
         if (parts < 1) parts = 1;
     }
+    // thick grids hold 3D sweeps, whose consecutive points change cell every few points: replaced runs go to the wide
+    // flush list (SCAT).  Flat grids hold planar scans, whose points stay in a cell for hundreds of points.
+    const bool scat = set.grid.size[2] > 4;
+#define NDT_LAUNCH_BUILD_V(SDW, MODE, NICE_, SCAT_, GRID)                                                            \
+    hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE, NICE_, SCAT_>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set,   \
+                       (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,           \
+                       map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg, \
+                       __builtin_inff())
 #define NDT_LAUNCH_BUILD(SDW, MODE, GRID)                                                                            \
     do {                                                                                                             \
-        if (nice)                                                                                                    \
-            hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE, true>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set,   \
-                               (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,   \
-                               map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift,       \
-                               s2_shift, dbg, __builtin_inff());                                                     \
-        else                                                                                                         \
-            hipLaunchKernelGGL((ndt_build_kernel<SDW, MODE, false>), GRID, dim3(NDT_BUILD_THREADS), 0, stream, set,  \
-                               (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,   \
-                               map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift,       \
-                               s2_shift, dbg, __builtin_inff());                                                     \
+        if (nice && scat) NDT_LAUNCH_BUILD_V(SDW, MODE, true, true, GRID);                                           \
+        else if (nice) NDT_LAUNCH_BUILD_V(SDW, MODE, true, false, GRID);                                             \
+        else if (scat) NDT_LAUNCH_BUILD_V(SDW, MODE, false, true, GRID);                                             \
+        else NDT_LAUNCH_BUILD_V(SDW, MODE, false, false, GRID);                                                      \
     } while (0)
 #define NDT_LAUNCH_BUILD_SD(MODE, GRID)                                                                              \
     do {                                                                                                             \
@@ -937,13 +969,14 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         unsigned fin_parts = (unsigned)(512 / count);
         if (fin_parts > 32u) fin_parts = 32u;
         if (fin_parts < 1u) fin_parts = 1u;
-        hipLaunchKernelGGL((ndt_build_kernel<0, 2, false>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream,
+        hipLaunchKernelGGL((ndt_build_kernel<0, 2, false, false>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream,
                            set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
                            map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg,
                            __builtin_inff());
     }
 #undef NDT_LAUNCH_BUILD_SD
 #undef NDT_LAUNCH_BUILD
+#undef NDT_LAUNCH_BUILD_V
     return hipGetLastError();
 }
 
@@ -974,23 +1007,23 @@ hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t cou
     if (parts < 1) parts = 1;
     hipError_t e = hipMemset2DAsync(&set.counters[first].overflow, sizeof(NdtMapCounters), 0, 2 * sizeof(uint32_t), count, stream);
     if (e != hipSuccess) return e;
-#define NDT_LAUNCH_ACC(SDW)                                                                                           \
+    const bool scat = set.grid.size[2] > 4;
+#define NDT_LAUNCH_ACC_V(SDW, NICE_, SCAT_)                                                                          \
+    hipLaunchKernelGGL((ndt_build_kernel<SDW, 1, NICE_, SCAT_>), dim3(parts, (unsigned)count), dim3(NDT_BUILD_THREADS), 0, \
+                       stream, set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes, \
+                       map_stride_bytes, range_limit, range_origins_dev, 0, 0.0, s1_shift, s2_shift, 0, zf)
+#define NDT_LAUNCH_ACC(SDW)                                                                                          \
     do {                                                                                                             \
-        if (nice)                                                                                                    \
-            hipLaunchKernelGGL((ndt_build_kernel<SDW, 1, true>), dim3(parts, (unsigned)count), dim3(NDT_BUILD_THREADS), 0, \
-                               stream, set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points,              \
-                               (unsigned)stride_bytes, map_stride_bytes, range_limit, range_origins_dev, 0, 0.0,     \
-                               s1_shift, s2_shift, 0, zf);                                                           \
-        else                                                                                                         \
-            hipLaunchKernelGGL((ndt_build_kernel<SDW, 1, false>), dim3(parts, (unsigned)count), dim3(NDT_BUILD_THREADS), 0, \
-                               stream, set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points,              \
-                               (unsigned)stride_bytes, map_stride_bytes, range_limit, range_origins_dev, 0, 0.0,     \
-                               s1_shift, s2_shift, 0, zf);                                                           \
+        if (nice && scat) NDT_LAUNCH_ACC_V(SDW, true, true);                                                         \
+        else if (nice) NDT_LAUNCH_ACC_V(SDW, true, false);                                                           \
+        else if (scat) NDT_LAUNCH_ACC_V(SDW, false, true);                                                           \
+        else NDT_LAUNCH_ACC_V(SDW, false, false);                                                                    \
     } while (0)
     if (sdw == 3) NDT_LAUNCH_ACC(3);
     else if (sdw == 4) NDT_LAUNCH_ACC(4);
     else NDT_LAUNCH_ACC(0);
 #undef NDT_LAUNCH_ACC
+#undef NDT_LAUNCH_ACC_V
     return hipGetLastError();
 }
 
