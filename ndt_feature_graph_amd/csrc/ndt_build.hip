@@ -346,7 +346,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         tile += R;
         int cs0 = -2, cs1 = -3;                // empty (negative, and never equal to the "no cell" slot -1)
         int mru1 = 0;                          // 1: run 1 was used more recently than run 0
-        double rn = 0, rn1 = 0;
+        unsigned rn = 0, rn1 = 0;              // points in the two runs (counts: one register each)
         double sd[3] = {0, 0, 0}, se[6] = {0, 0, 0, 0, 0, 0};
         double sd1[3] = {0, 0, 0}, se1[6] = {0, 0, 0, 0, 0, 0};
         auto load_point = [&](unsigned r, int j, float &fx, float &fy, float &fz) {
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
                     // atomics whenever it is full)
                     const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);
                     const int victim = to1 ? cs1 : cs0;
-                    double vn = to1 ? rn1 : rn, v3[3], v6[6];
+                    double vn = (double)(to1 ? rn1 : rn), v3[3], v6[6];
 #pragma unroll
                     for (int k = 0; k < 3; k++) v3[k] = to1 ? sd1[k] : sd[k];
 #pragma unroll
@@ -428,14 +428,14 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
                     const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);   // an empty run first, else the older one
                     // (one copy of the code per run: selecting the victim's ten sums first would cost twenty registers)
                     if (to1) {
-                        if (cs1 >= 0) evict_run(cs1, rn1, sd1, se1);
+                        if (cs1 >= 0) evict_run(cs1, (double)rn1, sd1, se1);
                         cs1 = slot; rn1 = 0;
 #pragma unroll
                         for (int k = 0; k < 3; k++) sd1[k] = 0;
 #pragma unroll
                         for (int k = 0; k < 6; k++) se1[k] = 0;
                     } else {
-                        if (cs0 >= 0) evict_run(cs0, rn, sd, se);
+                        if (cs0 >= 0) evict_run(cs0, (double)rn, sd, se);
                         cs0 = slot; rn = 0;
 #pragma unroll
                         for (int k = 0; k < 3; k++) sd[k] = 0;
@@ -457,14 +457,14 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
             }
             const bool in0 = slot == cs0, in1 = slot == cs1;          // cs0 / cs1 are never -1
             if (in0) {
-                rn += 1.0;
+                rn += 1u;
                 sd[0] += x; sd[1] += y; sd[2] += z;
                 se[0] = fma(x, x, se[0]); se[1] = fma(x, y, se[1]); se[2] = fma(x, z, se[2]);
                 se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
             }
             if (__ballot(in1)) {
                 if (in1) {
-                    rn1 += 1.0;
+                    rn1 += 1u;
                     sd1[0] += x; sd1[1] += y; sd1[2] += z;
                     se1[0] = fma(x, x, se1[0]); se1[1] = fma(x, y, se1[1]); se1[2] = fma(x, z, se1[2]);
                     se1[3] = fma(y, y, se1[3]); se1[4] = fma(y, z, se1[4]); se1[5] = fma(z, z, se1[5]);
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
             if (__ballot(swap)) {
                 if (swap) {
                     double t;
-                    t = rn1; rn1 = rn; rn = t;
+                    { const unsigned tn = rn1; rn1 = rn; rn = tn; }
 #pragma unroll
                     for (int k = 0; k < 3; k++) { t = sd1[k]; sd1[k] = sd[k]; sd[k] = t; }
 #pragma unroll
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
                     // second pass: the lanes' run 1
                     const bool has = cs1 >= 0;
                     cs = cs1;
-                    rn = has ? rn1 : 0.0;
+                    rn = has ? rn1 : 0u;
 #pragma unroll
                     for (int k = 0; k < 3; k++) sd[k] = has ? sd1[k] : 0.0;
 #pragma unroll
@@ -583,13 +583,13 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
                 for (int o = 1; o < 64; o <<= 1) {
                     bool take = o < rem;
                     double t;
-                    t = __shfl_down(rn, o, 64); if (take) rn += t;
+                    { const unsigned tn = __shfl_down(rn, o, 64); if (take) rn += tn; }
 #pragma unroll
                     for (int k = 0; k < 3; k++) { t = __shfl_down(sd[k], o, 64); if (take) sd[k] += t; }
 #pragma unroll
                     for (int k = 0; k < 6; k++) { t = __shfl_down(se[k], o, 64); if (take) se[k] += t; }
                 }
-                push_runs(head && cs >= 0, cs, rn, sd, se);
+                push_runs(head && cs >= 0, cs, (double)rn, sd, se);
             }
             ndt_wave_sync();
             if (s_qcnt[wave]) {                  // records of the replaced runs; the table goes back to empty
