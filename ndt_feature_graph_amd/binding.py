@@ -35,8 +35,10 @@ def build_library(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     extra = os.environ.get("NDTGPU_BUILD_FLAGS", "").split()      # experiments only (-DNDT_MATCH_PROF ...)
+    # (spills of the solver's helper functions go to scratch, not to AGPRs: with AGPRs in use the narrow matcher kernel
+    #  would not fit two workgroups per CU)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", *extra, *srcs, "-o", _SO + ".tmp"]
+           "-Wno-unused-function", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", *extra, *srcs, "-o", _SO + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

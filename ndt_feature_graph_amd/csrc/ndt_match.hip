@@ -32,7 +32,6 @@
 
 #define NDT_MATCH_THREADS 512
 #define NDT_MATCH_WAVES (NDT_MATCH_THREADS / 64)
-#define NDT_QL 2048          // entries of a wave's hit list (source lane << 24 | target cell)
 
 namespace {
 
@@ -227,11 +226,15 @@ struct HitCache {                   // what a wave remembers of its last evaluat
 };
 template <int NW>
 struct EvalShared {
+    // a wave of a wide (8-wave) workgroup remembers the hit list of one group of 64 source cells, a wave of a narrow
+    // (4-wave) workgroup those of two groups: either way registrations of up to 512 source cells are covered
+    static constexpr int G = NW >= 8 ? 1 : 2;          // remembered groups per wave
+    static constexpr int QL = NW >= 8 ? 2048 : 1024;   // entries of one hit list (source lane << 24 | target cell)
     double src[NW * 9 * 64];        // per wave: the transformed source tile, one column per lane
-    uint32_t queue[NW * NDT_QL];    // per wave: the hit list of its group (source lane << 24 | target cell)
+    uint32_t queue[NW * G * QL];    // per wave and group: the hit list
     uint2 win[NW * 7 * 64];         // per wave: decoded probe windows (up to 7 runs x 64 lanes)
-    int cell[NW * 3 * 64];          // per wave: the target-grid index of every lane's transformed mean, last evaluation
-    HitCache cache[NW];
+    int cell[NW * G * 3 * 64];      // per wave and group: the target-grid index of every lane's transformed mean, last evaluation
+    HitCache cache[NW * G];
     double part[NW * 32];           // wave partials (range-partitioned evaluations)
     double sums[32];                // the evaluation's result
 };
@@ -335,11 +338,12 @@ NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double
 //   registration this evaluation belongs to: when the wave's last evaluation had the same key and group and no mean
 //   has left its cell since (the small steps of a line search), PROBE is skipped and the list is used again.
 // On return every hit of the group has been summed into w.acc.
-template <int NN, bool WITH_H>
+template <int NN, bool WITH_H, int QL>
 NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int base, int stride, int end,
                       const rigid &T, double lfd1, double lfd2, unsigned cache_key)
 {
     constexpr int W = 2 * NN + 1;
+    constexpr int NDT_QL = QL;
     const unsigned lane = threadIdx.x & 63u;
     const int i = base + (int)lane * stride;
     const bool vi = i < end;
@@ -466,10 +470,10 @@ NDT_D void wave_eval_init(WaveEval<WITH_H> &w, EvalShared<NW> &sh)
 {
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     w.mysrc = sh.src + wave * (9 * 64);
-    w.myq = sh.queue + wave * NDT_QL;
+    w.myq = sh.queue + wave * (EvalShared<NW>::G * EvalShared<NW>::QL);
     w.mywin = sh.win + wave * (7 * 64);
-    w.mycell = sh.cell + wave * (3 * 64);
-    w.cache = sh.cache + wave;
+    w.mycell = sh.cell + wave * (EvalShared<NW>::G * 3 * 64);
+    w.cache = sh.cache + wave * EvalShared<NW>::G;
     w.terms = 0;
 #pragma unroll
     for (int k = 0; k < WaveEval<WITH_H>::NACC; k++) w.acc[k] = 0.0;
@@ -494,26 +498,33 @@ NDT_D double wave_totals(const WaveEval<WITH_H> &w)
 // One evaluation of derivativesNDT over source cells [0, msrc), transformed by T, on the 8 waves of a wide
 // workgroup: the cells are dealt to the waves in turn (even a small range keeps all waves busy).  Result in sh.sums[0..6]
 // ([7..27] when WITH_H, [28] = pair terms).  Ends with a barrier.
-template <int NN, bool WITH_H>
+template <int NN, bool WITH_H, int NW = NDT_MATCH_WAVES>
 NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &T, double lfd1,
-                       double lfd2, EvalShared<NDT_MATCH_WAVES> &sh, unsigned cache_key = 0u)
+                       double lfd2, EvalShared<NW> &sh, unsigned cache_key = 0u)
 {
-    constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3;
+    constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3, G = EvalShared<NW>::G, QL = EvalShared<NW>::QL;
     const unsigned tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
     WaveEval<WITH_H> w;
-    wave_eval_init<NDT_MATCH_WAVES, WITH_H>(w, sh);
-    // cells are dealt to the waves in turn (cell i -> wave i mod 8): cells are ranked in slot order, so a contiguous
+    wave_eval_init<NW, WITH_H>(w, sh);
+    // cells are dealt to the waves in turn (cell i -> wave i mod NW): cells are ranked in slot order, so a contiguous
     // share would be one strip of the map, and strips differ a lot in how many neighbours their cells have
-    const unsigned key = msrc <= 64 * NDT_MATCH_WAVES ? cache_key : 0u;   // a wave remembers the hit list of ONE group
-    for (int base = (int)wave; base < msrc; base += 64 * NDT_MATCH_WAVES)
-        eval_group<NN, WITH_H>(w, tg, src, base, NDT_MATCH_WAVES, msrc, T, lfd1, lfd2, key);
+    const unsigned key = msrc <= 64 * NW * G ? cache_key : 0u;   // a wave remembers the hit lists of G groups
+    int gi = 0;
+    for (int base = (int)wave; base < msrc; base += 64 * NW, gi++) {
+        if (key) {                                                   // this group's remembered list, cells, header
+            w.myq = sh.queue + (wave * G + gi) * QL;
+            w.mycell = sh.cell + (wave * G + gi) * (3 * 64);
+            w.cache = sh.cache + wave * G + gi;
+        }
+        eval_group<NN, WITH_H, QL>(w, tg, src, base, NW, msrc, T, lfd1, lfd2, key);
+    }
     const double tot = wave_totals<WITH_H>(w);
     if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) sh.part[wave * 32 + (lane >> SH)] = tot;
     if (lane == 0) sh.part[wave * 32 + 28] = (double)w.terms;
     __syncthreads();
     if (tid < (unsigned)NACC || tid == 28u) {
         double s = 0;
-        for (int k = 0; k < NDT_MATCH_WAVES; k++) s += sh.part[k * 32 + tid];
+        for (int k = 0; k < NW; k++) s += sh.part[k * 32 + tid];
         sh.sums[tid] = s;             // [28]: number of (source, target) pair terms of this evaluation
     }
     __syncthreads();
@@ -548,14 +559,17 @@ size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups)
     return sizeof(NdtMatchWork) + (n_pairs + n_groups + 1) * sizeof(unsigned) + 8 + n_pairs * sizeof(NdtParkedState);
 }
 
-template <int NN>
-__global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
+// NW = 8: one wide workgroup per CU (a registration finishes soonest).  NW = 4: two narrow workgroups per CU, each with
+// its own registration: one's serial solver steps and latency-bound probing overlap the other's pair terms (more
+// registrations per second, each of them slower) -- chosen for large batches (ndt_launch_match).
+template <int NN, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ndt_match_kernel(
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
     double *__restrict__ T16, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res,
     const double *__restrict__ Q36 /* per pair Tcov^-1 (matchFusion soft constraint) or NULL */,
     unsigned n_pairs, int park_iters, char *__restrict__ work_mem)
 {
-    __shared__ EvalShared<NDT_MATCH_WAVES> sh;
+    __shared__ EvalShared<NW> sh;
     __shared__ MatchState st;
     __shared__ int s_job, s_next, s_skip;
     // per-registration state that outlives an evaluation sits in LDS, not in registers: the evaluation needs ~220
@@ -565,7 +579,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
     __shared__ NdtMatchParamsDev s_prm; // the solver takes the parameters by reference: LDS, not a scratch copy
     __shared__ unsigned s_session;      // names the registration this workgroup is working on (key of the waves' hit lists)
     if (threadIdx.x == 0) { s_prm = prm; s_session = 0u; }
-    if (threadIdx.x < NDT_MATCH_WAVES) sh.cache[threadIdx.x].key = 0u;
+    if (threadIdx.x < NW * EvalShared<NW>::G) sh.cache[threadIdx.x].key = 0u;
 
     NdtMatchWork *work = reinterpret_cast<NdtMatchWork *>(work_mem);
     unsigned *ids = reinterpret_cast<unsigned *>(work_mem + sizeof(NdtMatchWork));
@@ -639,8 +653,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_kernel(
             // it only after the evaluation's closing barrier, when nobody reads it any more
             const int with_h = st.with_h;
             long long c0 = __builtin_readcyclecounter();
-            if (with_h) eval_derivs<NN, true>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh, s_session);
-            else eval_derivs<NN, false>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh, s_session);
+            if (with_h) eval_derivs<NN, true, NW>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh, s_session);
+            else eval_derivs<NN, false, NW>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh, s_session);
             long long c1 = __builtin_readcyclecounter();
             if (threadIdx.x == 0) {
                 s_cnt[with_h ? 3 : 2] += (long long)sh.sums[28];
@@ -1070,15 +1084,21 @@ hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
                             NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters,
-                            void *work_dev, hipStream_t stream)
+                            int narrow, void *work_dev, hipStream_t stream)
 {
     if (n_pairs == 0) return hipSuccess;
     // ticket counters and the parked list start at zero
     hipError_t e = hipMemsetAsync(work_dev, 0, sizeof(NdtMatchWork) + (n_pairs + n_groups + 1) * sizeof(unsigned), stream);
     if (e != hipSuccess) return e;
 #define NDT_LAUNCH_MATCH(NN)                                                                                         \
-    hipLaunchKernelGGL(ndt_match_kernel<NN>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev, sset, \
-                       sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, (char *)work_dev)
+    do {                                                                                                             \
+        if (narrow)                                                                                                  \
+            hipLaunchKernelGGL((ndt_match_kernel<NN, 4>), dim3(n_groups), dim3(256), 0, stream, tset, tidx_dev, sset, \
+                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, (char *)work_dev); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((ndt_match_kernel<NN, 8>), dim3(n_groups), dim3(512), 0, stream, tset, tidx_dev, sset, \
+                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, (char *)work_dev); \
+    } while (0)
     switch (prm.n_neighbours) {
     case 0: NDT_LAUNCH_MATCH(0); break;
     case 1: NDT_LAUNCH_MATCH(1); break;

@@ -10,7 +10,10 @@
 #include "ndt_math.h"
 #include <float.h>
 
-#define NDT_HDN static __host__ __device__ __attribute__((noinline))
+#ifndef NDT_SOLVER_VGPRS
+#define NDT_SOLVER_VGPRS
+#endif
+#define NDT_HDN static __host__ __device__ __attribute__((noinline)) NDT_SOLVER_VGPRS
 
 enum { PH_NEWTON = 0, PH_LS_TRIAL = 1, PH_FINAL = 2 };
 

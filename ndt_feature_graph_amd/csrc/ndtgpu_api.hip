@@ -646,14 +646,18 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
                                        ndtgpu_match_result *results_dev, const double *Q36_dev, hipStream_t st)
 {
     if (n_pairs == 0) return NDTGPU_OK;
-    // one persistent workgroup per CU (the kernel's registers and LDS allow exactly one); pairs are pulled from
+    // persistent workgroups (one wide or two narrow ones per CU: registers and LDS allow no more); pairs are pulled from
     // a ticket counter.  NDTGPU_PARK_ITERS: iterations after which a long registration yields to a fresh pair.
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
         n_cu = 256;
     const char *park_env = getenv("NDTGPU_PARK_ITERS");       // read per call: tests switch it
     const int park_iters = park_env ? atoi(park_env) : 6;
-    const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
+    // Batches that give every CU several registrations run TWO narrow (4-wave) workgroups per CU: more registrations per
+    // second, each of them slower (csrc/ndt_match.hip).  NDTGPU_NARROW=0 / 1 forces one form.
+    const char *narrow_env = getenv("NDTGPU_NARROW");
+    const int narrow = narrow_env ? (atoi(narrow_env) != 0) : (n_pairs >= 8 * (size_t)n_cu);   // measured: 1024 pairs 2.59 (wide) / 2.94 ms, 499 500 edges 185 / 139 ms
+    const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu * (narrow ? 2u : 1u));
     // The work area (ticket counters, parked solver states) belongs to the target set: a launch on another stream
     // waits for the previous one, and growing the area waits for everything that may still use the old one.
     if (ts->work_ev_valid && ts->work_stream != st) HIP_TRY(hipStreamWaitEvent(st, ts->work_ev, 0));
@@ -663,7 +667,7 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
     if (wrc != NDTGPU_OK) return wrc;
     if (ts->profiling) HIP_TRY(hipEventRecord(ts->ev[2], st));
     hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
-                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, n_groups, park_iters,
+                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, n_groups, park_iters, narrow,
                                     ts->work, st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
     if (ts->profiling) { HIP_TRY(hipEventRecord(ts->ev[3], st)); ts->ev_valid[1] = true; }
