@@ -147,6 +147,7 @@ hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const Ndt
                                     hipStream_t stream);
 size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups);
 size_t ndt_match_coop_work_bytes(size_t n_groups);
+size_t ndt_match_coop_ctrl_bytes();
 unsigned ndt_match_coop_capacity(int n_neighbours);
 hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                                  const uint32_t *sidx_dev, double *T16_dev, size_t pair_begin, size_t pair_count,

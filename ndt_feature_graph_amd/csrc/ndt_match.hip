@@ -892,6 +892,7 @@ struct NdtCoopCtrl {
 };
 static_assert(sizeof(NdtCoopCtrl) % 64 == 0, "control block keeps the partials aligned");
 size_t ndt_match_coop_work_bytes(size_t n_groups) { return sizeof(NdtCoopCtrl) + n_groups * 32 * sizeof(double); }   // multiple of 64
+size_t ndt_match_coop_ctrl_bytes() { return sizeof(NdtCoopCtrl); }   // what a launch sequence must find zeroed
 
 // Grid barrier number `epoch` (1, 2, ...).  Arrivals on ONE counter serialise at the L2 (~50-100 ns each: 30 us for
 // 256 workgroups), so workgroups arrive on one of up to 16 group counters and the last arrival of a group bumps

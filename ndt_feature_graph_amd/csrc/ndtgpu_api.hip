@@ -823,7 +823,9 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     if (capacity == 0) return NDTGPU_OK;                                          // no occupancy figure: persistent kernel instead
     if (groups > capacity) groups = capacity;
     const size_t per_launch = std::max<size_t>(1, capacity / groups);
-    HIP_TRY(hipMemset2DAsync(ts->work, stride, 0, 64 + 16 * 16 * sizeof(unsigned), n_pairs, st));   // control blocks (NdtCoopCtrl)
+    // the whole control block of every pair (barrier counters only grow during a launch sequence: a counter left over
+    // from the previous call would stall the first barrier of this one)
+    HIP_TRY(hipMemset2DAsync(ts->work, stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
     static std::mutex coop_mutex;
     std::vector<unsigned> ctrl(n_pairs * 4);
     {
