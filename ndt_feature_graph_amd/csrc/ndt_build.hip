@@ -306,7 +306,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     // an Inf passes the range test when no range is set and is then out of the grid.  Returns true when the
     // reference's fp64 formulas must decide (bin_exact): the point is within the fp32 error bound of a cell face or
     // of the range sphere (frac_lim < 0 sends every point there: odd grid sizes, absurd centres).
-    auto bin_fast = [&](float fx, float fy, float fz, int &ix, int &iy, int &iz, int &slot) -> bool {
+    // (the cell index leaves as the three floats floor() made: the offset arithmetic wants them as floats again)
+    auto bin_fast = [&](float fx, float fy, float fz, float &gx, float &gy, float &gz, int &slot) -> bool {
         const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
         const float dd = dx * dx + dy * dy + dz * dz;
         const bool okz = fz <= z_max32;                                 // addPointCloud's maxz (+inf otherwise)
@@ -316,14 +317,16 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
         const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
         const float tx = fabsf((vx - flx) - 0.5f), ty = fabsf((vy - fly) - 0.5f), tz = fabsf((vz - flz) - 0.5f);
-        ix = (int)flx; iy = (int)fly; iz = (int)flz;
+        const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+        gx = flx; gy = fly; gz = flz;
         const bool inb = ((unsigned)ix < gsx) & ((unsigned)iy < gsy) & ((unsigned)iz < gsz);
         const int sl = (int)(((unsigned)ix * gsy + (unsigned)iy) * gsz + (unsigned)iz);
         slot = (okr & inb) ? sl : -1;
         return (okr | (near_r & okz)) & (near_r | !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim));
     };
     // ... and the reference's own formulas for those few points
-    auto bin_exact = [&](float fx, float fy, float fz, int &ix, int &iy, int &iz, int &slot) {
+    auto bin_exact = [&](float fx, float fy, float fz, float &gx, float &gy, float &gz, int &slot) {
+        int ix = (int)gx, iy = (int)gy, iz = (int)gz;
         const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
         const float dd = dx * dx + dy * dy + dz * dz;
         const bool okz = fz <= z_max32;
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         if (!(fabsf((vz - floorf(vz)) - 0.5f) <= frac_lim)) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
         slot = (ok && (unsigned)ix < gsx && (unsigned)iy < gsy && (unsigned)iz < gsz)
                    ? (int)(((unsigned)ix * gsy + (unsigned)iy) * gsz + (unsigned)iz) : -1;
+        gx = (float)ix; gy = (float)iy; gz = (float)iz;           // (only cells of the grid matter: exact below 2^24)
     };
     for (unsigned tile = tile_begin; tile < tile_end;) {
         const unsigned R = min((unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         // consecutive points alternate between two cells; a lane that walks into the next cell keeps the old one as
         // well).  A third cell replaces the run that was used least recently; the replaced run goes to the wave's LDS
         // table.  Nothing here touches LDS or memory on the common path.
-        auto add_point = [&](float fx, float fy, float fz, int ix, int iy, int iz, int slot) {
+        auto add_point = [&](float fx, float fy, float fz, float gx, float gy, float gz, int slot) {
             const bool newc = (slot >= 0) & (slot != cs0) & (slot != cs1);
             if (__ballot(newc)) {
                 if (SCAT) {
@@ -447,13 +451,13 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
             // offset from the point's own cell origin: |d| <= one cell, no cancellation later on
             double x, y, z;
             if (NICE) {
-                x = (double)(fx - fmaf((float)ix, res32, c0x32));
-                y = (double)(fy - fmaf((float)iy, res32, c0y32));
-                z = (double)(fz - fmaf((float)iz, res32, c0z32));
+                x = (double)(fx - fmaf(gx, res32, c0x32));
+                y = (double)(fy - fmaf(gy, res32, c0y32));
+                z = (double)(fz - fmaf(gz, res32, c0z32));
             } else {
-                x = (double)fx - (cx + ((double)ix - hx) * res);
-                y = (double)fy - (cy + ((double)iy - hy) * res);
-                z = (double)fz - (cz + ((double)iz - hz) * res);
+                x = (double)fx - (cx + ((double)gx - hx) * res);
+                y = (double)fy - (cy + ((double)gy - hy) * res);
+                z = (double)fz - (cz + ((double)gz - hz) * res);
             }
             const bool in0 = slot == cs0, in1 = slot == cs1;          // cs0 / cs1 are never -1
             if (in0) {
@@ -530,15 +534,16 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
             float ax, ay, az, bx, by, bz;
             load_point(r, j, ax, ay, az);
             load_point(r, j + 1, bx, by, bz);
-            int aix, aiy, aiz, aslot, bix, biy, biz, bslot;
-            const bool na = bin_fast(ax, ay, az, aix, aiy, aiz, aslot);
-            const bool nb = bin_fast(bx, by, bz, bix, biy, biz, bslot);
+            float agx, agy, agz, bgx, bgy, bgz;
+            int aslot, bslot;
+            const bool na = bin_fast(ax, ay, az, agx, agy, agz, aslot);
+            const bool nb = bin_fast(bx, by, bz, bgx, bgy, bgz, bslot);
             if (__ballot(na | nb)) {
-                if (na) bin_exact(ax, ay, az, aix, aiy, aiz, aslot);
-                if (nb) bin_exact(bx, by, bz, bix, biy, biz, bslot);
+                if (na) bin_exact(ax, ay, az, agx, agy, agz, aslot);
+                if (nb) bin_exact(bx, by, bz, bgx, bgy, bgz, bslot);
             }
-            add_point(ax, ay, az, aix, aiy, aiz, aslot);
-            add_point(bx, by, bz, bix, biy, biz, bslot);
+            add_point(ax, ay, az, agx, agy, agz, aslot);
+            add_point(bx, by, bz, bgx, bgy, bgz, bslot);
         }
         }   // rounds
         {

@@ -32,6 +32,7 @@
 
 #define NDT_MATCH_THREADS 512
 #define NDT_MATCH_WAVES (NDT_MATCH_THREADS / 64)
+#define NDT_VW 8             // shares the source cells of an evaluation are dealt to (= waves of a wide workgroup)
 
 namespace {
 
@@ -226,16 +227,17 @@ struct HitCache {                   // what a wave remembers of its last evaluat
 };
 template <int NW>
 struct EvalShared {
-    // a wave of a wide (8-wave) workgroup remembers the hit list of one group of 64 source cells, a wave of a narrow
-    // (4-wave) workgroup those of two groups: either way registrations of up to 512 source cells are covered
-    static constexpr int G = NW >= 8 ? 1 : 2;          // remembered groups per wave
+    // The source cells are dealt to NDT_VW = 8 SHARES (cell i -> share i mod 8) whatever the workgroup's width: a wave
+    // of a wide (8-wave) workgroup sums one share, a wave of a narrow (4-wave) workgroup two, one after the other.
+    // Shares, their hit lists and their partial sums are the same either way, so the two forms agree bit for bit.
+    // A share remembers the hit list of one group of 64 cells (registrations of up to 512 source cells are covered).
     static constexpr int QL = NW >= 8 ? 2048 : 1024;   // entries of one hit list (source lane << 24 | target cell)
     double src[NW * 9 * 64];        // per wave: the transformed source tile, one column per lane
-    uint32_t queue[NW * G * QL];    // per wave and group: the hit list
+    uint32_t queue[NDT_VW * QL];    // per share: the hit list
     uint2 win[NW * 7 * 64];         // per wave: decoded probe windows (up to 7 runs x 64 lanes)
-    int cell[NW * G * 3 * 64];      // per wave and group: the target-grid index of every lane's transformed mean, last evaluation
-    HitCache cache[NW * G];
-    double part[NW * 32];           // wave partials (range-partitioned evaluations)
+    int cell[NDT_VW * 3 * 64];      // per share: the target-grid index of every lane's transformed mean, last evaluation
+    HitCache cache[NDT_VW];
+    double part[NDT_VW * 32];       // the shares' partial sums
     double sums[32];                // the evaluation's result
 };
 
@@ -470,13 +472,9 @@ NDT_D void wave_eval_init(WaveEval<WITH_H> &w, EvalShared<NW> &sh)
 {
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     w.mysrc = sh.src + wave * (9 * 64);
-    w.myq = sh.queue + wave * (EvalShared<NW>::G * EvalShared<NW>::QL);
     w.mywin = sh.win + wave * (7 * 64);
-    w.mycell = sh.cell + wave * (EvalShared<NW>::G * 3 * 64);
-    w.cache = sh.cache + wave * EvalShared<NW>::G;
+    w.myq = sh.queue; w.mycell = sh.cell; w.cache = sh.cache;     // (set per share)
     w.terms = 0;
-#pragma unroll
-    for (int k = 0; k < WaveEval<WITH_H>::NACC; k++) w.acc[k] = 0.0;
 #ifdef NDT_MATCH_PROF
     for (int k = 0; k < 6; k++) w.prof[k] = 0;
     w.pt = clock64();
@@ -502,29 +500,31 @@ template <int NN, bool WITH_H, int NW = NDT_MATCH_WAVES>
 NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &T, double lfd1,
                        double lfd2, EvalShared<NW> &sh, unsigned cache_key = 0u)
 {
-    constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3, G = EvalShared<NW>::G, QL = EvalShared<NW>::QL;
+    constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3, QL = EvalShared<NW>::QL;
     const unsigned tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
     WaveEval<WITH_H> w;
     wave_eval_init<NW, WITH_H>(w, sh);
-    // cells are dealt to the waves in turn (cell i -> wave i mod NW): cells are ranked in slot order, so a contiguous
-    // share would be one strip of the map, and strips differ a lot in how many neighbours their cells have
-    const unsigned key = msrc <= 64 * NW * G ? cache_key : 0u;   // a wave remembers the hit lists of G groups
-    int gi = 0;
-    for (int base = (int)wave; base < msrc; base += 64 * NW, gi++) {
-        if (key) {                                                   // this group's remembered list, cells, header
-            w.myq = sh.queue + (wave * G + gi) * QL;
-            w.mycell = sh.cell + (wave * G + gi) * (3 * 64);
-            w.cache = sh.cache + wave * G + gi;
-        }
-        eval_group<NN, WITH_H, QL>(w, tg, src, base, NW, msrc, T, lfd1, lfd2, key);
+    // cells are dealt to the shares in turn (cell i -> share i mod 8): cells are ranked in slot order, so a contiguous
+    // part would be one strip of the map, and strips differ a lot in how many neighbours their cells have
+    const unsigned key = msrc <= 64 * NDT_VW ? cache_key : 0u;   // a share remembers the hit list of ONE group
+#pragma unroll 1
+    for (unsigned v = wave; v < (unsigned)NDT_VW; v += (unsigned)NW) {
+        w.myq = sh.queue + v * QL;
+        w.mycell = sh.cell + v * (3 * 64);
+        w.cache = sh.cache + v;
+        w.terms = 0;
+#pragma unroll
+        for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
+        for (int base = (int)v; base < msrc; base += 64 * NDT_VW)
+            eval_group<NN, WITH_H, QL>(w, tg, src, base, NDT_VW, msrc, T, lfd1, lfd2, key);
+        const double tot = wave_totals<WITH_H>(w);
+        if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) sh.part[v * 32 + (lane >> SH)] = tot;
+        if (lane == 0) sh.part[v * 32 + 28] = (double)w.terms;
     }
-    const double tot = wave_totals<WITH_H>(w);
-    if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) sh.part[wave * 32 + (lane >> SH)] = tot;
-    if (lane == 0) sh.part[wave * 32 + 28] = (double)w.terms;
     __syncthreads();
     if (tid < (unsigned)NACC || tid == 28u) {
         double s = 0;
-        for (int k = 0; k < NW; k++) s += sh.part[k * 32 + tid];
+        for (int k = 0; k < NDT_VW; k++) s += sh.part[k * 32 + tid];
         sh.sums[tid] = s;             // [28]: number of (source, target) pair terms of this evaluation
     }
     __syncthreads();
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     __shared__ NdtMatchParamsDev s_prm; // the solver takes the parameters by reference: LDS, not a scratch copy
     __shared__ unsigned s_session;      // names the registration this workgroup is working on (key of the waves' hit lists)
     if (threadIdx.x == 0) { s_prm = prm; s_session = 0u; }
-    if (threadIdx.x < NW * EvalShared<NW>::G) sh.cache[threadIdx.x].key = 0u;
+    if (threadIdx.x < NDT_VW) sh.cache[threadIdx.x].key = 0u;
 
     NdtMatchWork *work = reinterpret_cast<NdtMatchWork *>(work_mem);
     unsigned *ids = reinterpret_cast<unsigned *>(work_mem + sizeof(NdtMatchWork));
