@@ -34,7 +34,7 @@ fetch, write, sq = pmc("prof_fetch"), pmc("prof_write"), pmc("prof_sq")
 sys.path.insert(0, root)
 from ndt_feature_graph_amd import binding
 out = {"round": tag, "lib_version": binding.lib().ndtgpu_version().decode(),   # bench.py refuses a summary of another binary
-       "command": "python bench.py --steps 10 --warmup 2 --no-cpu (1024 pairs x 100k pts, two-buffer pipeline; *_serial: same with --no-pipeline)",
+       "command": "python bench.py --steps 10 --warmup 2 --no-cpu (1024 pairs x 100k pts per step: one build launch of 2048 scans + one matcher launch, three-buffer pipeline; *_serial: same with --no-pipeline)",
        "note": "FETCH_SIZE / WRITE_SIZE are in KB per dispatch (rocprofv3, separate --pmc passes, --kernel-include-regex ndt_). "
                "On gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM): "
                "hbm_read_bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken at face value (uncalibrated).",
