@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o bench -- $CMD > gpurun_out/bench_kt.log 2>&1
-# the same workload without the two-buffer pipeline: kernel durations with the chip to themselves
+# the same workload without the pipeline: kernel durations with the chip to themselves
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_serial -o bench -- $CMD --no-pipeline > gpurun_out/bench_kt_serial.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_fetch -o bench -- $CMD > gpurun_out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_write -o bench -- $CMD > gpurun_out/bench_write.log 2>&1
