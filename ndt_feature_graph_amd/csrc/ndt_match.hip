@@ -1,5 +1,5 @@
 // ndt_match.hip -- D2D-NDT matcher on CDNA4 (gfx950): K4 derivatives + K5 Newton / More-Thuente,
-// one PERSISTENT workgroup per scan pair (K6 batch driver = the grid).
+// PERSISTENT workgroups, one scan pair at a time each (K6 batch driver = the grid).
 //
 // Replaces (reference call sites; perception_oru semantics per SURVEY.md App. A.4-A.6):
 //   NDTMatcherD2D::match(target, source, T, true)          ndt_feature/src/ndt_feature_src/ndt_feature_graph.cpp:273
@@ -15,13 +15,15 @@
 //   * the source cells are never copied or re-written: each evaluation applies the composed pose
 //     (trial step x current pose) to the original 80-byte records (the reference re-allocates every
 //     cell per trial, fusion.h:563-589).
-//   * one 512-thread workgroup runs a registration; every wave owns an equal contiguous share of the source cells
-//     and walks it in groups of 64.  Per group: PROBE (each lane owns a source cell and reads the (2n+1)^3
-//     neighbourhood of its transformed mean as bit windows of the target's rank bitmap) pushes hits into a per-wave
-//     LDS queue by ballot/mbcnt compaction; TERM pops 64 (source, target) pairs so that all 64 lanes do the fp64
-//     pair term densely (444 instructions with the Hessian, 165 without).
-//   * 1+6+21 fp64 partial sums per lane -> fixed butterfly over the wave (permlane swaps) -> 8 LDS partials ->
-//     fixed-order sum.
+//   * a workgroup runs a registration.  The source cells are dealt to 8 SHARES (cell i -> share i mod 8); a wave of a
+//     wide (8-wave) workgroup sums one share, a wave of a narrow (4-wave) workgroup two.  Per share and group of 64
+//     cells: PROBE (each lane owns a source cell and reads the (2n+1)^3 neighbourhood of its transformed mean as bit
+//     windows of the target's rank bitmap), every lane counts its hits, a wave scan places them in the share's hit
+//     list (kept in LDS and reused while no mean leaves its target cell); TERM takes the list 64 (source, target)
+//     pairs at a time so that all 64 lanes do the fp64 pair term densely (444 instructions with the Hessian, 165
+//     without).
+//   * 1+6+21 fp64 partial sums per lane -> fixed butterfly over the wave (permlane swaps) -> 8 LDS partials (one per
+//     share) -> fixed-order sum: wide and narrow workgroups give the same bits.
 //   * persistent workgroups pull pairs from a ticket counter; registrations that run long are parked until every
 //     pair has started, then finished side by side (NdtMatchWork below).
 //   * no atomics in the sums, fixed summation order -> run-to-run identical.
