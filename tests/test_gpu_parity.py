@@ -82,6 +82,36 @@ def test_build_device_pointer_path_and_stride16(N, O):
     assert_cells_equal(ms.export_cells(1), cpu, 0.5)
 
 
+@pytest.mark.parametrize("n_maps,n_pts,stride_dw,res,centre,size", [
+    (300, 5003, 3, 0.5, (0.0, 0.0, 0.0), [100, 100, 1]),          # one workgroup per map, last super-tile ragged
+    (260, 4096, 4, 0.4, (3.3, -1.7, 0.1), [60, 60, 1.2]),         # pcl::PointXYZ records, cell origins not fp32 numbers
+    (3, 20011, 3, 0.5, (0.0, 0.0, 0.0), [100, 100, 1]),           # a few maps: split accumulate + finalise launches
+    (2, 9001, 4, 1.0, (-2.5, 4.0, 0.0), [80, 80, 2]),
+    (513, 3000, 3, 0.3, (0.0, 0.0, 0.0), [60, 60, 0.6]),          # more maps than resident workgroups, 0.3 m cells
+])
+def test_build_launch_shapes_and_strides(N, O, n_maps, n_pts, stride_dw, res, centre, size):
+    """Every launch shape (one workgroup per map / several per map + finalise), staged record stride (12 B, 16 B; any
+    other stride: test_build_odd_grid_and_generic_stride) and grid kind (fp32 cell origins or not) of the build kernel
+    against the oracle, with scans whose length is not a multiple of anything and a few NaN points."""
+    import torch
+    from ndt_feature_graph_amd import synth
+    seeds = [31 + (k % 7) for k in range(n_maps)]
+    g = np.random.default_rng(n_maps * 1000 + n_pts)
+    poses = np.stack([g.uniform(-1, 1, 7), g.uniform(-1, 1, 7), g.uniform(-3.1, 3.1, 7)], axis=1)
+    base = synth.scan_2d([31 + k for k in range(7)], poses, n_pts).numpy()         # 7 distinct scans
+    base[:, ::97, 0] = np.nan                                                      # dropped beams
+    scans = base[np.arange(n_maps) % 7]
+    rec = np.full((n_maps, n_pts, stride_dw), 7.0, dtype=np.float32)
+    rec[:, :, :3] = scans
+    ms = N.MapSet(res, list(centre), size, n_maps=n_maps, max_cells=4096)
+    dev = torch.from_numpy(rec).cuda()
+    ms.build(dev, range_limit=25.0)                                                # [B, N, 3] or [B, N, 4] records
+    torch.cuda.synchronize()
+    ref = [oracle_map(O, base[k], res, size, centre=centre, rng=25.0).export_cells() for k in range(7)]
+    for m in sorted(set([0, 1, 6, 7, n_maps // 2, n_maps - 1]) & set(range(n_maps))):
+        assert_cells_equal(ms.export_cells(m), ref[m % 7], res)
+
+
 def test_build_golden_cells(N, golden):
     for k in range(6):
         pts = golden["cell%d_pts" % k]
