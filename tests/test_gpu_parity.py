@@ -112,6 +112,26 @@ def test_build_launch_shapes_and_strides(N, O, n_maps, n_pts, stride_dw, res, ce
         assert_cells_equal(ms.export_cells(m), ref[m % 7], res)
 
 
+@pytest.mark.parametrize("n_maps", [4, 264])
+def test_build_3d_sweeps_thick_grid(N, O, n_maps):
+    """3D sweeps (consecutive points change cell every few points) in a thick grid: replaced runs go through the wide
+    flush list, with a few maps (split launches) and with one workgroup per map."""
+    import torch
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_3d([1, 2], rings=16, azimuths=700)
+    base = np.concatenate([pr["fixed"].numpy(), pr["moving"].numpy()])             # 4 distinct sweeps of 11 200 points
+    res, size, rng = 0.5, [80.0, 80.0, 10.0], 60.0
+    ms = N.MapSet(res, [0, 0, 0], size, n_maps=n_maps, max_cells=16384)
+    assert ms.info()["cells_per_axis"][2] > 4
+    ms.build(torch.from_numpy(base[np.arange(n_maps) % 4]).cuda(), range_limit=rng)
+    torch.cuda.synchronize()
+    ref = [oracle_map(O, base[k], res, size, rng=rng).export_cells() for k in range(4)]
+    assert len(ref[0][3]) > 500
+    for m in sorted(set([0, 1, 2, 3, n_maps // 2, n_maps - 1])):
+        assert ms.counters(m)["overflow"] == 0
+        assert_cells_equal(ms.export_cells(m), ref[m % 4], res)
+
+
 def test_build_golden_cells(N, golden):
     for k in range(6):
         pts = golden["cell%d_pts" % k]
