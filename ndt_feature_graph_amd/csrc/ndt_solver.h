@@ -17,13 +17,18 @@
 
 enum { PH_NEWTON = 0, PH_LS_TRIAL = 1, PH_FINAL = 2 };
 
+struct MTState {
+    double stp, finit, dginit, dgtest, width, width1, stx, fx, dgx, sty, fy, dgy, stmin, stmax;
+    int brackt, stage1, nfev, infoc;
+};
+
 struct MatchState {
     rigid T, Tbest, Teval;
     double score_best, score_here;
     double incr[6];
-    // More-Thuente (fusion.h:400-408, 485-521)
-    double stp, finit, dginit, dgtest, width, width1, stx, fx, dgx, sty, fy, dgy, stmin, stmax;
-    int brackt, stage1, nfev, infoc;
+    // More-Thuente (fusion.h:400-408, 485-521): one block, copied to registers by the functions that work on it (the
+    // state lives in LDS: field-by-field access is one dependent LDS round trip after the other)
+    MTState mt;
     int itr_ctr, fevals, ret, exit_code, phase, with_h, done;
     // The first More-Thuente trial (stp = 1) is usually accepted, and the next Newton iteration then evaluates
     // score, gradient AND Hessian at exactly the pose of that trial.  While trials keep being accepted first
@@ -78,7 +83,7 @@ NDT_HD double absmax3(double a, double b, double c) { return dmax(dmax(fabs(a), 
 
 // MoreThuente::cstep = MINPACK mcstep (published algorithm: More & Thuente, ACM TOMS 20(3), 1994);
 // call sites fusion.h:756,775.
-NDT_HDN int mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
+NDT_HD int mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy, double &dy,
                                      double &stp, double fp, double dp, int &brackt, double stmin, double stmax)
 {
     int info = 0;
@@ -170,28 +175,28 @@ NDT_HDN int mt_cstep(double &stx, double &fx, double &dx, double &sty, double &f
 }
 
 // head of the More-Thuente while(1) body (fusion.h:523-561): pick the trial step and request its evaluation
-NDT_HDN void mt_request_trial(MatchState &st)
+NDT_HD void mt_request_trial(MatchState &st, MTState &m)
 {
     const double stpmax = 4.0, stpmin = 0.001, xtol = 0.01;
     const int maxfev = 40;
-    if (st.brackt) {
-        st.stmin = dmin(st.stx, st.sty);
-        st.stmax = dmax(st.stx, st.sty);
+    if (m.brackt) {
+        m.stmin = dmin(m.stx, m.sty);
+        m.stmax = dmax(m.stx, m.sty);
     } else {
-        st.stmin = st.stx;
-        st.stmax = st.stp + 4 * (st.stp - st.stx);
+        m.stmin = m.stx;
+        m.stmax = m.stp + 4 * (m.stp - m.stx);
     }
-    st.stp = dmax(st.stp, stpmin);
-    st.stp = dmin(st.stp, stpmax);
-    if ((st.brackt && ((st.stp <= st.stmin) || (st.stp >= st.stmax))) || (st.nfev >= maxfev - 1) ||
-        (st.infoc == 0) || (st.brackt && (st.stmax - st.stmin <= xtol * st.stmax)))
-        st.stp = st.stx;
+    m.stp = dmax(m.stp, stpmin);
+    m.stp = dmin(m.stp, stpmax);
+    if ((m.brackt && ((m.stp <= m.stmin) || (m.stp >= m.stmax))) || (m.nfev >= maxfev - 1) ||
+        (m.infoc == 0) || (m.brackt && (m.stmax - m.stmin <= xtol * m.stmax)))
+        m.stp = m.stx;
     double pincr[6];
-    for (int a = 0; a < 6; a++) pincr[a] = st.stp * st.incr[a];
+    for (int a = 0; a < 6; a++) pincr[a] = m.stp * st.incr[a];
     rigid ps;
     pose_to_rigid(pincr, ps);
     rigid_mul(ps, st.T, st.Teval);     // trial cells = ps * nextNDT (fusion.h:556-589)
-    st.trial_has_h = (st.nfev == 0 && st.spec_ok) ? 1 : 0;
+    st.trial_has_h = (m.nfev == 0 && st.spec_ok) ? 1 : 0;
     st.with_h = st.trial_has_h;
     st.phase = PH_LS_TRIAL;
 }
@@ -362,27 +367,29 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     // throws its step away (:1018-1023: step_size = max(step_size_ndt, 0)); its only possible side effect,
     // flipping the increment when dginit >= 0, cannot trigger here because dginit <= 0 was just checked on
     // the same total gradient.  The step is decided by the NDT-only line search on the NDT-only score.
-    st.finit = sums[0];
-    st.dginit = 0;
+    MTState m;
+    m.finit = sums[0];
+    m.dginit = 0;
 #pragma unroll
-    for (int a = 0; a < 6; a++) st.dginit += st.incr[a] * sums[1 + a];
-    if (!st.use_prior && !st.use_tikhonov) st.dginit = dginit;
-    if (st.dginit >= 0.0) {                // fusion.h:456-479
+    for (int a = 0; a < 6; a++) m.dginit += st.incr[a] * sums[1 + a];
+    if (!st.use_prior && !st.use_tikhonov) m.dginit = dginit;
+    if (m.dginit >= 0.0) {                // fusion.h:456-479
         for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
-        st.dginit = -st.dginit;
-        if (st.dginit >= 0.0) {
+        m.dginit = -m.dginit;
+        if (m.dginit >= 0.0) {
             apply_step(st, 0.1, prm);
             return;
         }
     }
-    st.stp = 1.0;
-    st.brackt = 0; st.stage1 = 1; st.nfev = 0; st.infoc = 1;
-    st.dgtest = 0.11111 * st.dginit;
-    st.width = 4.0 - 0.001;
-    st.width1 = 2 * st.width;
-    st.stx = 0.0; st.fx = st.finit; st.dgx = st.dginit;
-    st.sty = 0.0; st.fy = st.finit; st.dgy = st.dginit;
-    mt_request_trial(st);
+    m.stp = 1.0;
+    m.brackt = 0; m.stage1 = 1; m.nfev = 0; m.infoc = 1;
+    m.dgtest = 0.11111 * m.dginit;
+    m.width = 4.0 - 0.001;
+    m.width1 = 2 * m.width;
+    m.stx = 0.0; m.fx = m.finit; m.dgx = m.dginit;
+    m.sty = 0.0; m.fy = m.finit; m.dgy = m.dginit;
+    mt_request_trial(st, m);
+    st.mt = m;
 }
 
 // tail of the More-Thuente while(1) body after the trial evaluation (fusion.h:637-790)
@@ -401,50 +408,53 @@ NDT_HDN void linesearch_step(MatchState &st, const double *sums, const NdtMatchP
 {
     const double ftol = 0.11111, gtol = 0.99999, stpmax = 4.0, stpmin = 0.001, xtol = 0.01, recoverystep = 0.1;
     const int maxfev = 40;
+    MTState m = st.mt;
     st.fevals++;
     double f = sums[0];
     double dg = 0;
     for (int a = 0; a < 6; a++) dg += st.incr[a] * sums[1 + a];
-    st.nfev++;
-    double ftest1 = st.finit + st.stp * st.dgtest;
+    m.nfev++;
+    double ftest1 = m.finit + m.stp * m.dgtest;
     int info = 0;
-    if ((st.brackt && ((st.stp <= st.stmin) || (st.stp >= st.stmax))) || (st.infoc == 0)) info = 6;
-    if ((st.stp == stpmax) && (f <= ftest1) && (dg <= st.dgtest)) info = 5;
-    if ((st.stp == stpmin) && ((f > ftest1) || (dg >= st.dgtest))) info = 4;
-    if (st.nfev >= maxfev) info = 3;
-    if (st.brackt && (st.stmax - st.stmin <= xtol * st.stmax)) info = 2;
-    if ((f <= ftest1) && (fabs(dg) <= gtol * (-st.dginit))) info = 1;
+    if ((m.brackt && ((m.stp <= m.stmin) || (m.stp >= m.stmax))) || (m.infoc == 0)) info = 6;
+    if ((m.stp == stpmax) && (f <= ftest1) && (dg <= m.dgtest)) info = 5;
+    if ((m.stp == stpmin) && ((f > ftest1) || (dg >= m.dgtest))) info = 4;
+    if (m.nfev >= maxfev) info = 3;
+    if (m.brackt && (m.stmax - m.stmin <= xtol * m.stmax)) info = 2;
+    if ((f <= ftest1) && (fabs(dg) <= gtol * (-m.dginit))) info = 1;
     if (info != 0) {
-        const bool first_accepted = (info == 1) && (st.nfev == 1);
+        const bool first_accepted = (info == 1) && (m.nfev == 1);
 
         const bool reuse = first_accepted && st.trial_has_h;      // sums hold the Hessian at the accepted pose
         st.spec_ok = first_accepted ? 1 : 0;
-        apply_step(st, (info == 1) ? st.stp : recoverystep, prm);
+        st.mt = m;
+        apply_step(st, (info == 1) ? m.stp : recoverystep, prm);
         st.reuse_sums = (reuse && !st.done) ? 1 : 0;   // match_state_step consumes the sums once more
         return;
     }
-    if (st.stage1 && (f <= ftest1) && (dg >= dmin(ftol, gtol) * st.dginit)) st.stage1 = 0;
-    if (st.stage1 && (f <= st.fx) && (f > ftest1)) {
-        double fm = f - st.stp * st.dgtest;
-        double fxm = st.fx - st.stx * st.dgtest;
-        double fym = st.fy - st.sty * st.dgtest;
-        double dgm = dg - st.dgtest;
-        double dgxm = st.dgx - st.dgtest;
-        double dgym = st.dgy - st.dgtest;
-        st.infoc = mt_cstep(st.stx, fxm, dgxm, st.sty, fym, dgym, st.stp, fm, dgm, st.brackt, st.stmin, st.stmax);
-        st.fx = fxm + st.stx * st.dgtest;
-        st.fy = fym + st.sty * st.dgtest;
-        st.dgx = dgxm + st.dgtest;
-        st.dgy = dgym + st.dgtest;
+    if (m.stage1 && (f <= ftest1) && (dg >= dmin(ftol, gtol) * m.dginit)) m.stage1 = 0;
+    if (m.stage1 && (f <= m.fx) && (f > ftest1)) {
+        double fm = f - m.stp * m.dgtest;
+        double fxm = m.fx - m.stx * m.dgtest;
+        double fym = m.fy - m.sty * m.dgtest;
+        double dgm = dg - m.dgtest;
+        double dgxm = m.dgx - m.dgtest;
+        double dgym = m.dgy - m.dgtest;
+        m.infoc = mt_cstep(m.stx, fxm, dgxm, m.sty, fym, dgym, m.stp, fm, dgm, m.brackt, m.stmin, m.stmax);
+        m.fx = fxm + m.stx * m.dgtest;
+        m.fy = fym + m.sty * m.dgtest;
+        m.dgx = dgxm + m.dgtest;
+        m.dgy = dgym + m.dgtest;
     } else {
-        st.infoc = mt_cstep(st.stx, st.fx, st.dgx, st.sty, st.fy, st.dgy, st.stp, f, dg, st.brackt, st.stmin, st.stmax);
+        m.infoc = mt_cstep(m.stx, m.fx, m.dgx, m.sty, m.fy, m.dgy, m.stp, f, dg, m.brackt, m.stmin, m.stmax);
     }
-    if (st.brackt) {
-        if (fabs(st.sty - st.stx) >= 0.66 * st.width1) st.stp = st.stx + 0.5 * (st.sty - st.stx);
-        st.width1 = st.width;
-        st.width = fabs(st.sty - st.stx);
+    if (m.brackt) {
+        if (fabs(m.sty - m.stx) >= 0.66 * m.width1) m.stp = m.stx + 0.5 * (m.sty - m.stx);
+        m.width1 = m.width;
+        m.width = fabs(m.sty - m.stx);
     }
-    mt_request_trial(st);
+    mt_request_trial(st, m);
+    st.mt = m;
 }
 
 
