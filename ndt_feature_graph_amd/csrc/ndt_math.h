@@ -382,7 +382,11 @@ NDT_HD bool chol_is_pd(const double (&A)[N][N], double (&l)[N][N], double (&dinv
 #pragma unroll
         for (int k = 0; k < j; k++) d -= l[j][k] * l[j][k];
         pd = pd && (d > 0.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+        double inv = rsqrt(d > 0.0 ? d : 1.0);       // v_rsq_f64 + refinement: a quarter of the sqrt + division chain
+#else
         double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+#endif
         l[j][j] = d * inv;
         dinv[j] = inv;
 #pragma unroll
