@@ -140,7 +140,8 @@ NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int s
 // MODE 0: fused build, one workgroup per map (batches: B workgroups fill the chip)
 // MODE 1: accumulate only, gridDim.x workgroups share one map (gridDim.y maps): a single scan or a small
 //         batch then streams on many CUs; the atomics are memory-side, hence coherent across XCDs
-// MODE 2: finalise only (phases 0, B, C, D), one workgroup per map, after a MODE 1 launch
+// MODE 2: finalise only (phases 0, B, C, D) after a MODE 1 launch; with `dbg` != 0 phases 0 and B only
+// MODE 3: phases C and D on gridDim.x workgroups per map (big grids), after a MODE 2 launch with `dbg` != 0
 // (no minimum-waves hint: __launch_bounds__(256, 2) halves the speed of phase A although the register count stays at
 //  250 -- measured 1.79 vs 0.94 ms -- and 3 / 4 waves per SIMD spill: 2.53 / 1.92 ms)
 // SCAT: clouds whose consecutive points change cell every few points (3D sweeps): a replaced run goes straight to a
@@ -149,7 +150,7 @@ template <int STRIDE_DW, int MODE, bool NICE, bool SCAT>
 #ifndef NDT_BUILD_WPE
 #define NDT_BUILD_WPE
 #endif
-__global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) NDT_BUILD_WPE void ndt_build_kernel(
+__global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BUILD_THREADS) NDT_BUILD_WPE void ndt_build_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
     size_t map_stride_bytes, double range_limit, const double *__restrict__ range_origins, int n_min,
     double eval_factor, int s1_shift, int s2_shift, int dbg, float z_max32)
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     const unsigned tid = threadIdx.x;
     // the wave index through readfirstlane: everything derived from it (tile ranges, staging bases) is scalar
     const unsigned lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const unsigned nthreads = (MODE == 2) ? NDT_FIN_THREADS : NDT_BUILD_THREADS, nwaves = nthreads / 64;
+    const unsigned nthreads = (MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BUILD_THREADS, nwaves = nthreads / 64;
     const unsigned map_local = (MODE == 0) ? blockIdx.x : blockIdx.y;
     // MODE 2: gridDim.x workgroups share phases 0 and B of one map; the last one to finish runs phases C and D
     const unsigned fin_parts = (MODE == 2) ? gridDim.x : 1u, fin_part = (MODE == 2) ? blockIdx.x : 0u;
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     bc.q1 = ldexp(inv_res, s1_shift);
     bc.q2 = ldexp(inv_res * inv_res, s2_shift);
     bc.dbg = dbg;
-    bc.idc = s_idc + ((MODE == 2) ? 0u : wave) * NDT_IDC;
-    if (MODE != 2) bc.idc[lane & (NDT_IDC - 1)] = ~0ull;
+    bc.idc = s_idc + ((MODE == 2 || MODE == 3) ? 0u : wave) * NDT_IDC;
+    if (MODE != 2 && MODE != 3) bc.idc[lane & (NDT_IDC - 1)] = ~0ull;
     double ox = 0, oy = 0, oz = 0;
     if (range_origins) { ox = range_origins[map_local * 3]; oy = range_origins[map_local * 3 + 1]; oz = range_origins[map_local * 3 + 2]; }
     const char *pts = xyz + (size_t)map_local * map_stride_bytes;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     const float frac_lim = (force_exact || !(face_guard < 0.25f)) ? -1.0f : 0.5f - face_guard;
 
     // ---------------- phase 0: forget the previous content of the slot -> rank table -------------
-    if (MODE != 1) {
+    if (MODE != 1 && MODE != 3) {
         unsigned old = ctr->n_cells;
         if (old > cap) old = cap;
         for (unsigned i = fin_part * nthreads + tid; i < old; i += nthreads * fin_parts) {
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         if (MODE == 0 && tid == 0) ctr->overflow = 0;
     }
     if (tid == 0) { s_base = 0; s_dropped = 0; }
-    if (MODE != 2) {
+    if (MODE != 2 && MODE != 3) {
         for (unsigned i = tid; i < NDT_BUILD_WAVES * NDT_QRUNS; i += nthreads) s_qslot[i] = -1;
         for (unsigned i = tid; i < NDT_BUILD_WAVES * 10 * NDT_QRUNS; i += nthreads) s_qval[i] = 0.0;
         if (tid < NDT_BUILD_WAVES) s_qcnt[tid] = 0u;
@@ -262,9 +263,9 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     const unsigned tiles_per_part = (n_tiles + n_parts - 1) / n_parts;
     const unsigned part_begin = min(n_tiles, part * tiles_per_part), part_end = min(n_tiles, part_begin + tiles_per_part);
     const unsigned tiles_per_wave = (part_end - part_begin + NDT_BUILD_WAVES - 1) / NDT_BUILD_WAVES;
-    const unsigned tile_begin = (MODE == 2) ? 0u : min(part_end, part_begin + wave * tiles_per_wave);
-    const unsigned tile_end = (MODE == 2) ? 0u : min(part_end, tile_begin + tiles_per_wave);
-    const unsigned awave = (MODE == 2) ? 0u : wave;   // phase-A per-wave LDS regions (unused when finalising)
+    const unsigned tile_begin = (MODE == 2 || MODE == 3) ? 0u : min(part_end, part_begin + wave * tiles_per_wave);
+    const unsigned tile_end = (MODE == 2 || MODE == 3) ? 0u : min(part_end, tile_begin + tiles_per_wave);
+    const unsigned awave = (MODE == 2 || MODE == 3) ? 0u : wave;   // phase-A per-wave LDS regions (unused when finalising)
     // the flush list below lives in the same bytes as doubles: the float view may alias it (no type-based reordering
     // of the next round's staging stores against the list's loads)
     typedef float __attribute__((may_alias)) tile_f32;
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     NdtAcc *tmp_base = bc.acc;                            // cell record written over its own accumulator
     unsigned binned = 0;
     const double IS1 = ldexp(1.0, -s1_shift), IS2 = ldexp(1.0, -s2_shift);
-    for (unsigned id = fin_part * nthreads + tid; id < n_alloc; id += nthreads * fin_parts) {
+    for (unsigned id = fin_part * nthreads + tid; MODE != 3 && id < n_alloc; id += nthreads * fin_parts) {
         NdtAcc a = bc.acc[id];
         NdtCell c;
         c.n = 0;
@@ -717,6 +718,12 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     }
     if (binned) atomicAdd(&s_dropped, binned);
     __syncthreads();
+    if (MODE == 2 && dbg != 0) {
+        // big grid: the ranking is a launch of its own (MODE 3, several workgroups per map); publish this workgroup's
+        // share of the binned points and stop
+        if (tid == 0 && s_dropped) atomicAdd(&ctr->n_dropped, s_dropped);
+        return;
+    }
     if (MODE == 2 && fin_parts > 1u) {
         // publish this workgroup's share (binned points, cell records, cleared bits) and draw a ticket: the
         // workgroup that draws the last one has everybody's phase B behind it and goes on alone
@@ -735,6 +742,21 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         }
         __syncthreads();
     }
+    // MODE 3: gridDim.x workgroups rank one map.  A workgroup takes the next SEGMENT of the bitmap (segments are handed
+    // out in arrival order: whoever holds segment s only ever waits for workgroups that are already running), counts its
+    // Gaussian cells, publishes the count and adds up the counts of the segments before it.
+    uint32_t *agg = set.rank_agg + (size_t)map * (NDT_RANK_SEGS + 2);
+    __shared__ unsigned s_seg, s_segbase;
+    unsigned seg = 0, n_segs = 1;
+    if (MODE == 3) {
+        n_segs = gridDim.x;
+        if (tid == 0) {
+            s_seg = atomicAdd(&agg[NDT_RANK_SEGS], 1u);
+            s_dropped = __hip_atomic_load(&ctr->n_dropped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        seg = s_seg;
+    }
 
     // ---------------- phase C: rank Gaussian cells in slot order from the occupancy bitmap ------------
     long long t2 = __builtin_readcyclecounter();
@@ -750,8 +772,10 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         }
         return vmask;
     };
-    const unsigned words_per_wave = (bm_words + nwaves - 1) / nwaves;
-    const unsigned wb = min(bm_words, wave * words_per_wave), we = min(bm_words, wb + words_per_wave);
+    const unsigned words_per_seg = (bm_words + n_segs - 1) / n_segs;
+    const unsigned sb = min(bm_words, seg * words_per_seg), se_ = min(bm_words, sb + words_per_seg);
+    const unsigned words_per_wave = (se_ - sb + nwaves - 1) / nwaves;
+    const unsigned wb = min(se_, sb + wave * words_per_wave), we = min(se_, wb + words_per_wave);
     // More touched cells than accumulators (overflow): slots whose id is past the capacity still have their bit
     // and must be filtered through the work table; otherwise the bitmap IS the set of Gaussian cells.
     const bool ovf = __hip_atomic_load(&ctr->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
@@ -778,6 +802,22 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         unsigned c2 = s_wave_cnt[k];
         if (k < wave) running += c2;
         total_cells += c2;
+    }
+    if (MODE == 3) {
+        if (tid == 0) {
+            __hip_atomic_store(&agg[seg], 0x80000000u | total_cells, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned before = 0;
+            for (unsigned q = 0; q < seg; q++) {
+                unsigned v;
+                while (((v = __hip_atomic_load(&agg[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0x80000000u) == 0u)
+                    __builtin_amdgcn_s_sleep(4);
+                before += v & 0x7FFFFFFFu;
+            }
+            s_segbase = before;
+        }
+        __syncthreads();
+        running += s_segbase;
+        total_cells += s_segbase;      // (cells up to the end of this segment)
     }
     if (!ovf) {
         // Pass 2, usual case (the bitmap holds exactly the Gaussian cells): 32 words per wave and step, one half
@@ -860,6 +900,20 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
     }
     if (tid == 0) s_base = total_cells;
     __syncthreads();
+    if (MODE == 3) {
+        // the last segment knows the number of cells; the workgroup that finishes last cleans up for everybody
+        __shared__ unsigned s_done;
+        if (tid == 0) {
+            if (seg == n_segs - 1u) ctr->n_cells = total_cells;
+            __threadfence();
+            s_done = atomicAdd(&agg[NDT_RANK_SEGS + 1], 1u);
+        }
+        __syncthreads();
+        if (s_done != n_segs - 1u) return;
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        if (tid < NDT_RANK_SEGS + 2) agg[tid] = 0u;          // the tickets and counts rest at zero between builds
+    }
 
     // ---------------- phase D: leave the scratch zeroed, publish counters -----------------------------
     long long t3 = __builtin_readcyclecounter();
@@ -868,7 +922,7 @@ __global__ __launch_bounds__(MODE == 2 ? NDT_FIN_THREADS : NDT_BUILD_THREADS) ND
         for (unsigned k = tid; k < n_alloc * 20u; k += nthreads) z[k] = 0ull;
     }
     if (tid == 0) {
-        ctr->n_cells = s_base;
+        if (MODE != 3) ctr->n_cells = s_base;
         if (set.cell_sel) set.cell_sel[map] = 0u;
         ctr->n_alloc = 0;
         ctr->n_dropped = n_points - s_dropped;          // s_dropped holds the number of binned points here
@@ -982,10 +1036,19 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         unsigned fin_parts = (unsigned)(512 / count);
         if (fin_parts > 32u) fin_parts = 32u;
         if (fin_parts < 1u) fin_parts = 1u;
+        // big grids (a 400 x 400 x 40 grid has 200 k bitmap words): the ranking is a third launch on the same number of
+        // workgroups per map instead of the last workgroup of the second one walking the whole bitmap alone
+        const unsigned bm_words = (unsigned)((set.grid.slots + 31) / 32);
+        const int split_rank = (fin_parts > 1u && bm_words >= 16384u) ? 1 : 0;
         hipLaunchKernelGGL((ndt_build_kernel<0, 2, false, false>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream,
                            set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
-                           map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, dbg,
+                           map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, split_rank,
                            __builtin_inff());
+        if (split_rank)
+            hipLaunchKernelGGL((ndt_build_kernel<0, 3, false, false>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0,
+                               stream, set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
+                               map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, 0,
+                               __builtin_inff());
     }
 #undef NDT_LAUNCH_BUILD_SD
 #undef NDT_LAUNCH_BUILD

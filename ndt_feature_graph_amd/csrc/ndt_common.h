@@ -55,6 +55,8 @@ struct NdtGrid {               // geometry shared by all maps of a set
     uint32_t max_cells;
 };
 
+#define NDT_RANK_SEGS 32       // at most this many workgroups rank one map (ndt_build_kernel MODE 3)
+
 struct NdtMapCounters {        // per map, device resident
     uint32_t n_alloc;          // ids handed out during accumulation (0 between builds)
     uint32_t n_cells;          // Gaussian cells after finalize
@@ -74,6 +76,8 @@ struct NdtSetView {            // what kernels see of a mapset
     NdtCell *cells;            // [n_maps][max_cells]
     NdtAcc *acc;               // [n_maps][max_cells]
     uint32_t *acc_slot;        // [n_maps][max_cells] slot of each accumulator id
+    uint32_t *rank_agg;        // [n_maps][NDT_RANK_SEGS + 2] ranking of big grids on several workgroups: per segment
+                               //   (1 << 31 | Gaussian cells in it) once counted, then a segment ticket and a done ticket; zero between builds
     NdtMapCounters *counters;  // [n_maps]
     double *centres;           // [n_maps][3]
     // incremental (fused) node maps -- allocated by ndtgpu_mapset_enable_occupancy, NULL otherwise:

@@ -173,6 +173,7 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
     ALLOC(s->v.cells, n_maps * (size_t)cap * sizeof(NdtCell));
     ALLOC(s->v.acc, n_maps * (size_t)cap * sizeof(NdtAcc));
     ALLOC(s->v.acc_slot, n_maps * (size_t)cap * sizeof(uint32_t));
+    ALLOC(s->v.rank_agg, n_maps * (size_t)(NDT_RANK_SEGS + 2) * sizeof(uint32_t));
     ALLOC(s->v.counters, n_maps * sizeof(NdtMapCounters));
     ALLOC(s->v.centres, n_maps * 3 * sizeof(double));
 #undef ALLOC
@@ -182,6 +183,7 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
         (e = hipMemset(s->v.bitmap, 0, n_maps * (size_t)((g.slots + 31) / 32) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemset(s->v.acc, 0, n_maps * (size_t)cap * sizeof(NdtAcc))) != hipSuccess ||
         (e = hipMemset(s->v.counters, 0, n_maps * sizeof(NdtMapCounters))) != hipSuccess ||
+        (e = hipMemset(s->v.rank_agg, 0, n_maps * (size_t)(NDT_RANK_SEGS + 2) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemcpy(s->v.centres, s->centres_host.data(), n_maps * 3 * sizeof(double), hipMemcpyHostToDevice)) !=
             hipSuccess) {
         ndtgpu_mapset_destroy(s);
@@ -202,6 +204,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (s->v.cells) (void)hipFree(s->v.cells);
     if (s->v.acc) (void)hipFree(s->v.acc);
     if (s->v.acc_slot) (void)hipFree(s->v.acc_slot);
+    if (s->v.rank_agg) (void)hipFree(s->v.rank_agg);
     if (s->v.counters) (void)hipFree(s->v.counters);
     if (s->v.centres) (void)hipFree(s->v.centres);
     if (s->v.occ) (void)hipFree(s->v.occ);
