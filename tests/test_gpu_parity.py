@@ -112,22 +112,24 @@ def test_build_launch_shapes_and_strides(N, O, n_maps, n_pts, stride_dw, res, ce
         assert_cells_equal(ms.export_cells(m), ref[m % 7], res)
 
 
-@pytest.mark.parametrize("n_maps", [4, 264])
-def test_build_3d_sweeps_thick_grid(N, O, n_maps):
+@pytest.mark.parametrize("n_maps,res,centre", [(4, 0.5, (0.0, 0.0, 0.0)), (264, 0.5, (0.0, 0.0, 0.0)), (4, 0.4, (0.13, -0.07, 0.02)),
+                                               (260, 0.4, (0.13, -0.07, 0.02)), (3, 0.2, (0.0, 0.0, 0.0))])
+def test_build_3d_sweeps_thick_grid(N, O, n_maps, res, centre):
     """3D sweeps (consecutive points change cell every few points) in a thick grid: replaced runs go through the wide
-    flush list, with a few maps (split launches) and with one workgroup per map."""
+    flush list, with a few maps (split launches; the 0.2 m grid is big enough for the ranking launch on several
+    workgroups per map) and with one workgroup per map, on grids with and without fp32 cell origins."""
     import torch
     from ndt_feature_graph_amd import synth
     pr = synth.pair_3d([1, 2], rings=16, azimuths=700)
     base = np.concatenate([pr["fixed"].numpy(), pr["moving"].numpy()])             # 4 distinct sweeps of 11 200 points
-    res, size, rng = 0.5, [80.0, 80.0, 10.0], 60.0
-    ms = N.MapSet(res, [0, 0, 0], size, n_maps=n_maps, max_cells=16384)
+    size, rng = [80.0, 80.0, 10.0], 60.0
+    ms = N.MapSet(res, list(centre), size, n_maps=n_maps, max_cells=16384)
     assert ms.info()["cells_per_axis"][2] > 4
     ms.build(torch.from_numpy(base[np.arange(n_maps) % 4]).cuda(), range_limit=rng)
     torch.cuda.synchronize()
-    ref = [oracle_map(O, base[k], res, size, rng=rng).export_cells() for k in range(4)]
+    ref = [oracle_map(O, base[k], res, size, centre=centre, rng=rng).export_cells() for k in range(4)]
     assert len(ref[0][3]) > 500
-    for m in sorted(set([0, 1, 2, 3, n_maps // 2, n_maps - 1])):
+    for m in sorted(set([0, 1, 2, 3, n_maps // 2, n_maps - 1]) & set(range(n_maps))):
         assert ms.counters(m)["overflow"] == 0
         assert_cells_equal(ms.export_cells(m), ref[m % 4], res)
 
@@ -256,6 +258,13 @@ def test_capacity_overflow_is_reported(N):
     ms.build(pts[None], range_limit=30.0)
     with pytest.raises(N.NdtGpuError) as e:
         ms.num_cells()
+    assert e.value.status == -4
+    # ... also when a big grid is ranked by several workgroups per map (split launches), and the set stays usable
+    p3 = synth.pair_3d([1], rings=16, azimuths=700)["fixed"].numpy()
+    big = N.MapSet(0.2, [0, 0, 0], [80, 80, 10], n_maps=2, max_cells=300)
+    big.build(np.concatenate([p3, p3]), range_limit=60.0)
+    with pytest.raises(N.NdtGpuError) as e:
+        big.num_cells(1)
     assert e.value.status == -4
 
 
