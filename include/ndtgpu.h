@@ -222,8 +222,12 @@ ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *targ
                                  const ndtgpu_match_params *prm, ndtgpu_match_result *results,
                                  ndtgpu_stream stream);
 /* device-resident variant for pipelines: T16_dev / results_dev are DEVICE buffers, idx arrays
- * DEVICE uint32; asynchronous on `stream`, no host synchronisation.  Always the persistent kernel (a batch of a few
- * very large maps is better served by ndtgpu_match_batch, which spreads a registration over several CUs).
+ * DEVICE uint32.  A batch that fills the chip (more than one registration per two CUs) is one launch of persistent
+ * workgroups: asynchronous on `stream`, no host synchronisation; a registration's result does not depend on its batch.
+ * A small batch of LARGE maps (at least 1024 cells, few enough pairs for a handful of cooperative launches) whose
+ * indices are sane is spread over several CUs per registration like ndtgpu_match_batch does: an order of magnitude
+ * sooner done, same result to 1e-9 (another summation order); its indices and poses make a round trip through the host
+ * and the call SYNCHRONISES (NDTGPU_COOP=0 keeps it on the persistent kernel and asynchronous).
  * The indices are range-checked on the device and a map whose build overflowed max_cells is refused: such a pair gets
  * converged = 0 and exit_code -2 / -3, its pose stays untouched.  The work area (ticket counters, parked solver
  * states) belongs to the TARGET set: calls on different streams with the same target set are ordered by an event;

@@ -682,6 +682,10 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
     return NDTGPU_OK;
 }
 
+static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                double *T16, size_t n_pairs, const NdtMatchParamsDev &p, const double *Q36,
+                                ndtgpu_match_result *results, hipStream_t st, bool *done);
+
 ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss,
                                         const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs,
                                         const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
@@ -693,6 +697,57 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
     p.fusion_flags = 0;
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
+    // A batch that cannot fill the chip (one persistent workgroup per registration would leave most CUs idle) takes the
+    // cooperative launches of the host-pointer API when its indices are sane and its maps are large enough to be split:
+    // poses and indices make a round trip through the host (a few hundred bytes per registration) and the call
+    // SYNCHRONISES.  Anything unusual (an index out of range, a truncated map) stays on the persistent kernel, which
+    // reports it per registration.
+    {
+        hipStream_t st = (hipStream_t)stream;
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+        const char *coop_env = getenv("NDTGPU_COOP");
+        if (n_pairs > 0 && n_pairs <= (size_t)n_cu / 2 && !(coop_env && atoi(coop_env) == 0)) {
+            std::vector<uint32_t> ti(n_pairs), si(n_pairs);
+            HIP_TRY(hipMemcpyAsync(ti.data(), tidx_dev, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(si.data(), sidx_dev, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            bool sane = true;
+            for (size_t k = 0; k < n_pairs && sane; k++) sane = ti[k] < ts->n_maps && si[k] < ss->n_maps;
+            uint32_t max_cells = 0;
+            if (sane) {
+                std::vector<NdtMapCounters> ct(n_pairs), cs(n_pairs);
+                for (size_t k = 0; k < n_pairs; k++) {
+                    HIP_TRY(hipMemcpyAsync(&ct[k], ts->v.counters + ti[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + si[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
+                }
+                HIP_TRY(hipStreamSynchronize(st));
+                for (size_t k = 0; k < n_pairs && sane; k++) {
+                    sane = ct[k].overflow == 0u && cs[k].overflow == 0u;
+                    max_cells = std::max(max_cells, cs[k].n_cells);
+                }
+            }
+            // (maps of at least 1024 cells: there a registration gains an order of magnitude from 8+ workgroups; smaller
+            //  maps stay on the persistent kernel, whose result for a registration never depends on its batch)
+            if (sane && max_cells >= 1024u) {
+                std::vector<double> T(n_pairs * 16);
+                std::vector<ndtgpu_match_result> r(n_pairs);
+                HIP_TRY(hipMemcpyAsync(T.data(), T16_dev, n_pairs * 16 * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (ts->work_ev_valid) HIP_TRY(hipEventSynchronize(ts->work_ev));   // an earlier launch may still use the work area
+                bool done = false;
+                ndtgpu_status crc = match_coop(ts, ti.data(), ss, si.data(), T.data(), n_pairs, p, nullptr, r.data(), st, &done);
+                if (crc != NDTGPU_OK) return crc;
+                if (done) {
+                    HIP_TRY(hipMemcpyAsync(T16_dev, T.data(), n_pairs * 16 * sizeof(double), hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(results_dev, r.data(), n_pairs * sizeof(ndtgpu_match_result), hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    return NDTGPU_OK;
+                }
+            }
+        }
+    }
     return match_device_core(ts, tidx_dev, ss, sidx_dev, T16_dev, n_pairs, p, results_dev, nullptr, (hipStream_t)stream);
 }
 
@@ -827,6 +882,13 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     if (capacity == 0) return NDTGPU_OK;                                          // no occupancy figure: persistent kernel instead
     if (groups > capacity) groups = capacity;
     const size_t per_launch = std::max<size_t>(1, capacity / groups);
+    // The launches run one after the other: beyond a few of them the persistent kernel (every registration on its own
+    // CU, all at once) is sooner done.  Measured with 12 k-cell 3D maps (96 workgroups each, 2 registrations per launch):
+    // 32 pairs 25.7 ms against 33.2 ms, 64 pairs 51 ms against 33.5 ms; 2D maps (3 workgroups each): one launch only.
+    {
+        const size_t launches = (n_pairs + per_launch - 1) / per_launch;
+        if (n_pairs > NDTGPU_HOST_LOOP_MAX && launches > std::max<size_t>(1, groups / 6)) return NDTGPU_OK;
+    }
     // the whole control block of every pair (barrier counters only grow during a launch sequence: a counter left over
     // from the previous call would stall the first barrier of this one)
     HIP_TRY(hipMemset2DAsync(ts->work, stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
