@@ -693,6 +693,34 @@ def test_device_pointer_batch_checks_indices_and_overflow(N):
     assert np.all(ro["exit_code"] == -3) and np.array_equal(To, T0.cpu().numpy())
 
 
+def test_device_pointer_small_batch_of_large_maps(N, monkeypatch):
+    """ndtgpu_match_batch_device spreads a small batch of large maps over several CUs per registration (cooperative
+    launches, host round trip of the poses) instead of one CU each: same answer as the persistent kernel to 1e-9."""
+    import torch
+    from ndt_feature_graph_amd import binding, synth
+    dev = torch.device("cuda", 0)
+    pr = synth.pair_3d([1, 2], rings=32, azimuths=1500)
+    ms = N.MapSet(0.25, [0, 0, 0], [100, 100, 10], n_maps=4, max_cells=32768)
+    ms.build(torch.cat([pr["fixed"], pr["moving"]]).contiguous().to(dev), range_limit=70.0)
+    torch.cuda.synchronize()
+    assert min(ms.num_cells(k) for k in range(4)) >= 1024
+    T0 = pr["T_init"].transpose(1, 2).contiguous().reshape(2, 16).to(dev)
+    ti = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+    si = torch.tensor([2, 3], dtype=torch.int32, device=dev)
+    out = {}
+    for coop in ("1", "0"):
+        monkeypatch.setenv("NDTGPU_COOP", coop)
+        T16 = T0.clone()
+        res = torch.zeros((2, 64), dtype=torch.uint8, device=dev)
+        binding.match_batch_device(ms, ti, ms, si, T16, res, 2, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        out[coop] = (T16.cpu().numpy(), res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(2).copy())
+    assert np.max(np.abs(out["1"][0] - out["0"][0])) < 1e-9
+    assert np.array_equal(out["1"][1]["iterations"], out["0"][1]["iterations"]) and np.all(out["1"][1]["converged"] == 1)
+    # the cooperative launches use many workgroups per registration: far fewer shader clocks on the critical path
+    assert out["1"][1]["cycles_eval"].max() * 4 < out["0"][1]["cycles_eval"].max()
+
+
 def test_config4_replay_small(N, O):
     """configs[3] at CI size: a short trajectory of nodes in one building, one NDT map per node, ALL node
     pairs as candidate edges (NDTFeatureGraph::computeAllPossibleLinks order), edges dealt block-cyclically
