@@ -115,42 +115,71 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
 #pragma clang fp contract(off)
     const unsigned map_local = blockIdx.y, map = first + map_local;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_points) return;
     const NdtGrid g = set.grid;
-    const float *pf = reinterpret_cast<const float *>(xyz + (size_t)map_local * map_stride_bytes + (size_t)i * stride_bytes);
-    const float ex = pf[0], ey = pf[1], ez = pf[2];
-    if (ex != ex || ey != ey || ez != ez) return;
+    // (no early return: the lanes of a wave add up their updates of a cell before one of them issues the atomic)
+    bool beam = i < n_points;
+    float ex = 0, ey = 0, ez = 0;
+    if (beam) {
+        const float *pf = reinterpret_cast<const float *>(xyz + (size_t)map_local * map_stride_bytes + (size_t)i * stride_bytes);
+        ex = pf[0]; ey = pf[1]; ez = pf[2];
+    }
+    if (ex != ex || ey != ey || ez != ez) beam = false;
     const double origin[3] = {origins[map_local * 3], origins[map_local * 3 + 1], origins[map_local * 3 + 2]};
     const double dx = (double)ex - origin[0], dy = (double)ey - origin[1], dz = (double)ez - origin[2];
     const double l = sqrt(dx * dx + dy * dy + dz * dz);
-    if (l > 200.0) return;                            // addPointCloud: max_range
-    if ((double)ez > maxz) return;                    // traceLine: the whole point is dropped
-    const int N = (int)(l / g.res);
-    if (N <= 2) return;
+    if (l > 200.0) beam = false;                      // addPointCloud: max_range
+    if ((double)ez > maxz) beam = false;              // traceLine: the whole point is dropped
+    int N = beam ? (int)(l / g.res) : 0;
+    if (N <= 2) N = 0;
     const double sx = dx / (double)(float)N, sy = dy / (double)(float)N, sz = dz / (double)(float)N;
     const double cx = set.centres[map * 3], cy = set.centres[map * 3 + 1], cz = set.centres[map * 3 + 2];
     const int32_t *table = set.table + (size_t)map * g.slots;
     const NdtCell *cells = ndt_cells_of(set, map, set.cell_sel[map]);
     long long *delta = set.occ_delta + (size_t)map * g.slots;
     int iox = 0, ioy = 0, ioz = 0;                    // idxo = idyo = idzo = 0 like upstream
-    for (int k = 0; k < N - 2; k++) {
-        const double f = (double)(float)(k + 1);
-        const float px = (float)(origin[0] + f * sx), py = (float)(origin[1] + f * sy), pz = (float)(origin[2] + f * sz);
-        const int ix = lazygrid_index((double)px, cx, g.res, g.size[0]);
-        const int iy = lazygrid_index((double)py, cy, g.res, g.size[1]);
-        const int iz = lazygrid_index((double)pz, cz, g.res, g.size[2]);
-        if (ix == iox && iy == ioy && iz == ioz) continue;
-        iox = ix; ioy = iy; ioz = iz;
-        if ((unsigned)ix >= (unsigned)g.size[0] || (unsigned)iy >= (unsigned)g.size[1] || (unsigned)iz >= (unsigned)g.size[2]) continue;
-        const int slot = (ix * g.size[1] + iy) * g.size[2] + iz;
-        const int r = table[slot];
-        float upd = -0.2f;                            // seen empty, no Gaussian to argue with
-        if (r >= 0) {
-            const NdtCell c = cells[r];
-            if (!beam_evidence(c, origin, ex, ey, ez, sensor_noise, &upd)) continue;
+    const unsigned lane = threadIdx.x & 63u;
+    // Neighbouring beams walk through the same cells at the same step (100 k beams per turn: the 64 beams of a wave are
+    // 4 cm apart at 10 m).  64 atomics on ONE address in one instruction are served one after the other at the L2
+    // (the launch ran at 11 G updates/s); the lanes of a wave therefore add up the updates of a cell -- integers, so
+    // the sum is exact and the result the same -- and one lane adds the sum.
+    for (int k = 0; __ballot(k < N - 2); k++) {
+        int slot = -1;
+        long long val = 0;
+        if (k < N - 2) {
+            const double f = (double)(float)(k + 1);
+            const float px = (float)(origin[0] + f * sx), py = (float)(origin[1] + f * sy), pz = (float)(origin[2] + f * sz);
+            const int ix = lazygrid_index((double)px, cx, g.res, g.size[0]);
+            const int iy = lazygrid_index((double)py, cy, g.res, g.size[1]);
+            const int iz = lazygrid_index((double)pz, cz, g.res, g.size[2]);
+            if (!(ix == iox && iy == ioy && iz == ioz)) {
+                iox = ix; ioy = iy; ioz = iz;
+                if ((unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] && (unsigned)iz < (unsigned)g.size[2]) {
+                    const int sl = (ix * g.size[1] + iy) * g.size[2] + iz;
+                    const int r = table[sl];
+                    float upd = -0.2f;                // seen empty, no Gaussian to argue with
+                    bool ok = true;
+                    if (r >= 0) {
+                        const NdtCell c = cells[r];
+                        ok = beam_evidence(c, origin, ex, ey, ez, sensor_noise, &upd);
+                    }
+                    if (ok) {
+                        slot = sl;
+                        val = (long long)((double)upd * 4294967296.0);   // exact: a float below 1 in magnitude times 2^32 is an integer
+                    }
+                }
+            }
         }
-        // exact: a float below 1 in magnitude times 2^32 is an integer
-        atomicAdd(reinterpret_cast<unsigned long long *>(delta + slot), (unsigned long long)(long long)((double)upd * 4294967296.0));
+        unsigned long long todo = __ballot(slot >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int s0 = __shfl(slot, leader, 64);
+            const bool mine = slot == s0;
+            long long v = mine ? val : 0ll;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((int)lane == leader) atomicAdd(reinterpret_cast<unsigned long long *>(delta + s0), (unsigned long long)v);
+            todo &= ~__ballot(mine);
+        }
     }
 }
 
