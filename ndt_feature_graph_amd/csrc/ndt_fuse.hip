@@ -107,6 +107,19 @@ NDT_D unsigned fuse_wave_incl_scan(unsigned v)
 
 }  // namespace
 
+// Sum of a 32-bit integer over the 64 lanes of a wave, in the vector ALU (DPP row shifts and broadcasts, no LDS
+// round trips): inclusive scan within the rows of 16, row totals handed on by the two row broadcasts, total in lane 63.
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // LazyGrid::traceLine + the occupancy half of NDTMap::addPointCloud.  grid (ceil(n / 256), maps).
 extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
     NdtSetView set, unsigned first, const char *__restrict__ xyz, unsigned n_points, unsigned stride_bytes,
@@ -174,9 +187,9 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
             const int leader = __ffsll((long long)todo) - 1;
             const int s0 = __shfl(slot, leader, 64);
             const bool mine = slot == s0;
-            long long v = mine ? val : 0ll;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            // |val| < 2^32: the low 20 bits and the (signed) rest are summed as two 32-bit integers, exactly
+            const long long mv = mine ? val : 0ll;
+            const long long v = ((long long)wave_sum_i32((int)(mv >> 20)) << 20) + (long long)wave_sum_i32((int)(mv & 0xFFFFF));
             if ((int)lane == leader) atomicAdd(reinterpret_cast<unsigned long long *>(delta + s0), (unsigned long long)v);
             todo &= ~__ballot(mine);
         }
