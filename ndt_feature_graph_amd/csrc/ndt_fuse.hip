@@ -151,6 +151,18 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
     long long *delta = set.occ_delta + (size_t)map * g.slots;
     int iox = 0, ioy = 0, ioz = 0;                    // idxo = idyo = idzo = 0 like upstream
     const unsigned lane = threadIdx.x & 63u;
+    // cell index of a sample: fp32 fast path v = fma(p, 1/res, 0.5 + size/2 - c/res) with the error bound of
+    // csrc/ndt_build.hip (samples within it of a cell face, odd grid sizes and absurd centres take the reference's fp64
+    // formula): three fp32 operations per axis instead of an fp64 division
+    const double inv_res = 1.0 / g.res;
+    const float inv32 = (float)inv_res;
+    const float kx32 = (float)(0.5 + g.size[0] / 2.0 - cx * inv_res), ky32 = (float)(0.5 + g.size[1] / 2.0 - cy * inv_res),
+                kz32 = (float)(0.5 + g.size[2] / 2.0 - cz * inv_res);
+    const bool force_exact = ((g.size[0] | g.size[1] | g.size[2]) & 1) != 0;
+    const float kmax = fmaxf(fmaxf(fabsf(kx32), fabsf(ky32)), fabsf(kz32));
+    const float smax = (float)max(max(g.size[0], g.size[1]), g.size[2]) + 1.0f;
+    const float face_guard = 2.4e-7f * (smax + kmax);
+    const float frac_lim = (force_exact || !(face_guard < 0.25f)) ? -1.0f : 0.5f - face_guard;
     // Neighbouring beams walk through the same cells at the same step (100 k beams per turn: the 64 beams of a wave are
     // 4 cm apart at 10 m).  64 atomics on ONE address in one instruction are served one after the other at the L2
     // (the launch ran at 11 G updates/s); the lanes of a wave therefore add up the updates of a cell -- integers, so
@@ -161,9 +173,16 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
         if (k < N - 2) {
             const double f = (double)(float)(k + 1);
             const float px = (float)(origin[0] + f * sx), py = (float)(origin[1] + f * sy), pz = (float)(origin[2] + f * sz);
-            const int ix = lazygrid_index((double)px, cx, g.res, g.size[0]);
-            const int iy = lazygrid_index((double)py, cy, g.res, g.size[1]);
-            const int iz = lazygrid_index((double)pz, cz, g.res, g.size[2]);
+            const float vx = fmaf(px, inv32, kx32), vy = fmaf(py, inv32, ky32), vz = fmaf(pz, inv32, kz32);
+            const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
+            int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+            const bool nx = !(fabsf((vx - flx) - 0.5f) <= frac_lim), ny = !(fabsf((vy - fly) - 0.5f) <= frac_lim),
+                       nz = !(fabsf((vz - flz) - 0.5f) <= frac_lim);
+            if (__ballot(nx | ny | nz)) {                 // (rare; a sample far outside the grid is out of bounds on either path)
+                if (nx) ix = lazygrid_index((double)px, cx, g.res, g.size[0]);
+                if (ny) iy = lazygrid_index((double)py, cy, g.res, g.size[1]);
+                if (nz) iz = lazygrid_index((double)pz, cz, g.res, g.size[2]);
+            }
             if (!(ix == iox && iy == ioy && iz == ioz)) {
                 iox = ix; ioy = iy; ioz = iz;
                 if ((unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] && (unsigned)iz < (unsigned)g.size[2]) {
