@@ -38,7 +38,9 @@
 #define NDT_BUILD_THREADS 256
 #define NDT_BUILD_WAVES (NDT_BUILD_THREADS / 64)
 #define NDT_FIN_THREADS 1024  // finalise-only launch (MODE 2): more waves to hide the dependent table loads
+#ifndef NDT_PPL
 #define NDT_PPL 8            // consecutive points per lane per tile
+#endif
 #define NDT_TILE (64 * NDT_PPL)
 #ifndef NDT_ROUNDS
 #define NDT_ROUNDS 8
@@ -50,6 +52,8 @@
 #define NDT_EMPTY (-1)
 
 namespace {
+
+constexpr int ndt_gcd(int a, int b) { return b == 0 ? a : ndt_gcd(b, a % b); }
 
 NDT_D unsigned wave_incl_scan(unsigned v)
 {
@@ -493,7 +497,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             if (full) {
                 // d = lane + 64k walks (owner, e) = divmod(d, ROW) with period P in k (64 P = RS ROW): P lane constants
                 // per super-tile; everything else is a wave-uniform base (scalar) or an immediate LDS offset
-                constexpr int P = (ROW % 64 == 0) ? 1 : (ROW == 24 ? 3 : (64 % ROW == 0 ? 1 : ROW));
+                constexpr int P = ROW / ndt_gcd(ROW, 64);                         // 8 points of 12 bytes: 3; of 16 bytes: 1
                 constexpr int RS = 64 * P / ROW;
                 static_assert((64 * P) % ROW == 0 && ROW % P == 0, "staging period");
                 unsigned goff[P], loff[P];
