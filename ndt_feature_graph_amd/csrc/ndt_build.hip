@@ -55,15 +55,17 @@ namespace {
 
 constexpr int ndt_gcd(int a, int b) { return b == 0 ? a : ndt_gcd(b, a % b); }
 
+// inclusive scan over the 64 lanes in the vector ALU (DPP row shifts, then the two row broadcasts): no LDS round trips
 NDT_D unsigned wave_incl_scan(unsigned v)
 {
-    const unsigned lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        unsigned t = __shfl_up(v, o, 64);
-        if (lane >= (unsigned)o) v += t;
-    }
-    return v;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+    return (unsigned)x;
 }
 
 struct BuildCtx {
