@@ -90,6 +90,33 @@ NDT_D double pl_swap_add(double a, double b, bool rows16)
     return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
 }
 
+// value of lane (l ^ O) for O = 1, 2, 4, 8 in the vector ALU: quad permutes for 1 and 2; lane ^ 4 is the half-row mirror
+// (^ 7) of the quad reversal (^ 3), lane ^ 8 the row mirror (^ 15) of the half-row mirror (^ 7).  No LDS round trip.
+template <int O>
+NDT_D double xor_lane(double x)
+{
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8, "within a row of 16 lanes");
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    if constexpr (O == 1) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true);
+    } else if constexpr (O == 2) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, true);
+    } else if constexpr (O == 4) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x1B, 0xf, 0xf, true);    // quad_perm [3,2,1,0]
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x1B, 0xf, 0xf, true);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, true);   // row_half_mirror
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, true);   // row_half_mirror
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, true);
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, true);   // row_mirror
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, true);
+    }
+    return __hiloint2double(hi, lo);
+}
+
 template <int N, int HALF, int O>
 NDT_D void wave_sum_step(double (&v)[N], unsigned lane)
 {
@@ -100,7 +127,7 @@ NDT_D void wave_sum_step(double (&v)[N], unsigned lane)
         } else {
             const bool up = (lane & (unsigned)O) != 0;
             const double keep = up ? v[k + HALF] : v[k], send = up ? v[k] : v[k + HALF];
-            v[k] = keep + __shfl_xor(send, O, 64);
+            v[k] = keep + xor_lane<O>(send);
         }
     }
     if constexpr (HALF > 1) wave_sum_step<N, HALF / 2, O / 2>(v, lane);   // static indices only: v stays in registers
@@ -113,8 +140,13 @@ NDT_D double wave_sum_all(double (&v)[N])
     const unsigned lane = threadIdx.x & 63u;
     wave_sum_step<N, N / 2, 32>(v, lane);
     double t = v[0];
-#pragma unroll
-    for (int o = 64 / (2 * N); o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+    if constexpr (N == 8) {          // 8 values: the lane bits 2, 1, 0 are left
+        t += xor_lane<4>(t);
+        t += xor_lane<2>(t);
+        t += xor_lane<1>(t);
+    } else {                         // 32 values: lane bit 0 is left
+        t += xor_lane<1>(t);
+    }
     return t;
 }
 
