@@ -21,29 +21,53 @@ class NdtGpuError(RuntimeError):
 
 
 def library_path():
-    return _SO
+    """The in-tree library; NDTGPU_LIB names another build of it (A/B measurements of kernel variants)."""
+    return os.environ.get("NDTGPU_LIB") or _SO
+
+
+# per-source flags.  ndt_match.hip: the solver's pivoted LDL^T picks one of several statically indexed register swaps; with
+# common-code sinking the optimiser merges those branches into ONE swap with computed indices, and the register array
+# goes to the stack (the only private segment the matcher kernels would have).
+_SOURCE_FLAGS = {"ndt_match.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 
 def build_library(force=False, verbose=False):
-    """hipcc cross-compiles the kernels + C-ABI for gfx950 into the in-tree libndtgpu.so."""
+    """hipcc cross-compiles the kernels + C-ABI for gfx950 into the in-tree libndtgpu.so (one object per source, in
+    parallel, then one link)."""
     csrc = os.path.join(_HERE, "csrc")
+    so = library_path()
     srcs = [os.path.join(csrc, s) for s in _SOURCES]
-    deps = srcs + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(_ROOT, "include", "ndtgpu.h")]
-    if not force and os.path.exists(_SO) and os.path.getmtime(_SO) >= max(os.path.getmtime(d) for d in deps):
-        return _SO
+    deps = srcs + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(_ROOT, "include", "ndtgpu.h"), os.path.abspath(__file__)]
+    if not force and os.path.exists(so) and os.path.getmtime(so) >= max(os.path.getmtime(d) for d in deps):
+        return so
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     extra = os.environ.get("NDTGPU_BUILD_FLAGS", "").split()      # experiments only (-DNDT_MATCH_PROF ...)
-    # (spills of the solver's helper functions go to scratch, not to AGPRs: with AGPRs in use the narrow matcher kernel
-    #  would not fit two workgroups per CU)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", *extra, *srcs, "-o", _SO + ".tmp"]
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    # (spills never go to AGPRs: with AGPRs in use the matcher kernel would not keep 256 architectural VGPRs at two
+    #  waves per SIMD)
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+              "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", *extra]
+    jobs = []
+    for name, src in zip(_SOURCES, srcs):
+        obj = os.path.join(objdir, name + ".o")
+        cmd = common + _SOURCE_FLAGS.get(name, []) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((subprocess.Popen(cmd), cmd, obj))
+    objs = []
+    for proc, cmd, obj in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        objs.append(obj)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", so + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(_SO + ".tmp", _SO)
-    return _SO
+        print(" ".join(link))
+    subprocess.check_call(link)
+    os.replace(so + ".tmp", so)
+    return so
 
 
 class GridParams(C.Structure):
@@ -102,9 +126,10 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(_SO):
-        raise NdtGpuError(-2, "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % _SO)
-    L = C.CDLL(_SO)
+    so = library_path()
+    if not os.path.exists(so):
+        raise NdtGpuError(-2, "HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % so)
+    L = C.CDLL(so)
     vp, dp, u32p, i32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
     L.ndtgpu_version.restype = C.c_char_p
     L.ndtgpu_last_error.restype = C.c_char_p

@@ -149,7 +149,8 @@ hipError_t ndt_launch_overlap(const NdtSetView &rset, const uint32_t *ridx_dev, 
                               long long *nb_dev, hipStream_t stream);
 hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const NdtCell *cells_dev, size_t n_cells,
                                     hipStream_t stream);
-size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups);
+size_t ndt_match_work_bytes(size_t n_pairs, size_t n_slots);
+size_t ndt_match_abort_offset();   // offset in the work area of the word the matcher raises when it gave up
 size_t ndt_match_coop_work_bytes(size_t n_groups);
 size_t ndt_match_coop_ctrl_bytes();
 unsigned ndt_match_coop_capacity(int n_neighbours);
@@ -159,8 +160,8 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_de
                                  unsigned n_groups, unsigned cells_per_group, void *work_dev, hipStream_t stream);
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                            NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters, int narrow,
-                            void *work_dev, hipStream_t stream);
+                            NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters, int slots,
+                            unsigned double_thresh, void *work_dev, hipStream_t stream);
 hipError_t ndt_launch_covariance(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                                  const uint32_t *sidx_dev, const double *T16_dev, size_t n_links, int n_neighbours,
                                  double lfd1, double lfd2, int mode, double *cov36_dev, int *status_dev, hipStream_t stream);

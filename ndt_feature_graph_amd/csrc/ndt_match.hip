@@ -191,30 +191,52 @@ NDT_D double exp_nonpos(double x)
     return x < -745.2 ? 0.0 : v;
 }
 
+// 1 / x for a finite x of ordinary magnitude (|det(CSum)| > 1e-12): hardware reciprocal + two Newton steps -- five
+// instructions against the eleven of the IEEE division sequence, last-bit accurate away from the denormal range.
+NDT_D double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // One (source cell, target cell) term of NDTMatcherD2D::derivativesNDT + updateGradientHessianLocal
 // (SURVEY.md App. A.4).  m, C: source mean / covariance already in the target frame.
 // acc: [0] score, [1..6] gradient, [7..27] upper triangle of the Hessian (row-major).
+// With x = m - mu, B = (C + Cj)^-1, q = (B x, (m - C B x) x B x) [so that x^T B (dx/dp_a) ... = 2 q_a], s = -d1 exp(-d2/2 x^T B x):
+//   score += s,   gradient_a += 2 f q_a,   Hessian_ab += 2 f (h_ab - d2 q_a q_b),   f = -(d2 / 2) s,
+// h = half the second-order bracket of the reference formula (the factor 2 of every term is applied once, in 2 f).
 template <bool WITH_H>
 NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, double *acc)
 {
-    d3 x = m - mu;
-    sym3 B;
-    if (!inverse_check(C + Cj, B)) return;          // CSum.computeInverseAndDetWithCheck
-    d3 xB = mul(B, x);
-    double l = dot(x, xB);
+    const d3 x = m - mu;
+    const sym3 S = C + Cj;
+    // CSum.computeInverseAndDetWithCheck: adjugate / determinant, |det| > 1e-12
+    sym3 A;
+    A.xx = S.yy * S.zz - S.yz * S.yz;
+    A.xy = S.yz * S.xz - S.xy * S.zz;
+    A.xz = S.xy * S.yz - S.yy * S.xz;
+    const double det = S.xx * A.xx + S.xy * A.xy + S.xz * A.xz;
+    if (!(fabs(det) > NDT_DET_EPS)) return;
+    A.yy = S.xx * S.zz - S.xz * S.xz;
+    A.yz = S.xy * S.xz - S.xx * S.yz;
+    A.zz = S.xx * S.yy - S.xy * S.xy;
+    const double id = rcp_nr(det);
+    const d3 xB = id * mul(A, x);                    // B x
+    const double l = dot(x, xB);
     if (!(l * 0.0 == 0.0)) return;                   // if(l*0 != 0) continue;
-    double sh = -lfd1 * exp_nonpos(-lfd2 * l * 0.5);
-    double f = -(lfd2 * 0.5) * sh;
-    d3 w = mul(C, xB);
-    d3 c = cross(w, xB);                             // x^T B Z_k B x = 2 c_k
-    d3 d = cross(m, xB);                             // x^T B j_k     = d_k   (j_k = e_k x m)
-    double Q[6] = {2.0 * xB.x, 2.0 * xB.y, 2.0 * xB.z, 2.0 * (d.x - c.x), 2.0 * (d.y - c.y), 2.0 * (d.z - c.z)};
+    const double sh = -lfd1 * exp_nonpos(-lfd2 * l * 0.5);
+    const double f2 = -lfd2 * sh;                    // 2 f
+    const d3 w = mul(C, xB);
+    const d3 qr = cross(m - w, xB);                  // x^T B j_k - x^T B Z_k B x / 2,  j_k = e_k x m
+    const double q[6] = {xB.x, xB.y, xB.z, qr.x, qr.y, qr.z};
     acc[0] += sh;
 #pragma unroll
-    for (int a = 0; a < 6; a++) acc[1 + a] += f * Q[a];
+    for (int a = 0; a < 6; a++) acc[1 + a] += f2 * q[a];
     if (!WITH_H) return;
 
-    const double kq = lfd2 * 0.5;
+    const sym3 B = {A.xx * id, A.xy * id, A.xz * id, A.yy * id, A.yz * id, A.zz * id};
     d3 j[3] = {ex_cross(m), ey_cross(m), ez_cross(m)};
     d3 Bj[3], p[3], r[3], u[3];
     p[0] = ex_cross(xB); p[1] = ey_cross(xB); p[2] = ez_cross(xB);
@@ -228,10 +250,13 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
     const double Bm[3][3] = {{B.xx, B.xy, B.xz}, {B.xy, B.yy, B.yz}, {B.xz, B.yz, B.zz}};
     const double Bjv[3][3] = {{Bj[0].x, Bj[0].y, Bj[0].z}, {Bj[1].x, Bj[1].y, Bj[1].z}, {Bj[2].x, Bj[2].y, Bj[2].z}};
     const double uv[3][3] = {{u[0].x, u[0].y, u[0].z}, {u[1].x, u[1].y, u[1].z}, {u[2].x, u[2].y, u[2].z}};
-    // 2 x^T B H_ik, H_ik = e_i x (e_k x m), i <= k
-    const double xBH[3][3] = {{-2.0 * (xB.y * m.y + xB.z * m.z), 2.0 * xB.y * m.x, 2.0 * xB.z * m.x},
-                              {0.0, -2.0 * (xB.x * m.x + xB.z * m.z), 2.0 * xB.z * m.y},
-                              {0.0, 0.0, -2.0 * (xB.x * m.x + xB.y * m.y)}};
+    // x^T B H_ik, H_ik = e_i x (e_k x m), i <= k
+    const double xBH[3][3] = {{-(xB.y * m.y + xB.z * m.z), xB.y * m.x, xB.z * m.x},
+                              {0.0, -(xB.x * m.x + xB.z * m.z), xB.z * m.y},
+                              {0.0, 0.0, -(xB.x * m.x + xB.y * m.y)}};
+    double qk[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) qk[a] = lfd2 * q[a];
     int o = 7;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
@@ -239,15 +264,14 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
         for (int b = a; b < 6; b++) {
             double h;
             if (b < 3) {
-                h = 2.0 * Bm[a][b];
+                h = Bm[a][b];
             } else if (a < 3) {
-                h = 2.0 * Bjv[b - 3][a] - 2.0 * uv[b - 3][a];
+                h = Bjv[b - 3][a] - uv[b - 3][a];
             } else {
                 int i = a - 3, k = b - 3;
-                h = 2.0 * dot(j[i], Bj[k]) + xBH[i][k] - 2.0 * (dot(u[i], j[k]) + dot(u[k], j[i])) +
-                    2.0 * dot(u[i], r[k]) + 2.0 * dot(p[i], r[k]);
+                h = dot(j[i], Bj[k]) + xBH[i][k] - (dot(u[i], j[k]) + dot(u[k], j[i])) + dot(u[i], r[k]) + dot(p[i], r[k]);
             }
-            acc[o++] += f * (h - kq * Q[a] * Q[b]);
+            acc[o++] += f2 * (h - qk[a] * q[b]);
         }
     }
 }
@@ -276,12 +300,24 @@ struct EvalShared {
 };
 
 // What a wave carries through an evaluation: its accumulators, its hit queue, its share of the LDS.
+#if defined(NDT_MATCH_PROF) && !defined(NDT_MATCH_TL)
+#define NDT_MATCH_TL
+#endif
+#ifdef NDT_MATCH_TL
+// timeline of one launch of the persistent matcher (100 MHz wall clock): per pair {first start, parked, resumed, end},
+// then per workgroup the time its last wave left, then [.. + 1024] the launch's first time stamp
+#define NDT_TL_PAIRS 4096
+__device__ long long g_tl[4 * NDT_TL_PAIRS + 1024 + 8];
+#define NDT_TL(pair, k) { if ((pair) < NDT_TL_PAIRS) g_tl[4 * (pair) + (k)] = (long long)wall_clock64(); }
+#else
+#define NDT_TL(pair, k)
+#endif
 #ifdef NDT_MATCH_PROF   // experiments: section clocks of wave 0 (src+transform, probe, pop, term, reduce)
 __device__ long long g_prof[16];   // [0..5]: gradient-only evaluations (5 sections + count), [8..13]: with Hessian
 #ifndef NDT_PROF_TID
 #define NDT_PROF_TID 0
 #endif
-#define NDT_PROF_T(k) { if (threadIdx.x == NDT_PROF_TID) { long long n_ = clock64(); w.prof[k] += n_ - w.pt; w.pt = n_; } }
+#define NDT_PROF_T(k) { if ((threadIdx.x & 63u) == NDT_PROF_TID) { long long n_ = clock64(); w.prof[k] += n_ - w.pt; w.pt = n_; } }
 #else
 #define NDT_PROF_T(k)
 #endif
@@ -337,30 +373,30 @@ NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double
             }
         }
     } else {
-        bool v0 = lane < n;
-        uint32_t en0 = v0 ? w.myq[lane] : 0u;
-        d3 mu0 = {0, 0, 0};
-        sym3 Cj0 = {0, 0, 0, 0, 0, 0};
-        if (v0) {
-            gcell_ptr tc = tg.cells + (en0 & 0xFFFFFFu);
-            mu0 = d3{tc->mean[0], tc->mean[1], tc->mean[2]};
-            Cj0 = sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
-        }
-#pragma unroll 1
-        for (unsigned e0 = 0; e0 < n; e0 += 64u) {
-            const bool v1 = e0 + 64u + lane < n;
-            uint32_t en1 = 0u;
-            d3 mu1 = {0, 0, 0};
-            sym3 Cj1 = {0, 0, 0, 0, 0, 0};
-            if (v1) {
-                en1 = w.myq[e0 + 64u + lane];
-                gcell_ptr tc = tg.cells + (en1 & 0xFFFFFFu);
-                mu1 = d3{tc->mean[0], tc->mean[1], tc->mean[2]};
-                Cj1 = sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
+        // two register sets that take turns (no rotation moves): while one batch is computed the next one's list
+        // entries and target cells are on their way
+        bool vA, vB;
+        uint32_t enA = 0u, enB = 0u;
+        d3 muA = {0, 0, 0}, muB = {0, 0, 0};
+        sym3 CjA = {0, 0, 0, 0, 0, 0}, CjB = {0, 0, 0, 0, 0, 0};
+        auto fetch = [&](unsigned e, bool &v, uint32_t &en, d3 &mu, sym3 &Cj) {
+            v = e + lane < n;
+            if (v) {
+                en = w.myq[e + lane];
+                gcell_ptr tc = tg.cells + (en & 0xFFFFFFu);
+                mu = d3{tc->mean[0], tc->mean[1], tc->mean[2]};
+                Cj = sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
             }
+        };
+        fetch(0u, vA, enA, muA, CjA);
+#pragma unroll 1
+        for (unsigned e0 = 0; e0 < n; e0 += 128u) {
+            fetch(e0 + 64u, vB, enB, muB, CjB);
             __builtin_amdgcn_sched_barrier(0);       // (the loads stay above the arithmetic)
-            if (v0) pair_term<false>(tile_m(en0 >> 24), tile_C(en0 >> 24), mu0, Cj0, lfd1, lfd2, w.acc);
-            v0 = v1; en0 = en1; mu0 = mu1; Cj0 = Cj1;
+            if (vA) pair_term<false>(tile_m(enA >> 24), tile_C(enA >> 24), muA, CjA, lfd1, lfd2, w.acc);
+            fetch(e0 + 128u, vA, enA, muA, CjA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (vB) pair_term<false>(tile_m(enB >> 24), tile_C(enB >> 24), muB, CjB, lfd1, lfd2, w.acc);
         }
     }
     w.terms += n;
@@ -573,172 +609,378 @@ NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &
 
 }  // namespace
 
-// Work distribution of the persistent matcher.  Registrations differ 10x in length (most converge in 5-9
-// Newton iterations, a few run into ITR_MAX with long line searches) and a long one that STARTS late sets the
-// launch time.  Workgroups therefore pull pairs from a ticket counter, and a registration that is still running
-// after `park_iters` iterations is parked (its solver state, ~1 KB, goes to global memory) whenever a pair that
-// has not started yet can be taken instead: every registration starts before any long tail is run, and the
-// tails then run side by side on otherwise idle CUs.
+// ---- the persistent matcher: a scheduler of WAVE tasks ------------------------------------------------------------
+// A workgroup (8 waves, one per CU: 256 VGPRs each) keeps R registrations in flight ("slots", all state in LDS).  The
+// unit of work is a SHARE of an evaluation: the source cells of a registration are dealt to NDT_VW = 8 shares, and a
+// wave that has nothing to do takes the next share of whichever slot has one -- transform, PROBE, TERM, wave sum, one
+// row of partial sums into LDS.  The wave that delivers the LAST share of an evaluation adds the eight rows in fixed
+// order and runs the solver step (csrc/ndt_solver.h) right there: its accumulators are dead, nothing lives across the
+// step, and the other seven waves are already working on the other slot's shares.  No workgroup barrier after the
+// start:
+//   * a wave never waits for its workgroup's slowest wave, and the serial solver step of one registration hides
+//     behind the pair terms of the other (the CU-time of a registration drops by a third);
+//   * when only one registration is left on a CU its 8 shares occupy the 8 waves: a lone registration is as fast as
+//     it can be on one CU.  The same kernel serves the bulk and the tail.
+// Shares, their hit lists and their partial sums are the same whoever computes them and the rows are added in share
+// order: a registration's result does not depend on R, on the batch it is in or on timing -- bit for bit.
+//
+// Work distribution across workgroups.  Registrations differ 10x in length (most converge in 5-9 Newton iterations, a
+// few run into ITR_MAX with long line searches) and a long one that STARTS late sets the launch time.  Slots pull
+// pairs from a ticket counter, and a registration that is still running after `park_iters` iterations is parked (its
+// solver state, ~1.5 KB, goes to global memory) whenever a pair that has not started yet can be taken instead: every
+// registration starts before any long tail is run.  When the tickets are gone the parked registrations are resumed, at
+// most ONE of them per workgroup unless more are waiting than there are workgroups (a resumed registration is a long
+// one: two of them on one CU would run at half speed each while other CUs have nothing left to do).
 //   fresh   : next pair that has not started
 //   reserve : parked-list slots handed out;  head : parked-list slots consumed
 //   ids[s]  : 0 = slot not written yet, 1 = cancelled, pair + 2 = parked pair
-// A slot is reserved BEFORE the fresh ticket is drawn, so a workgroup whose own ticket draw failed and that then
-// sees head == reserve knows that no registration can be parked any more, and may exit.
+// A list slot is reserved BEFORE the fresh ticket is drawn, so whoever sees the tickets exhausted and then
+// head == reserve knows that no registration can be parked any more; a workgroup whose slots have all seen that exits,
+// and its CU is free for the next launch (bench.py's pipeline).
 struct NdtMatchWork {
-    unsigned fresh, reserve, head, pad;
+    unsigned fresh, reserve, head;
+    unsigned abort;        // a wave that found nothing to do for about a second raises it and everybody leaves (guard against
+                           // a scheduling bug hanging the device; ndt_match_aborted())
 };
 struct NdtParkedState {
     MatchState st;
-    long long cyc_eval, cyc_solver, terms_g, terms_h;
+    unsigned long long cnt[4];
 };
-size_t ndt_match_work_bytes(size_t n_pairs, size_t n_groups)
+size_t ndt_match_abort_offset() { return offsetof(NdtMatchWork, abort); }
+size_t ndt_match_work_bytes(size_t n_pairs, size_t n_slots)
 {
-    return sizeof(NdtMatchWork) + (n_pairs + n_groups + 1) * sizeof(unsigned) + 8 + n_pairs * sizeof(NdtParkedState);
+    return sizeof(NdtMatchWork) + (n_pairs + n_slots + 1) * sizeof(unsigned) + 8 + n_pairs * sizeof(NdtParkedState);
 }
 
-// NW = 8: one wide workgroup per CU (a registration finishes soonest).  NW = 4: two narrow workgroups per CU, each with
-// its own registration: one's serial solver steps and latency-bound probing overlap the other's pair terms (more
-// registrations per second, each of them slower) -- chosen for large batches (ndt_launch_match).
-template <int NN, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ndt_match_kernel(
+namespace {
+enum { SLOT_FREE = 0, SLOT_BUSY = 1, SLOT_RUN = 2, SLOT_CLOSED = 3 };
+enum { TASK_NONE = -1, TASK_EXIT = -2, TASK_LOAD = 0x100 };
+
+template <int QL>
+struct MatchSlot {
+    MatchState st;
+    NewtonWs ws;
+    MapView tg, sv;
+    unsigned long long cnt[4];      // wave cycles in share tasks, wave cycles in solver steps, pair terms g / h
+    uint32_t queue[NDT_VW * QL];    // per share: the hit list
+    int cell[NDT_VW * 3 * 64];      // per share: the target-grid index of every lane's transformed mean, last evaluation
+    HitCache cache[NDT_VW];
+    double part[NDT_VW * 32];       // the shares' partial sums
+    double sums[32];                // the evaluation's result
+    unsigned state;                 // SLOT_*
+    unsigned next;                  // next share to hand out (>= NDT_VW: none)
+    unsigned done;                  // shares delivered
+    unsigned session;               // names the registration (key of the hit lists)
+    unsigned pair;
+    unsigned retry;                 // shader clock (low word) before which a FREE slot is not looked at again
+    int with_h;                     // the request: evaluate with the Hessian?
+    int preset;                     // a fresh ticket drawn while parking (-1: none)
+    int resumed;                    // the registration came from the parked list
+    long long t_pub;                // (timeline builds) shader clock when the running request was published
+    unsigned long long wall;        // (timeline builds) sum over evaluations of publish -> last share delivered
+};
+
+// one share of one evaluation: on return the wave's row of partial sums is in S.part
+template <int NN, bool WITH_H, int QL>
+NDT_D void run_share(MatchSlot<QL> &S, unsigned v, double *wsrc, uint2 *wwin, double lfd1, double lfd2)
+{
+    constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3;
+    const unsigned lane = threadIdx.x & 63u;
+    WaveEval<WITH_H> w;
+    w.mysrc = wsrc; w.mywin = wwin;
+    w.myq = S.queue + v * QL;
+    w.mycell = S.cell + v * (3 * 64);
+    w.cache = S.cache + v;
+    w.terms = 0;
+#ifdef NDT_MATCH_PROF
+    for (int k = 0; k < 6; k++) w.prof[k] = 0;
+    w.pt = clock64();
+#endif
+#pragma unroll
+    for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
+    const int msrc = S.sv.n_cells;
+    const unsigned key = msrc <= 64 * NDT_VW ? S.session : 0u;   // a share remembers the hit list of ONE group
+    for (int base = (int)v; base < msrc; base += 64 * NDT_VW)
+        eval_group<NN, WITH_H, QL>(w, S.tg, S.sv.cells, base, NDT_VW, msrc, S.st.Teval, lfd1, lfd2, key);
+    const double tot = wave_totals<WITH_H>(w);
+    if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) S.part[v * 32 + (lane >> SH)] = tot;
+    if (lane == 0) S.part[v * 32 + 28] = (double)w.terms;
+    NDT_PROF_T(4)
+#ifdef NDT_MATCH_PROF
+    if (lane == 0) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&g_prof[k + (WITH_H ? 8 : 0)], (unsigned long long)w.prof[k]); atomicAdd((unsigned long long *)&g_prof[5 + (WITH_H ? 8 : 0)], 1ull); }
+#endif
+}
+
+template <int QL>
+NDT_D void slot_result(const MatchSlot<QL> &S, double *T16, NdtMatchResultDev *res)
+{
+    NdtMatchResultDev &o = res[S.pair];
+    match_state_result(S.st, T16 + (size_t)S.pair * 16, o);
+    o.n_source = S.sv.n_cells;
+    o.n_target = S.tg.n_cells;
+    o.cycles_eval = (long long)(S.cnt[0] / NDT_MATCH_WAVES);    // CU-time: wave cycles / waves of a CU
+    o.cycles_solver = (long long)S.cnt[1];                      // wave cycles of the solver steps
+    o.pair_terms_g = (long long)S.cnt[2];
+    o.pair_terms_h = (long long)S.cnt[3];
+#ifdef NDT_MATCH_TL
+    o.pair_terms_g = (long long)S.wall;      // timeline builds: wall clocks of the evaluations instead
+#endif
+}
+
+NDT_D unsigned lds_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+NDT_D void lds_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+NDT_D unsigned clock_lo() { return (unsigned)__builtin_readcyclecounter(); }
+}  // namespace
+
+template <int NN, int R>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ndt_match_kernel(
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
     double *__restrict__ T16, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res,
-    const double *__restrict__ Q36 /* per pair Tcov^-1 (matchFusion soft constraint) or NULL */,
-    unsigned n_pairs, int park_iters, char *__restrict__ work_mem)
+    const double *__restrict__ Q36 /* per pair Tcov^-1 (matchFusion) or NULL */,
+    unsigned n_pairs, int park_iters, unsigned double_thresh, char *__restrict__ work_mem)
 {
-    __shared__ EvalShared<NW> sh;
-    __shared__ MatchState st;
-    __shared__ int s_job, s_next, s_skip;
-    // per-registration state that outlives an evaluation sits in LDS, not in registers: the evaluation needs ~220
-    // VGPRs, and what is live across it would be spilled to scratch memory
-    __shared__ MapView s_tg, s_sv;
-    __shared__ long long s_cnt[4];      // thread 0: shader clocks in evaluations / in the solver, pair terms g / h
-    __shared__ NdtMatchParamsDev s_prm; // the solver takes the parameters by reference: LDS, not a scratch copy
-    __shared__ unsigned s_session;      // names the registration this workgroup is working on (key of the waves' hit lists)
-    if (threadIdx.x == 0) { s_prm = prm; s_session = 0u; }
-    if (threadIdx.x < NDT_VW) sh.cache[threadIdx.x].key = 0u;
+    constexpr int QL = 1024;
+    typedef MatchSlot<QL> Slot;
+    __shared__ Slot slots[R];
+    __shared__ double w_src[NDT_MATCH_WAVES * 9 * 64];   // per wave: the transformed source tile, one column per lane
+    __shared__ uint2 w_win[NDT_MATCH_WAVES * 7 * 64];    // per wave: decoded probe windows (up to 7 runs x 64 lanes)
+    __shared__ NdtMatchParamsDev s_prm;
+    __shared__ unsigned s_session, s_resumed, s_closed;
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    if (tid == 0) { s_prm = prm; s_session = 0u; s_resumed = 0u; s_closed = 0u; }
+    if (tid < (unsigned)R) {
+        Slot &S = slots[tid];
+        S.state = SLOT_FREE; S.next = NDT_VW; S.done = 0u; S.retry = clock_lo(); S.preset = -1; S.resumed = 0;
+    }
+    if (tid < (unsigned)(R * NDT_VW)) slots[tid / NDT_VW].cache[tid % NDT_VW].key = 0u;
+    __syncthreads();                    // the only workgroup barrier of the kernel
+#ifdef NDT_MATCH_TL
+    if (tid == 0) atomicMin((unsigned long long *)&g_tl[4 * NDT_TL_PAIRS + 1024], (unsigned long long)wall_clock64());
+#endif
 
     NdtMatchWork *work = reinterpret_cast<NdtMatchWork *>(work_mem);
     unsigned *ids = reinterpret_cast<unsigned *>(work_mem + sizeof(NdtMatchWork));
-    const unsigned n_ids = n_pairs + gridDim.x + 1;
+    const unsigned n_ids = n_pairs + gridDim.x * (unsigned)R + 1u;
     NdtParkedState *parked =
         reinterpret_cast<NdtParkedState *>(work_mem + ((sizeof(NdtMatchWork) + n_ids * sizeof(unsigned) + 7) & ~(size_t)7));
+    double *const wsrc = w_src + wave * (9 * 64);
+    uint2 *const wwin = w_win + wave * (7 * 64);
 
-    if (threadIdx.x == 0) s_next = -1;
+    unsigned idle_spins = 0u;
     for (;;) {
-        // ---- take a job: the one drawn while parking, else a fresh pair, else a parked registration ----------
-        if (threadIdx.x == 0) {
-            int job = s_next;               // >= 0: fresh pair, <= -2: resume parked pair (-2 - pair), -1: none
-            s_next = -1;
-            if (job == -1) {
-                unsigned f = atomicAdd(&work->fresh, 1u);
-                if (f < n_pairs) job = (int)f;
-            }
-            while (job == -1) {
-                unsigned h = __hip_atomic_load(&work->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned r = __hip_atomic_load(&work->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (h >= r) break;          // nothing parked, nothing can be parked any more
-                if (atomicCAS(&work->head, h, h + 1u) != h) continue;
-                unsigned v;
-                while ((v = __hip_atomic_load(&ids[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
-                    __builtin_amdgcn_s_sleep(8);
-                if (v >= 2u) job = -2 - (int)(v - 2u);
-            }
-            s_job = job;
-            s_session = s_session + 1u ? s_session + 1u : 1u;
-        }
-        __syncthreads();
-        const int job = s_job;
-        if (job == -1) return;
-        const bool resumed = job <= -2;
-        const unsigned pair = resumed ? (unsigned)(-2 - job) : (unsigned)job;
-
-        if (threadIdx.x == 0) {
-            // the indices and the maps come from device memory the host never saw: check them here
-            const uint32_t ti = tidx[pair], si = sidx[pair];
-            const bool bad_index = ti >= tset.n_maps || si >= sset.n_maps;
-            const bool truncated = !bad_index && (tset.counters[ti].overflow != 0u || sset.counters[si].overflow != 0u);
-            s_skip = 0;
-            if (bad_index || truncated) {
-                NdtMatchResultDev *o = res + pair;      // (converged = 0; the pose is left untouched)
-                o->converged = 0; o->iterations = 0; o->fevals = 0;
-                o->exit_code = bad_index ? -2 : -3;     // -2 map index out of range, -3 a map needed more cells than max_cells
-                o->score = 0.0; o->n_source = 0; o->n_target = 0;
-                o->cycles_eval = 0; o->cycles_solver = 0; o->pair_terms_g = 0; o->pair_terms_h = 0;
-                s_skip = 1;
-            }
-        }
-        __syncthreads();
-        if (s_skip) { __syncthreads(); continue; }
-        if (threadIdx.x == 0) {
-            s_tg = map_view(tset, tidx[pair]);
-            s_sv = map_view(sset, sidx[pair]);
-            if (resumed) {
-                const NdtParkedState &ps = parked[pair];
-                st = ps.st;
-                s_cnt[0] = ps.cyc_eval; s_cnt[1] = ps.cyc_solver; s_cnt[2] = ps.terms_g; s_cnt[3] = ps.terms_h;
-            } else {
-                match_state_init(st, T16 + (size_t)pair * 16, s_prm, Q36 ? Q36 + (size_t)pair * 36 : nullptr);
-                s_cnt[0] = s_cnt[1] = s_cnt[2] = s_cnt[3] = 0;
-            }
-        }
-        __syncthreads();
-
-        bool parked_now = false;
-        while (!st.done) {
-            // the request (pose, with / without Hessian) is read from LDS where the solver left it: thread 0 rewrites
-            // it only after the evaluation's closing barrier, when nobody reads it any more
-            const int with_h = st.with_h;
-            long long c0 = __builtin_readcyclecounter();
-            if (with_h) eval_derivs<NN, true, NW>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh, s_session);
-            else eval_derivs<NN, false, NW>(s_tg, s_sv.cells, s_sv.n_cells, st.Teval, s_prm.lfd1, s_prm.lfd2, sh, s_session);
-            long long c1 = __builtin_readcyclecounter();
-            if (threadIdx.x == 0) {
-                s_cnt[with_h ? 3 : 2] += (long long)sh.sums[28];
-                s_cnt[0] += c1 - c0;
-#ifdef NDT_MATCH_PROF
-                const int ph_ = st.phase;
-#endif
-                match_state_step(st, sh.sums, s_prm);
-                s_cnt[1] += (long long)__builtin_readcyclecounter() - c1;
-#ifdef NDT_MATCH_PROF
-                atomicAdd((unsigned long long *)&g_prof[ph_ == PH_NEWTON ? 6 : 14], (unsigned long long)((long long)__builtin_readcyclecounter() - c1));
-                atomicAdd((unsigned long long *)&g_prof[ph_ == PH_NEWTON ? 7 : 15], 1ull);
-#endif
-                // about to start another Newton iteration of a long registration: hand the CU to a pair that has
-                // not started yet, if there is one
-                s_job = 0;
-                if (!st.done && st.phase == PH_NEWTON && park_iters > 0 && st.itr_ctr >= park_iters &&
-                    __hip_atomic_load(&work->fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_pairs) {
-                    const unsigned slot = atomicAdd(&work->reserve, 1u);
-                    const unsigned f = atomicAdd(&work->fresh, 1u);
-                    if (f < n_pairs) {
-                        NdtParkedState &ps = parked[pair];
-                        ps.st = st;
-                        ps.cyc_eval = s_cnt[0]; ps.cyc_solver = s_cnt[1]; ps.terms_g = s_cnt[2]; ps.terms_h = s_cnt[3];
-                        __hip_atomic_store(&ids[slot], pair + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        s_next = (int)f;
-                        s_job = 1;
-                    } else {
-                        __hip_atomic_store(&ids[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- find something to do: a share of a running evaluation, else a free slot to fill -------------------
+        int task = TASK_NONE;
+        bool running = false;           // a registration of this workgroup is between two evaluations: shares are about to appear
+        if (lane == 0) {
+#pragma unroll 1
+            for (unsigned r = 0; r < (unsigned)R && task == TASK_NONE; r++) {
+                const unsigned s = (wave + r) % (unsigned)R;
+                Slot &S = slots[s];
+                if (lds_load(&S.state) == SLOT_RUN) {
+                    running = true;
+                    if (lds_load(&S.next) < (unsigned)NDT_VW) {
+                        const unsigned v = atomicAdd(&S.next, 1u);
+                        if (v < (unsigned)NDT_VW) task = (int)(s * 16u + v);
                     }
                 }
             }
-            __syncthreads();
-            if (s_job == 1) { parked_now = true; break; }
+            if (task == TASK_NONE) {
+                const unsigned now = clock_lo();
+#pragma unroll 1
+                for (unsigned s = 0; s < (unsigned)R && task == TASK_NONE; s++) {
+                    Slot &S = slots[s];
+                    if (lds_load(&S.state) == SLOT_FREE && (int)(now - lds_load(&S.retry)) >= 0 &&
+                        atomicCAS(&S.state, (unsigned)SLOT_FREE, (unsigned)SLOT_BUSY) == (unsigned)SLOT_FREE)
+                        task = TASK_LOAD + (int)s;
+                }
+            }
+            if (task == TASK_NONE && lds_load(&s_closed) >= (unsigned)R) task = TASK_EXIT;
+        }
+        task = __builtin_amdgcn_readfirstlane(task);
+#ifdef NDT_MATCH_TL
+        if (task == TASK_EXIT && lane == 0 && blockIdx.x < 1024u) atomicMax((unsigned long long *)&g_tl[4 * NDT_TL_PAIRS + blockIdx.x], (unsigned long long)wall_clock64());
+#endif
+        if (task == TASK_EXIT) return;
+        if (task == TASK_NONE) {
+            // (S_WAKEUP from the publishing wave would let idle waves sleep long and still react at once; on this
+            //  hardware / runtime a kernel that executes it faults intermittently -- measured, 3 runs of 3 -- so the
+            //  waves poll: at short intervals while a solver step of their workgroup is under way, else rarely)
+            if (__builtin_amdgcn_readfirstlane(running ? 1 : 0)) __builtin_amdgcn_s_sleep(2);
+            else __builtin_amdgcn_s_sleep(16);
+            idle_spins += 1u;
+            if ((idle_spins & 1023u) == 0u) {
+                if (idle_spins > (1u << 24)) __hip_atomic_store(&work->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_load(&work->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            }
+            continue;
+        }
+        idle_spins = 0u;
+
+        if (task >= TASK_LOAD) {
+            // ---- fill a slot: the ticket drawn while parking, else a fresh pair, else a parked registration ----
+            if (lane == 0) {
+                const unsigned s = (unsigned)(task - TASK_LOAD);
+                Slot &S = slots[s];
+                unsigned new_state = SLOT_BUSY;
+                while (new_state == SLOT_BUSY) {
+                    int job = S.preset;         // >= 0: fresh pair, <= -2: resume parked pair (-2 - pair), -1: none
+                    S.preset = -1;
+                    if (job == -1) {
+                        // slots beyond a workgroup's first draw once every workgroup has had its first ticket (a batch
+                        // that cannot fill the chip keeps one registration per CU)
+                        const unsigned f0 = __hip_atomic_load(&work->fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (f0 < n_pairs && (s == 0u || f0 >= gridDim.x)) {
+                            const unsigned f = atomicAdd(&work->fresh, 1u);
+                            if (f < n_pairs) job = (int)f;
+                        }
+                    }
+                    while (job == -1) {
+                        const unsigned f1 = __hip_atomic_load(&work->fresh, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned h = __hip_atomic_load(&work->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned rsv = __hip_atomic_load(&work->reserve, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (h >= rsv) {
+                            // nothing parked; with the tickets gone nothing can be parked any more either
+                            new_state = f1 >= n_pairs ? SLOT_CLOSED : SLOT_FREE;
+                            break;
+                        }
+                        // a resumed registration is a long one: a workgroup runs one of them at a time unless more
+                        // of them are waiting than other workgroups can take
+                        if (lds_load(&s_resumed) != 0u && rsv - h <= double_thresh) { new_state = SLOT_FREE; break; }
+                        if (atomicCAS(&work->head, h, h + 1u) != h) continue;
+                        unsigned v, spins = 0u;
+                        while ((v = __hip_atomic_load(&ids[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 22)) { __hip_atomic_store(&work->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); v = 1u; break; }
+                        }
+                        if (v >= 2u) job = -2 - (int)(v - 2u);
+                    }
+                    if (job == -1) break;
+                    const bool resumed = job <= -2;
+                    const unsigned pair = resumed ? (unsigned)(-2 - job) : (unsigned)job;
+                    // the indices and the maps come from device memory the host never saw: check them here
+                    const uint32_t ti = tidx[pair], si = sidx[pair];
+                    const bool bad_index = ti >= tset.n_maps || si >= sset.n_maps;
+                    const bool truncated = !bad_index && (tset.counters[ti].overflow != 0u || sset.counters[si].overflow != 0u);
+                    if (bad_index || truncated) {
+                        NdtMatchResultDev *o = res + pair;      // (converged = 0; the pose is left untouched)
+                        o->converged = 0; o->iterations = 0; o->fevals = 0;
+                        o->exit_code = bad_index ? -2 : -3;     // -2 map index out of range, -3 a map needed more cells than max_cells
+                        o->score = 0.0; o->n_source = 0; o->n_target = 0;
+                        o->cycles_eval = 0; o->cycles_solver = 0; o->pair_terms_g = 0; o->pair_terms_h = 0;
+                        continue;
+                    }
+                    S.tg = map_view(tset, ti);
+                    S.sv = map_view(sset, si);
+                    S.pair = pair;
+                    if (resumed) {
+                        const NdtParkedState &ps = parked[pair];
+                        S.st = ps.st;
+                        S.cnt[0] = ps.cnt[0]; S.cnt[1] = ps.cnt[1]; S.cnt[2] = ps.cnt[2]; S.cnt[3] = ps.cnt[3];
+                    } else {
+                        match_state_init(S.st, T16 + (size_t)pair * 16, s_prm, Q36 ? Q36 + (size_t)pair * 36 : nullptr);
+                        S.cnt[0] = S.cnt[1] = S.cnt[2] = S.cnt[3] = 0ull;
+                        if (S.st.done) { slot_result(S, T16, res); continue; }   // parameters the solver rejects
+                    }
+                    NDT_TL(pair, resumed ? 2 : 0)
+                    S.resumed = resumed ? 1 : 0;
+                    S.session = atomicAdd(&s_session, 1u) + 1u;      // (a workgroup never sees 2^32 registrations)
+                    S.with_h = S.st.with_h;
+                    S.done = 0u;
+                    if (resumed) atomicAdd(&s_resumed, 1u);
+                    new_state = SLOT_RUN;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (new_state == SLOT_RUN) {
+#ifdef NDT_MATCH_TL
+                    S.t_pub = __builtin_readcyclecounter(); if (!S.resumed) S.wall = 0ull;
+#endif
+                    lds_store(&S.state, SLOT_RUN);
+                    lds_store(&S.next, 0u);
+                } else {
+                    if (new_state == SLOT_FREE) lds_store(&S.retry, clock_lo() + 2048u);
+                    else atomicAdd(&s_closed, 1u);
+                    lds_store(&S.state, new_state);
+                }
+            }
+            continue;
         }
 
-        if (threadIdx.x == 0 && !parked_now) {
-            NdtMatchResultDev &o = res[pair];
-            match_state_result(st, T16 + (size_t)pair * 16, o);
-            o.n_source = s_sv.n_cells;
-            o.n_target = s_tg.n_cells;
-            o.cycles_eval = s_cnt[0];
-            o.cycles_solver = s_cnt[1];
-            o.pair_terms_g = s_cnt[2];
-            o.pair_terms_h = s_cnt[3];
+        // ---- one share of an evaluation ---------------------------------------------------------------------------
+        Slot &S = slots[task >> 4];
+        {
+            const unsigned v = (unsigned)task & 15u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the request was published before `next`
+            const long long c0 = __builtin_readcyclecounter();
+            const int with_h = S.with_h;
+            if (with_h) run_share<NN, true, QL>(S, v, wsrc, wwin, s_prm.lfd1, s_prm.lfd2);
+            else run_share<NN, false, QL>(S, v, wsrc, wwin, s_prm.lfd1, s_prm.lfd2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the row of partial sums before the count
+            unsigned d = 0;
+            if (lane == 0) {
+                atomicAdd(&S.cnt[0], (unsigned long long)((long long)__builtin_readcyclecounter() - c0));
+                d = atomicAdd(&S.done, 1u);
+            }
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)d) != (unsigned)NDT_VW - 1u) continue;
         }
-        __syncthreads();
+        // ---- this wave delivered the last share: add the rows in share order and run the solver step (lane 0; nothing
+        //      of the evaluation is live any more) ---------------------------------------------------------------
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < 29u) {
+            double a = 0;
+#pragma unroll
+            for (int k = 0; k < NDT_VW; k++) a += S.part[k * 32 + lane];
+            S.sums[lane] = a;             // [28]: number of (source, target) pair terms of this evaluation
+        }
+        ndt_wave_sync();
+        if (lane == 0) {
+            const long long c1 = __builtin_readcyclecounter();
+#ifdef NDT_MATCH_TL
+            S.wall += (unsigned long long)(c1 - S.t_pub);
+#endif
+            S.cnt[S.with_h ? 3 : 2] += (unsigned long long)S.sums[28];
+            match_state_step(S.st, S.sums, s_prm, S.ws);
+            S.cnt[1] += (unsigned long long)((long long)__builtin_readcyclecounter() - c1);
+            bool release = false;
+            if (S.st.done) {
+                slot_result(S, T16, res);
+                NDT_TL(S.pair, 3)
+                release = true;
+            } else if (S.st.phase == PH_NEWTON && park_iters > 0 && S.st.itr_ctr >= park_iters &&
+                       __hip_atomic_load(&work->fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_pairs) {
+                // about to start another Newton iteration of a long registration: hand the slot to a pair that has
+                // not started yet, if there is one
+                const unsigned pair = S.pair;
+                const unsigned slot = atomicAdd(&work->reserve, 1u);
+                const unsigned f = atomicAdd(&work->fresh, 1u);
+                if (f < n_pairs) {
+                    NdtParkedState &ps = parked[pair];
+                    ps.st = S.st;
+                    ps.cnt[0] = S.cnt[0]; ps.cnt[1] = S.cnt[1]; ps.cnt[2] = S.cnt[2]; ps.cnt[3] = S.cnt[3];
+                    __hip_atomic_store(&ids[slot], pair + 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    NDT_TL(pair, 1)
+                    S.preset = (int)f;
+                    release = true;
+                } else {
+                    __hip_atomic_store(&ids[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            lds_store(&S.done, 0u);
+            if (release) {
+                if (S.resumed) atomicSub(&s_resumed, 1u);
+                lds_store(&S.retry, clock_lo());
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lds_store(&S.state, SLOT_FREE);
+            } else {
+                S.with_h = S.st.with_h;      // the next request: pose in S.st.Teval, with / without Hessian
+#ifdef NDT_MATCH_TL
+                S.t_pub = __builtin_readcyclecounter();
+#endif
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lds_store(&S.next, 0u);
+            }
+        }
     }
 }
 
@@ -965,6 +1207,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
 {
     __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     __shared__ MatchState st;       // workgroup 0 only
+    __shared__ NewtonWs s_ws;
     __shared__ rigid s_T;
     __shared__ int s_with_h, s_done;
 
@@ -1031,7 +1274,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
             if (threadIdx.x == 0) {
                 long long d0 = __builtin_readcyclecounter();
                 if (s_with_h) terms_h += (long long)sh.sums[28]; else terms_g += (long long)sh.sums[28];
-                match_state_step(st, sh.sums, prm);
+                match_state_step(st, sh.sums, prm, s_ws);
                 ctrl->Teval = st.Teval; ctrl->with_h = st.with_h; ctrl->done = st.done;
                 cyc_solver += (long long)__builtin_readcyclecounter() - d0;
             }
@@ -1122,20 +1365,21 @@ hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
                             NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters,
-                            int narrow, void *work_dev, hipStream_t stream)
+                            int slots, unsigned double_thresh, void *work_dev, hipStream_t stream)
 {
     if (n_pairs == 0) return hipSuccess;
+    if (slots != 1 && slots != 2) return hipErrorInvalidValue;
     // ticket counters and the parked list start at zero
-    hipError_t e = hipMemsetAsync(work_dev, 0, sizeof(NdtMatchWork) + (n_pairs + n_groups + 1) * sizeof(unsigned), stream);
+    hipError_t e = hipMemsetAsync(work_dev, 0, sizeof(NdtMatchWork) + (n_pairs + (size_t)n_groups * slots + 1) * sizeof(unsigned), stream);
     if (e != hipSuccess) return e;
 #define NDT_LAUNCH_MATCH(NN)                                                                                         \
     do {                                                                                                             \
-        if (narrow)                                                                                                  \
-            hipLaunchKernelGGL((ndt_match_kernel<NN, 4>), dim3(n_groups), dim3(256), 0, stream, tset, tidx_dev, sset, \
-                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, (char *)work_dev); \
+        if (slots == 2)                                                                                              \
+            hipLaunchKernelGGL((ndt_match_kernel<NN, 2>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev, sset, \
+                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, double_thresh, (char *)work_dev); \
         else                                                                                                         \
-            hipLaunchKernelGGL((ndt_match_kernel<NN, 8>), dim3(n_groups), dim3(512), 0, stream, tset, tidx_dev, sset, \
-                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, (char *)work_dev); \
+            hipLaunchKernelGGL((ndt_match_kernel<NN, 1>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev, sset, \
+                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, double_thresh, (char *)work_dev); \
     } while (0)
     switch (prm.n_neighbours) {
     case 0: NDT_LAUNCH_MATCH(0); break;
@@ -1165,6 +1409,22 @@ hipError_t ndt_launch_derivatives(const NdtSetView &tset, size_t tmap, const Ndt
 #undef NDT_LAUNCH_DERIV
     return hipGetLastError();
 }
+
+#ifdef NDT_MATCH_TL
+extern "C" int ndtgpu_debug_timeline(long long *out, int reset)      // out: 4 * 4096 + 1024 + 8 values
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const size_t n = 4 * NDT_TL_PAIRS + 1024 + 8;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), n * sizeof(long long)) != hipSuccess) return -1;
+    if (reset) {
+        static long long z[4 * NDT_TL_PAIRS + 1024 + 8];
+        for (size_t k = 0; k < n; k++) z[k] = 0;
+        z[4 * NDT_TL_PAIRS + 1024] = 0x7fffffffffffffffll;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 #ifdef NDT_MATCH_PROF
 extern "C" int ndtgpu_debug_prof(long long out[16], int reset)

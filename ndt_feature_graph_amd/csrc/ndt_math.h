@@ -2,6 +2,7 @@
 #pragma once
 #include "ndt_common.h"
 #include <math.h>
+#include <utility>
 
 struct d3 { double x, y, z; };
 
@@ -477,98 +478,127 @@ NDT_HD void ldlt_solve_ws(int n, const double *A, const double *b, double *x, do
 // 6x6 version of ldlt_solve with every index a compile-time constant (the matrix lives in registers):
 // the data-dependent pivot only selects which statically indexed swap runs.  Same pivot rule (largest
 // |diagonal| of the remaining block, first one on ties), same elimination and substitution formulas,
-// hence the same arithmetic as ldlt_solve / Eigen's LDLT::solve on a 6x6 system.
+// hence the same arithmetic as ldlt_solve / Eigen's LDLT::solve on a 6x6 system.  Only the lower triangle is
+// stored (21 values): the elimination of the full matrix reads its upper row K, which is the not yet scaled column K
+// by symmetry, and the substitutions only ever read the lower triangle -- same products, same results, a third of
+// the registers.
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): loops whose indices are constants from the start.
+// (With `#pragma unroll` the indices only become constants after the unroller has run; by then the optimiser may have
+// merged the branches of a pivot switch into indexed accesses, and the register array goes to the stack.)
+template <int... Is, class F>
+NDT_HD void ndt_static_for_impl(std::integer_sequence<int, Is...>, F &&f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+NDT_HD void ndt_static_for(F &&f) { ndt_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 namespace ndt_ldlt6 {
+NDT_HD constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 template <int K, int C>
-NDT_HD void swap_kc(double (&a)[6][6], double (&y)[6])
+NDT_HD void swap_kc(double (&a)[21], double (&y)[6])
 {
-#pragma unroll
-    for (int j = 0; j < 6; j++) { double t = a[K][j]; a[K][j] = a[C][j]; a[C][j] = t; }
-#pragma unroll
-    for (int i = 0; i < 6; i++) { double t = a[i][K]; a[i][K] = a[i][C]; a[i][C] = t; }
-    double t = y[K]; y[K] = y[C]; y[C] = t;
+    // symmetric exchange of the indices K < C (rows and columns)
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i != K && i != C) { double t = a[tri(i, K)]; a[tri(i, K)] = a[tri(i, C)]; a[tri(i, C)] = t; }
+    });
+    double t = a[tri(K, K)]; a[tri(K, K)] = a[tri(C, C)]; a[tri(C, C)] = t;
+    t = y[K]; y[K] = y[C]; y[C] = t;
 }
 template <int K>
-NDT_HD void swap_k(double (&a)[6][6], double (&y)[6], int piv)
+NDT_HD void swap_k(double (&a)[21], double (&y)[6], int piv)
 {
-    switch (piv) {
-    case 1: if (K < 1) swap_kc<K, (K < 1 ? 1 : K)>(a, y); break;
-    case 2: if (K < 2) swap_kc<K, (K < 2 ? 2 : K)>(a, y); break;
-    case 3: if (K < 3) swap_kc<K, (K < 3 ? 3 : K)>(a, y); break;
-    case 4: if (K < 4) swap_kc<K, (K < 4 ? 4 : K)>(a, y); break;
-    case 5: if (K < 5) swap_kc<K, (K < 5 ? 5 : K)>(a, y); break;
-    default: break;
-    }
+    if constexpr (K < 1) { if (piv == 1) swap_kc<K, 1>(a, y); }
+    if constexpr (K < 2) { if (piv == 2) swap_kc<K, 2>(a, y); }
+    if constexpr (K < 3) { if (piv == 3) swap_kc<K, 3>(a, y); }
+    if constexpr (K < 4) { if (piv == 4) swap_kc<K, 4>(a, y); }
+    if constexpr (K < 5) { if (piv == 5) swap_kc<K, 5>(a, y); }
 }
 template <int K>
 NDT_HD void unswap_k(double (&y)[6], int piv)
 {
     // x[perm[i]] = y[i]: undo the row exchanges in reverse order
-#pragma unroll
-    for (int c = K + 1; c < 6; c++)
-        if (piv == c) { double t = y[K]; y[K] = y[c]; y[c] = t; }
+    ndt_static_for<6>([&](auto Cc) __attribute__((always_inline)) {
+        constexpr int c = decltype(Cc)::value;
+        if constexpr (c > K) { if (piv == c) { double t = y[K]; y[K] = y[c]; y[c] = t; } }
+    });
 }
 template <int K>
-NDT_HD void step(double (&a)[6][6], double (&y)[6], int (&pivs)[6])
+NDT_HD void step(double (&a)[21], double (&y)[6], int (&pivs)[6])
 {
     int piv = K;
-    double best = fabs(a[K][K]);
-#pragma unroll
-    for (int i = K + 1; i < 6; i++)
-        if (fabs(a[i][i]) > best) { best = fabs(a[i][i]); piv = i; }
+    double best = fabs(a[tri(K, K)]);
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (i > K) { if (fabs(a[tri(i, i)]) > best) { best = fabs(a[tri(i, i)]); piv = i; } }
+    });
     pivs[K] = piv;
     if (piv != K) swap_k<K>(a, y, piv);
-    const double d = a[K][K];
+    const double d = a[tri(K, K)];
     if (fabs(d) > 2.2250738585072014e-308) {
-#pragma unroll
-        for (int i = K + 1; i < 6; i++) {
-            const double l = a[i][K] / d;
-#pragma unroll
-            for (int j = K + 1; j < 6; j++) a[i][j] -= l * a[K][j];
-            a[i][K] = l;
-        }
-#pragma unroll
-        for (int j = K + 1; j < 6; j++) a[K][j] = 0.0;
+        ndt_static_for<6>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i > K) {
+                // (rows in descending order: row i needs the unscaled column entries a(j, K), j <= i, and scales its own last)
+                constexpr int r = 5 + (K + 1) - i;
+                const double l = a[tri(r, K)] / d;
+                ndt_static_for<6>([&](auto J) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J)::value;
+                    if constexpr (j > K && j <= r) a[tri(r, j)] -= l * a[tri(j, K)];
+                });
+                a[tri(r, K)] = l;
+            }
+        });
     }
+}
+// the matrix as its lower triangle a[tri(i, j)], i >= j; y: right-hand side in, solution out
+NDT_HD void solve_packed(double (&a)[21], double (&y)[6])
+{
+    int pivs[6];
+    step<0>(a, y, pivs);
+    step<1>(a, y, pivs);
+    step<2>(a, y, pivs);
+    step<3>(a, y, pivs);
+    step<4>(a, y, pivs);
+    pivs[5] = 5;
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        ndt_static_for<6>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j < i) y[i] -= a[tri(i, j)] * y[j];
+        });
+    });
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        const double d = a[tri(i, i)];
+        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;
+    });
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = 5 - decltype(I)::value;
+        ndt_static_for<6>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j > i) y[i] -= a[tri(j, i)] * y[j];
+        });
+    });
+    unswap_k<4>(y, pivs[4]);
+    unswap_k<3>(y, pivs[3]);
+    unswap_k<2>(y, pivs[2]);
+    unswap_k<1>(y, pivs[1]);
+    unswap_k<0>(y, pivs[0]);
 }
 }  // namespace ndt_ldlt6
 
 NDT_HD void ldlt_solve_static6(const double (&A)[6][6], const double (&b)[6], double (&x)[6])
 {
-    double a[6][6], y[6];
-    int pivs[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
+    double a[21], y[6];
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
         y[i] = b[i];
-#pragma unroll
-        for (int j = 0; j < 6; j++) a[i][j] = 0.5 * (A[i][j] + A[j][i]);
-    }
-    ndt_ldlt6::step<0>(a, y, pivs);
-    ndt_ldlt6::step<1>(a, y, pivs);
-    ndt_ldlt6::step<2>(a, y, pivs);
-    ndt_ldlt6::step<3>(a, y, pivs);
-    ndt_ldlt6::step<4>(a, y, pivs);
-    pivs[5] = 5;
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = 0; j < i; j++) y[i] -= a[i][j] * y[j];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const double d = a[i][i];
-        y[i] = (fabs(d) > 2.2250738585072014e-308) ? y[i] / d : 0.0;
-    }
-#pragma unroll
-    for (int i = 5; i >= 0; i--)
-#pragma unroll
-        for (int j = i + 1; j < 6; j++) y[i] -= a[j][i] * y[j];
-    ndt_ldlt6::unswap_k<4>(y, pivs[4]);
-    ndt_ldlt6::unswap_k<3>(y, pivs[3]);
-    ndt_ldlt6::unswap_k<2>(y, pivs[2]);
-    ndt_ldlt6::unswap_k<1>(y, pivs[1]);
-    ndt_ldlt6::unswap_k<0>(y, pivs[0]);
-#pragma unroll
-    for (int i = 0; i < 6; i++) x[i] = y[i];
+        ndt_static_for<6>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j <= i) a[ndt_ldlt6::tri(i, j)] = 0.5 * (A[i][j] + A[j][i]);
+        });
+    });
+    ndt_ldlt6::solve_packed(a, y);
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) { x[decltype(I)::value] = y[decltype(I)::value]; });
 }
 
 // LazyGrid::getIndexForPoint: idx = floor((p - centre)/res + 0.5) + size/2.0, double -> int.

@@ -13,9 +13,16 @@
 #ifndef NDT_SOLVER_VGPRS
 #define NDT_SOLVER_VGPRS
 #endif
+#ifdef NDT_SOLVER_INLINE
+#define NDT_HDN NDT_HD
+#else
 #define NDT_HDN static __host__ __device__ __attribute__((noinline)) NDT_SOLVER_VGPRS
+#endif
 
 enum { PH_NEWTON = 0, PH_LS_TRIAL = 1, PH_FINAL = 2 };
+// what a stage of the solver asks its caller to run next (stages never call each other: a value that lives across a call
+// sits in a callee-saved register, and saving those is the only thing that would give the kernels a stack)
+enum { NEXT_NONE = 0, NEXT_APPLY_STEP = 1, NEXT_REQUEST_TRIAL = 2 };
 
 struct MTState {
     double stp, finit, dginit, dgtest, width, width1, stx, fx, dgx, sty, fy, dgy, stmin, stmax;
@@ -29,6 +36,7 @@ struct MatchState {
     // More-Thuente (fusion.h:400-408, 485-521): one block, copied to registers by the functions that work on it (the
     // state lives in LDS: field-by-field access is one dependent LDS round trip after the other)
     MTState mt;
+    double step_size;      // NEXT_APPLY_STEP: the step apply_step takes
     int itr_ctr, fevals, ret, exit_code, phase, with_h, done;
     // The first More-Thuente trial (stp = 1) is usually accepted, and the next Newton iteration then evaluates
     // score, gradient AND Hessian at exactly the pose of that trial.  While trials keep being accepted first
@@ -174,36 +182,43 @@ NDT_HD int mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy
     return info;
 }
 
-// head of the More-Thuente while(1) body (fusion.h:523-561): pick the trial step and request its evaluation
-NDT_HD void mt_request_trial(MatchState &st, MTState &m)
+// head of the More-Thuente while(1) body (fusion.h:523-561): pick the trial step and request its evaluation.
+// A stage of its own (the More-Thuente block is handed over in st.mt): the trial pose costs three rigid transforms
+// in registers.
+NDT_HDN void mt_request_trial(MatchState &st)
 {
     const double stpmax = 4.0, stpmin = 0.001, xtol = 0.01;
     const int maxfev = 40;
-    if (m.brackt) {
-        m.stmin = dmin(m.stx, m.sty);
-        m.stmax = dmax(m.stx, m.sty);
+    double stp = st.mt.stp, stmin, stmax;
+    const double stx = st.mt.stx, sty = st.mt.sty;
+    const int brackt = st.mt.brackt, nfev = st.mt.nfev, infoc = st.mt.infoc;
+    if (brackt) {
+        stmin = dmin(stx, sty);
+        stmax = dmax(stx, sty);
     } else {
-        m.stmin = m.stx;
-        m.stmax = m.stp + 4 * (m.stp - m.stx);
+        stmin = stx;
+        stmax = stp + 4 * (stp - stx);
     }
-    m.stp = dmax(m.stp, stpmin);
-    m.stp = dmin(m.stp, stpmax);
-    if ((m.brackt && ((m.stp <= m.stmin) || (m.stp >= m.stmax))) || (m.nfev >= maxfev - 1) ||
-        (m.infoc == 0) || (m.brackt && (m.stmax - m.stmin <= xtol * m.stmax)))
-        m.stp = m.stx;
+    stp = dmax(stp, stpmin);
+    stp = dmin(stp, stpmax);
+    if ((brackt && ((stp <= stmin) || (stp >= stmax))) || (nfev >= maxfev - 1) ||
+        (infoc == 0) || (brackt && (stmax - stmin <= xtol * stmax)))
+        stp = stx;
+    st.mt.stp = stp; st.mt.stmin = stmin; st.mt.stmax = stmax;
     double pincr[6];
-    for (int a = 0; a < 6; a++) pincr[a] = m.stp * st.incr[a];
+    for (int a = 0; a < 6; a++) pincr[a] = stp * st.incr[a];
     rigid ps;
     pose_to_rigid(pincr, ps);
     rigid_mul(ps, st.T, st.Teval);     // trial cells = ps * nextNDT (fusion.h:556-589)
-    st.trial_has_h = (m.nfev == 0 && st.spec_ok) ? 1 : 0;
+    st.trial_has_h = (nfev == 0 && st.spec_ok) ? 1 : 0;
     st.with_h = st.trial_has_h;
     st.phase = PH_LS_TRIAL;
 }
 
 // pose update + convergence tests (fusion.h:1032-1080)
-NDT_HDN void apply_step(MatchState &st, double step_size, const NdtMatchParamsDev &prm)
+NDT_HDN void apply_step(MatchState &st, const NdtMatchParamsDev &prm)
 {
+    const double step_size = st.step_size;
     double inorm = 0;
     for (int a = 0; a < 6; a++) {
         st.incr[a] *= step_size;
@@ -227,7 +242,53 @@ NDT_HDN void apply_step(MatchState &st, double step_size, const NdtMatchParamsDe
     else { st.phase = PH_NEWTON; st.with_h = 1; }
 }
 
-NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
+// ---- one Newton iteration (fusion.h:857-1031) in STAGES ------------------------------------------------------
+// The stages are separate functions (not inlined on the device) that hand their results over through a NewtonWs
+// block (LDS on the device): each stage then keeps its own 6x6 matrices in registers.  As one function the iteration
+// needs more than the 256 VGPRs of a wave and spills to scratch memory; as stages no stage leaves the caller-saved
+// registers, so the kernels that run the solver have no private segment at all.
+struct NewtonWs {
+    double H[36];           // the system matrix (row-major; after soft constraint / Tikhonov / dof padding)
+    double g[6];            // the gradient the system is solved for (scg, fusion.h:913)
+    double gpre[6];         // NDT + soft-constraint gradient before the Tikhonov transformation: what
+                            // lineSearchMTFusionTcov evaluates at the current pose (fusion.h:82-89)
+    double dx[6];           // H^-1 g
+    double H2[36];          // H^T H + Q of the Tikhonov stage
+    double gnorm;
+    int is_pd, pad;
+};
+
+// inactive dofs (NDTMatcherD2D_2D): decoupled and given the diagonal value of the first active dof, which leaves
+// lambda_min / lambda_max of the active block unchanged (a diagonal entry is a Rayleigh quotient) and yields a zero
+// increment for them; then the system goes to the workspace
+NDT_HD void newton_mask(double (&H)[6][6], double (&g)[6], const NdtMatchParamsDev &prm, NewtonWs &ws)
+{
+    double pad = 0.0;
+    bool havepad = false;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        bool on = (prm.dof_mask >> a) & 1;
+        if (!on) g[a] = 0.0;
+        if (on && !havepad) { pad = H[a][a]; havepad = true; }
+    }
+    double gnorm = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        bool on_a = (prm.dof_mask >> a) & 1;
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            bool on_b = (prm.dof_mask >> b) & 1;
+            if (!(on_a && on_b)) H[a][b] = (a == b) ? pad : 0.0;
+            ws.H[a * 6 + b] = H[a][b];
+        }
+        ws.g[a] = g[a];
+        gnorm += g[a] * g[a];
+    }
+    ws.gnorm = sqrt(gnorm);
+}
+
+// stage 1: score, best pose, Hessian / gradient assembly (fusion.h:857-920), inactive dofs, gradient norm
+NDT_HDN void newton_assemble(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, NewtonWs &ws)
 {
     st.fevals++;
     st.score_here = sums[0];
@@ -253,9 +314,6 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
 #pragma unroll
             for (int b = 0; b < 6; b++) H[a][b] += st.Q[a * 6 + b] + st.Q[b * 6 + a];
     }
-    double pad = 0.0;
-    bool havepad = false;
-    double gnorm = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         g[a] = sums[1 + a];
@@ -265,108 +323,150 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
             for (int j = 0; j < 6; j++) gp += (st.Q[a * 6 + j] + st.Q[j * 6 + a]) * st.pose_local[j];
             g[a] += gp;
         }
+        ws.gpre[a] = g[a];
     }
-    if (st.use_tikhonov) {
-        // fusion.h:894-911 with P = I:  g <- H^T g + Q x0,  H <- H^T H + Q,  score += x0^T Q x0
-        tikhonov_x0(st);
-        double g2[6], H2[6][6];
+    if (st.use_tikhonov) {                 // (stage 1b takes over: the two matrices of H^T H do not fit beside this one)
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-            double s1 = 0;
+            ws.g[a] = g[a];
 #pragma unroll
-            for (int k = 0; k < 6; k++) s1 += H[k][a] * g[k] + st.Q[a * 6 + k] * st.x0[k];
-            g2[a] = s1;
-#pragma unroll
-            for (int b = 0; b < 6; b++) {
-                double s2 = st.Q[a * 6 + b];
-#pragma unroll
-                for (int k = 0; k < 6; k++) s2 += H[k][a] * H[k][b];
-                H2[a][b] = s2;
-            }
+            for (int b = 0; b < 6; b++) ws.H[a * 6 + b] = H[a][b];
         }
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-            g[a] = g2[a];
-#pragma unroll
-            for (int b = 0; b < 6; b++) H[a][b] = H2[a][b];
-        }
-        st.score_here += tikhonov_score(st);
-        if (st.score_here < st.score_best) {   // fusion.h:914-920
-            st.Tbest = st.T;
-            st.score_best = st.score_here;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        bool on = (prm.dof_mask >> a) & 1;
-        if (!on) g[a] = 0.0;
-        if (on && !havepad) { pad = H[a][a]; havepad = true; }
-    }
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        bool on_a = (prm.dof_mask >> a) & 1;
-#pragma unroll
-        for (int b = 0; b < 6; b++) {
-            bool on_b = (prm.dof_mask >> b) & 1;
-            if (!(on_a && on_b)) H[a][b] = (a == b) ? pad : 0.0;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 6; a++) gnorm += g[a] * g[a];
-    gnorm = sqrt(gnorm);
-    // fusion.h:922-940.  evals += regularizer with the same regularizer for every eigenvalue, then
-    // H = V diag(evals) V^T, i.e. H + regularizer*I: only lambda_min and lambda_max are needed
-    // (sym6_extreme_eigs: tridiagonalisation + Laguerre, no eigenvectors).  A positive definite H (the
-    // usual case near the optimum) is certified by an unpivoted Cholesky and skips even that.
-    double Lf[6][6], Ldinv[6];
-    const bool is_pd = chol_is_pd<6>(H, Lf, Ldinv);
-    if (!is_pd) {
-        double minC, maxC;
-        sym6_extreme_eigs(H, minC, maxC);
-        if (minC < 0) {
-            double regularizer = gnorm;
-            regularizer = (regularizer + minC > 0) ? regularizer : 0.001 * maxC - minC;
-#pragma unroll
-            for (int a = 0; a < 6; a++) H[a][a] += regularizer;
-        }
-    }
-    if (gnorm <= prm.delta_score) {        // fusion.h:943-965
-        if (st.score_here > st.score_best) st.T = st.Tbest;
-        st.exit_code = 1;
-        st.done = 1;
         return;
     }
-    // fusion.h:966  pose_increment_v = -Hessian.ldlt().solve(score_gradient).  The padded 6x6 system
-    // performs exactly the arithmetic of the active block (the padding is decoupled, its solution 0).
-    // A Hessian that the Cholesky test certified positive definite is solved with that factor (same
-    // solution up to rounding, a fraction of the pivoted factorisation's serial latency).
-    double dxs[6];
-    if (is_pd) chol_solve<6>(Lf, Ldinv, g, dxs);
-    else ldlt_solve_static6(H, g, dxs);
+    newton_mask(H, g, prm, ws);
+}
+
+// stage 1b: the generalised Tikhonov regularisation (fusion.h:894-911 with P = I):  g <- H^T g + Q x0,
+// H <- H^T H + Q,  score += x0^T Q x0.  Matrices stay in the workspace (loops, not registers: matchFusion only).
+NDT_HDN void newton_tikhonov(MatchState &st, const NdtMatchParamsDev &prm, NewtonWs &ws)
+{
+    tikhonov_x0(st);
+#pragma unroll 1
+    for (int a = 0; a < 6; a++) {
+        double s1 = 0;
+#pragma unroll 1
+        for (int k = 0; k < 6; k++) s1 += ws.H[k * 6 + a] * ws.g[k] + st.Q[a * 6 + k] * st.x0[k];
+        ws.dx[a] = s1;                      // (dx is free until stage 2)
+#pragma unroll 1
+        for (int b = 0; b < 6; b++) {
+            double s2 = st.Q[a * 6 + b];
+#pragma unroll 1
+            for (int k = 0; k < 6; k++) s2 += ws.H[k * 6 + a] * ws.H[k * 6 + b];
+            ws.H2[a * 6 + b] = s2;
+        }
+    }
+    st.score_here += tikhonov_score(st);
+    if (st.score_here < st.score_best) {   // fusion.h:914-920
+        st.Tbest = st.T;
+        st.score_best = st.score_here;
+    }
+    double H[6][6], g[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        g[a] = ws.dx[a];
+#pragma unroll
+        for (int b = 0; b < 6; b++) H[a][b] = ws.H2[a * 6 + b];
+    }
+    newton_mask(H, g, prm, ws);
+}
+
+// stage 2: is H positive definite (the usual case near the optimum)?  An unpivoted Cholesky certifies it, and its
+// factor then solves the Newton system (same solution as the pivoted LDL^T up to rounding, a fraction of its serial
+// latency); otherwise stages 3 and 4 run.
+NDT_HDN void newton_factor(NewtonWs &ws)
+{
+    double H[6][6], Lf[6][6], Ldinv[6], g[6], dx[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        g[a] = ws.g[a];
+#pragma unroll
+        for (int b = 0; b < 6; b++) H[a][b] = ws.H[a * 6 + b];
+    }
+    const bool is_pd = chol_is_pd<6>(H, Lf, Ldinv);
+    ws.is_pd = is_pd ? 1 : 0;
+    if (is_pd) {
+        chol_solve<6>(Lf, Ldinv, g, dx);
+#pragma unroll
+        for (int a = 0; a < 6; a++) ws.dx[a] = dx[a];
+    }
+}
+
+// stage 3 (H not positive definite): fusion.h:922-940.  evals += regularizer with the same regularizer for every
+// eigenvalue, then H = V diag(evals) V^T, i.e. H + regularizer * I: only lambda_min and lambda_max are needed
+// (sym6_extreme_eigs: tridiagonalisation + Laguerre, no eigenvectors).
+NDT_HDN void newton_regularize(NewtonWs &ws)
+{
+    double H[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 6; b++) H[a][b] = ws.H[a * 6 + b];
+    double minC, maxC;
+    sym6_extreme_eigs(H, minC, maxC);
+    if (minC < 0) {
+        double regularizer = ws.gnorm;
+        regularizer = (regularizer + minC > 0) ? regularizer : 0.001 * maxC - minC;
+#pragma unroll
+        for (int a = 0; a < 6; a++) ws.H[a * 7] = H[a][a] + regularizer;
+    }
+}
+
+// stage 4 (H not positive definite): fusion.h:966  Hessian.ldlt().solve(score_gradient).  The padded 6x6 system
+// performs exactly the arithmetic of the active block (the padding is decoupled, its solution 0).
+NDT_HDN void newton_ldlt(NewtonWs &ws)
+{
+    double a[21], y[6];
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        y[i] = ws.g[i];
+        ndt_static_for<6>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j <= i) a[ndt_ldlt6::tri(i, j)] = 0.5 * (ws.H[i * 6 + j] + ws.H[j * 6 + i]);
+        });
+    });
+    ndt_ldlt6::solve_packed(a, y);
+    ndt_static_for<6>([&](auto I) __attribute__((always_inline)) { ws.dx[decltype(I)::value] = y[decltype(I)::value]; });
+}
+
+// stage 5: the increment, the direction tests and the start of the line search (fusion.h:966-1031, 444-521)
+NDT_HDN int newton_finish(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, const NewtonWs &ws)
+{
     double dginit = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         bool on = (prm.dof_mask >> a) & 1;
-        double d = on ? -dxs[a] : 0.0;
+        double d = on ? -ws.dx[a] : 0.0;
         st.incr[a] = d;
-        dginit += d * g[a];
+        dginit += d * ws.g[a];
     }
     if (dginit > 0) {                      // fusion.h:976-997
         if (st.score_here > st.score_best) st.T = st.Tbest;
         st.exit_code = 2;
         st.done = 1;
-        return;
+        return NEXT_NONE;
     }
     if (!prm.step_control) {
-        apply_step(st, 1.0, prm);
-        return;
+        st.step_size = 1.0;
+        return NEXT_APPLY_STEP;
+    }
+    // With the soft constraint the reference first runs lineSearchMTFusionTcov (fusion.h:1008-1010) and throws its
+    // step away (:1018-1023: step_size = max(step_size_ndt, 0)).  What survives is its side effect on the increment,
+    // which it takes by reference: when increment . (g_ndt + g_mahalanobis) >= 0 the increment is NEGATED IN PLACE
+    // (fusion.h:89-95) before lineSearchMT sees it.  Without Tikhonov that gradient is the one dginit <= 0 was just
+    // tested on (only dginit == 0 flips); with Tikhonov scg = H^T g + Q x0 is another vector and the flip is live.
+    if (st.use_prior) {
+        double dtcov = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) dtcov += st.incr[a] * ws.gpre[a];
+        if (dtcov >= 0.0) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
+        }
     }
     // lineSearchMT: its initial derivativesNDT(nextNDT) equals this evaluation (same cells), so the
-    // score and gradient are reused instead of being recomputed (fusion.h:444-453).
-    // With the soft constraint the reference also runs lineSearchMTFusionTcov first (fusion.h:1008-1010) but
-    // throws its step away (:1018-1023: step_size = max(step_size_ndt, 0)); its only possible side effect,
-    // flipping the increment when dginit >= 0, cannot trigger here because dginit <= 0 was just checked on
-    // the same total gradient.  The step is decided by the NDT-only line search on the NDT-only score.
+    // score and gradient are reused instead of being recomputed (fusion.h:444-453).  The step is decided by the
+    // NDT-only line search on the NDT-only score.
     MTState m;
     m.finit = sums[0];
     m.dginit = 0;
@@ -377,8 +477,8 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
         for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
         m.dginit = -m.dginit;
         if (m.dginit >= 0.0) {
-            apply_step(st, 0.1, prm);
-            return;
+            st.step_size = 0.1;
+            return NEXT_APPLY_STEP;
         }
     }
     m.stp = 1.0;
@@ -388,8 +488,28 @@ NDT_HDN void newton_step(MatchState &st, const double *sums, const NdtMatchParam
     m.width1 = 2 * m.width;
     m.stx = 0.0; m.fx = m.finit; m.dgx = m.dginit;
     m.sty = 0.0; m.fy = m.finit; m.dgy = m.dginit;
-    mt_request_trial(st, m);
     st.mt = m;
+    return NEXT_REQUEST_TRIAL;
+}
+
+NDT_HD void newton_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, NewtonWs &ws)
+{
+    newton_assemble(st, sums, prm, ws);
+    if (st.use_tikhonov) newton_tikhonov(st, prm, ws);
+    if (ws.gnorm <= prm.delta_score) {     // fusion.h:943-965 (the regularisation before it has no other effect)
+        if (st.score_here > st.score_best) st.T = st.Tbest;
+        st.exit_code = 1;
+        st.done = 1;
+        return;
+    }
+    newton_factor(ws);
+    if (!ws.is_pd) {
+        newton_regularize(ws);
+        newton_ldlt(ws);
+    }
+    const int next = newton_finish(st, sums, prm, ws);
+    if (next == NEXT_APPLY_STEP) apply_step(st, prm);
+    else if (next == NEXT_REQUEST_TRIAL) mt_request_trial(st);
 }
 
 // tail of the More-Thuente while(1) body after the trial evaluation (fusion.h:637-790)
@@ -404,7 +524,7 @@ NDT_HD void match_state_final(MatchState &st, const double *sums)
     st.done = 1;
 }
 
-NDT_HDN void linesearch_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
+NDT_HDN int linesearch_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
 {
     const double ftol = 0.11111, gtol = 0.99999, stpmax = 4.0, stpmin = 0.001, xtol = 0.01, recoverystep = 0.1;
     const int maxfev = 40;
@@ -425,36 +545,44 @@ NDT_HDN void linesearch_step(MatchState &st, const double *sums, const NdtMatchP
     if (info != 0) {
         const bool first_accepted = (info == 1) && (m.nfev == 1);
 
-        const bool reuse = first_accepted && st.trial_has_h;      // sums hold the Hessian at the accepted pose
+        // sums hold the Hessian at the accepted pose: match_state_step consumes them once more (unless apply_step ends
+        // the registration)
+        st.reuse_sums = (first_accepted && st.trial_has_h) ? 1 : 0;
         st.spec_ok = first_accepted ? 1 : 0;
         st.mt = m;
-        apply_step(st, (info == 1) ? m.stp : recoverystep, prm);
-        st.reuse_sums = (reuse && !st.done) ? 1 : 0;   // match_state_step consumes the sums once more
-        return;
+        st.step_size = (info == 1) ? m.stp : recoverystep;
+        return NEXT_APPLY_STEP;
     }
     if (m.stage1 && (f <= ftest1) && (dg >= dmin(ftol, gtol) * m.dginit)) m.stage1 = 0;
-    if (m.stage1 && (f <= m.fx) && (f > ftest1)) {
-        double fm = f - m.stp * m.dgtest;
-        double fxm = m.fx - m.stx * m.dgtest;
-        double fym = m.fy - m.sty * m.dgtest;
-        double dgm = dg - m.dgtest;
-        double dgxm = m.dgx - m.dgtest;
-        double dgym = m.dgy - m.dgtest;
-        m.infoc = mt_cstep(m.stx, fxm, dgxm, m.sty, fym, dgym, m.stp, fm, dgm, m.brackt, m.stmin, m.stmax);
-        m.fx = fxm + m.stx * m.dgtest;
-        m.fy = fym + m.sty * m.dgtest;
-        m.dgx = dgxm + m.dgtest;
-        m.dgy = dgym + m.dgtest;
-    } else {
-        m.infoc = mt_cstep(m.stx, m.fx, m.dgx, m.sty, m.fy, m.dgy, m.stp, f, dg, m.brackt, m.stmin, m.stmax);
+    // (fusion.h:737-776: in the first stage the modified function f - stp * dgtest is handed to cstep.  Both cases go
+    //  through the same by-value call: selecting between the addresses of m.fx / fxm would put the block on the stack.)
+    {
+        const bool mod = m.stage1 && (f <= m.fx) && (f > ftest1);
+        double fp = f, dp = dg, fxm = m.fx, fym = m.fy, dgxm = m.dgx, dgym = m.dgy;
+        if (mod) {
+            fp = f - m.stp * m.dgtest;
+            fxm = m.fx - m.stx * m.dgtest;
+            fym = m.fy - m.sty * m.dgtest;
+            dp = dg - m.dgtest;
+            dgxm = m.dgx - m.dgtest;
+            dgym = m.dgy - m.dgtest;
+        }
+        m.infoc = mt_cstep(m.stx, fxm, dgxm, m.sty, fym, dgym, m.stp, fp, dp, m.brackt, m.stmin, m.stmax);
+        if (mod) {
+            fxm = fxm + m.stx * m.dgtest;
+            fym = fym + m.sty * m.dgtest;
+            dgxm = dgxm + m.dgtest;
+            dgym = dgym + m.dgtest;
+        }
+        m.fx = fxm; m.fy = fym; m.dgx = dgxm; m.dgy = dgym;
     }
     if (m.brackt) {
         if (fabs(m.sty - m.stx) >= 0.66 * m.width1) m.stp = m.stx + 0.5 * (m.sty - m.stx);
         m.width1 = m.width;
         m.width = fabs(m.sty - m.stx);
     }
-    mt_request_trial(st, m);
     st.mt = m;
+    return NEXT_REQUEST_TRIAL;
 }
 
 
@@ -491,16 +619,18 @@ NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchPa
 
 // consumes the sums of the evaluation that was requested (sums[0] score, [1..6] gradient, [7..27] upper
 // triangle of the Hessian) and either requests the next evaluation or finishes
-NDT_HD void match_state_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm)
+NDT_HD void match_state_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, NewtonWs &ws)
 {
     if (st.phase == PH_LS_TRIAL) {
         st.reuse_sums = 0;
-        linesearch_step(st, sums, prm);
-        // an accepted first trial that was evaluated with its Hessian: the evaluation apply_step just requested
-        // is the one these sums come from (same cells, same pose)
+        const int next = linesearch_step(st, sums, prm);
+        if (next == NEXT_REQUEST_TRIAL) { mt_request_trial(st); return; }
+        apply_step(st, prm);
+        // an accepted first trial that was evaluated with its Hessian: the evaluation apply_step just requested (the
+        // next Newton iteration's, or the final one) is the one these sums come from (same cells, same pose)
         if (!st.reuse_sums) return;
     }
-    if (st.phase == PH_NEWTON) newton_step(st, sums, prm);
+    if (st.phase == PH_NEWTON) newton_step(st, sums, prm, ws);
     else if (st.phase == PH_FINAL) match_state_final(st, sums);
 }
 

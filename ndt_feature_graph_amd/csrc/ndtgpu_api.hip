@@ -94,7 +94,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.2.6 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.3.0 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -650,29 +650,32 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
                                        ndtgpu_match_result *results_dev, const double *Q36_dev, hipStream_t st)
 {
     if (n_pairs == 0) return NDTGPU_OK;
-    // persistent workgroups (one wide or two narrow ones per CU: registers and LDS allow no more); pairs are pulled from
-    // a ticket counter.  NDTGPU_PARK_ITERS: iterations after which a long registration yields to a fresh pair.
+    // persistent workgroups, one per CU (8 waves x 256 VGPRs), each with `slots` registrations in flight whose evaluation
+    // shares its waves take in turn (csrc/ndt_match.hip); pairs are pulled from a ticket counter.
+    // NDTGPU_PARK_ITERS: iterations after which a long registration yields to a fresh pair.  NDTGPU_SLOTS=1: one
+    // registration per workgroup (A/B; the results are the same bits).  NDTGPU_DOUBLE_THRESH: a workgroup resumes a
+    // second parked registration only when more than this many are waiting.
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
         n_cu = 256;
     const char *park_env = getenv("NDTGPU_PARK_ITERS");       // read per call: tests switch it
     const int park_iters = park_env ? atoi(park_env) : 6;
-    // Batches that give every CU several registrations run TWO narrow (4-wave) workgroups per CU: more registrations per
-    // second, each of them slower (csrc/ndt_match.hip).  NDTGPU_NARROW=0 / 1 forces one form.
-    const char *narrow_env = getenv("NDTGPU_NARROW");
-    const int narrow = narrow_env ? (atoi(narrow_env) != 0) : (n_pairs >= 8 * (size_t)n_cu);   // measured: 1024 pairs 2.59 (wide) / 2.94 ms, 499 500 edges 185 / 139 ms
-    const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu * (narrow ? 2u : 1u));
+    const char *slots_env = getenv("NDTGPU_SLOTS");
+    const int slots = (slots_env && atoi(slots_env) == 1) ? 1 : 2;
+    const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
+    const char *dbl_env = getenv("NDTGPU_DOUBLE_THRESH");
+    const unsigned double_thresh = dbl_env ? (unsigned)atoi(dbl_env) : n_groups;
     // The work area (ticket counters, parked solver states) belongs to the target set: a launch on another stream
     // waits for the previous one, and growing the area waits for everything that may still use the old one.
     if (ts->work_ev_valid && ts->work_stream != st) HIP_TRY(hipStreamWaitEvent(st, ts->work_ev, 0));
-    const size_t need = ndt_match_work_bytes(n_pairs, n_groups);
+    const size_t need = ndt_match_work_bytes(n_pairs, (size_t)n_groups * slots);
     if (need > ts->work_bytes && ts->work_ev_valid) HIP_TRY(hipEventSynchronize(ts->work_ev));
     ndtgpu_status wrc = ts->ensure_work(need);
     if (wrc != NDTGPU_OK) return wrc;
     if (ts->profiling) HIP_TRY(hipEventRecord(ts->ev[2], st));
     hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
-                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, n_groups, park_iters, narrow,
-                                    ts->work, st);
+                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, n_groups, park_iters, slots,
+                                    double_thresh, ts->work, st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
     if (ts->profiling) { HIP_TRY(hipEventRecord(ts->ev[3], st)); ts->ev_valid[1] = true; }
     if (!ts->work_ev) HIP_TRY(hipEventCreateWithFlags(&ts->work_ev, hipEventDisableTiming));
@@ -770,9 +773,12 @@ static ndtgpu_status match_persistent_host(ndtgpu_mapset *ts, const uint32_t *ti
     rc = match_device_core(ts, (const uint32_t *)(base + off_ti), ss, (const uint32_t *)(base + off_si), (double *)base, n_pairs, p,
                            (ndtgpu_match_result *)(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr, st);
     if (rc != NDTGPU_OK) return rc;
+    unsigned aborted = 0;
     HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&aborted, (char *)ts->work + ndt_match_abort_offset(), sizeof aborted, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (aborted) return fail(NDTGPU_ERR_HIP, "match: the persistent matcher gave up (a wave found no work for ~1 s)");
     return NDTGPU_OK;
 }
 
@@ -798,6 +804,7 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
         if (groups < 1) groups = 1;
         if (groups > max_groups) groups = max_groups;
         MatchState ms;
+        NewtonWs ws;
         match_state_init(ms, T16 + 16 * k, p, Q36 ? Q36 + 36 * k : nullptr);
         while (!ms.done) {
             hipError_t e = ndt_launch_eval(ts->v, tidx[k], ss->v, sidx[k], ms.Teval, p.n_neighbours, ms.with_h, p.lfd1,
@@ -812,7 +819,7 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
                 sums[q] = s;
             }
             if (ms.with_h) terms_h += (long long)sums[28]; else terms_g += (long long)sums[28];
-            match_state_step(ms, sums, p);
+            match_state_step(ms, sums, p, ws);
         }
         NdtMatchResultDev o;
         match_state_result(ms, T16 + 16 * k, o);

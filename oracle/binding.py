@@ -218,6 +218,14 @@ def match_fusion(target, source, T0, Tcov, use_soft_constraints=True, tikhonov=F
                                            score=R.score, exit_code=R.exit_code)
 
 
+def tcov_flips(reset=False):
+    """How often lineSearchMTFusionTcov's in-place negation of the increment (fusion.h:89-95) has fired (test aid)."""
+    L = lib()
+    L.oracle_debug_tcov_flips.restype = C.c_long
+    L.oracle_debug_tcov_flips.argtypes = [C.c_int]
+    return int(L.oracle_debug_tcov_flips(int(bool(reset))))
+
+
 def pose_to_T(p):
     p = _f64(p)
     T = np.zeros(16)

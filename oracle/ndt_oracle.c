@@ -1353,6 +1353,15 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
                         const oracle_match_params *prm, const double *Q /* Tcov^-1 or NULL */, int flags,
                         oracle_match_result *res);
 
+/* test aid: how often the in-place negation of lineSearchMTFusionTcov ([fusion.h]:89-95) has fired since the last reset */
+static long g_tcov_flips = 0;
+long oracle_debug_tcov_flips(int reset)
+{
+    long v = g_tcov_flips;
+    if (reset) g_tcov_flips = 0;
+    return v;
+}
+
 int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double T[16],
                      const oracle_match_params *prm, oracle_match_result *res)
 {
@@ -1364,8 +1373,8 @@ int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double 
  * useSoftConstraints the score / gradient / Hessian get the Mahalanobis terms of X = pose_local_v
  * ([fusion.h]:875-890, 1098-1110); the step length comes from NDTMatcherD2D::lineSearchMT because the
  * result of lineSearchMTFusionTcov is overwritten ([fusion.h]:1008-1023: step_size_feat == 0 ->
- * step_size = max(step_size_ndt, 0)); that discarded search can only flip the increment when
- * dginit >= 0, which the loop has just excluded ([fusion.h]:976), so it is not evaluated here. */
+ * step_size = max(step_size_ndt, 0)); what survives of that discarded search is the in-place negation of the
+ * increment when increment . (g_ndt + g_mahalanobis) >= 0 ([fusion.h]:89-95), restated in match_common. */
 int oracle_match_fusion(const oracle_map *target, const oracle_map *source, double T[16],
                         const oracle_match_params *prm, const double Tcov[36], int use_soft_constraints,
                         oracle_match_result *res)
@@ -1430,6 +1439,10 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
             for (int i = 0; i < 6; i++) g6[i] += gq[i];
             for (int i = 0; i < 36; i++) H36[i] += Hq[i];
         }
+        /* what lineSearchMTFusionTcov evaluates at the current pose ([fusion.h]:77-89): NDT + Mahalanobis gradient,
+         * BEFORE the Tikhonov transformation */
+        double g_tcov[6];
+        memcpy(g_tcov, g6, sizeof g_tcov);
         if (tikhonov) { /* [fusion.h]:894-911, P = I */
             double g2[6], H2[36];
             tikhonov_x0(T, Tinit, x0);
@@ -1499,6 +1512,20 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
         /* [fusion.h]:1000-1032 */
         double step_size = 1.0;
         if (prm->step_control) {
+            /* [fusion.h]:1008-1010: with useSoftConstraints lineSearchMTFusionTcov runs first.  Its step is overwritten
+             * ([fusion.h]:1018-1023: step_size_feat == 0 -> step_size = max(step_size_ndt, 0)), but it takes the increment
+             * BY REFERENCE and negates it in place when increment . (g_ndt + g_mahalanobis) >= 0 ([fusion.h]:89-95);
+             * lineSearchMT then starts from the negated vector.  Without Tikhonov that gradient is scg, on which
+             * dginit <= 0 was just established (only dginit == 0 flips); with Tikhonov scg = H^T g + Q x0 is another
+             * vector and the flip is reachable.  The discarded search itself is not evaluated. */
+            if (soft) {
+                double dtcov = 0;
+                for (int a = 0; a < 6; a++) dtcov += incr[a] * g_tcov[a];
+                if (dtcov >= 0.0) {
+                    for (int a = 0; a < 6; a++) incr[a] = -incr[a];
+                    g_tcov_flips++;
+                }
+            }
             /* the line search sees only the active dofs' gradient through incr (inactive entries are 0) */
             step_size = line_search_mt(incr, target, next, scratch, n, prm, &fevals);
         }

@@ -123,6 +123,8 @@ int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double 
 /* ndt_feature::matchFusion (ndt_matcher_d2d_fusion.h:797-1155) with empty feature maps and without the
  * Tikhonov variant: NDT term + (optionally) the odometry soft constraint x^T Tcov^-1 x.
  * Tcov: 6x6 row-major.  Returns -2 when Tcov is singular. */
+/* test aid: number of in-place negations of the increment by lineSearchMTFusionTcov ([fusion.h]:89-95) so far */
+long oracle_debug_tcov_flips(int reset);
 int oracle_match_fusion(const oracle_map *target, const oracle_map *source, double T[16],
                         const oracle_match_params *prm, const double Tcov[36], int use_soft_constraints,
                         oracle_match_result *res);

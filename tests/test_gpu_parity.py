@@ -461,25 +461,31 @@ def test_persistent_cooperative_and_host_driven_paths_agree(N, O, monkeypatch):
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
 
 
-def test_narrow_and_wide_workgroups_agree(N, O, monkeypatch):
-    """Large batches run two narrow (4-wave) workgroups per CU, small ones one wide (8-wave) workgroup
-    (NDTGPU_NARROW forces either): the source cells are dealt to 8 shares either way (a narrow workgroup's wave sums two
-    of them, one after the other), so a registration's result does not depend on the form its batch ran in -- bit for
-    bit; narrow workgroups park and resume like wide ones."""
-    n = 700                                                      # > 512 narrow workgroups: tickets are drawn twice
+def test_one_and_two_registrations_per_workgroup_agree(N, O, monkeypatch):
+    """The persistent matcher keeps two registrations in flight per workgroup and its waves take the eight shares of
+    their evaluations in whatever order they come free (NDTGPU_SLOTS=1: one registration per workgroup).  Shares,
+    their hit lists and their partial sums are the same whoever computes them and are added in share order, so a
+    registration's result does not depend on the form or on timing -- bit for bit; parking and the rule that a
+    workgroup resumes one parked registration at a time (NDTGPU_DOUBLE_THRESH) are bit neutral too."""
+    n = 700                                                      # > 512 slots: tickets are drawn twice
     pr, tg, sr, om = _pair_maps(N, O, [1 + (k % 24) for k in range(24)], 6000, 1.0, oracle_maps=False)
     idx = np.arange(n) % 24
     T0 = pr["T_init"].numpy()[idx]
     monkeypatch.setenv("NDTGPU_COOP", "0")
-    monkeypatch.setenv("NDTGPU_NARROW", "0")
+    monkeypatch.setenv("NDTGPU_SLOTS", "1")
     Tw, rw = N.match_batch(tg, idx, sr, idx, T0)
-    monkeypatch.setenv("NDTGPU_NARROW", "1")
+    monkeypatch.setenv("NDTGPU_SLOTS", "2")
     Tn, rn = N.match_batch(tg, idx, sr, idx, T0)
+    Tn2, rn2 = N.match_batch(tg, idx, sr, idx, T0)
+    assert np.array_equal(Tn, Tn2) and np.array_equal(rn["score"], rn2["score"])      # run to run
     monkeypatch.setenv("NDTGPU_PARK_ITERS", "1")
     Tp, rp = N.match_batch(tg, idx, sr, idx, T0)
     assert np.array_equal(Tn, Tp) and np.array_equal(rn["fevals"], rp["fevals"])      # parking is bit neutral
+    monkeypatch.setenv("NDTGPU_DOUBLE_THRESH", "0")
+    Tq, rq = N.match_batch(tg, idx, sr, idx, T0)
+    assert np.array_equal(Tn, Tq) and np.array_equal(rn["fevals"], rq["fevals"])
     assert np.array_equal(Tn, Tw)
-    for f in ("converged", "iterations", "fevals", "score"):
+    for f in ("converged", "iterations", "fevals", "score", "pair_terms_g", "pair_terms_h"):
         assert np.array_equal(rn[f], rw[f]), f
 
 
