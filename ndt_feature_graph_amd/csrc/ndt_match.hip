@@ -29,6 +29,10 @@
 //   * no atomics in the sums, fixed summation order -> run-to-run identical.
 //   * MFMA is not used: nothing here is a dense contraction (3x3 / 6x6 per-pair expressions).
 #include "ndt_math.h"
+#ifdef NDT_MATCH_PROF
+__device__ long long g_solver_prof[16];
+#define NDT_SOLVER_STAGE_PROF
+#endif
 #include "ndt_solver.h"
 #include <float.h>
 
@@ -226,7 +230,11 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
     const d3 xB = id * mul(A, x);                    // B x
     const double l = dot(x, xB);
     if (!(l * 0.0 == 0.0)) return;                   // if(l*0 != 0) continue;
+#ifdef NDT_EXP_NO_EXP
+    const double sh = -lfd1 * (1.0 - lfd2 * l * 0.5);
+#else
     const double sh = -lfd1 * exp_nonpos(-lfd2 * l * 0.5);
+#endif
     const double f2 = -lfd2 * sh;                    // 2 f
     const d3 w = mul(C, xB);
     const d3 qr = cross(m - w, xB);                  // x^T B j_k - x^T B Z_k B x / 2,  j_k = e_k x m
@@ -361,42 +369,47 @@ NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double
         return sym3{w.mysrc[3 * 64 + sl], w.mysrc[4 * 64 + sl], w.mysrc[5 * 64 + sl],
                     w.mysrc[6 * 64 + sl], w.mysrc[7 * 64 + sl], w.mysrc[8 * 64 + sl]};
     };
+    // The list entries and target cells of the NEXT batch are fetched while this one is computed.  Every lane fetches
+    // (lanes past the end of the list fetch its last entry again): a fetch under a lane mask is a branch the wave may
+    // skip, and the wait counts the compiler then has to use (the smaller of the two paths) would make every batch wait
+    // for the prefetch it has just issued.
+    auto fetch = [&](unsigned e, uint32_t &en, d3 &mu, sym3 &Cj) {
+        en = w.myq[min(e + lane, n - 1u)];
+#ifdef NDT_EXP_FIXED_TARGET
+        gcell_ptr tc = tg.cells + (en & 0x1u);
+#else
+        gcell_ptr tc = tg.cells + (en & 0xFFFFFFu);
+#endif
+        mu = d3{tc->mean[0], tc->mean[1], tc->mean[2]};
+        Cj = sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
+    };
+    if (n == 0u) return;
     if constexpr (WITH_H) {
+        uint32_t en0, en1;
+        d3 mu0, mu1;
+        sym3 Cj0, Cj1;
+        fetch(0u, en0, mu0, Cj0);
 #pragma unroll 1
         for (unsigned e0 = 0; e0 < n; e0 += 64u) {
-            if (e0 + lane < n) {
-                const uint32_t en = w.myq[e0 + lane];
-                gcell_ptr tc = tg.cells + (en & 0xFFFFFFu);
-                d3 mu = {tc->mean[0], tc->mean[1], tc->mean[2]};
-                sym3 Cj = {tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
-                pair_term<true>(tile_m(en >> 24), tile_C(en >> 24), mu, Cj, lfd1, lfd2, w.acc);
-            }
+            fetch(e0 + 64u, en1, mu1, Cj1);
+            __builtin_amdgcn_sched_barrier(0);       // (the loads stay above the arithmetic)
+            if (e0 + lane < n) pair_term<true>(tile_m(en0 >> 24), tile_C(en0 >> 24), mu0, Cj0, lfd1, lfd2, w.acc);
+            en0 = en1; mu0 = mu1; Cj0 = Cj1;
         }
     } else {
-        // two register sets that take turns (no rotation moves): while one batch is computed the next one's list
-        // entries and target cells are on their way
-        bool vA, vB;
-        uint32_t enA = 0u, enB = 0u;
-        d3 muA = {0, 0, 0}, muB = {0, 0, 0};
-        sym3 CjA = {0, 0, 0, 0, 0, 0}, CjB = {0, 0, 0, 0, 0, 0};
-        auto fetch = [&](unsigned e, bool &v, uint32_t &en, d3 &mu, sym3 &Cj) {
-            v = e + lane < n;
-            if (v) {
-                en = w.myq[e + lane];
-                gcell_ptr tc = tg.cells + (en & 0xFFFFFFu);
-                mu = d3{tc->mean[0], tc->mean[1], tc->mean[2]};
-                Cj = sym3{tc->cov[0], tc->cov[1], tc->cov[2], tc->cov[3], tc->cov[4], tc->cov[5]};
-            }
-        };
-        fetch(0u, vA, enA, muA, CjA);
+        // two register sets that take turns (no rotation moves: they would be a tenth of the gradient-only term)
+        uint32_t enA, enB;
+        d3 muA, muB;
+        sym3 CjA, CjB;
+        fetch(0u, enA, muA, CjA);
 #pragma unroll 1
         for (unsigned e0 = 0; e0 < n; e0 += 128u) {
-            fetch(e0 + 64u, vB, enB, muB, CjB);
-            __builtin_amdgcn_sched_barrier(0);       // (the loads stay above the arithmetic)
-            if (vA) pair_term<false>(tile_m(enA >> 24), tile_C(enA >> 24), muA, CjA, lfd1, lfd2, w.acc);
-            fetch(e0 + 128u, vA, enA, muA, CjA);
+            fetch(e0 + 64u, enB, muB, CjB);
             __builtin_amdgcn_sched_barrier(0);
-            if (vB) pair_term<false>(tile_m(enB >> 24), tile_C(enB >> 24), muB, CjB, lfd1, lfd2, w.acc);
+            if (e0 + lane < n) pair_term<false>(tile_m(enA >> 24), tile_C(enA >> 24), muA, CjA, lfd1, lfd2, w.acc);
+            fetch(e0 + 128u, enA, muA, CjA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (e0 + 64u + lane < n) pair_term<false>(tile_m(enB >> 24), tile_C(enB >> 24), muB, CjB, lfd1, lfd2, w.acc);
         }
     }
     w.terms += n;
@@ -1427,6 +1440,53 @@ extern "C" int ndtgpu_debug_timeline(long long *out, int reset)      // out: 4 *
 #endif
 
 #ifdef NDT_MATCH_PROF
+// n evaluations of one pair at one pose in one workgroup (wide form): shader clocks per evaluation
+template <int NN>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ndt_eval_loop_kernel(
+    NdtSetView tset, unsigned tmap, NdtSetView sset, unsigned smap, rigid T, int with_h, int n_iter, int reuse, double lfd1,
+    double lfd2, long long *out)
+{
+    __shared__ EvalShared<NDT_MATCH_WAVES> sh;
+    __shared__ rigid s_T;
+    const MapView tg = map_view(tset, tmap);
+    const MapView sv = map_view(sset, smap);
+    if (threadIdx.x == 0) s_T = T;
+    if (threadIdx.x < NDT_VW) sh.cache[threadIdx.x].key = 0u;
+    __syncthreads();
+    const long long c0 = __builtin_readcyclecounter();
+    for (int it = 0; it < n_iter; it++) {
+        if (with_h) eval_derivs<NN, true>(tg, sv.cells, sv.n_cells, s_T, lfd1, lfd2, sh, reuse ? 7u : 0u);
+        else eval_derivs<NN, false>(tg, sv.cells, sv.n_cells, s_T, lfd1, lfd2, sh, reuse ? 7u : 0u);
+    }
+    const long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { out[blockIdx.x * 4] = c1 - c0; out[blockIdx.x * 4 + 1] = (long long)sh.sums[28]; out[blockIdx.x * 4 + 2] = sv.n_cells; }
+}
+extern "C" int ndtgpu_debug_eval_loop(void *tsv, unsigned tmap, void *ssv, unsigned smap, const double *T16, int with_h, int n_iter,
+                                      int reuse, int n_groups, double lfd1, double lfd2, long long *out_host)
+{
+    const NdtSetView &tset = *reinterpret_cast<const NdtSetView *>(tsv), &sset = *reinterpret_cast<const NdtSetView *>(ssv);
+    rigid T;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T.r[r * 3 + c] = T16[c * 4 + r]; T.t[r] = T16[12 + r]; }
+    long long *out_dev = nullptr;
+    if (hipMalloc(&out_dev, n_groups * 4 * sizeof(long long)) != hipSuccess) return -1;
+    hipLaunchKernelGGL(ndt_eval_loop_kernel<2>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, 0, tset, tmap, sset, smap, T, with_h, n_iter,
+                       reuse, lfd1, lfd2, out_dev);
+    int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+    if (rc == 0 && hipMemcpy(out_host, out_dev, n_groups * 4 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+    hipFree(out_dev);
+    return rc;
+}
+
+extern "C" int ndtgpu_debug_solver_prof(long long out[16], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_solver_prof), 16 * sizeof(long long)) != hipSuccess) return -1;
+    if (reset) {
+        long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_solver_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int ndtgpu_debug_prof(long long out[16], int reset)
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;

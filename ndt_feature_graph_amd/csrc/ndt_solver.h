@@ -492,9 +492,16 @@ NDT_HDN int newton_finish(MatchState &st, const double *sums, const NdtMatchPara
     return NEXT_REQUEST_TRIAL;
 }
 
+#if defined(NDT_SOLVER_STAGE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+// stage clocks of the solver (profiling builds of ndt_match.hip, which defines g_solver_prof): [2k] cycles, [2k + 1] calls of stage k
+#define NDT_STAGE(k, call) { long long t0_ = __builtin_readcyclecounter(); call; atomicAdd((unsigned long long *)&g_solver_prof[2 * (k)], (unsigned long long)((long long)__builtin_readcyclecounter() - t0_)); atomicAdd((unsigned long long *)&g_solver_prof[2 * (k) + 1], 1ull); }
+#else
+#define NDT_STAGE(k, call) { call; }
+#endif
+
 NDT_HD void newton_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, NewtonWs &ws)
 {
-    newton_assemble(st, sums, prm, ws);
+    NDT_STAGE(0, newton_assemble(st, sums, prm, ws))
     if (st.use_tikhonov) newton_tikhonov(st, prm, ws);
     if (ws.gnorm <= prm.delta_score) {     // fusion.h:943-965 (the regularisation before it has no other effect)
         if (st.score_here > st.score_best) st.T = st.Tbest;
@@ -502,14 +509,15 @@ NDT_HD void newton_step(MatchState &st, const double *sums, const NdtMatchParams
         st.done = 1;
         return;
     }
-    newton_factor(ws);
+    NDT_STAGE(1, newton_factor(ws))
     if (!ws.is_pd) {
-        newton_regularize(ws);
-        newton_ldlt(ws);
+        NDT_STAGE(2, newton_regularize(ws))
+        NDT_STAGE(3, newton_ldlt(ws))
     }
-    const int next = newton_finish(st, sums, prm, ws);
-    if (next == NEXT_APPLY_STEP) apply_step(st, prm);
-    else if (next == NEXT_REQUEST_TRIAL) mt_request_trial(st);
+    int next;
+    NDT_STAGE(4, next = newton_finish(st, sums, prm, ws))
+    if (next == NEXT_APPLY_STEP) NDT_STAGE(5, apply_step(st, prm))
+    else if (next == NEXT_REQUEST_TRIAL) NDT_STAGE(6, mt_request_trial(st))
 }
 
 // tail of the More-Thuente while(1) body after the trial evaluation (fusion.h:637-790)
@@ -623,9 +631,10 @@ NDT_HD void match_state_step(MatchState &st, const double *sums, const NdtMatchP
 {
     if (st.phase == PH_LS_TRIAL) {
         st.reuse_sums = 0;
-        const int next = linesearch_step(st, sums, prm);
-        if (next == NEXT_REQUEST_TRIAL) { mt_request_trial(st); return; }
-        apply_step(st, prm);
+        int next;
+        NDT_STAGE(7, next = linesearch_step(st, sums, prm))
+        if (next == NEXT_REQUEST_TRIAL) { NDT_STAGE(6, mt_request_trial(st)) return; }
+        NDT_STAGE(5, apply_step(st, prm))
         // an accepted first trial that was evaluated with its Hessian: the evaluation apply_step just requested (the
         // next Newton iteration's, or the final one) is the one these sums come from (same cells, same pose)
         if (!st.reuse_sums) return;

@@ -441,7 +441,8 @@ def test_persistent_cooperative_and_host_driven_paths_agree(N, O, monkeypatch):
     Tb, rb = N.match_batch(tg, idx, sr, idx, T0)                 # persistent kernel
     monkeypatch.delenv("NDTGPU_COOP")
     Tc, rc = N.match_batch(tg, idx, sr, idx, T0)                 # one cooperative launch, a few workgroups per pair
-    assert np.max(np.abs(Tc - Tb)) < 1e-9 and np.array_equal(rc["iterations"], rb["iterations"])
+    # (another summation order: agreement to rounding of the sums, far inside the 1e-4 m / rad of the metric)
+    assert np.max(np.abs(Tc - Tb)) < 1e-8 and np.array_equal(rc["iterations"], rb["iterations"])
     for b in (0, 5, 11):
         Ts, rs = N.match_d2d(tg, b, sr, b, T0[b])                # cooperative kernel, whole chip
         monkeypatch.setenv("NDTGPU_HOST_LOOP", "1")
@@ -449,13 +450,13 @@ def test_persistent_cooperative_and_host_driven_paths_agree(N, O, monkeypatch):
         monkeypatch.delenv("NDTGPU_HOST_LOOP")
         for Tx, rx in ((Ts, rs), (Th, rh)):
             dt, dr = pose_close(Tx, Tb[b])
-            assert dt < 1e-9 and dr < 1e-9
+            assert dt < 1e-8 and dr < 1e-8
             assert rx["iterations"] == rb["iterations"][b] and rx["converged"] == rb["converged"][b]
         monkeypatch.setenv("NDTGPU_COOP_CELLS", "16")            # many workgroups: another partition, same answer
         T3, r3 = N.match_d2d(tg, b, sr, b, T0[b])
         monkeypatch.delenv("NDTGPU_COOP_CELLS")
         dt, dr = pose_close(T3, Tb[b])
-        assert dt < 1e-9 and dr < 1e-9 and abs(int(r3["fevals"]) - int(rs["fevals"])) <= 2   # a line-search trial more or less
+        assert dt < 1e-8 and dr < 1e-8 and abs(int(r3["fevals"]) - int(rs["fevals"])) <= 2   # a line-search trial more or less
         To, ro = O.match_d2d(om[b][0], om[b][1], T0[b])
         dt, dr = pose_close(Ts, To)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
@@ -701,7 +702,7 @@ def test_device_pointer_batch_checks_indices_and_overflow(N):
 
 def test_device_pointer_small_batch_of_large_maps(N, monkeypatch):
     """ndtgpu_match_batch_device spreads a small batch of large maps over several CUs per registration (cooperative
-    launches, host round trip of the poses) instead of one CU each: same answer as the persistent kernel to 1e-9."""
+    launches, host round trip of the poses) instead of one CU each: same answer as the persistent kernel to 1e-8."""
     import torch
     from ndt_feature_graph_amd import binding, synth
     dev = torch.device("cuda", 0)
@@ -721,7 +722,7 @@ def test_device_pointer_small_batch_of_large_maps(N, monkeypatch):
         binding.match_batch_device(ms, ti, ms, si, T16, res, 2, stream=torch.cuda.current_stream())
         torch.cuda.synchronize()
         out[coop] = (T16.cpu().numpy(), res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(2).copy())
-    assert np.max(np.abs(out["1"][0] - out["0"][0])) < 1e-9
+    assert np.max(np.abs(out["1"][0] - out["0"][0])) < 1e-8
     assert np.array_equal(out["1"][1]["iterations"], out["0"][1]["iterations"]) and np.all(out["1"][1]["converged"] == 1)
     # the cooperative launches use many workgroups per registration: far fewer shader clocks on the critical path
     assert out["1"][1]["cycles_eval"].max() * 4 < out["0"][1]["cycles_eval"].max()

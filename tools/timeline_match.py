@@ -27,6 +27,7 @@ NTL = 4 * 4096 + 1024 + 8
 tl = np.zeros(NTL, dtype=np.int64)
 prof = np.zeros(16, dtype=np.int64)
 HAVE_PROF = hasattr(L, 'ndtgpu_debug_prof')
+sprof = np.zeros(16, dtype=np.int64); sp = sprof.ctypes.data_as(C.POINTER(C.c_longlong))
 tlp = tl.ctypes.data_as(C.POINTER(C.c_longlong)); pp = prof.ctypes.data_as(C.POINTER(C.c_longlong))
 
 
@@ -38,12 +39,15 @@ def run(idx_t, tag):
     for rep in range(2):                                     # second run is the measured one
         T16.copy_(Ti[idx.long()])
         L.ndtgpu_debug_timeline(tlp, 1)
-        if HAVE_PROF: L.ndtgpu_debug_prof(pp, 1)
+        if HAVE_PROF: L.ndtgpu_debug_prof(pp, 1); L.ndtgpu_debug_solver_prof(sp, 1)
         binding.match_batch_device(ts, idx, ss, idx, T16, res, n, stream=st)
         torch.cuda.synchronize()
     ms = ts.last_kernel_ms(1)
     L.ndtgpu_debug_timeline(tlp, 0)
-    if HAVE_PROF: L.ndtgpu_debug_prof(pp, 0)
+    if HAVE_PROF:
+        L.ndtgpu_debug_prof(pp, 0); L.ndtgpu_debug_solver_prof(sp, 0)
+        names = ["assemble", "factor", "regularize", "ldlt", "finish", "apply_step", "request_trial", "linesearch"]
+        print("   solver stages (cycles per call x calls): " + "  ".join("%s %.0f x %d" % (names[k], sprof[2 * k] / max(1, sprof[2 * k + 1]), sprof[2 * k + 1]) for k in range(8)))
     r = res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(n)
     t0 = tl[4 * 4096 + 1024]
     us = lambda x: (x - t0) / 100.0
