@@ -222,16 +222,18 @@ ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *targ
                                  const ndtgpu_match_params *prm, ndtgpu_match_result *results,
                                  ndtgpu_stream stream);
 /* device-resident variant for pipelines: T16_dev / results_dev are DEVICE buffers, idx arrays
- * DEVICE uint32.  A batch that fills the chip (more than one registration per two CUs) is one launch of persistent
- * workgroups: asynchronous on `stream`, no host synchronisation; a registration's result does not depend on its batch.
- * A small batch of LARGE maps (at least 1024 cells, few enough pairs for a handful of cooperative launches) whose
- * indices are sane is spread over several CUs per registration like ndtgpu_match_batch does: an order of magnitude
- * sooner done, same result to 1e-9 (another summation order); its indices and poses make a round trip through the host
- * and the call SYNCHRONISES (NDTGPU_COOP=0 keeps it on the persistent kernel and asynchronous).
+ * DEVICE uint32.  ONE launch of persistent workgroups, ALWAYS asynchronous on `stream`: no host synchronisation, safe
+ * under stream capture; a registration's result does not depend on its batch.
+ * Opt-in (environment NDTGPU_DEVICE_COOP=1, read per call): a small batch of LARGE maps (at least 1024 cells, few
+ * enough pairs for a handful of cooperative launches) whose indices are sane is spread over several CUs per
+ * registration like ndtgpu_match_batch does -- an order of magnitude sooner done, same result to 1e-8 (another
+ * summation order) -- but its indices and poses make a round trip through the host and the call then SYNCHRONISES
+ * `stream` and the streams of the last builds of both sets.
  * The indices are range-checked on the device and a map whose build overflowed max_cells is refused: such a pair gets
  * converged = 0 and exit_code -2 / -3, its pose stays untouched.  The work area (ticket counters, parked solver
- * states) belongs to the TARGET set: calls on different streams with the same target set are ordered by an event;
- * builds of the involved maps must be ordered before the call by the caller (same stream, or an event). */
+ * states) belongs to the TARGET set: calls on different streams with the same target set -- through this entry or the
+ * host-pointer ones -- are ordered by an event; builds of the involved maps must be ordered before the call by the
+ * caller (same stream, or an event). */
 ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *target_set, const uint32_t *target_idx_dev,
                                         ndtgpu_mapset *source_set, const uint32_t *source_idx_dev,
                                         double *T16_dev, size_t n_pairs, const ndtgpu_match_params *prm,

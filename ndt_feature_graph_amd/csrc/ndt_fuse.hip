@@ -28,6 +28,9 @@
 #include "ndt_math.h"
 
 #define NDT_FUSE_THREADS 1024
+// the finalise kernel: 512 threads = 8 waves = 256 VGPRs each (at 1024 threads the 128-register budget spilled the
+// Gaussian update of a cell -- 110 registers, 292 bytes of scratch per lane)
+#define NDT_FIN2_THREADS 512
 #define NDT_EMPTY (-1)
 
 namespace {
@@ -216,14 +219,14 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
 }
 
 // computeNDTCells of an incremental update: one workgroup per map.
-extern "C" __global__ __launch_bounds__(NDT_FUSE_THREADS) void ndt_fuse_finalize_kernel(
+extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize_kernel(
     NdtSetView set, unsigned first, unsigned n_points, int n_min, double eval_factor, double maxnumpoints,
     float occupancy_limit, int s1_shift, int s2_shift)
 {
-    __shared__ unsigned s_wave_cnt[NDT_FUSE_THREADS / 64];
+    __shared__ unsigned s_wave_cnt[NDT_FIN2_THREADS / 64];
     __shared__ unsigned s_binned;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr unsigned nthreads = NDT_FUSE_THREADS, nwaves = NDT_FUSE_THREADS / 64;
+    constexpr unsigned nthreads = NDT_FIN2_THREADS, nwaves = NDT_FIN2_THREADS / 64;
     const unsigned map = first + blockIdx.x;
     const NdtGrid g = set.grid;
     const uint32_t cap = g.max_cells;
@@ -615,7 +618,7 @@ hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, co
     hipError_t e = ndt_launch_accumulate(set, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, 200.0,
                                          origins_dev, prm.maxz, nice, &s1, &s2, stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ndt_fuse_finalize_kernel, dim3((unsigned)count), dim3(NDT_FUSE_THREADS), 0, stream, set,
+    hipLaunchKernelGGL(ndt_fuse_finalize_kernel, dim3((unsigned)count), dim3(NDT_FIN2_THREADS), 0, stream, set,
                        (unsigned)first, (unsigned)n_points, prm.n_min, prm.eval_factor, prm.maxnumpoints,
                        (float)prm.occupancy_limit, s1, s2);
     return hipGetLastError();

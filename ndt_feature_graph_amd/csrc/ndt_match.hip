@@ -1040,10 +1040,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
     }
     __syncthreads();
     eval_derivs<NN, true>(tg, sv.cells, sv.n_cells, s_T, lfd1, lfd2, sh);
-    double Hu[21];
-    if (tid == 0)
-        for (int k = 0; k < 21; k++) Hu[k] = sh.sums[7 + k];
-    __syncthreads();
+    // (the Hessian stays in sh.sums[7..27]: the pass below only writes sh.part)
     // J^T J: 21 sums over the source cells
     const double sigmaS = 0.03 * 0.03;
     double jj[32];
@@ -1095,35 +1092,37 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
         if ((lane & 1u) == 0u && (lane >> 1) < 21u) sh.part[wave * 32 + (lane >> 1)] = tot;
     }
     __syncthreads();
+    // H^-1 (sigma_S J^T J) H^-1 on thread 0; the matrices live in LDS (the pivot search indexes them dynamically:
+    // as local arrays they would go to scratch memory)
+    __shared__ double s_H[6][12], s_JK[6][6], s_tmp[6][6];
     if (tid == 0) {
-        double H[6][12], JK[6][6];
         int o = 0;
         for (int a = 0; a < 6; a++)
             for (int b = a; b < 6; b++) {
                 double s2 = 0;
                 for (int k = 0; k < NDT_MATCH_WAVES; k++) s2 += sh.part[k * 32 + o];
-                JK[a][b] = JK[b][a] = sigmaS * s2;
-                H[a][b] = H[b][a] = Hu[o];
+                s_JK[a][b] = s_JK[b][a] = sigmaS * s2;
+                s_H[a][b] = s_H[b][a] = sh.sums[7 + o];
                 o++;
             }
         // H^-1 by Gauss-Jordan with partial pivoting (Eigen: cov.inverse())
         bool ok = true;
         for (int a = 0; a < 6; a++)
-            for (int b = 0; b < 6; b++) H[a][6 + b] = (a == b) ? 1.0 : 0.0;
+            for (int b = 0; b < 6; b++) s_H[a][6 + b] = (a == b) ? 1.0 : 0.0;
         for (int c = 0; c < 6 && ok; c++) {
             int piv = c;
             for (int r = c + 1; r < 6; r++)
-                if (fabs(H[r][c]) > fabs(H[piv][c])) piv = r;
-            if (H[piv][c] == 0.0) { ok = false; break; }
+                if (fabs(s_H[r][c]) > fabs(s_H[piv][c])) piv = r;
+            if (s_H[piv][c] == 0.0) { ok = false; break; }
             if (piv != c)
-                for (int j = 0; j < 12; j++) { const double t = H[c][j]; H[c][j] = H[piv][j]; H[piv][j] = t; }
-            const double d = H[c][c];
-            for (int j = 0; j < 12; j++) H[c][j] /= d;
+                for (int j = 0; j < 12; j++) { const double t = s_H[c][j]; s_H[c][j] = s_H[piv][j]; s_H[piv][j] = t; }
+            const double d = s_H[c][c];
+            for (int j = 0; j < 12; j++) s_H[c][j] /= d;
             for (int r = 0; r < 6; r++) {
                 if (r == c) continue;
-                const double f = H[r][c];
+                const double f = s_H[r][c];
                 if (f != 0.0)
-                    for (int j = 0; j < 12; j++) H[r][j] -= f * H[c][j];
+                    for (int j = 0; j < 12; j++) s_H[r][j] -= f * s_H[c][j];
             }
         }
         double *out = cov36 + (size_t)link * 36;
@@ -1131,17 +1130,16 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
             for (int k = 0; k < 36; k++) out[k] = 0.0;
             status[link] = 1;                      // singular Hessian
         } else {
-            double tmp[6][6];
             for (int a = 0; a < 6; a++)
                 for (int b = 0; b < 6; b++) {
                     double s2 = 0;
-                    for (int k = 0; k < 6; k++) s2 += H[a][6 + k] * JK[k][b];
-                    tmp[a][b] = s2;
+                    for (int k = 0; k < 6; k++) s2 += s_H[a][6 + k] * s_JK[k][b];
+                    s_tmp[a][b] = s2;
                 }
             for (int a = 0; a < 6; a++)
                 for (int b = 0; b < 6; b++) {
                     double s2 = 0;
-                    for (int k = 0; k < 6; k++) s2 += tmp[a][k] * H[k][6 + b];
+                    for (int k = 0; k < 6; k++) s2 += s_tmp[a][k] * s_H[k][6 + b];
                     out[a * 6 + b] = s2;
                 }
             status[link] = 0;
@@ -1221,6 +1219,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     __shared__ MatchState st;       // workgroup 0 only
     __shared__ NewtonWs s_ws;
+    __shared__ NdtMatchParamsDev s_prm;     // the solver takes the parameters by reference: LDS, not a private copy
     __shared__ rigid s_T;
     __shared__ int s_with_h, s_done;
 
@@ -1246,8 +1245,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     unsigned target = 0;
     long long terms_g = 0, terms_h = 0;
 
+    if (threadIdx.x == 0) s_prm = prm;
+    __syncthreads();
     if (g == 0 && threadIdx.x == 0) {
-        match_state_init(st, T16, prm, Q36);
+        match_state_init(st, T16, s_prm, Q36);
         ctrl->Teval = st.Teval; ctrl->with_h = st.with_h; ctrl->done = st.done;
     }
     long long cyc_eval = 0, cyc_solver = 0, cyc_bar = 0;
@@ -1287,7 +1288,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
             if (threadIdx.x == 0) {
                 long long d0 = __builtin_readcyclecounter();
                 if (s_with_h) terms_h += (long long)sh.sums[28]; else terms_g += (long long)sh.sums[28];
-                match_state_step(st, sh.sums, prm, s_ws);
+                match_state_step(st, sh.sums, s_prm, s_ws);
                 ctrl->Teval = st.Teval; ctrl->with_h = st.with_h; ctrl->done = st.done;
                 cyc_solver += (long long)__builtin_readcyclecounter() - d0;
             }

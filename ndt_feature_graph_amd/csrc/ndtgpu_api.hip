@@ -700,19 +700,21 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
     p.fusion_flags = 0;
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
-    // A batch that cannot fill the chip (one persistent workgroup per registration would leave most CUs idle) takes the
-    // cooperative launches of the host-pointer API when its indices are sane and its maps are large enough to be split:
-    // poses and indices make a round trip through the host (a few hundred bytes per registration) and the call
-    // SYNCHRONISES.  Anything unusual (an index out of range, a truncated map) stays on the persistent kernel, which
-    // reports it per registration.
+    // Opt-in (NDTGPU_DEVICE_COOP=1): a batch that cannot fill the chip (one persistent workgroup per registration would
+    // leave most CUs idle) takes the cooperative launches of the host-pointer API when its indices are sane and its maps
+    // are large enough to be split: poses and indices make a round trip through the host (a few hundred bytes per
+    // registration) and the call SYNCHRONISES.  By default this entry never synchronises.
     {
         hipStream_t st = (hipStream_t)stream;
         int dev = 0, n_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
-        const char *coop_env = getenv("NDTGPU_COOP");
+        const char *dc_env = getenv("NDTGPU_DEVICE_COOP");
+        const char *coop_env = (dc_env && atoi(dc_env) != 0) ? "1" : "0";
         if (n_pairs > 0 && n_pairs <= (size_t)n_cu / 2 && !(coop_env && atoi(coop_env) == 0)) {
             std::vector<uint32_t> ti(n_pairs), si(n_pairs);
+            HIP_TRY(hipStreamSynchronize(ts->last_stream));      // the map counters read below come from the builds
+            HIP_TRY(hipStreamSynchronize(ss->last_stream));
             HIP_TRY(hipMemcpyAsync(ti.data(), tidx_dev, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(si.data(), sidx_dev, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -803,6 +805,7 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
         unsigned groups = (cs.n_cells + 511u) / 512u;
         if (groups < 1) groups = 1;
         if (groups > max_groups) groups = max_groups;
+        ts->ev_valid[1] = false;
         MatchState ms;
         NewtonWs ws;
         match_state_init(ms, T16 + 16 * k, p, Q36 ? Q36 + 36 * k : nullptr);
@@ -874,6 +877,9 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     const size_t total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
     ndtgpu_status rc = ts->ensure_stage(total);
     if (rc != NDTGPU_OK) return rc;
+    // an asynchronous launch of the persistent matcher (ndtgpu_match_batch_device on another stream) may still be using
+    // the work area of this target set: wait for it before the area is grown, cleared or handed to the launches below
+    if (ts->work_ev_valid) HIP_TRY(hipEventSynchronize(ts->work_ev));
     const size_t stride = ndt_match_coop_work_bytes(groups);
     rc = ts->ensure_work(n_pairs * stride);
     if (rc != NDTGPU_OK) return rc;
@@ -913,6 +919,7 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
         HIP_TRY(hipMemcpy2DAsync(ctrl.data(), 16, ts->work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
+    ts->ev_valid[1] = false;          // (ndtgpu_last_kernel_ms(1): no persistent launch was timed by this call)
     // A registration whose grid barrier gave up (it cannot with a co-resident grid; the bounded spin stays as a guard
     // against a foreign kernel holding CUs) is run again on the persistent kernel: the call does not fail.
     std::vector<size_t> bad;
@@ -989,7 +996,9 @@ ndtgpu_status ndtgpu_match_fusion_batch(ndtgpu_mapset *ts, const uint32_t *tidx,
                                         const ndtgpu_match_params *prm, int use_soft_constraints,
                                         ndtgpu_match_result *results, ndtgpu_stream stream)
 {
-    const int flags = use_soft_constraints & 3;   // bit 0 useSoftConstraints, bit 1 useTikhonovRegularization
+    if (use_soft_constraints < 0 || use_soft_constraints > 3)
+        return fail(NDTGPU_ERR_INVALID, "match_fusion: use_soft_constraints is a 2-bit set (bit 0 useSoftConstraints, bit 1 useTikhonovRegularization)");
+    const int flags = use_soft_constraints;       // bit 0 useSoftConstraints, bit 1 useTikhonovRegularization
     if (!flags) return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, nullptr, 0, results, stream);
     if (!Tcov36) return fail(NDTGPU_ERR_INVALID, "match_fusion: Tcov missing");
     std::vector<double> Q(36 * n_pairs);

@@ -1,0 +1,82 @@
+"""Randomised parity campaigns as part of the GPU suite (slices of tools/parity_campaign.py / parity_campaign_3d.py):
+many seeds, HIP path (grid build + D2D matcher) against the C oracle.  Tolerance of the metric: 1e-4 m / 1e-4 rad
+(BASELINE.json north_star); what is asserted here is far tighter and includes the control flow (iteration counts,
+convergence flags)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4
+
+
+@pytest.fixture(scope="module")
+def N():
+    import ndt_feature_graph_amd as N
+    if N.device_count() < 1:
+        pytest.fail("no HIP device visible: the HIP path cannot run (there is no CPU fallback)")
+    return N
+
+
+@pytest.fixture(scope="module")
+def O():
+    import oracle
+    return oracle
+
+
+def test_parity_campaign_2d_300_pairs(N, O):
+    """300 random 2D pairs (seeds 5000-5299, 20 k points, 0.5 m cells) through the persistent matcher."""
+    import torch
+    from ndt_feature_graph_amd import synth
+    n, npts, res, size, rng = 300, 20000, 0.5, [100.0, 100.0, 1.0], 30.0
+    seeds = list(range(5000, 5000 + n))
+    pr = synth.pair_2d(seeds, npts)
+    fixed, moving, T0 = pr["fixed"].numpy(), pr["moving"].numpy(), pr["T_init"].numpy()
+    ms = N.MapSet(res, [0, 0, 0], size, n_maps=2 * n, max_cells=4096)
+    ms.build(torch.from_numpy(np.concatenate([fixed, moving])).cuda(), range_limit=rng)
+    torch.cuda.synchronize()
+    idx = np.arange(n)
+    T, r = N.match_batch(ms, idx, ms, idx + n, T0)
+    worst_t = worst_r = 0.0
+    it_diff = conv_diff = beyond = 0
+    for k in range(n):
+        a = O.OracleMap(res, [0, 0, 0], size); a.load_points(fixed[k], rng); a.compute_cells()
+        b = O.OracleMap(res, [0, 0, 0], size); b.load_points(moving[k], rng); b.compute_cells()
+        assert r["n_target"][k] == a.num_cells() and r["n_source"][k] == b.num_cells(), seeds[k]
+        To, ro = O.match_d2d(a, b, T0[k])
+        dt = float(np.linalg.norm(T[k][:3, 3] - To[:3, 3]))
+        dr = float(np.linalg.norm(T[k][:3, :3] - To[:3, :3]))
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (seeds[k], dt, dr)
+        worst_t, worst_r = max(worst_t, dt), max(worst_r, dr)
+        it_diff += int(r["iterations"][k] != ro["iterations"])
+        conv_diff += int(bool(r["converged"][k]) != ro["converged"])
+        beyond += int(dt > 1e-6 or dr > 1e-6)
+    print("2D campaign: worst |dt| %.3e m |dR| %.3e, iteration counts differ on %d, beyond 1e-6 on %d" % (worst_t, worst_r, it_diff, beyond))
+    assert conv_diff == 0
+    # a step norm that sits on DELTA_SCORE can cost a pair an iteration more or less (1 of 1500 at the end of round 2)
+    assert it_diff <= 2 and beyond <= 2, (it_diff, beyond)
+
+
+def test_parity_campaign_3d_8_pairs(N, O):
+    """8 random pairs of 48 k-point 3D sweeps at 0.25 m (thick grid: wide flush list, multi-workgroup ranking,
+    cooperative matcher): identical cell sets and point counts on all 16 maps, poses, iteration counts."""
+    from ndt_feature_graph_amd import synth
+    n = 8
+    seeds = list(range(300, 300 + n))
+    pr = synth.pair_3d(seeds, rings=32, azimuths=1500)
+    fixed, moving, T0 = pr["fixed"].numpy(), pr["moving"].numpy(), pr["T_init"].numpy()
+    res, size, rng = 0.25, [100.0, 100.0, 10.0], 70.0
+    ms = N.MapSet(res, [0, 0, 0], size, n_maps=2 * n, max_cells=32768)
+    ms.build(np.concatenate([fixed, moving]), range_limit=rng)
+    idx = np.arange(n)
+    T, r = N.match_batch(ms, idx, ms, idx + n, T0)
+    for k in range(n):
+        a = O.OracleMap(res, [0, 0, 0], size); a.load_points(fixed[k], rng); a.compute_cells()
+        b = O.OracleMap(res, [0, 0, 0], size); b.load_points(moving[k], rng); b.compute_cells()
+        for m, om in ((k, a), (n + k, b)):
+            g, o = ms.export_cells(m), om.export_cells()
+            assert np.array_equal(g[2], o[2]) and np.array_equal(g[3], o[3]), (seeds[k], m)
+        To, ro = O.match_d2d(a, b, T0[k])
+        dt = float(np.linalg.norm(T[k][:3, 3] - To[:3, 3]))
+        dr = float(np.linalg.norm(T[k][:3, :3] - To[:3, :3]))
+        assert dt <= 1e-6 and dr <= 1e-6, (seeds[k], dt, dr)
+        assert r["iterations"][k] == ro["iterations"] and bool(r["converged"][k]) == ro["converged"], seeds[k]

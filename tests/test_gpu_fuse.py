@@ -229,21 +229,24 @@ def test_ray_walk_known_answer(N, O):
     assert np.max(np.abs(om.occupancy() - occ)) < 1e-6
 
 
-def test_order_free_vs_reference_order(N, O):
-    """What the order-free semantics change against the reference's beam-after-beam walk, on a 16-scan node map:
-    the same Gaussian cells, the same N and moments, occupancies within float accumulation error."""
-    clouds, origins, _ = node_scans(7, 16, 20000)
-    ms, om_free = fuse_both(N, O, clouds, origins, 0.5, [100, 100, 1], check_every=False)
-    om_seq = O.OracleMap(0.5, [0, 0, 0], [100, 100, 1])
-    for k in range(len(clouds)):
-        kw = dict(maxz=100.0, sensor_noise=0.1) if k == 0 else dict(maxz=25.0, sensor_noise=0.06)
-        om_seq.add_point_cloud(origins[k], clouds[k], order_free=False, **kw)
-        om_seq.compute_cells_full()
-    a, b = ms.export_cells(0), om_seq.export_cells()
-    ia, ib = set(map(tuple, a[2])), set(map(tuple, b[2]))
-    assert len(ia ^ ib) <= max(2, len(ib) // 100), (len(ia), len(ib), len(ia ^ ib))
-    do = np.abs(ms.occupancy(0) - om_seq.occupancy())
-    assert do.max() < 0.5 and np.mean(do > 1e-2) < 0.01, (float(do.max()), float(np.mean(do > 1e-2)))
+@pytest.mark.parametrize("seeds", [[7, 2, 10], [12, 14, 21]])
+def test_order_free_vs_reference_order(N, O, seeds):
+    """What the order-free semantics change against the reference's beam-after-beam walk (a cell that loses its Gaussian
+    half way through a cloud is treated as empty by the remaining beams; float accumulation of the occupancy): on
+    16-scan node maps NOTHING that the matcher sees -- exactly the same Gaussian cells, the same N per cell, the same
+    moments; occupancies within float accumulation error.  (tests/test_oracle.py runs the same comparison, oracle
+    against oracle, on 20 node maps.)"""
+    for seed in seeds:
+        clouds, origins, _ = node_scans(seed, 16, 20000)
+        ms, om_free = fuse_both(N, O, clouds, origins, 0.5, [100, 100, 1], check_every=False)
+        om_seq = O.OracleMap(0.5, [0, 0, 0], [100, 100, 1])
+        for k in range(len(clouds)):
+            kw = dict(maxz=100.0, sensor_noise=0.1) if k == 0 else dict(maxz=25.0, sensor_noise=0.06)
+            om_seq.add_point_cloud(origins[k], clouds[k], order_free=False, **kw)
+            om_seq.compute_cells_full()
+        cells_equal(ms.export_cells(0), om_seq.export_cells(), 0.5)       # index sets, N: exact; moments 1e-9 / 1e-8
+        do = np.abs(ms.occupancy(0) - om_seq.occupancy())
+        assert do.max() < 1e-2, (seed, float(do.max()))
 
 
 def test_plain_build_leaves_occupancy(N, O):

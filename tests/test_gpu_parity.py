@@ -667,6 +667,34 @@ def test_match_fusion_tikhonov_parity(N, O):
         assert max(pose_close(Tp[b], Tb[b])[0] for b in range(B)) > 1e-6        # the regulariser changes the result
 
 
+def test_match_fusion_tcov_line_search_negates_the_increment(N, O):
+    """useSoftConstraints + useTikhonovRegularization (the offline tool's defaults): the reference first runs
+    lineSearchMTFusionTcov (fusion.h:1008-1010), throws its step away (:1018-1023) and keeps its side effect: the
+    increment, taken by reference, is negated in place when increment . (g_ndt + g_mahalanobis) >= 0 (fusion.h:89-95) --
+    a test on ANOTHER gradient than the loop's dginit (scg = H^T g + Q x0 with Tikhonov, fusion.h:907, 973).
+    Pairs on which that flip fires (the oracle counts them), started three initial offsets out: the HIP state machine
+    (csrc/ndt_solver.h newton_finish) must follow the oracle through it -- iterations, exit, score and pose."""
+    seeds = [3, 4, 7, 8, 9]
+    pr, tg, sr, om = _pair_maps(N, O, seeds, 8000, 1.0)
+    T0 = pr["T_init"].numpy().copy()
+    T0[:, :3, 3] *= 3.0
+    B = len(seeds)
+    covs = np.stack([np.diag([2e-3, 2e-3, 1.0, 1.0, 1.0, 4e-4])] * B)
+    idx = np.arange(B)
+    Tb, rb = N.match_fusion_batch(tg, idx, sr, idx, T0, covs, use_soft_constraints=True, tikhonov=True)
+    flips = 0
+    for b in range(B):
+        O.binding.tcov_flips(reset=True)
+        To, ro = O.match_fusion(om[b][0], om[b][1], T0[b], covs[b], use_soft_constraints=True, tikhonov=True)
+        flips += O.binding.tcov_flips(reset=True)
+        dt, dr = pose_close(Tb[b], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
+        assert rb["iterations"][b] == ro["iterations"] and bool(rb["converged"][b]) == ro["converged"], b
+        assert rb["exit_code"][b] == ro["exit_code"], b
+        assert abs(rb["score"][b] - ro["score"]) < 1e-6 * abs(ro["score"])
+    assert flips >= B          # the flip fired on these pairs (7, 8: several times)
+
+
 def test_device_pointer_batch_checks_indices_and_overflow(N):
     """ndtgpu_match_batch_device takes its indices from device memory: an index out of range and a map whose build
     overflowed max_cells are refused per pair (exit codes -2 / -3, pose untouched), the other pairs are registered."""
@@ -701,8 +729,9 @@ def test_device_pointer_batch_checks_indices_and_overflow(N):
 
 
 def test_device_pointer_small_batch_of_large_maps(N, monkeypatch):
-    """ndtgpu_match_batch_device spreads a small batch of large maps over several CUs per registration (cooperative
-    launches, host round trip of the poses) instead of one CU each: same answer as the persistent kernel to 1e-8."""
+    """Opt-in (NDTGPU_DEVICE_COOP=1): ndtgpu_match_batch_device spreads a small batch of large maps over several CUs per
+    registration (cooperative launches, host round trip of the poses: the call then synchronises) instead of one CU
+    each: same answer as the always-asynchronous default (persistent kernel) to 1e-8."""
     import torch
     from ndt_feature_graph_amd import binding, synth
     dev = torch.device("cuda", 0)
@@ -716,7 +745,7 @@ def test_device_pointer_small_batch_of_large_maps(N, monkeypatch):
     si = torch.tensor([2, 3], dtype=torch.int32, device=dev)
     out = {}
     for coop in ("1", "0"):
-        monkeypatch.setenv("NDTGPU_COOP", coop)
+        monkeypatch.setenv("NDTGPU_DEVICE_COOP", coop)
         T16 = T0.clone()
         res = torch.zeros((2, 64), dtype=torch.uint8, device=dev)
         binding.match_batch_device(ms, ti, ms, si, T16, res, 2, stream=torch.cuda.current_stream())
