@@ -19,6 +19,11 @@ plus the labelled OpenMP all-cores figure) and `parity` compares the GPU poses o
   python bench.py --config 4 [--nodes N] [--gated]     configs[3]: replay harness -- N node maps, all-pairs (or gated)
                                                        candidate edges sharded over the ranks, nodes/s, edges/s and the
                                                        final all-gather reported separately
+  python bench.py --config 5                           configs[4]: 3D mode -- one 200 k-point pair (latency) and a batch of
+                                                       64 sweeps / 32 pairs (throughput), roofline of build and matcher
+  python bench.py --config fuse                        the node-map path: add_cloud of 256 node maps (ray
+                                                       tracing + accumulate + finalise), then matcher, covariance and
+                                                       occupancy overlap of the 19 900 links of 200 fused maps
 """
 import argparse
 import json
@@ -33,7 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
 
 
 def cpu_info():
@@ -173,6 +178,155 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         dist.destroy_process_group()
 
 
+def _timed(torch, fn, reps=5, warm=2):
+    """median wall time [ms] of fn() bracketed by device synchronisation"""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(1e3 * (time.perf_counter() - c0))
+    return float(np.median(ts))
+
+
+def config5(args, torch, N, binding, synth, dev):
+    """BASELINE configs[4]: 3D mode, 200 k-point Velodyne-style clouds, 0.25 m voxels, 6-DoF.  One pair through the
+    host-synchronous call (latency: the reference's call shape) and a batch of 64 sweeps = 32 pairs resident in HBM
+    (throughput).  Rooflines: the build against HBM (12 N + 80 M bytes per sweep), the matcher against the fp64 peak."""
+    res, size, rng, cap = 0.25, [100.0, 100.0, 10.0], 70.0, 120000
+    B = 32
+    pr = synth.pair_3d(torch.arange(1, B + 1, device=dev), device=dev)
+    sweeps = torch.cat([pr["fixed"], pr["moving"]]).contiguous()                  # [64, 200000, 3]
+    NP = int(sweeps.shape[1])
+    ms = N.MapSet(res, [0, 0, 0], size, n_maps=2 * B, max_cells=cap)
+    ms.profiling(True)
+    st = torch.cuda.current_stream()
+    Ti = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)
+    T16 = Ti.clone()
+    results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    ti = torch.arange(B, dtype=torch.int32, device=dev)
+    si = ti + B
+    build_ms = _timed(torch, lambda: ms.build(sweeps, range_limit=rng, stream=st))
+    cells = ms.num_cells_all().astype(np.float64)
+
+    def match():
+        T16.copy_(Ti)
+        binding.match_batch_device(ms, ti, ms, si, T16, results, B, stream=st)
+    match_ms = _timed(torch, match)
+    r = results.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
+    step_ms = _timed(torch, lambda: (ms.build(sweeps, range_limit=rng, stream=st), match()))
+    build_bytes = 2 * B * 12.0 * NP + 80.0 * cells.sum()
+    gflop = (130.0 * float(r["pair_terms_g"].sum()) + 610.0 * float(r["pair_terms_h"].sum())) / 1e9
+    # one pair, host-synchronous (cooperative launches: the registration is spread over the chip)
+    one = N.MapSet(res, [0, 0, 0], size, n_maps=2, max_cells=cap)
+    two = torch.stack([pr["fixed"][0], pr["moving"][0]]).contiguous()
+    T0 = pr["T_init"][0].cpu().numpy()
+    pair_ms = _timed(torch, lambda: (one.build(two, range_limit=rng, stream=st), N.match_d2d(one, 0, one, 1, T0)))
+    out = {"metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)", "value": B / (step_ms * 1e-3), "unit": "registrations/s",
+           "n_gpus": 1, "steps": 5, "warmup": 2, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "configs[4]: 3D mode, %d sweeps of %d points (64 rings), 0.25 m voxels, grid 100x100x10 m, range 70 m, "
+                                  "6-DoF D2D, n_neighbours 2; one step = build of the 64 sweeps + match of the 32 pairs (serial, one stream)" % (2 * B, NP),
+                      "mean_cells_per_map": float(cells.mean())},
+           "roofline": {"kernel": "ndt_build_kernel (MODE 1 accumulate + MODE 2/3 finalise, 64 sweeps)", "bound": "hbm",
+                        "achieved": build_bytes / build_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": build_bytes / build_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "algorithmic bytes 12 N + 80 M per sweep / wall time of the build call (three launches); atomic-rate "
+                                "bound: ~1 flush record per 6 points on ring-ordered sweeps (DESIGN.md 7)"},
+           "kernels": {"build_64_sweeps": {"ms": build_ms, "points_per_s": 2 * B * NP / (build_ms * 1e-3), "algorithmic_bytes": build_bytes},
+                       "match_32_pairs": {"ms": match_ms, "fp64_gflop": gflop, "fp64_tflops": gflop / match_ms,
+                                          "frac_of_fp64_peak": gflop / match_ms / 78.6, "mean_iterations": float(r["iterations"].mean()),
+                                          "converged_frac": float(r["converged"].mean()),
+                                          "note": "persistent matcher, one registration per workgroup slot: 32 registrations of ~12 k "
+                                                  "source cells on 32 CUs (a batch that cannot fill the chip)"}},
+           "single_pair": {"ms_build_x2_plus_match": pair_ms, "note": "host-synchronous ndtgpu_mapset_build + ndtgpu_match_d2d (cooperative launches)"}}
+    print(json.dumps(out))
+
+
+def config_fuse(args, torch, N, binding, synth, dev):
+    """The node-map path of SURVEY 8(f): ndtgpu_mapset_add_cloud (= NDTMap::addPointCloud + computeNDTCells: ray tracing,
+    accumulate, finalise) of 256 node maps with one 100 k-point cloud each, then the per-link work of the offline
+    refinement on 200 fused node maps (16 scans each): matcher, NDTMatcherD2D::covariance and overlapNDTOccupancyScore of
+    all 19 900 links.  Algorithmic bytes per add_cloud: 12 N (points) + 12 slots (occupancy + evidence) + 2 x 80 M (cells)."""
+    res, size, rng = args.res, [100.0, 100.0, 1.0], 30.0
+    NP, Bm = args.points, 256
+    poses = torch.zeros((Bm, 3), dtype=torch.float64)
+    poses[:, 0] = torch.linspace(-1.5, 1.5, Bm, dtype=torch.float64)
+    scans = synth.scan_2d(torch.full((Bm,), 77, dtype=torch.int64, device=dev), poses.to(dev), NP, chunk_bytes=2 << 30).contiguous()
+    ms = N.MapSet(res, [0, 0, 0], size, n_maps=Bm, max_cells=4096)
+    ms.enable_occupancy()
+    origins = np.concatenate([poses[:, :2].numpy(), np.zeros((Bm, 1))], axis=1)
+    st = torch.cuda.current_stream()
+
+    def add():
+        ms.clear()
+        ms.add_cloud(scans, origins, stream=st, maxz=100.0, sensor_noise=0.1)
+    add_ms = _timed(torch, add)
+    clear_ms = _timed(torch, lambda: ms.clear())
+    cells = ms.num_cells_all().astype(np.float64)
+    slots = int(size[0] / res) * int(size[1] / res) * max(1, int(size[2] / res))
+    add_bytes = Bm * (12.0 * NP + 12.0 * slots) + 2 * 80.0 * cells.sum()
+    # 200 fused node maps of 16 scans (20 k points each), all-pairs links
+    nn, ns, npts = 200, 16, 20000
+    nodes = N.MapSet(res, [0, 0, 0], size, n_maps=nn, max_cells=4096)
+    nodes.enable_occupancy()
+    t = torch.linspace(0.0, 2.0 * np.pi, nn + 1, dtype=torch.float64)[:-1]
+    node_pose = torch.stack([1.6 * torch.sin(t), 1.2 * torch.sin(2.0 * t + 0.3), 0.35 * torch.sin(3.0 * t)], dim=1)
+    node_T = synth.pose2d_to_T(node_pose).numpy()
+    c0 = time.perf_counter()
+    for k in range(ns):
+        p = node_pose.clone()
+        p[:, 0] += 0.01 * k * torch.cos(node_pose[:, 2]); p[:, 1] += 0.01 * k * torch.sin(node_pose[:, 2])
+        sc = synth.scan_2d(torch.full((nn,), 321, dtype=torch.int64, device=dev), p.to(dev), npts).contiguous()
+        # the cloud in the node frame: the scan frame is 1 cm x k ahead of the node frame
+        sc[:, :, 0] += 0.01 * k
+        org = np.tile(np.array([[0.01 * k, 0.0, 0.0]]), (nn, 1))
+        nodes.add_cloud(sc, org, stream=st, **(dict(maxz=100.0, sensor_noise=0.1) if k == 0 else dict(maxz=25.0, sensor_noise=0.06)))
+    torch.cuda.synchronize()
+    fuse_total_ms = 1e3 * (time.perf_counter() - c0)
+    iu = np.triu_indices(nn, 1)
+    ti, si = iu[0].astype(np.uint32), iu[1].astype(np.uint32)
+    T0 = np.einsum("eij,ejk->eik", np.linalg.inv(node_T[ti]), node_T[si])
+    n_links = len(ti)
+    holder = {}
+
+    def m():
+        holder["T"], holder["r"] = N.match_batch(nodes, ti, nodes, si, T0, delta_score=1e-3)
+    match_ms = _timed(torch, m, reps=3, warm=1)
+    cov_ms = _timed(torch, lambda: binding.covariance(nodes, ti, nodes, si, holder["T"]), reps=3, warm=1)
+    ovl_ms = _timed(torch, lambda: binding.overlap_score(nodes, ti, nodes, si, holder["T"]), reps=3, warm=1)
+    r = holder["r"]
+    mcells = nodes.num_cells_all().astype(np.float64)
+    gflop = (130.0 * float(r["pair_terms_g"].sum()) + 610.0 * float(r["pair_terms_h"].sum())) / 1e9
+    cov_bytes = n_links * 80.0 * 2 * mcells.mean()          # both cell maps of a link, once (they then live in L2)
+    ovl_bytes = n_links * 4.0 * slots * 2                   # the occupancy arrays of both maps
+    out = {"metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)", "value": n_links / (match_ms * 1e-3), "unit": "registrations/s",
+           "n_gpus": 1, "steps": 3, "warmup": 1, "ms_per_step": match_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "node-map path (SURVEY 8f): add_cloud of %d node maps x %d points; %d links of %d fused node maps (%d scans x %d "
+                                  "points each): matcher (edge preset), covariance, occupancy overlap; host arrays in and out" % (Bm, NP, n_links, nn, ns, npts),
+                      "mean_cells_fused_map": float(mcells.mean())},
+           "roofline": {"kernel": "ndtgpu_mapset_add_cloud = ndt_raytrace_kernel + ndt_build_kernel<.,1> + ndt_fuse_finalize_kernel", "bound": "hbm",
+                        "achieved": add_bytes / add_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": add_bytes / add_ms / 1e6 / HBM_PEAK_GBS,
+                        "traffic": None,
+                        "note": "algorithmic bytes (12 N + 12 slots) per map + 2 x 80 M / wall time of the call (three launches, includes the "
+                                "clear of the previous content: %.3f ms); the ray walk is VALU bound (~30 samples per beam, 3 exact cell "
+                                "indices per sample), profiles/r03_fuse_*" % clear_ms},
+           "kernels": {"add_cloud_256_maps": {"ms": add_ms, "us_per_scan": 1e3 * add_ms / Bm, "algorithmic_bytes": add_bytes},
+                       "fuse_200_nodes_16_scans": {"ms_total_incl_synthesis": fuse_total_ms},
+                       "match_links": {"ms": match_ms, "us_per_link": 1e3 * match_ms / n_links, "fp64_gflop": gflop,
+                                       "frac_of_fp64_peak": gflop / match_ms / 78.6, "converged_frac": float(r["converged"].mean()),
+                                       "mean_iterations": float(r["iterations"].mean())},
+                       "covariance_links": {"ms": cov_ms, "us_per_link": 1e3 * cov_ms / n_links, "algorithmic_bytes": cov_bytes,
+                                            "GBps": cov_bytes / cov_ms / 1e6},
+                       "overlap_links": {"ms": ovl_ms, "us_per_link": 1e3 * ovl_ms / n_links, "algorithmic_bytes": ovl_bytes,
+                                         "GBps": ovl_bytes / ovl_ms / 1e6, "frac_of_hbm_peak": ovl_bytes / ovl_ms / 1e6 / HBM_PEAK_GBS}}}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,8 +336,9 @@ def main():
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--res", type=float, default=0.5)
     ap.add_argument("--cpu-sample", type=int, default=128, help="pairs timed on the CPU oracle (0 = skip): 6 passes of ~2 s")
-    ap.add_argument("--config", type=int, default=3, choices=[3, 4],
-                    help="3: BASELINE configs[2], the batch the metric is quoted on (default); 4: configs[3], the graph replay harness")
+    ap.add_argument("--config", type=str, default="3", choices=["3", "4", "5", "fuse"],
+                    help="3: BASELINE configs[2], the batch the metric is quoted on (default); 4: configs[3], the graph replay harness; "
+                         "5: configs[4], 3D mode; fuse: the node-map path (add_cloud, link covariance and overlap)")
     ap.add_argument("--nodes", type=int, default=1000, help="--config 4: node maps (5000 = the full config; 1000 by default)")
     ap.add_argument("--gated", action="store_true", help="--config 4: only the edges the reference's link gates keep")
     ap.add_argument("--no-cpu", action="store_true")
@@ -212,8 +367,12 @@ def main():
     B, NP, res = args.pairs, args.points, args.res
     size_m = [100.0, 100.0, 1.0]           # gustav_laser_tf.launch:16-18
     rng_lim = 30.0                          # sensor_range, launch:22
-    if args.config == 4:
+    if args.config == "4":
         return config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_lim)
+    if args.config == "5":
+        return config5(args, torch, N, binding, synth, dev)
+    if args.config == "fuse":
+        return config_fuse(args, torch, N, binding, synth, dev)
 
     # ---- synthetic batch, generated on the GPU, resident in HBM before the timed region -----
     seeds = torch.arange(1 + rank * B, 1 + (rank + 1) * B, dtype=torch.int64, device=dev)

@@ -1,8 +1,10 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + HBM PMC counters of the bench command.
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + HBM PMC counters of the bench command, and of the
+# 3D (--config 5) and node-map (--config fuse) benches.
 # PMC passes are separate (--pmc never combined with trace domains) and restricted to our kernels.
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
+ulimit -c 0
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o bench -- $CMD > gpurun_out/bench_kt.log 2>&1
 # the same workload without the pipeline: kernel durations with the chip to themselves
@@ -10,6 +12,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_seria
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_fetch -o bench -- $CMD > gpurun_out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_write -o bench -- $CMD > gpurun_out/bench_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_sq -o bench -- $CMD > gpurun_out/bench_sq.log 2>&1
+for c in 5 fuse; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_$c -o bench -- python bench.py --config $c > gpurun_out/bench_kt_$c.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_fetch_$c -o bench -- python bench.py --config $c > gpurun_out/bench_fetch_$c.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_write_$c -o bench -- python bench.py --config $c > gpurun_out/bench_write_$c.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_sq_$c -o bench -- python bench.py --config $c > gpurun_out/bench_sq_$c.log 2>&1
+  python bench.py --config $c > gpurun_out/bench_c$c.log 2>&1
+done
 python bench.py > gpurun_out/bench_full.log 2>&1
-tail -1 gpurun_out/bench_full.log
-find gpurun_out/prof_kt gpurun_out/prof_kt_serial gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq -name "*.csv" | head -20
+tail -1 gpurun_out/bench_full.log | cut -c1-400
+tail -1 gpurun_out/bench_c5.log | cut -c1-400
+tail -1 gpurun_out/bench_cfuse.log | cut -c1-400
+find gpurun_out/prof_kt gpurun_out/prof_kt_serial gpurun_out/prof_kt_5 gpurun_out/prof_kt_fuse gpurun_out/prof_sq_fuse -name "*.csv" | head -20

@@ -2,7 +2,7 @@
 """Turns gpurun_out/prof_* (rocprofv3 CSV) into the committed profiles/rNN_* summaries.
 usage: python tools/summarize_profiles.py r02"""
 import collections, csv, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 # kernel stats
@@ -51,3 +51,46 @@ for key, r in serial.items():
     out["kernels"][key]["avg_ns_serial"] = float(r["AverageNs"])
 json.dump(out, open(os.path.join(pr, "%s_pmc_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
+
+
+# ---- the 3D (--config 5) and node-map (--config fuse) benches: kernel statistics + per-kernel counters -------------
+import re
+def short(name):
+    return re.sub(r"<.*", "", name.replace("void ", "")).split("(")[0].strip()
+for c in ("5", "fuse"):
+    kt = os.path.join(go, "prof_kt_%s" % c, "bench_kernel_stats.csv")
+    if not os.path.exists(kt):
+        continue
+    rows = list(csv.DictReader(open(kt)))
+    with open(os.path.join(pr, "%s_c%s_kernel_stats.csv" % (tag, c)), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(list(rows[0].keys()))
+        for r in rows[:24]:
+            w.writerow([(v[:110] if isinstance(v, str) else v) for v in r.values()])
+    def pmc_all(dirname):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        fn = os.path.join(go, dirname, "bench_counter_collection.csv")
+        if not os.path.exists(fn):
+            return {}
+        for r in csv.DictReader(open(fn)):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        return {k: {cn: sum(v) / len(v) for cn, v in d.items()} for k, d in agg.items()}
+    fe, wr, sq_ = pmc_all("prof_fetch_%s" % c), pmc_all("prof_write_%s" % c), pmc_all("prof_sq_%s" % c)
+    res = {"round": tag, "lib_version": out["lib_version"], "command": "python bench.py --config %s" % c,
+           "note": out["note"] + "  Averages over ALL dispatches of a kernel name in the run (several launch shapes of ndt_build_kernel share a name).",
+           "kernels": {}}
+    for k in sorted(set(fe) | set(wr) | set(sq_)):
+        d = {"sq_per_dispatch": sq_.get(k, {})}
+        if k in fe and k in wr:
+            d.update({"FETCH_SIZE_KB": fe[k]["FETCH_SIZE"], "WRITE_SIZE_KB": wr[k]["WRITE_SIZE"],
+                      "hbm_bytes_per_launch": 2 * fe[k]["FETCH_SIZE"] * 1024 + wr[k]["WRITE_SIZE"] * 1024})
+        q = d["sq_per_dispatch"]
+        if q.get("SQ_WAVE_CYCLES"):
+            d["wait_any_over_wave_cycles"] = q.get("SQ_WAIT_ANY", 0) / q["SQ_WAVE_CYCLES"]
+            d["valu_per_wave"] = q.get("SQ_INSTS_VALU", 0) / max(1.0, q.get("SQ_WAVES", 1))
+        for r in rows:
+            if short(r["Name"]) == k:
+                d.setdefault("avg_ns_by_shape", []).append([r["Name"][:70], float(r["AverageNs"]), int(r["Calls"])])
+        res["kernels"][k] = d
+    json.dump(res, open(os.path.join(pr, "%s_c%s_pmc.json" % (tag, c)), "w"), indent=1)
+    print("config", c, "->", list(res["kernels"].keys()))
