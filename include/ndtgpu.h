@@ -246,12 +246,38 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *target_set, const uint32_
  * Tcov36: HOST, n_pairs x 36 doubles, row-major 6x6 covariance of (x,y,z,roll,pitch,yaw).
  * use_soft_constraints is a bit set: bit 0 = useSoftConstraints, bit 1 = useTikhonovRegularization (fusion.h:894-911,
  * 1113-1115: g <- H^T g + Q x0, H <- H^T H + Q, score += x0^T Q x0 with x0 the 2D pose vector of T Tinit^-1 and
- * Q = Tcov^-1); 0 degenerates to ndtgpu_match_batch.  Feature terms (FLIRT) are not part of the path (disabled in
- * every shipped configuration). */
+ * Q = Tcov^-1); 0 degenerates to ndtgpu_match_batch.  Feature / odometry-cell maps: ndtgpu_match_fusion_feat_batch. */
 ndtgpu_status ndtgpu_match_fusion_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx,
                                         ndtgpu_mapset *source_set, const uint32_t *source_idx, double *T16,
                                         const double *Tcov36, size_t n_pairs, const ndtgpu_match_params *prm,
                                         int use_soft_constraints, ndtgpu_match_result *results, ndtgpu_stream stream);
+/* The feature / odometry-cell maps of ndt_feature::matchFusion (targetNDT_feat, sourceNDT_feat, corr_feat;
+ * ndt_matcher_d2d_fusion.h:797-801): two CellVector maps whose cells correspond one to one.  The fuser fills them with
+ * FLIRT matches and / or 40 copies of an odometry cell pair (ndt_feature_fuser_hmt.cpp:291-334: target mean
+ * Tnow * Tmotion.translation(), source mean Tinit * 0, covariance odom_cov, the last source cell un-rotated).
+ * Correspondence i of registration k is entry offsets[k] + i of the four arrays (corr_feat[i] = (i, i)); at most 64 per
+ * registration.  All arrays HOST. */
+typedef struct ndtgpu_feat_pairs {
+    const uint32_t *offsets;     /* [n_pairs + 1], non-decreasing */
+    const double *src_mean;      /* [total][3]   cells of sourceNDT_feat: moved by T like the source map */
+    const double *src_cov;       /* [total][6]   xx xy xz yy yz zz */
+    const double *tgt_mean;      /* [total][3]   cells of targetNDT_feat */
+    const double *tgt_cov;       /* [total][6] */
+} ndtgpu_feat_pairs;
+/* ndt_feature::matchFusion with useFeat (ndt_matcher_d2d_fusion.h:797-1155; call site ndt_feature_fuser_hmt.cpp:353-357
+ * with use_odom_or_features): per Newton iteration the sums of NDTMatcherFeatureD2D::derivativesNDT over the
+ * correspondences (the same pair term as the D2D matcher, known correspondence) are added to the NDT sums (fusion.h:858-
+ * 871); with step control NDTMatcherD2D::lineSearchMT runs on the NDT maps, then NDTMatcherFeatureD2D::lineSearchMT on
+ * the feature maps with the (possibly negated) increment the first one left, and the step is the smaller of the two, the
+ * larger one when either is 0 (fusion.h:1013-1023); the final score includes the feature score (fusion.h:1085-1096).
+ * flags: bit 0 useSoftConstraints, bit 1 useTikhonovRegularization, bit 2 step_control_fusion.  With bit 2 set and bit 0
+ * clear the reference runs the JOINT line search lineSearchMTFusion (fusion.h:390-793) instead: NOT built, rejected
+ * with NDTGPU_ERR_INVALID.  `fevals` counts derivative evaluations of the NDT maps.  feat == NULL: ndtgpu_match_fusion_batch. */
+ndtgpu_status ndtgpu_match_fusion_feat_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx,
+                                             ndtgpu_mapset *source_set, const uint32_t *source_idx, double *T16,
+                                             const double *Tcov36, const ndtgpu_feat_pairs *feat, size_t n_pairs,
+                                             const ndtgpu_match_params *prm, int flags, ndtgpu_match_result *results,
+                                             ndtgpu_stream stream);
 /* NDTMatcherD2D::covariance(target, source, T, cov) for n_links registered links (ndt_feature_graph.cpp:296-298;
  * ndt_feature_fuser_hmt.cpp:403-405): cov = H^-1 (0.03^2 J^T J) H^-1, H = D2D Hessian at T (prm->n_neighbours, lfd1,
  * lfd2), one row of J per source cell that falls into a Gaussian target cell.  PROVENANCE: perception_oru, restated from

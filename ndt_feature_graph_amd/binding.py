@@ -110,7 +110,8 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_last_kernel_ms", "ndtgpu_mapset_counters", "ndtgpu_match_fusion_batch",
            "ndtgpu_mapset_enable_occupancy", "ndtgpu_default_fuse_params", "ndtgpu_mapset_add_cloud",
            "ndtgpu_mapset_add_cloud_host", "ndtgpu_mapset_clear", "ndtgpu_mapset_export_occupancy",
-           "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch", "ndtgpu_mapset_discard_cells", "ndtgpu_mapset_import_occupancy"]
+           "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch", "ndtgpu_mapset_discard_cells", "ndtgpu_mapset_import_occupancy",
+           "ndtgpu_match_fusion_feat_batch"]
 
 _lib = None
 
@@ -399,6 +400,39 @@ def match_fusion_batch(target_set, target_idx, source_set, source_idx, T, Tcov, 
                                            si.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), _dp(cov), n, C.byref(p),
                                            int(bool(use_soft_constraints)) | (2 if tikhonov else 0), C.c_void_p(res.ctypes.data),
                                            _stream_ptr(stream)))
+    return np.transpose(Tc, (0, 2, 1)).copy(), res
+
+
+class FeatPairs(C.Structure):
+    _fields_ = [("offsets", C.POINTER(C.c_uint32)), ("src_mean", C.POINTER(C.c_double)), ("src_cov", C.POINTER(C.c_double)),
+                ("tgt_mean", C.POINTER(C.c_double)), ("tgt_cov", C.POINTER(C.c_double))]
+
+
+def match_fusion_feat_batch(target_set, target_idx, source_set, source_idx, T, Tcov, feat, use_soft_constraints=True,
+                            tikhonov=False, step_control_fusion=False, stream=None, **params):
+    """ndt_feature::matchFusion with feature / odometry-cell maps.  feat: one entry per pair, each a tuple
+    (src_mean [k,3], src_cov [k,6], tgt_mean [k,3], tgt_cov [k,6]) of k <= 64 corresponding cells (k may be 0)."""
+    ti = np.ascontiguousarray(target_idx, dtype=np.uint32)
+    si = np.ascontiguousarray(source_idx, dtype=np.uint32)
+    n = ti.shape[0]
+    Tc = np.ascontiguousarray(np.transpose(np.asarray(T, dtype=np.float64).reshape(n, 4, 4), (0, 2, 1))).copy()
+    cov = np.ascontiguousarray(np.asarray(Tcov, dtype=np.float64).reshape(n, 36))
+    off = np.zeros(n + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([len(f[0]) for f in feat])
+    cat = lambda j, w: np.ascontiguousarray(np.concatenate([np.asarray(f[j], dtype=np.float64).reshape(-1, w) for f in feat]
+                                                           + [np.zeros((1, w))]))
+    sm, sc, tm, tc = cat(0, 3), cat(1, 6), cat(2, 3), cat(3, 6)
+    fp = FeatPairs(off.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(sm), _dp(sc), _dp(tm), _dp(tc))
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    p = match_params(**params)
+    L = lib()
+    L.ndtgpu_match_fusion_feat_batch.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.POINTER(C.c_uint32),
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(FeatPairs), C.c_size_t,
+                                                 C.POINTER(MatchParams), C.c_int, C.c_void_p, C.c_void_p]
+    flags = int(bool(use_soft_constraints)) | (2 if tikhonov else 0) | (4 if step_control_fusion else 0)
+    _check(L.ndtgpu_match_fusion_feat_batch(target_set.h, ti.ctypes.data_as(C.POINTER(C.c_uint32)), source_set.h,
+                                            si.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), _dp(cov), C.byref(fp), n,
+                                            C.byref(p), flags, C.c_void_p(res.ctypes.data), _stream_ptr(stream)))
     return np.transpose(Tc, (0, 2, 1)).copy(), res
 
 

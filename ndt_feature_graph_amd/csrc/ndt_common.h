@@ -160,7 +160,8 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_de
                                  unsigned n_groups, unsigned cells_per_group, void *work_dev, hipStream_t stream);
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                            NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters, int slots,
+                            NdtMatchResultDev *res_dev, const double *Q36_dev, const unsigned *feat_off_dev,
+                            const double *feat_cells_dev, unsigned n_groups, int park_iters, int slots,
                             unsigned double_thresh, void *work_dev, hipStream_t stream);
 hipError_t ndt_launch_covariance(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                                  const uint32_t *sidx_dev, const double *T16_dev, size_t n_links, int n_neighbours,

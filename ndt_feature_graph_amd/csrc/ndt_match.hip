@@ -689,6 +689,12 @@ struct MatchSlot {
     int with_h;                     // the request: evaluate with the Hessian?
     int preset;                     // a fresh ticket drawn while parking (-1: none)
     int resumed;                    // the registration came from the parked list
+    // matchFusion feature / odometry-cell maps with known correspondence (fusion.h:858-871): n_feat pairs of
+    // {source mean[3], cov[6], target mean[3], cov[6]} in global memory, their sums at the Newton pose / a trial pose
+    const double *feat;
+    unsigned n_feat;
+    int code;                       // hand-over of a stage's NEXT_* code from lane 0 to the wave
+    double fsums[32], ftrial[8];
     long long t_pub;                // (timeline builds) shader clock when the running request was published
     unsigned long long wall;        // (timeline builds) sum over evaluations of publish -> last share delivered
 };
@@ -740,6 +746,115 @@ NDT_D void slot_result(const MatchSlot<QL> &S, double *T16, NdtMatchResultDev *r
 #endif
 }
 
+// NDTMatcherFeatureD2D::derivativesNDT: the pair terms of the n <= 64 correspondences, source cells moved by T
+// (pseudoTransformNDT), one term per lane; out[0] score, [1..6] gradient, [7..27] Hessian (WITH_H).  All lanes.
+template <bool WITH_H>
+NDT_D void feat_eval(const double *__restrict__ feat, unsigned n, const rigid &T, double lfd1, double lfd2, double *out)
+{
+    constexpr int NACC = WITH_H ? 28 : 7, NP = WITH_H ? 32 : 8, SH = WITH_H ? 1 : 3;
+    const unsigned lane = threadIdx.x & 63u;
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+    if (lane < n) {
+        const double *c = feat + (size_t)lane * 18;
+        const d3 m = apply(T, d3{c[0], c[1], c[2]});
+        const sym3 C = rotate_cov(T.r, sym3{c[3], c[4], c[5], c[6], c[7], c[8]});
+        pair_term<WITH_H>(m, C, d3{c[9], c[10], c[11]}, sym3{c[12], c[13], c[14], c[15], c[16], c[17]}, lfd1, lfd2, acc);
+    }
+    double vv[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) vv[k] = k < NACC ? acc[k] : 0.0;
+    const double tot = wave_sum_all<NP>(vv);
+    if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) out[lane >> SH] = tot;
+}
+
+// matcher_feat_d2d.lineSearchMT(pose_increment_v, nextNDT_feat, targetNDT_feat) (fusion.h:1015-1017) after the NDT line
+// search, then fusion.h:1018-1032: the smaller of the two steps (the larger one when either is 0) and the pose update.
+// The More-Thuente driver is the one of the NDT search (same block st.mt, same stages), fed with the feature sums; a
+// trial costs one pair-term batch of this wave, no share tasks.  Its evaluations are not counted in `fevals` (which
+// counts derivative evaluations of the NDT maps).  All lanes.
+template <int QL>
+NDT_D void feat_linesearch_and_apply(MatchSlot<QL> &S, const NdtMatchParamsDev &prm)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    MatchState &st = S.st;
+    if (lane == 0) {
+        st.step_ndt = st.step_size;
+        st.fevals_saved = st.fevals;
+        // what survives of the NDT search: was its first trial (evaluated with its Hessian) accepted at full length?
+        S.code = (st.reuse_sums ? 4 : 0) | (st.spec_ok ? 8 : 0);
+        double dg0 = 0;
+        for (int a = 0; a < 6; a++) dg0 += st.incr[a] * S.fsums[1 + a];
+        if (dg0 >= 0.0) S.code |= 16;                      // the feature search negates the increment in place
+        S.code |= mt_start(st, S.fsums[0], S.fsums + 1) << 8;
+    }
+    ndt_wave_sync();
+    const int keep = S.code & 0xff;
+    int next = S.code >> 8;
+    while (next == NEXT_REQUEST_TRIAL) {
+        if (lane == 0) mt_request_trial(st);
+        ndt_wave_sync();
+        feat_eval<false>(S.feat, S.n_feat, st.Teval, prm.lfd1, prm.lfd2, S.ftrial);
+        ndt_wave_sync();
+        if (lane == 0) S.code = linesearch_step(st, S.ftrial, prm);
+        ndt_wave_sync();
+        next = S.code;
+    }
+    if (lane == 0) {
+        const double step_feat = st.step_size, step_ndt = st.step_ndt;
+        double step;
+        if (step_ndt != 0.0 && step_feat != 0.0) step = step_ndt < step_feat ? step_ndt : step_feat;
+        else step = step_ndt > step_feat ? step_ndt : step_feat;
+        st.fevals = st.fevals_saved;
+        st.spec_ok = (keep & 8) ? 1 : 0;
+        // the Hessian sums of an accepted first NDT trial belong to the pose T would have had after that step
+        st.reuse_sums = ((keep & 4) && !(keep & 16) && step == step_ndt) ? 1 : 0;
+        st.step_size = step;
+        apply_step(st, prm);
+    }
+    ndt_wave_sync();
+}
+
+// The solver step of a slot whose evaluation (S.sums) is complete.  Without feature maps: match_state_step on lane 0.
+// With them the wave walks the same stages itself, because the feature sums are evaluated by all of its lanes.
+template <int QL>
+NDT_D void slot_step(MatchSlot<QL> &S, const NdtMatchParamsDev &prm)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    MatchState &st = S.st;
+    if (S.n_feat == 0u) {
+        if (lane == 0) match_state_step(st, S.sums, prm, S.ws);
+        return;
+    }
+    int phase = st.phase;
+    if (phase == PH_LS_TRIAL) {
+        if (lane == 0) { st.reuse_sums = 0; S.code = linesearch_step(st, S.sums, prm); }
+        ndt_wave_sync();
+        if (S.code == NEXT_REQUEST_TRIAL) { if (lane == 0) mt_request_trial(st); return; }
+        feat_linesearch_and_apply(S, prm);                // the NDT search is over: st.step_size = step_size_ndt
+        if (!st.reuse_sums) return;
+        phase = st.phase;
+    }
+    if (phase == PH_NEWTON) {
+        feat_eval<true>(S.feat, S.n_feat, st.Teval, prm.lfd1, prm.lfd2, S.fsums);
+        ndt_wave_sync();
+        if (lane == 0) S.code = newton_solve(st, S.sums, S.fsums, prm, S.ws);
+        ndt_wave_sync();
+        const int next = S.code;
+        if (next == NEXT_NONE) return;
+        if (next == NEXT_REQUEST_TRIAL) { if (lane == 0) mt_request_trial(st); return; }
+        // NEXT_APPLY_STEP: no step control (full step), or the NDT search gave its recovery step at once
+        if (!prm.step_control) { if (lane == 0) apply_step(st, prm); return; }
+        if (lane == 0) st.reuse_sums = 0;
+        feat_linesearch_and_apply(S, prm);
+    } else if (phase == PH_FINAL) {
+        feat_eval<false>(S.feat, S.n_feat, st.Teval, prm.lfd1, prm.lfd2, S.fsums);
+        ndt_wave_sync();
+        if (lane == 0) match_state_final(st, S.sums, S.fsums);
+    }
+}
+
 NDT_D unsigned lds_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 NDT_D void lds_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 NDT_D unsigned clock_lo() { return (unsigned)__builtin_readcyclecounter(); }
@@ -750,6 +865,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
     double *__restrict__ T16, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res,
     const double *__restrict__ Q36 /* per pair Tcov^-1 (matchFusion) or NULL */,
+    const unsigned *__restrict__ feat_off /* [n_pairs + 1] first correspondence of every pair, or NULL */,
+    const double *__restrict__ feat_cells /* 18 doubles per correspondence */,
     unsigned n_pairs, int park_iters, unsigned double_thresh, char *__restrict__ work_mem)
 {
     constexpr int QL = 1024;
@@ -897,6 +1014,13 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                         if (S.st.done) { slot_result(S, T16, res); continue; }   // parameters the solver rejects
                     }
                     NDT_TL(pair, resumed ? 2 : 0)
+                    S.n_feat = 0u; S.feat = nullptr;
+                    if (feat_off) {
+                        const unsigned f0 = feat_off[pair], f1 = feat_off[pair + 1u];
+                        S.n_feat = f1 > f0 ? (f1 - f0 > 64u ? 64u : f1 - f0) : 0u;     // (the host refused more than 64)
+                        S.feat = feat_cells + (size_t)f0 * 18;
+                    }
+                    S.st.use_feat = S.n_feat ? 1 : 0;
                     S.resumed = resumed ? 1 : 0;
                     S.session = atomicAdd(&s_session, 1u) + 1u;      // (a workgroup never sees 2^32 registrations)
                     S.with_h = S.st.with_h;
@@ -947,13 +1071,14 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
             S.sums[lane] = a;             // [28]: number of (source, target) pair terms of this evaluation
         }
         ndt_wave_sync();
+        const long long c1 = __builtin_readcyclecounter();
+        slot_step(S, s_prm);
+        ndt_wave_sync();
         if (lane == 0) {
-            const long long c1 = __builtin_readcyclecounter();
 #ifdef NDT_MATCH_TL
             S.wall += (unsigned long long)(c1 - S.t_pub);
 #endif
             S.cnt[S.with_h ? 3 : 2] += (unsigned long long)S.sums[28];
-            match_state_step(S.st, S.sums, s_prm, S.ws);
             S.cnt[1] += (unsigned long long)((long long)__builtin_readcyclecounter() - c1);
             bool release = false;
             if (S.st.done) {
@@ -1378,7 +1503,8 @@ hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView
 
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
-                            NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups, int park_iters,
+                            NdtMatchResultDev *res_dev, const double *Q36_dev, const unsigned *feat_off_dev,
+                            const double *feat_cells_dev, unsigned n_groups, int park_iters,
                             int slots, unsigned double_thresh, void *work_dev, hipStream_t stream)
 {
     if (n_pairs == 0) return hipSuccess;
@@ -1390,10 +1516,10 @@ hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, co
     do {                                                                                                             \
         if (slots == 2)                                                                                              \
             hipLaunchKernelGGL((ndt_match_kernel<NN, 2>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev, sset, \
-                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, double_thresh, (char *)work_dev); \
+                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, feat_off_dev, feat_cells_dev, (unsigned)n_pairs, park_iters, double_thresh, (char *)work_dev); \
         else                                                                                                         \
             hipLaunchKernelGGL((ndt_match_kernel<NN, 1>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev, sset, \
-                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, (unsigned)n_pairs, park_iters, double_thresh, (char *)work_dev); \
+                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, feat_off_dev, feat_cells_dev, (unsigned)n_pairs, park_iters, double_thresh, (char *)work_dev); \
     } while (0)
     switch (prm.n_neighbours) {
     case 0: NDT_LAUNCH_MATCH(0); break;

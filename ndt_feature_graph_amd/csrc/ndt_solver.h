@@ -47,6 +47,11 @@ struct MatchState {
     int use_prior;
     double pose_local[6];
     double Q[36];
+    // matchFusion feature / odometry-cell terms (fusion.h:858-871, 1013-1023): the feature maps' sums are added to the
+    // NDT sums in the Newton system; the step is the smaller of the two line searches (NDT, then features)
+    int use_feat;
+    double step_ndt;       // result of the NDT line search while the feature line search runs
+    int fevals_saved, pad_feat;
     // matchFusion generalised Tikhonov regularisation (fusion.h:894-911): x0 = 2D pose vector of T Tinit^-1
     int use_tikhonov;
     rigid Tinit_inv;
@@ -288,10 +293,11 @@ NDT_HD void newton_mask(double (&H)[6][6], double (&g)[6], const NdtMatchParamsD
 }
 
 // stage 1: score, best pose, Hessian / gradient assembly (fusion.h:857-920), inactive dofs, gradient norm
-NDT_HDN void newton_assemble(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, NewtonWs &ws)
+NDT_HDN void newton_assemble(MatchState &st, const double *sums, const double *fsums, const NdtMatchParamsDev &prm, NewtonWs &ws)
 {
     st.fevals++;
     st.score_here = sums[0];
+    if (st.use_feat) st.score_here += fsums[0];          // fusion.h:863-871: score_here_ndt + score_here_feat
     if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:875-890
     if (!st.use_tikhonov && st.score_here < st.score_best) {   // fusion.h:914-920 (with Tikhonov: after its term, below)
         st.Tbest = st.T;
@@ -306,7 +312,11 @@ NDT_HDN void newton_assemble(MatchState &st, const double *sums, const NdtMatchP
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
-            for (int b = a; b < 6; b++) { H[a][b] = sums[o]; H[b][a] = sums[o]; o++; }
+            for (int b = a; b < 6; b++) {
+                double h = sums[o];
+                if (st.use_feat) h += fsums[o];     // Hessian += Hessian_feat
+                H[a][b] = h; H[b][a] = h; o++;
+            }
     }
     if (st.use_prior) {                    // + computeHessianMahalanobis = Q + Q^T   (fusion.h:11-22)
 #pragma unroll
@@ -317,6 +327,7 @@ NDT_HDN void newton_assemble(MatchState &st, const double *sums, const NdtMatchP
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         g[a] = sums[1 + a];
+        if (st.use_feat) g[a] += fsums[1 + a];
         if (st.use_prior) {                // + computeGradientMahalanobis = (Q + Q^T) X   (fusion.h:29-32)
             double gp = 0;
 #pragma unroll
@@ -429,6 +440,35 @@ NDT_HDN void newton_ldlt(NewtonWs &ws)
     ndt_static_for<6>([&](auto I) __attribute__((always_inline)) { ws.dx[decltype(I)::value] = y[decltype(I)::value]; });
 }
 
+// head of lineSearchMT (fusion.h:444-521) on the function whose value and gradient at the current pose are finit / g6:
+// direction test (the increment is negated IN PLACE when it points uphill, recovery step when it still does), then the
+// More-Thuente block.  NEXT_APPLY_STEP: the search is over (st.step_size = recovery step); NEXT_REQUEST_TRIAL: st.mt is set up.
+NDT_HD int mt_start(MatchState &st, double finit, const double *g6)
+{
+    MTState m;
+    m.finit = finit;
+    m.dginit = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) m.dginit += st.incr[a] * g6[a];
+    if (m.dginit >= 0.0) {                // fusion.h:456-479
+        for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
+        m.dginit = -m.dginit;
+        if (m.dginit >= 0.0) {
+            st.step_size = 0.1;
+            return NEXT_APPLY_STEP;
+        }
+    }
+    m.stp = 1.0;
+    m.brackt = 0; m.stage1 = 1; m.nfev = 0; m.infoc = 1;
+    m.dgtest = 0.11111 * m.dginit;
+    m.width = 4.0 - 0.001;
+    m.width1 = 2 * m.width;
+    m.stx = 0.0; m.fx = m.finit; m.dgx = m.dginit;
+    m.sty = 0.0; m.fy = m.finit; m.dgy = m.dginit;
+    st.mt = m;
+    return NEXT_REQUEST_TRIAL;
+}
+
 // stage 5: the increment, the direction tests and the start of the line search (fusion.h:966-1031, 444-521)
 NDT_HDN int newton_finish(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, const NewtonWs &ws)
 {
@@ -467,29 +507,7 @@ NDT_HDN int newton_finish(MatchState &st, const double *sums, const NdtMatchPara
     // lineSearchMT: its initial derivativesNDT(nextNDT) equals this evaluation (same cells), so the
     // score and gradient are reused instead of being recomputed (fusion.h:444-453).  The step is decided by the
     // NDT-only line search on the NDT-only score.
-    MTState m;
-    m.finit = sums[0];
-    m.dginit = 0;
-#pragma unroll
-    for (int a = 0; a < 6; a++) m.dginit += st.incr[a] * sums[1 + a];
-    if (!st.use_prior && !st.use_tikhonov) m.dginit = dginit;
-    if (m.dginit >= 0.0) {                // fusion.h:456-479
-        for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
-        m.dginit = -m.dginit;
-        if (m.dginit >= 0.0) {
-            st.step_size = 0.1;
-            return NEXT_APPLY_STEP;
-        }
-    }
-    m.stp = 1.0;
-    m.brackt = 0; m.stage1 = 1; m.nfev = 0; m.infoc = 1;
-    m.dgtest = 0.11111 * m.dginit;
-    m.width = 4.0 - 0.001;
-    m.width1 = 2 * m.width;
-    m.stx = 0.0; m.fx = m.finit; m.dgx = m.dginit;
-    m.sty = 0.0; m.fy = m.finit; m.dgy = m.dginit;
-    st.mt = m;
-    return NEXT_REQUEST_TRIAL;
+    return mt_start(st, sums[0], sums + 1);
 }
 
 #if defined(NDT_SOLVER_STAGE_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -499,15 +517,16 @@ NDT_HDN int newton_finish(MatchState &st, const double *sums, const NdtMatchPara
 #define NDT_STAGE(k, call) { call; }
 #endif
 
-NDT_HD void newton_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, NewtonWs &ws)
+// one Newton iteration up to the start of the line search: what the caller runs next (NEXT_NONE: the registration is over)
+NDT_HD int newton_solve(MatchState &st, const double *sums, const double *fsums, const NdtMatchParamsDev &prm, NewtonWs &ws)
 {
-    NDT_STAGE(0, newton_assemble(st, sums, prm, ws))
+    NDT_STAGE(0, newton_assemble(st, sums, fsums, prm, ws))
     if (st.use_tikhonov) newton_tikhonov(st, prm, ws);
     if (ws.gnorm <= prm.delta_score) {     // fusion.h:943-965 (the regularisation before it has no other effect)
         if (st.score_here > st.score_best) st.T = st.Tbest;
         st.exit_code = 1;
         st.done = 1;
-        return;
+        return NEXT_NONE;
     }
     NDT_STAGE(1, newton_factor(ws))
     if (!ws.is_pd) {
@@ -516,16 +535,23 @@ NDT_HD void newton_step(MatchState &st, const double *sums, const NdtMatchParams
     }
     int next;
     NDT_STAGE(4, next = newton_finish(st, sums, prm, ws))
+    return next;
+}
+
+NDT_HD void newton_step(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, NewtonWs &ws)
+{
+    const int next = newton_solve(st, sums, nullptr, prm, ws);
     if (next == NEXT_APPLY_STEP) NDT_STAGE(5, apply_step(st, prm))
     else if (next == NEXT_REQUEST_TRIAL) NDT_STAGE(6, mt_request_trial(st))
 }
 
 // tail of the More-Thuente while(1) body after the trial evaluation (fusion.h:637-790)
 // last evaluation at the returned pose (fusion.h:1085-1121)
-NDT_HD void match_state_final(MatchState &st, const double *sums)
+NDT_HD void match_state_final(MatchState &st, const double *sums, const double *fsums = nullptr)
 {
     st.fevals++;
     st.score_here = sums[0];
+    if (st.use_feat) st.score_here += fsums[0];           // fusion.h:1085-1096
     if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:1098-1110
     if (st.use_tikhonov) st.score_here += tikhonov_score(st);   // fusion.h:1113-1115: x0 of the LAST Newton evaluation
     if (st.score_here > st.score_best) st.T = st.Tbest;
@@ -600,6 +626,7 @@ NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchPa
 {
     st.use_prior = Q36 != nullptr && (prm.fusion_flags & 1);
     st.use_tikhonov = Q36 != nullptr && (prm.fusion_flags & 2);
+    st.use_feat = 0; st.step_ndt = 0.0; st.fevals_saved = 0; st.pad_feat = 0;     // (set by the caller that has feature maps)
     for (int a = 0; a < 6; a++) st.x0[a] = 0.0;
     for (int a = 0; a < 6; a++) st.pose_local[a] = 0.0;
     for (int a = 0; a < 36; a++) st.Q[a] = Q36 ? Q36[a] : 0.0;

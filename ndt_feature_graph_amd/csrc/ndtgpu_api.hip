@@ -647,7 +647,8 @@ static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result 
 // The persistent matcher on device-resident arguments: asynchronous on `stream`.
 static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss, const uint32_t *sidx_dev,
                                        double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &p,
-                                       ndtgpu_match_result *results_dev, const double *Q36_dev, hipStream_t st)
+                                       ndtgpu_match_result *results_dev, const double *Q36_dev, hipStream_t st,
+                                       const unsigned *feat_off_dev = nullptr, const double *feat_cells_dev = nullptr)
 {
     if (n_pairs == 0) return NDTGPU_OK;
     // persistent workgroups, one per CU (8 waves x 256 VGPRs), each with `slots` registrations in flight whose evaluation
@@ -674,8 +675,8 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
     if (wrc != NDTGPU_OK) return wrc;
     if (ts->profiling) HIP_TRY(hipEventRecord(ts->ev[2], st));
     hipError_t e = ndt_launch_match(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p,
-                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, n_groups, park_iters, slots,
-                                    double_thresh, ts->work, st);
+                                    reinterpret_cast<NdtMatchResultDev *>(results_dev), Q36_dev, feat_off_dev, feat_cells_dev,
+                                    n_groups, park_iters, slots, double_thresh, ts->work, st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: launch", e);
     if (ts->profiling) { HIP_TRY(hipEventRecord(ts->ev[3], st)); ts->ev_valid[1] = true; }
     if (!ts->work_ev) HIP_TRY(hipEventCreateWithFlags(&ts->work_ev, hipEventDisableTiming));
@@ -759,12 +760,16 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
 // host arrays -> staging -> persistent matcher -> host arrays; synchronous
 static ndtgpu_status match_persistent_host(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                            double *T16, size_t n_pairs, const NdtMatchParamsDev &p, const double *Q36,
-                                           ndtgpu_match_result *results, hipStream_t st)
+                                           ndtgpu_match_result *results, hipStream_t st,
+                                           const uint32_t *feat_off = nullptr, const double *feat_cells = nullptr)
 {
     size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
+    const size_t bQ_ = Q36 ? n_pairs * 36 * sizeof(double) : 0;
+    const size_t bFo = feat_off ? (n_pairs + 1) * sizeof(uint32_t) : 0, bFc = feat_off ? (size_t)feat_off[n_pairs] * 18 * sizeof(double) : 0;
     size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
            off_si = (off_ti + bI + 255) & ~(size_t)255, off_Q = (off_si + bI + 255) & ~(size_t)255,
-           total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
+           off_Fo = (off_Q + bQ_ + 255) & ~(size_t)255, off_Fc = (off_Fo + bFo + 255) & ~(size_t)255,
+           total = off_Fc + bFc;
     ndtgpu_status rc = ts->ensure_stage(total);
     if (rc != NDTGPU_OK) return rc;
     char *base = (char *)ts->stage;
@@ -772,8 +777,13 @@ static ndtgpu_status match_persistent_host(ndtgpu_mapset *ts, const uint32_t *ti
     HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
     if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (feat_off) {
+        HIP_TRY(hipMemcpyAsync(base + off_Fo, feat_off, bFo, hipMemcpyHostToDevice, st));
+        if (bFc) HIP_TRY(hipMemcpyAsync(base + off_Fc, feat_cells, bFc, hipMemcpyHostToDevice, st));
+    }
     rc = match_device_core(ts, (const uint32_t *)(base + off_ti), ss, (const uint32_t *)(base + off_si), (double *)base, n_pairs, p,
-                           (ndtgpu_match_result *)(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr, st);
+                           (ndtgpu_match_result *)(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr, st,
+                           feat_off ? (const unsigned *)(base + off_Fo) : nullptr, feat_off ? (const double *)(base + off_Fc) : nullptr);
     if (rc != NDTGPU_OK) return rc;
     unsigned aborted = 0;
     HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
@@ -1005,6 +1015,59 @@ ndtgpu_status ndtgpu_match_fusion_batch(ndtgpu_mapset *ts, const uint32_t *tidx,
     for (size_t k = 0; k < n_pairs; k++)
         if (!invert6(Tcov36 + 36 * k, Q.data() + 36 * k)) return fail(NDTGPU_ERR_INVALID, "match_fusion: singular Tcov");
     return match_batch_common(ts, tidx, ss, sidx, T16, n_pairs, prm, Q.data(), flags, results, stream);
+}
+
+ndtgpu_status ndtgpu_match_fusion_feat_batch(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
+                                             double *T16, const double *Tcov36, const ndtgpu_feat_pairs *feat, size_t n_pairs,
+                                             const ndtgpu_match_params *prm, int flags, ndtgpu_match_result *results,
+                                             ndtgpu_stream stream)
+{
+    if (!feat || !feat->offsets)
+        return ndtgpu_match_fusion_batch(ts, tidx, ss, sidx, T16, Tcov36, n_pairs, prm, flags & 3, results, stream);
+    if (flags < 0 || flags > 7) return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: flags is a 3-bit set");
+    if (!ts || !ss || (n_pairs && (!tidx || !sidx || !T16 || !results)))
+        return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: bad argument");
+    if (n_pairs == 0) return NDTGPU_OK;
+    // step_control_fusion (bit 2) only matters without the soft constraint (fusion.h:1004-1006): the JOINT line search
+    // lineSearchMTFusion (fusion.h:390-793) is not built
+    if ((flags & 4) && !(flags & 1)) {
+        bool any = false;
+        for (size_t k = 0; k < n_pairs && !any; k++) any = feat->offsets[k + 1] > feat->offsets[k];
+        if (any && to_dev(prm).step_control)
+            return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: step_control_fusion without useSoftConstraints selects lineSearchMTFusion, which is not built");
+    }
+    for (size_t k = 0; k < n_pairs; k++) {
+        if (tidx[k] >= ts->n_maps || sidx[k] >= ss->n_maps) return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: map index");
+        if (feat->offsets[k + 1] < feat->offsets[k]) return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: offsets must not decrease");
+        if (feat->offsets[k + 1] - feat->offsets[k] > 64u)
+            return fail(NDTGPU_ERR_CAPACITY, "match_fusion_feat: at most 64 correspondences per registration");
+    }
+    const size_t total = feat->offsets[n_pairs];
+    if (total && (!feat->src_mean || !feat->src_cov || !feat->tgt_mean || !feat->tgt_cov))
+        return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: cell arrays missing");
+    std::vector<double> Q;
+    if (flags & 3) {
+        if (!Tcov36) return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: Tcov missing");
+        Q.resize(36 * n_pairs);
+        for (size_t k = 0; k < n_pairs; k++)
+            if (!invert6(Tcov36 + 36 * k, Q.data() + 36 * k)) return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: singular Tcov");
+    }
+    std::vector<double> cells(total * 18);
+    for (size_t i = 0; i < total; i++) {
+        double *c = cells.data() + 18 * i;
+        for (int a = 0; a < 3; a++) { c[a] = feat->src_mean[3 * i + a]; c[9 + a] = feat->tgt_mean[3 * i + a]; }
+        for (int a = 0; a < 6; a++) { c[3 + a] = feat->src_cov[6 * i + a]; c[12 + a] = feat->tgt_cov[6 * i + a]; }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(ts->last_stream));
+    HIP_TRY(hipStreamSynchronize(ss->last_stream));
+    NdtMatchParamsDev p = to_dev(prm);
+    p.fusion_flags = flags & 3;
+    if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
+        return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
+    // (always the persistent matcher: the feature sums are evaluated inside its solver step)
+    return match_persistent_host(ts, tidx, ss, sidx, T16, n_pairs, p, Q.empty() ? nullptr : Q.data(), results, st, feat->offsets,
+                                 cells.data());
 }
 
 static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,

@@ -218,6 +218,29 @@ def match_fusion(target, source, T0, Tcov, use_soft_constraints=True, tikhonov=F
                                            score=R.score, exit_code=R.exit_code)
 
 
+def match_fusion_feat(target, source, T0, Tcov, feat, use_soft_constraints=True, tikhonov=False, **kw):
+    """ndt_feature::matchFusion with feature / odometry-cell maps: feat = (src_mean [k,3], src_cov [k,6], tgt_mean, tgt_cov)."""
+    prm = dict(DEFAULT_PARAMS)
+    prm.update(kw)
+    P = MatchParams(**prm)
+    R = MatchResult()
+    Tc = _f64(np.asarray(T0, dtype=np.float64).T.reshape(-1)).copy()
+    cov = _f64(np.asarray(Tcov, dtype=np.float64).reshape(-1))
+    sm, sc, tm, tc = [_f64(np.asarray(a, dtype=np.float64).reshape(-1)) for a in feat]
+    k = len(sm) // 3
+    L = lib()
+    L.oracle_match_fusion_feat.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(MatchParams), C.POINTER(C.c_double),
+                                           C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.POINTER(MatchResult)]
+    rc = L.oracle_match_fusion_feat(target.h, source.h, _dp(Tc), C.byref(P), _dp(cov),
+                                    int(bool(use_soft_constraints)) | (2 if tikhonov else 0), k, _dp(sm), _dp(sc), _dp(tm), _dp(tc),
+                                    C.byref(R))
+    if rc:
+        raise RuntimeError("oracle_match_fusion_feat rc=%d" % rc)
+    return Tc.reshape(4, 4).T.copy(), dict(converged=bool(R.converged), iterations=R.iterations, fevals=R.fevals,
+                                           score=R.score, exit_code=R.exit_code)
+
+
 def tcov_flips(reset=False):
     """How often lineSearchMTFusionTcov's in-place negation of the increment (fusion.h:89-95) has fired (test aid)."""
     L = lib()

@@ -926,6 +926,34 @@ static double derivatives_cells(const oracle_map *target, const ocell *src, size
     return score;
 }
 
+/* NDTMatcherFeatureD2D::derivativesNDT (perception_oru ndt_registration, restated from memory): the D2D pair term of
+ * derivativesNDT above for the KNOWN correspondences corr[i] = (i, i) of two CellVector maps -- no neighbourhood search.
+ * Call sites: [fusion.h]:858, 1087 and, through the virtual call inside lineSearchMT, :1016. */
+static double derivatives_feat(const ocell *tgt, const ocell *src, size_t n, int with_hessian, double lfd1, double lfd2,
+                               double g[6], double H[36])
+{
+    double score = 0;
+    memset(g, 0, 6 * sizeof(double));
+    memset(H, 0, 36 * sizeof(double));
+    for (size_t i = 0; i < n; i++) {
+        vec3 mm = {{src[i].mean[0], src[i].mean[1], src[i].mean[2]}};
+        mat3 CM = src[i].cov;
+        local_derivs L;
+        compute_derivatives_local(mm, CM, with_hessian, &L);
+        const ocell *tc = &tgt[i];
+        vec3 x = {{mm.v[0] - tc->mean[0], mm.v[1] - tc->mean[1], mm.v[2] - tc->mean[2]}};
+        mat3 CS = m3_add(tc->cov, CM), B;
+        double det;
+        if (!m3_inverse_check(CS, &B, &det)) continue;
+        double l = v3_dot(x, m3_v(B, x));
+        if (l * 0 != 0) continue;
+        double sh = -lfd1 * exp(-lfd2 * l / 2.0);
+        update_gradient_hessian_local(g, H, x, B, sh, &L, with_hessian, lfd2);
+        score += sh;
+    }
+    return score;
+}
+
 double oracle_derivatives(const oracle_map *target, const double *src_mean3, const double *src_cov9, size_t m,
                           int n_neighbours, int compute_hessian, double lfd1, double lfd2, double g[6],
                           double H[36])
@@ -1322,6 +1350,46 @@ static double line_search_mt(double incr[6], const oracle_map *target, const oce
     return oracle_mt_linesearch(ls_phi, &ctx, score_init, dginit, NULL, NULL);
 }
 
+typedef struct {
+    const ocell *tgt;   /* targetNDT_feat */
+    const ocell *cells; /* nextNDT_feat */
+    ocell *scratch;
+    size_t n;
+    const double *incr;
+    const oracle_match_params *prm;
+} lsf_ctx;
+
+static double lsf_phi(void *vctx, double stp, double *dg)
+{
+    lsf_ctx *c = (lsf_ctx *)vctx;
+    double pincr[6], ps[16], g[6], H[36];
+    for (int a = 0; a < 6; a++) pincr[a] = stp * c->incr[a];
+    oracle_pose_to_T(pincr, ps);
+    transform_cells(c->cells, c->scratch, c->n, ps);
+    double f = derivatives_feat(c->tgt, c->scratch, c->n, 0, c->prm->lfd1, c->prm->lfd2, g, H);
+    double d = 0;
+    for (int a = 0; a < 6; a++) d += c->incr[a] * g[a];
+    *dg = d;
+    return f;
+}
+
+/* NDTMatcherFeatureD2D::lineSearchMT = NDTMatcherD2D::lineSearchMT with the feature derivatives ([fusion.h]:1016) */
+static double line_search_mt_feat(double incr[6], const ocell *tgt, const ocell *cells, ocell *scratch, size_t n,
+                                  const oracle_match_params *prm)
+{
+    double g[6], H[36];
+    double score_init = derivatives_feat(tgt, cells, n, 0, prm->lfd1, prm->lfd2, g, H);
+    double dginit = 0;
+    for (int a = 0; a < 6; a++) dginit += incr[a] * g[a];
+    if (dginit >= 0.0) {
+        for (int a = 0; a < 6; a++) incr[a] = -incr[a];
+        dginit = -dginit;
+        if (dginit >= 0.0) return 0.1; /* recoverystep */
+    }
+    lsf_ctx ctx = {tgt, cells, scratch, n, incr, prm};
+    return oracle_mt_linesearch(lsf_phi, &ctx, score_init, dginit, NULL, NULL);
+}
+
 /* Gauss-Jordan with partial pivoting: Eigen's Tcov.inverse() ([fusion.h]:845) */
 static int invert6(const double *A, double *inv)
 {
@@ -1349,9 +1417,13 @@ static int invert6(const double *A, double *inv)
     return 1;
 }
 
+typedef struct {   /* the feature / odometry-cell maps of matchFusion: n cells each, corr_feat[i] = (i, i) */
+    size_t n;
+    const double *src_mean, *src_cov6, *tgt_mean, *tgt_cov6;
+} feat_maps;
 static int match_common(const oracle_map *target, const oracle_map *source, double T[16],
                         const oracle_match_params *prm, const double *Q /* Tcov^-1 or NULL */, int flags,
-                        oracle_match_result *res);
+                        const feat_maps *feat, oracle_match_result *res);
 
 /* test aid: how often the in-place negation of lineSearchMTFusionTcov ([fusion.h]:89-95) has fired since the last reset */
 static long g_tcov_flips = 0;
@@ -1365,7 +1437,7 @@ long oracle_debug_tcov_flips(int reset)
 int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double T[16],
                      const oracle_match_params *prm, oracle_match_result *res)
 {
-    return match_common(target, source, T, prm, NULL, 0, res);
+    return match_common(target, source, T, prm, NULL, 0, NULL, res);
 }
 
 /* ndt_feature::matchFusion ([fusion.h]:797-1155) with useNDT = true, useFeat = false (empty feature
@@ -1381,9 +1453,27 @@ int oracle_match_fusion(const oracle_map *target, const oracle_map *source, doub
 {
     /* use_soft_constraints: bit 0 = useSoftConstraints, bit 1 = useTikhonovRegularization ([fusion.h]:894-911) */
     double Q[36];
-    if (!(use_soft_constraints & 3)) return match_common(target, source, T, prm, NULL, 0, res);
+    if (!(use_soft_constraints & 3)) return match_common(target, source, T, prm, NULL, 0, NULL, res);
     if (!invert6(Tcov, Q)) return -2;
-    return match_common(target, source, T, prm, Q, use_soft_constraints & 3, res);
+    return match_common(target, source, T, prm, Q, use_soft_constraints & 3, NULL, res);
+}
+
+/* ndt_feature::matchFusion with useFeat ([fusion.h]:797-1155): n_feat correspondences between sourceNDT_feat and
+ * targetNDT_feat (cov6: xx xy xz yy yz zz).  flags: bit 0 useSoftConstraints, bit 1 useTikhonovRegularization.  The
+ * separate line searches of [fusion.h]:1007-1023 (the joint lineSearchMTFusion of :1004-1006 is not restated: it runs
+ * only with step_control_fusion and WITHOUT the soft constraint).  res->fevals counts NDT-map evaluations. */
+int oracle_match_fusion_feat(const oracle_map *target, const oracle_map *source, double T[16],
+                             const oracle_match_params *prm, const double Tcov[36], int flags, size_t n_feat,
+                             const double *src_mean, const double *src_cov6, const double *tgt_mean, const double *tgt_cov6,
+                             oracle_match_result *res)
+{
+    double Q[36];
+    feat_maps f = {n_feat, src_mean, src_cov6, tgt_mean, tgt_cov6};
+    if (flags & 3) {
+        if (!invert6(Tcov, Q)) return -2;
+        return match_common(target, source, T, prm, Q, flags & 3, &f, res);
+    }
+    return match_common(target, source, T, prm, NULL, 0, &f, res);
 }
 
 /* x0 = convertAffineToVector(forceEigenAffine3dTo2d(T * Tinit^-1))  ([fusion.h]:903-907, utils.h:30-68, 161-169) */
@@ -1404,10 +1494,22 @@ static void tikhonov_x0(const double T[16], const double Tinit[16], double x0[6]
     x0[3] = 0; x0[4] = 0; x0[5] = (D[1] > 0) ? ang : -ang;
 }
 
+static void feat_cell(ocell *c, const double *mean, const double *cov6)
+{
+    memset(c, 0, sizeof *c);
+    for (int a = 0; a < 3; a++) c->mean[a] = mean[a];
+    c->cov.m[0][0] = cov6[0]; c->cov.m[0][1] = c->cov.m[1][0] = cov6[1]; c->cov.m[0][2] = c->cov.m[2][0] = cov6[2];
+    c->cov.m[1][1] = cov6[3]; c->cov.m[1][2] = c->cov.m[2][1] = cov6[4]; c->cov.m[2][2] = cov6[5];
+    c->has_gaussian = 1;
+}
+
 static int match_common(const oracle_map *target, const oracle_map *source, double T[16],
-                        const oracle_match_params *prm, const double *Q, int flags, oracle_match_result *res)
+                        const oracle_match_params *prm, const double *Q, int flags, const feat_maps *feat,
+                        oracle_match_result *res)
 {
     const int soft = Q && (flags & 1), tikhonov = Q && (flags & 2);
+    const size_t nf = feat ? feat->n : 0;
+    const int use_feat = nf > 0;
     double Tinit[16], x0[6] = {0, 0, 0, 0, 0, 0};
     int dofs[6], nd = 0;
     for (int a = 0; a < 6; a++)
@@ -1429,10 +1531,24 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
     ocell *next = pseudo_transform(source, T, &n); /* [fusion.h]:840 */
     ocell *scratch = (ocell *)calloc(n ? n : 1, sizeof(ocell));
     double g6[6], H36[36];
+    /* nextNDT_feat = sourceNDT_feat.pseudoTransformNDT(T) ([fusion.h]:841); targetNDT_feat as given */
+    ocell *ftgt = (ocell *)calloc(nf ? nf : 1, sizeof(ocell)), *fnext = (ocell *)calloc(nf ? nf : 1, sizeof(ocell)),
+          *fscratch = (ocell *)calloc(nf ? nf : 1, sizeof(ocell));
+    for (size_t i = 0; i < nf; i++) {
+        feat_cell(&ftgt[i], feat->tgt_mean + 3 * i, feat->tgt_cov6 + 6 * i);
+        feat_cell(&fnext[i], feat->src_mean + 3 * i, feat->src_cov6 + 6 * i);
+    }
+    if (nf) transform_cells(fnext, fnext, nf, T);
 
     while (!convergence) {
         score_here = derivatives_cells(target, next, n, prm->n_neighbours, 1, prm->lfd1, prm->lfd2, g6, H36);
         fevals++;
+        if (use_feat) { /* [fusion.h]:858-871 */
+            double gf[6], Hf[36];
+            score_here += derivatives_feat(ftgt, fnext, nf, 1, prm->lfd1, prm->lfd2, gf, Hf);
+            for (int i = 0; i < 6; i++) g6[i] += gf[i];
+            for (int i = 0; i < 36; i++) H36[i] += Hf[i];
+        }
         if (soft) { /* [fusion.h]:875-890 */
             double gq[6], Hq[36];
             score_here += oracle_mahalanobis(pose_local, Q, gq, Hq);
@@ -1528,6 +1644,11 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
             }
             /* the line search sees only the active dofs' gradient through incr (inactive entries are 0) */
             step_size = line_search_mt(incr, target, next, scratch, n, prm, &fevals);
+            if (use_feat) { /* [fusion.h]:1015-1023 */
+                double step_size_feat = line_search_mt_feat(incr, ftgt, fnext, fscratch, nf, prm);
+                if (step_size != 0. && step_size_feat != 0.) step_size = step_size < step_size_feat ? step_size : step_size_feat;
+                else step_size = step_size > step_size_feat ? step_size : step_size_feat;
+            }
         }
         double inorm = 0;
         for (int a = 0; a < 6; a++) {
@@ -1541,6 +1662,7 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
         oracle_pose_to_T(incr, TR);
         T_mul(TR, T, T);
         transform_cells(next, next, n, TR);
+        if (nf) transform_cells(fnext, fnext, nf, TR);
         /* [fusion.h]:1070-1080 */
         if (itr_ctr > 0) convergence = (inorm < prm->delta_score);
         if (itr_ctr > prm->itr_max) {
@@ -1553,6 +1675,10 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
     /* [fusion.h]:1085-1121 */
     score_here = derivatives_cells(target, next, n, prm->n_neighbours, 0, prm->lfd1, prm->lfd2, g6, H36);
     fevals++;
+    if (use_feat) { /* [fusion.h]:1087-1096 */
+        double gf[6], Hf[36];
+        score_here += derivatives_feat(ftgt, fnext, nf, 0, prm->lfd1, prm->lfd2, gf, Hf);
+    }
     if (soft) { /* [fusion.h]:1098-1110 */
         double gq[6], Hq[36];
         score_here += oracle_mahalanobis(pose_local, Q, gq, Hq);
@@ -1572,5 +1698,8 @@ done_early:
     }
     free(next);
     free(scratch);
+    free(ftgt);
+    free(fnext);
+    free(fscratch);
     return 0;
 }

@@ -123,6 +123,12 @@ int oracle_match_d2d(const oracle_map *target, const oracle_map *source, double 
 /* ndt_feature::matchFusion (ndt_matcher_d2d_fusion.h:797-1155) with empty feature maps and without the
  * Tikhonov variant: NDT term + (optionally) the odometry soft constraint x^T Tcov^-1 x.
  * Tcov: 6x6 row-major.  Returns -2 when Tcov is singular. */
+/* ndt_feature::matchFusion with useFeat: n_feat correspondences (i <-> i) between the cells of sourceNDT_feat and
+ * targetNDT_feat (cov6: xx xy xz yy yz zz); flags bit 0 useSoftConstraints, bit 1 useTikhonovRegularization */
+int oracle_match_fusion_feat(const oracle_map *target, const oracle_map *source, double T[16],
+                             const oracle_match_params *prm, const double Tcov[36], int flags, size_t n_feat,
+                             const double *src_mean, const double *src_cov6, const double *tgt_mean, const double *tgt_cov6,
+                             oracle_match_result *res);
 /* test aid: number of in-place negations of the increment by lineSearchMTFusionTcov ([fusion.h]:89-95) so far */
 long oracle_debug_tcov_flips(int reset);
 int oracle_match_fusion(const oracle_map *target, const oracle_map *source, double T[16],

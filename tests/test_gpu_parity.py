@@ -695,6 +695,51 @@ def test_match_fusion_tcov_line_search_negates_the_increment(N, O):
     assert flips >= B          # the flip fired on these pairs (7, 8: several times)
 
 
+def _odom_cells(T_odom, odom_cov6, n=40):
+    """The odometry cells of NDTFeatureFuserHMT::update (ndt_feature_fuser_hmt.cpp:150-160, 322-334): n copies of
+    (source: mean 0, target: mean of the odometry translation), covariance odom_cov."""
+    sm = np.zeros((n, 3))
+    tm = np.tile(T_odom[:3, 3], (n, 1))
+    sc = np.tile(odom_cov6, (n, 1))
+    return sm, sc.copy(), tm, sc.copy()
+
+
+@pytest.mark.parametrize("soft,tikhonov", [(True, True), (True, False), (False, False)])
+def test_match_fusion_with_odometry_cells(N, O, soft, tikhonov):
+    """matchFusion with useFeat / useOdom (the fuser's defaults): 40 odometry cell pairs with known correspondence
+    (ndt_feature_fuser_hmt.cpp:322-334) whose NDTMatcherFeatureD2D sums join the NDT sums (fusion.h:858-871), a second
+    line search over the feature maps and the smaller of the two steps (fusion.h:1013-1023), the feature score in the
+    final score (fusion.h:1087-1096).  HIP against the oracle: pose, iterations, exit, score; and the cells matter."""
+    from ndt_feature_graph_amd import binding
+    seeds = list(range(31, 39))
+    pr, tg, sr, om = _pair_maps(N, O, seeds, 20000, 0.5)
+    T0 = pr["T_init"].numpy()
+    Tgt = pr["T_gt"].numpy()
+    B = len(seeds)
+    rng = np.random.default_rng(5)
+    covs = np.stack([np.diag([2e-3, 2e-3, 1.0, 1.0, 1.0, 4e-4])] * B)
+    odom_cov6 = np.array([4e-4, 1e-5, 0.0, 6e-4, 0.0, 0.01])
+    feats = []
+    for b in range(B):
+        Todo = Tgt[b].copy()
+        Todo[:2, 3] += rng.normal(scale=0.02, size=2)          # the odometry says roughly where the scan was taken
+        feats.append(_odom_cells(Todo, odom_cov6, 40 if b != 3 else 7))
+    feats[5] = tuple(a[:0] for a in feats[5])                  # a registration without cells in the same batch
+    idx = np.arange(B)
+    Tb, rb = binding.match_fusion_feat_batch(tg, idx, sr, idx, T0, covs, feats, use_soft_constraints=soft, tikhonov=tikhonov)
+    Tn, rn = N.match_fusion_batch(tg, idx, sr, idx, T0, covs, use_soft_constraints=soft, tikhonov=tikhonov)
+    for b in range(B):
+        To, ro = O.binding.match_fusion_feat(om[b][0], om[b][1], T0[b], covs[b], feats[b], use_soft_constraints=soft, tikhonov=tikhonov)
+        dt, dr = pose_close(Tb[b], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
+        assert rb["iterations"][b] == ro["iterations"] and bool(rb["converged"][b]) == ro["converged"], (b, rb["iterations"][b], ro["iterations"])
+        assert rb["exit_code"][b] == ro["exit_code"], b
+        assert abs(rb["score"][b] - ro["score"]) < 1e-6 * abs(ro["score"]), b
+    # no cells: the plain fusion matcher (which ran as a cooperative launch here: another summation order)
+    assert pose_close(Tb[5], Tn[5])[0] < 1e-8 and rb["iterations"][5] == rn["iterations"][5]
+    assert max(pose_close(Tb[b], Tn[b])[0] for b in range(B) if b != 5) > 1e-6     # the cells change the result
+
+
 def test_device_pointer_batch_checks_indices_and_overflow(N):
     """ndtgpu_match_batch_device takes its indices from device memory: an index out of range and a map whose build
     overflowed max_cells are refused per pair (exit codes -2 / -3, pose untouched), the other pairs are registered."""
