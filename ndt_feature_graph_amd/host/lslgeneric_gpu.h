@@ -98,10 +98,57 @@ public:
 };
 using SpatialIndex = LazyGrid;
 
+// lslgeneric::CellVector: a list of Gaussians without a grid (the feature / odometry-cell maps of matchFusion,
+// ndt_feature_fuser_hmt.cpp:291-334).  Lives on the host: these maps hold a few dozen cells with known correspondence.
+class CellVector {
+public:
+    CellVector() {}
+    ~CellVector() { for (NDTCell *c : cells_) delete c; }
+    CellVector(const CellVector &) = delete;
+    CellVector &operator=(const CellVector &) = delete;
+    void addCell(NDTCell *cell) { cells_.push_back(cell); }          // takes ownership
+    void addNDTCell(NDTCell *cell) { cells_.push_back(cell); }
+    NDTCell *getCellIdx(unsigned int idx) const { return idx < cells_.size() ? cells_[idx] : NULL; }
+    int size() const { return (int)cells_.size(); }
+
+private:
+    std::vector<NDTCell *> cells_;
+};
+
 class NDTMap {
 public:
     // new NDTMap(new LazyGrid(res))  -- takes ownership of idx like the reference (fuser_hmt.cpp:87, 195-196)
     explicit NDTMap(SpatialIndex *idx, bool /*dealloc*/ = false) : res_(idx->res) { delete idx; }
+    // NDTMap(CellVector*, dealloc) (fuser_hmt.cpp:303-304): a map over a cell list; only the cell-list calls below apply
+    explicit NDTMap(CellVector *cv, bool dealloc = false) : res_(0.), cv_(cv), cv_owned_(dealloc) {}
+    ~NDTMap() { if (cv_owned_) delete cv_; }
+    NDTMap(const NDTMap &) = delete;
+    NDTMap &operator=(const NDTMap &) = delete;
+    CellVector *getMyIndex() const { return cv_; }
+    // NDTMap::pseudoTransformNDTMap(T) of a cell-list map: a new map (caller deletes) with mean' = T mean, cov' = R cov R^T
+    NDTMap *pseudoTransformNDTMap(const Eigen::Affine3d &T) const
+    {
+        if (!cv_) throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTMap::pseudoTransformNDTMap: only for CellVector maps (grid maps: pseudoTransformNDT)");
+        CellVector *out = new CellVector();
+        const double *m = T.data();
+        for (int i = 0; i < cv_->size(); i++) {
+            const NDTCell *c = cv_->getCellIdx((unsigned)i);
+            Eigen::Vector3d mu = c->getMean(), t;
+            Eigen::Matrix3d C = c->getCov(), R, RC, RCRt;
+            for (int r = 0; r < 3; r++) {
+                t(r) = m[0 * 4 + r] * mu(0) + m[1 * 4 + r] * mu(1) + m[2 * 4 + r] * mu(2) + m[12 + r];
+                for (int k = 0; k < 3; k++) R(r, k) = m[k * 4 + r];
+            }
+            for (int r = 0; r < 3; r++)
+                for (int k = 0; k < 3; k++) RC(r, k) = R(r, 0) * C(0, k) + R(r, 1) * C(1, k) + R(r, 2) * C(2, k);
+            for (int r = 0; r < 3; r++)
+                for (int k = 0; k < 3; k++) RCRt(r, k) = RC(r, 0) * R(k, 0) + RC(r, 1) * R(k, 1) + RC(r, 2) * R(k, 2);
+            NDTCell *n = new NDTCell();
+            n->setMean(t); n->setCov(RCRt); n->setN(c->getN());
+            out->addCell(n);
+        }
+        return new NDTMap(out, true);
+    }
     // a map that lives in a shared pool (graph node maps, the fuser's per-scan map): geometry comes from the pool
     NDTMap(std::shared_ptr<ndtgpu_host::MapPool> pool, size_t slot) : pool_(std::move(pool)), slot_(slot), res_(pool_->resolution())
     {
@@ -320,6 +367,8 @@ private:
     std::shared_ptr<ndtgpu_host::MapPool> pool_, own_;
     size_t slot_ = 0;
     double res_;
+    CellVector *cv_ = nullptr;
+    bool cv_owned_ = false;
     double centre_[3] = {0, 0, 0}, size_[3] = {0, 0, 0}, origin_[3] = {0, 0, 0};
     bool have_geometry_ = false, have_size_ = false, have_origin_ = false, initialized_ = false;
     std::vector<pcl::PointXYZ> pending_;

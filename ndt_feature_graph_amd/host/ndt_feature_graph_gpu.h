@@ -113,6 +113,7 @@ private:
     {
         const double dist = std::sqrt(rel[0] * rel[0] + rel[1] * rel[1]), rot = rel[2];
         Eigen::Matrix3d R;
+        R.setZero();                        // motion_model.cpp:202 (with the real Eigen an unset matrix is garbage)
         R(0, 0) = params.Dd * dist * dist + params.Dt * rot * rot;
         R(1, 1) = params.Cd * dist * dist + params.Ct * rot * rot;
         R(2, 2) = params.Td * dist * dist + params.Tt * rot * rot;
@@ -121,16 +122,15 @@ private:
 };
 
 // ndt_feature::matchFusion (ndt_matcher_d2d_fusion.h:797-1155) -- the reference's full signature.  The whole Newton /
-// More-Thuente loop runs on the device (ndtgpu_match_fusion_batch).  The feature maps must be empty (useFeat == false).
-inline bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, lslgeneric::NDTMap * /*targetNDT_feat*/,
-                        lslgeneric::NDTMap * /*sourceNDT_feat*/, const std::vector<std::pair<int, int> > &corr_feat,
+// More-Thuente loop runs on the device (ndtgpu_match_fusion_batch / ndtgpu_match_fusion_feat_batch); the feature maps
+// are CellVector maps whose cells correspond through corr_feat (NDTMatcherFeatureD2D).
+inline bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, lslgeneric::NDTMap &targetNDT_feat,
+                        lslgeneric::NDTMap &sourceNDT_feat, const std::vector<std::pair<int, int> > &corr_feat,
                         Eigen::Affine3d &T, const Eigen::MatrixXd &Tcov, bool useInitialGuess, bool useNDT, bool useFeat,
                         bool step_control, int ITR_MAX = 30, int n_neighbours = 2, double DELTA_SCORE = 10e-4,
-                        bool useSoftConstraints = true, bool /*step_control_fusion*/ = true, bool useTikhonovRegularization = false,
+                        bool useSoftConstraints = true, bool step_control_fusion = true, bool useTikhonovRegularization = false,
                         ndtgpu_match_result *result = nullptr)
 {
-    if (useFeat || !corr_feat.empty())
-        throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "matchFusion: feature / odometry-cell terms (useFeat) are not implemented");
     if (!useNDT) throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "matchFusion: useNDT == false leaves nothing to match");
     lslgeneric::NDTMatcherD2D m;
     m.n_neighbours = n_neighbours;
@@ -147,14 +147,47 @@ inline bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourc
         for (int a = 0; a < 6; a++)
             for (int b = 0; b < 6; b++) c36[a * 6 + b] = Tcov(a, b);
     }
-    ndtgpu_host::check(ndtgpu_match_fusion_batch(targetNDT.handle(), &ti, sourceNDT.handle(), &si, T.data(), flags ? c36 : nullptr, 1,
-                                                 &p, flags, &r, nullptr), "ndtgpu_match_fusion_batch");
+    // the feature / odometry-cell maps: NDTMatcherFeatureD2D(corr_feat) pairs source cell corr.second with target cell corr.first
+    std::vector<double> sm, sc, tm, tc;
+    uint32_t off[2] = {0, 0};
+    if (useFeat) {
+        lslgeneric::CellVector *cvt = targetNDT_feat.getMyIndex(), *cvs = sourceNDT_feat.getMyIndex();
+        if (!cvt || !cvs) throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "matchFusion: the feature maps must be CellVector maps");
+        for (const auto &c : corr_feat) {
+            const lslgeneric::NDTCell *t = cvt->getCellIdx((unsigned)c.first), *s_ = cvs->getCellIdx((unsigned)c.second);
+            if (!t || !s_) continue;                    // (targetNDT.getCellIdx fails: the pair is skipped)
+            const Eigen::Vector3d mt = t->getMean(), ms = s_->getMean();
+            const Eigen::Matrix3d Ct = t->getCov(), Cs = s_->getCov();
+            for (int a = 0; a < 3; a++) { tm.push_back(mt(a)); sm.push_back(ms(a)); }
+            const int ij[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+            for (int k = 0; k < 6; k++) { tc.push_back(Ct(ij[k][0], ij[k][1])); sc.push_back(Cs(ij[k][0], ij[k][1])); }
+        }
+        off[1] = (uint32_t)(tm.size() / 3);
+    }
+    if (off[1]) {
+        ndtgpu_feat_pairs fp = {off, sm.data(), sc.data(), tm.data(), tc.data()};
+        ndtgpu_host::check(ndtgpu_match_fusion_feat_batch(targetNDT.handle(), &ti, sourceNDT.handle(), &si, T.data(), flags ? c36 : nullptr, &fp,
+                                                          1, &p, flags | (step_control_fusion ? 4 : 0), &r, nullptr),
+                           "ndtgpu_match_fusion_feat_batch");
+    } else {
+        ndtgpu_host::check(ndtgpu_match_fusion_batch(targetNDT.handle(), &ti, sourceNDT.handle(), &si, T.data(), flags ? c36 : nullptr, 1,
+                                                     &p, flags, &r, nullptr), "ndtgpu_match_fusion_batch");
+    }
     if (result) *result = r;
     return r.converged != 0;
 }
+// ndt_feature::addNDTCellToMap (utils.h): a copy of the cell joins the map's cell list
+inline void addNDTCellToMap(lslgeneric::NDTMap *map, lslgeneric::NDTCell *cell)
+{
+    lslgeneric::CellVector *cl = map->getMyIndex();
+    if (!cl) return;
+    lslgeneric::NDTCell *c = new lslgeneric::NDTCell();
+    c->setMean(cell->getMean()); c->setCov(cell->getCov()); c->setN(cell->getN());
+    cl->addCell(c);
+}
 // ndt_feature::matchFusion2d (ndt_matcher_d2d_fusion.h:1159-1176): NDTMatcherD2D_2D on the NDT maps
-inline bool matchFusion2d(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, lslgeneric::NDTMap * /*targetNDT_feat*/,
-                          lslgeneric::NDTMap * /*sourceNDT_feat*/, const std::vector<std::pair<int, int> > & /*corr_feat*/,
+inline bool matchFusion2d(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourceNDT, lslgeneric::NDTMap & /*targetNDT_feat*/,
+                          lslgeneric::NDTMap & /*sourceNDT_feat*/, const std::vector<std::pair<int, int> > & /*corr_feat*/,
                           Eigen::Affine3d &T, bool useInitialGuess, bool /*useNDT*/, bool /*useFeat*/, bool step_control, int ITR_MAX = 30,
                           int n_neighbours = 2, double DELTA_SCORE = 10e-4)
 {
@@ -280,9 +313,8 @@ public:
             fprintf(stderr, "NDT-FuserHMT: Call Initialize first!!\n");
             return Tnow;
         }
-        if (params_.useFeat || params_.useOdom)
-            throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: the FLIRT feature (useFeat) and odometry-cell (useOdom) terms are not "
-                                                         "implemented; every shipped configuration sets both to false");
+        // (useFeat: the FLIRT interest points are the ROS layer's; without them the RANSAC of fuser_hmt.cpp:250 finds no
+        //  matches, consistent_features is false and no feature cell is made -- which is what this mirror does)
         pcl::PointCloud<pcl::PointXYZ> cloud(cloudOrig);
         pcl::PointCloud<pcl::PointXYZ> cloud_orig(cloudOrig);
 
@@ -292,6 +324,16 @@ public:
         // Odometry 'constraints'
         MotionModel2d motion(motion_params_);
         Pose2d relpose(Tmotion.translation()[0], Tmotion.translation()[1], Tmotion.rotation().eulerAngles(0, 1, 2)[2]);
+        Pose2dCov relposecov = motion.getPose2dCov(relpose);
+        Eigen::Matrix3d odom_cov = relposecov.cov;
+        odom_cov(2, 0) = 0.; odom_cov(2, 1) = 0.; odom_cov(0, 2) = 0.; odom_cov(1, 2) = 0.;
+        odom_cov(2, 2) = 0.01;   // This is the height in the ndt feature vec and not rotational variance.
+        lslgeneric::NDTCell ndt_odom_cell;
+        ndt_odom_cell.setMean(Eigen::Vector3d(0., 0., 0.));
+        ndt_odom_cell.setCov(odom_cov);
+        lslgeneric::NDTCell ndt_odom_cell_prev;
+        ndt_odom_cell_prev.setMean(Tmotion.translation());
+        ndt_odom_cell_prev.setCov(odom_cov);
         Eigen::MatrixXd TmotionCov = motion.getCovMatrix6(relpose);
         TmotionCov(2, 2) = 1;   // z
         TmotionCov(3, 3) = 1;   // roll
@@ -346,15 +388,44 @@ public:
             discardCell(ndglobal, cloud.back());
         }
 
+        // NDT based feature matching (fuser_hmt.cpp:291-334): two CellVector maps with known correspondence
         std::vector<std::pair<int, int> > corr;
+        const bool consistent_features = false;        // no interest points, no matches (see above)
+        lslgeneric::CellVector *cv_prev_sensor_frame = new lslgeneric::CellVector();
+        lslgeneric::CellVector *cv_curr_sensor_frame = new lslgeneric::CellVector();
+        bool use_odom_or_features = true;
+        lslgeneric::NDTMap ndt_feat_prev_sensor_frame(cv_prev_sensor_frame, true);
+        lslgeneric::NDTMap ndt_feat_curr_sensor_frame(cv_curr_sensor_frame, true);
+        std::unique_ptr<lslgeneric::NDTMap> ndt_feat_prev_vehicle_frame(ndt_feat_prev_sensor_frame.pseudoTransformNDTMap(sensor_pose));
+        // The current frame is always in vehicle frame (to be moved Tinit in registration)
+        std::unique_ptr<lslgeneric::NDTMap> ndt_feat_curr_vehicle_frame(ndt_feat_curr_sensor_frame.pseudoTransformNDTMap(sensor_pose));
+        if (params_.useOdom) {
+            for (int i = 0; i < 40; i++) {   // "Quick HACK HERE."
+                addNDTCellToMap(ndt_feat_prev_vehicle_frame.get(), &ndt_odom_cell_prev);
+                addNDTCellToMap(ndt_feat_curr_vehicle_frame.get(), &ndt_odom_cell);
+                int tmp_size = (int)corr.size();
+                corr.push_back(std::pair<int, int>(tmp_size, tmp_size));
+            }
+        }
+        std::unique_ptr<lslgeneric::NDTMap> ndt_feat_prev(ndt_feat_prev_vehicle_frame->pseudoTransformNDTMap(Tnow /* *Tmotion */));
+        std::unique_ptr<lslgeneric::NDTMap> ndt_feat_curr(ndt_feat_curr_vehicle_frame->pseudoTransformNDTMap(Tinit));
+        // Remove the covariance rotation from the odometry (done when pseudo moving): the LAST cell only, like the reference
+        if (params_.useOdom) {
+            lslgeneric::CellVector *cl = ndt_feat_curr->getMyIndex();
+            cl->getCellIdx(cl->size() - 1)->setCov(odom_cov);
+        }
+        if (!params_.useFeat && !params_.useOdom) use_odom_or_features = false;   // both odom and feature are in the same pot
+        if (!params_.useOdom && !consistent_features) use_odom_or_features = false;
+
         bool match_ok = true;
         if (params_.fusion2d) {
-            match_ok = matchFusion2d(*map, ndglobal, nullptr, nullptr, corr, Tmotion_est, true, params_.useNDT, false, params_.stepcontrol,
-                                     params_.ITR_MAX, params_.neighbours, params_.DELTA_SCORE) || params_.fuseIncomplete;
+            match_ok = matchFusion2d(*map, ndglobal, *ndt_feat_prev, *ndt_feat_curr, corr, Tmotion_est, true, params_.useNDT, use_odom_or_features,
+                                     params_.stepcontrol, params_.ITR_MAX, params_.neighbours, params_.DELTA_SCORE) || params_.fuseIncomplete;
         } else {
-            match_ok = matchFusion(*map, ndglobal, nullptr, nullptr, corr, Tmotion_est, TmotionCov, true, params_.useNDT, false, params_.stepcontrol,
-                                   params_.ITR_MAX, params_.neighbours, params_.DELTA_SCORE, params_.useSoftConstraints, params_.stepControlFusion,
-                                   params_.useTikhonovRegularization, &last_match) || params_.fuseIncomplete;
+            match_ok = matchFusion(*map, ndglobal, *ndt_feat_prev, *ndt_feat_curr, corr, Tmotion_est, TmotionCov, true, params_.useNDT,
+                                   use_odom_or_features, params_.stepcontrol, params_.ITR_MAX, params_.neighbours, params_.DELTA_SCORE,
+                                   params_.useSoftConstraints, params_.stepControlFusion, params_.useTikhonovRegularization, &last_match) ||
+                       params_.fuseIncomplete;
         }
         if (params_.allMatchesValid) match_ok = true;
 
@@ -409,7 +480,43 @@ private:
     size_t pool_slot_ = 0;
 };
 
-class NDTFeatureLink {
+// interfaces.h:10-48 -- what the iSAM layer consumes (ndt_offline_mapper.h:40 takes NDTFeatureGraphInterface&)
+class NDTFeatureNodeInterface {
+public:
+    virtual ~NDTFeatureNodeInterface() {}
+    virtual const Eigen::Affine3d &getPose() const = 0;
+    virtual const Eigen::Matrix3d &getCov() const = 0;
+    virtual void setPose(const Eigen::Affine3d &pose) = 0;
+    virtual void setCov(const Eigen::Matrix3d &cov) = 0;
+};
+class NDTFeatureLinkInterface {
+public:
+    virtual ~NDTFeatureLinkInterface() {}
+    virtual const Eigen::Affine3d &getRelPose() const = 0;
+    virtual const Eigen::Matrix3d &getRelCov() const = 0;
+    virtual double getScore() const = 0;
+    virtual size_t getRefIdx() const = 0;
+    virtual size_t getMovIdx() const = 0;
+    friend std::ostream &operator<<(std::ostream &os, const NDTFeatureLinkInterface &obj)
+    {
+        os << "\n[" << obj.getRefIdx() << "<->" << obj.getMovIdx() << "] T: " << "[" << obj.getRelPose().translation()[0] << ","
+           << obj.getRelPose().translation()[1] << "](" << obj.getRelPose().rotation().eulerAngles(0, 1, 2)[2] << ")";
+        os << "\n score : " << obj.getScore();
+        return os;
+    }
+};
+class NDTFeatureGraphInterface {
+public:
+    virtual ~NDTFeatureGraphInterface() {}
+    virtual size_t getNbNodes() const = 0;
+    virtual NDTFeatureNodeInterface &getNodeInterface(size_t idx) = 0;
+    virtual const NDTFeatureNodeInterface &getNodeInterface(size_t idx) const = 0;
+    virtual size_t getNbLinks() const = 0;
+    virtual NDTFeatureLinkInterface &getLinkInterface(size_t idx) = 0;
+    virtual const NDTFeatureLinkInterface &getLinkInterface(size_t idx) const = 0;
+};
+
+class NDTFeatureLink : public NDTFeatureLinkInterface {
 public:
     NDTFeatureLink() : ref_idx(0), mov_idx(0), cov_3d(6, 6), score(0.) {}
     NDTFeatureLink(size_t ref, size_t mov) : ref_idx(ref), mov_idx(mov), cov_3d(6, 6), score(0.) {}
@@ -420,15 +527,16 @@ public:
     double score;
     bool converged = true;     // (added) replaces the stdin pause of graph.cpp:318-323
     int iterations = 0;
-    const Eigen::Affine3d &getRelPose() const { return T; }
-    const Eigen::Matrix3d &getRelCov() const { return cov; }
-    double getScore() const { return score; }
-    size_t getRefIdx() const { return ref_idx; }
-    size_t getMovIdx() const { return mov_idx; }
+    // Interfaces.
+    virtual const Eigen::Affine3d &getRelPose() const { return T; }
+    virtual const Eigen::Matrix3d &getRelCov() const { return cov; }
+    virtual double getScore() const { return score; }
+    virtual size_t getRefIdx() const { return ref_idx; }
+    virtual size_t getMovIdx() const { return mov_idx; }
     void force2D() { forceEigenAffine3dTo2dInPlace(this->T); }
 };
 
-class NDTFeatureNode {
+class NDTFeatureNode : public NDTFeatureNodeInterface {
 public:
     NDTFeatureNode() : map(NULL), nbUpdates(0), time_last_update(0) {}
     NDTFeatureFuserHMT *map;   // owned by the graph (ndt_feature_graph.h:78-88); node copies are shallow like the reference's
@@ -436,14 +544,30 @@ public:
     Eigen::Matrix3d cov;
     Eigen::Affine3d Tlocal_odom;   // Incremental odometry between successive local maps.
     Eigen::Affine3d Tlocal_fuse;   // Incremental fuse estimates between sucessive local maps.
+    pcl::PointCloud<pcl::PointXYZ> pts;   // Only for visualizaion purposes...
     int nbUpdates;
     double time_last_update;
+    // ndt_feature_node.h:81-96
+    void addCloud(Eigen::Affine3d &T_, const pcl::PointCloud<pcl::PointXYZ> &pc)
+    {
+        pcl::PointCloud<pcl::PointXYZ> moved(pc);
+        ndtgpu_host::transformPointCloudInPlace(T_, moved);
+        for (const auto &p : moved.points) this->pts.push_back(p);
+    }
+    pcl::PointCloud<pcl::PointXYZ> getGlobalPointCloud()
+    {
+        pcl::PointCloud<pcl::PointXYZ> out(this->pts);
+        ndtgpu_host::transformPointCloudInPlace(this->T, out);
+        return out;
+    }
+    pcl::PointCloud<pcl::PointXYZ> getLocalPointCloud() { return this->pts; }
     lslgeneric::NDTMap &getNDTMap() { return *(map->map); }
     NDTFeatureFuserHMT &getFuser() { return *map; }
-    const Eigen::Affine3d &getPose() const { return T; }
-    void setPose(const Eigen::Affine3d &pose) { T = pose; }
-    const Eigen::Matrix3d &getCov() const { return cov; }
-    void setCov(const Eigen::Matrix3d &c) { cov = c; }
+    // Interfaces.
+    virtual const Eigen::Affine3d &getPose() const { return T; }
+    virtual void setPose(const Eigen::Affine3d &pose) { T = pose; }
+    virtual const Eigen::Matrix3d &getCov() const { return cov; }
+    virtual void setCov(const Eigen::Matrix3d &c) { cov = c; }
     void force2D()
     {
         forceEigenAffine3dTo2dInPlace(this->T);
@@ -462,7 +586,7 @@ inline double overlapNDTOccupancyScore(NDTFeatureNode &ref, NDTFeatureNode &mov,
     return score;
 }
 
-class NDTFeatureGraph {
+class NDTFeatureGraph : public NDTFeatureGraphInterface {
 public:
     class Params {   // ndt_feature_graph.h:24-56
     public:
@@ -494,8 +618,13 @@ public:
     NDTFeatureGraph(const NDTFeatureGraph &) = delete;
     NDTFeatureGraph &operator=(const NDTFeatureGraph &) = delete;
 
-    size_t getNbNodes() const { return nodes_.size(); }
-    size_t getNbLinks() const { return links_.size(); }
+    // Interfaces (ndt_feature_graph.h: the graph IS-A NDTFeatureGraphInterface)
+    virtual size_t getNbNodes() const { return nodes_.size(); }
+    virtual NDTFeatureNodeInterface &getNodeInterface(size_t idx) { return nodes_[idx]; }
+    virtual const NDTFeatureNodeInterface &getNodeInterface(size_t idx) const { return nodes_[idx]; }
+    virtual size_t getNbLinks() const { return links_.size(); }
+    virtual NDTFeatureLinkInterface &getLinkInterface(size_t idx) { return links_[idx]; }
+    virtual const NDTFeatureLinkInterface &getLinkInterface(size_t idx) const { return links_[idx]; }
     NDTFeatureNode &getNode(size_t i) { return nodes_[i]; }
     NDTFeatureLink &getLink(size_t i) { return links_[i]; }
     lslgeneric::NDTMap *getMap(int i) { return nodes_[i].map->map; }
@@ -529,6 +658,10 @@ public:
         node.map->setSensorPose(sensor_pose_);
         initPose.setIdentity();   // keep each map in it's own ref frame (that is node.T)
         node.map->initialize(initPose, cloud, pts, preLoad);
+        if (params_.storePtsInNodes) {   // Add the cloud...
+            Eigen::Affine3d Tnow_local_sensor = initPose * sensor_pose_;
+            node.addCloud(Tnow_local_sensor, cloud);
+        }
         nodes_.push_back(node);
         Tnow = node.T;
     }
@@ -565,6 +698,12 @@ public:
         Tnow = node.T * Tnow_local;
         node.Tlocal_odom = node.Tlocal_odom * Tmotion;
         node.Tlocal_fuse = Tnow_local;
+        if (params_.storePtsInNodes) {
+            if (node.nbUpdates % params_.storePtsInNodesIncr == 0) {
+                Eigen::Affine3d Tnow_local_sensor = Tnow_local * sensor_pose_;
+                node.addCloud(Tnow_local_sensor, cloud);
+            }
+        }
         node.nbUpdates++;
         return Tnow;
     }

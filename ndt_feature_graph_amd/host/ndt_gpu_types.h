@@ -7,6 +7,7 @@
 #pragma once
 #include <cmath>
 #include <cstddef>
+#include <stdexcept>
 #include <vector>
 
 #ifdef NDTGPU_USE_EIGEN_PCL
@@ -59,12 +60,31 @@ struct Matrix3d {
                         (*this)(2, 0) * x[0] + (*this)(2, 1) * x[1] + (*this)(2, 2) * x[2]);
     }
     Matrix3d operator+(const Matrix3d &o) const { Matrix3d r; for (int k = 0; k < 9; k++) r.m[k] = m[k] + o.m[k]; return r; }
-    // Rx * Ry * Rz angles (Eigen's eulerAngles(0, 1, 2)) of a rotation matrix
-    Vector3d eulerAngles(int, int, int) const
+    // MatrixBase::eulerAngles(a0, a1, a2) as Eigen 3.3 computes it (Eigen/src/Geometry/EulerAngles.h), for three different
+    // axes: the first angle lands in [0, pi] -- a rotation about z alone whose R(1,2) is +1e-17 instead of 0 comes back as
+    // (pi, -pi, yaw - pi), which is what the fuser's relpose and rotation gates see upstream (fuser_hmt.cpp:124-126, 376,
+    // 386; the case utils_affine_test.cpp:32-58 prints).  Reproduced branch for branch, not "fixed".
+    Vector3d eulerAngles(int a0, int a1, int a2) const
     {
         const Matrix3d &R = *this;
-        const double ry = std::asin(std::fmax(-1.0, std::fmin(1.0, R(0, 2))));
-        return Vector3d(std::atan2(-R(1, 2), R(2, 2)), ry, std::atan2(-R(0, 1), R(0, 0)));
+        if (a0 == a2 || a0 == a1 || a1 == a2 || a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a2 < 0 || a2 > 2)
+            throw std::invalid_argument("eulerAngles: three different axes");
+        const int odd = ((a0 + 1) % 3 == a1) ? 0 : 1;
+        const int i = a0, j = (a0 + 1 + odd) % 3, k = (a0 + 2 - odd) % 3;
+        double res[3];
+        res[0] = std::atan2(R(j, k), R(k, k));
+        const double c2 = std::sqrt(R(i, i) * R(i, i) + R(i, j) * R(i, j));
+        if ((odd && res[0] < 0.0) || (!odd && res[0] > 0.0)) {
+            if (res[0] > 0.0) res[0] -= M_PI;
+            else res[0] += M_PI;
+            res[1] = std::atan2(-R(i, k), -c2);
+        } else {
+            res[1] = std::atan2(-R(i, k), c2);
+        }
+        const double s1 = std::sin(res[0]), c1 = std::cos(res[0]);
+        res[2] = std::atan2(s1 * R(k, i) - c1 * R(j, i), c1 * R(j, j) - s1 * R(k, j));
+        if (!odd) { res[0] = -res[0]; res[1] = -res[1]; res[2] = -res[2]; }
+        return Vector3d(res[0], res[1], res[2]);
     }
     const double *data() const { return m; }
     double *data() { return m; }

@@ -225,6 +225,26 @@ static bool matchFusion(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sourc
 }
 }  // namespace retyped
 
+// What the untouched iSAM layer does with the graph (optimizeGraphUsingISAM, ndt_offline_mapper.h:40-107), with the
+// optimiser replaced by "chain the link transforms from node 0": it only ever sees the three interfaces.
+static void rewrite_poses_through_the_interfaces(ndt_feature::NDTFeatureGraphInterface &graph)
+{
+    std::vector<Eigen::Affine3d> pose(graph.getNbNodes());
+    pose[0] = graph.getNodeInterface(0).getPose();
+    std::vector<bool> have(graph.getNbNodes(), false);
+    have[0] = true;
+    for (size_t pass = 0; pass < graph.getNbNodes(); pass++)
+        for (size_t i = 0; i < graph.getNbLinks(); i++) {
+            const ndt_feature::NDTFeatureLinkInterface &link = graph.getLinkInterface(i);
+            if (have[link.getRefIdx()] && !have[link.getMovIdx()]) {
+                pose[link.getMovIdx()] = pose[link.getRefIdx()] * link.getRelPose();
+                have[link.getMovIdx()] = true;
+            }
+        }
+    for (size_t i = 0; i < graph.getNbNodes(); i++)
+        if (have[i]) graph.getNodeInterface(i).setPose(pose[i]);
+}
+
 template <class F> static bool throws_invalid(F f)
 {
     try { f(); } catch (const ndtgpu_host::Error &e) { return e.status == NDTGPU_ERR_INVALID; }
@@ -243,6 +263,34 @@ int main()
     gp.newNodeTranslDist = 1.0;
     gp.maxNodes = 8;
     InterestPointVec no_pts;
+
+    // ---- 0. (no device needed) Eigen's eulerAngles(0, 1, 2) as the fuser uses it: first angle in [0, pi], the angles
+    //         rebuild the rotation; the cases of utils_affine_test.cpp:32-58 and the +-1e-17 quirk of a plane rotation
+    {
+        auto check_euler = [&](const Eigen::Affine3d &A, const char *what) {
+            const Eigen::Vector3d e = A.rotation().eulerAngles(0, 1, 2);
+            const Eigen::Affine3d B = ndtgpu_host::affine_from_pose(0, 0, 0, e[0], e[1], e[2]);
+            double err = 0;
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) err = std::max(err, std::fabs(A.rotation()(r, c) - B.rotation()(r, c)));
+            CHECK(e[0] >= 0.0 && e[0] <= M_PI + 1e-15 && err < 1e-12, "eulerAngles %s: (%.6f %.6f %.6f) rebuilds R to %.2e", what, e[0], e[1], e[2], err);
+            return e;
+        };
+        const double off = 0.001;
+        check_euler(ndtgpu_host::affine_from_pose(2., 0.1, 0., -M_PI + off, M_PI + off, M_PI + 0.9), "K8 a");
+        check_euler(ndtgpu_host::affine_from_pose(2., 0.1, 0., 0.00104309, -0.000766065, -3.11517), "K8 b");
+        const Eigen::Vector3d flat = check_euler(ndtgpu_host::affine_from_pose(0, 0, 0, 0, 0, 0.3), "plane rotation");
+        CHECK(std::fabs(flat[0]) < 1e-15 && std::fabs(flat[2] - 0.3) < 1e-15, "plane rotation: yaw %.17g", flat[2]);
+        Eigen::Affine3d q = ndtgpu_host::affine_from_pose(0, 0, 0, 0, 0, 0.3);
+        q.data()[9] = 1e-17;                 // R(1,2) = +1e-17: Eigen answers (pi, +-pi, yaw - pi)
+        const Eigen::Vector3d eq = q.rotation().eulerAngles(0, 1, 2);
+        CHECK(std::fabs(eq[0] - M_PI) < 1e-12 && std::fabs(std::fabs(eq[1]) - M_PI) < 1e-12 && std::fabs(eq[2] - (0.3 - M_PI)) < 1e-12,
+              "eulerAngles branch of R(1,2) > 0: (%.6f %.6f %.6f)", eq[0], eq[1], eq[2]);
+        MotionModel2d mm0;
+        const Eigen::Matrix3d Rm = mm0.getPose2dCov(Pose2d(0.5, 0.0, 0.0)).cov;    // (heading 0: the rotation of the covariance is the identity)
+        CHECK(Rm(0, 1) == 0.0 && Rm(1, 0) == 0.0 && Rm(0, 2) == 0.0 && Rm(2, 0) == 0.0 && Rm(1, 2) == 0.0 && Rm(2, 1) == 0.0 && Rm(0, 0) > 0,
+              "MotionModel2d::getMeasurementCov: off-diagonals must be zero (motion_model.cpp:202 R.setZero())");
+    }
 
     if (ndtgpu_device_count() < 1) {
         try {
@@ -312,6 +360,27 @@ int main()
     }
     std::vector<NDTFeatureLink> valid = graph.getValidLinks(links, 1.0, 3.0, 0.5, 1);
     CHECK(!valid.empty(), "no link survives the gates");
+    // the graph through the abstract interfaces (interfaces.h:10-48), as ndt_offline_mapper.h:40 takes it: the refined
+    // links rewrite the node poses; then back again
+    {
+        std::vector<Eigen::Affine3d> before;
+        for (size_t i = 0; i < graph.getNbNodes(); i++) before.push_back(graph.getNode(i).T);
+        graph.setLinks(links);
+        rewrite_poses_through_the_interfaces(graph);
+        double worst = 0;
+        for (size_t i = 0; i < graph.getNbNodes(); i++) {
+            double d, a;
+            pose_error(graph.getNode(i).T, before[i], d, a);
+            worst = std::fmax(worst, d);
+        }
+        std::ostringstream os;
+        os << graph.getLinkInterface(0);
+        std::printf("B: node poses rewritten through NDTFeatureGraphInterface from %zu registered links: they moved by at most %.3f m; link 0 prints as%s\n",
+                    graph.getNbLinks(), worst, os.str().c_str());
+        CHECK(worst < 0.1 && graph.getNbLinks() == links.size() && os.str().find("score") != std::string::npos, "interface consumer");
+        for (size_t i = 0; i < graph.getNbNodes(); i++) graph.getNodeInterface(i).setPose(before[i]);
+        graph.clearAllLinks();
+    }
 
     // ---- C. the re-typed host loop vs the device-resident matchFusion -----------------------------------------------------
     {
@@ -332,7 +401,8 @@ int main()
             retyped::g_evals = 0;
             bool rh = retyped::matchFusion(target, src, Th, Tcov, true, true, 30, 2, 1e-6, soft != 0);
             ndtgpu_match_result res;
-            bool rd = matchFusion(target, src, nullptr, nullptr, corr, Td, Tcov, true, true, false, true, 30, 2, 1e-6, soft != 0, true, false, &res);
+            lslgeneric::NDTMap feat_t(new lslgeneric::CellVector(), true), feat_s(new lslgeneric::CellVector(), true);   // empty feature maps
+            bool rd = matchFusion(target, src, feat_t, feat_s, corr, Td, Tcov, true, true, false, true, 30, 2, 1e-6, soft != 0, true, false, &res);
             double d, a;
             pose_error(Th, Td, d, a);
             std::printf("C: soft=%d  host loop (%d Hessian evaluations) vs device loop (%d iterations): |dt| %.2e m |dyaw| %.2e rad  ret %d/%d\n", soft,
@@ -373,11 +443,20 @@ int main()
               "unsupported cell update mode accepted");
         CHECK(throws_invalid([&] { local.loadPointCloud(pc, 30.0); local.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE, 1e5, 100.f); }),
               "occupancy_limit the plain build cannot honour accepted");
-        NDTFeatureFuserHMT::Params bad = fp;
-        bad.useFeat = true;
-        NDTFeatureFuserHMT fuser(bad);
-        fuser.initialize(Eigen::Affine3d::Identity(), pc, no_pts);
-        CHECK(throws_invalid([&] { fuser.update(Eigen::Affine3d::Identity(), pc, no_pts); }), "useFeat accepted");
+        // a fuser with the reference's DEFAULT feature switches (useFeat = useOdom = true, ndt_feature_fuser_hmt.h:77-79):
+        // no interest points -> no feature cells; the 40 odometry cell pairs join the registration
+        // (fuser_hmt.cpp:322-334, fusion.h:858-871, 1013-1023)
+        NDTFeatureFuserHMT::Params dflt = fp;
+        dflt.useFeat = true; dflt.useOdom = true;
+        NDTFeatureFuserHMT fuser(dflt);
+        fuser.setSensorPose(Eigen::Affine3d::Identity());
+        fuser.initialize(gt[0], corridor_scan(gt[0], 100), no_pts);
+        Eigen::Affine3d Tm = gt[0].inverse() * gt[1];
+        Eigen::Affine3d Tn = fuser.update(Tm, corridor_scan(gt[1], 101), no_pts);
+        double dd, da;
+        pose_error(Tn, gt[1], dd, da);
+        std::printf("D: fuser with useFeat / useOdom defaults: %d iterations, |dt| %.3f m |dyaw| %.4f rad from the true pose\n", fuser.last_match.iterations, dd, da);
+        CHECK(fuser.last_match.iterations > 0 && dd < 0.05 && da < 0.01, "fuser with odometry cells is off: %.3f m %.4f rad", dd, da);
     }
     // ---- E. the map wire format: toMessage / fromMessage round trip (ndtgraph_conversion.h:34-43, 129-158) -----------------
     {

@@ -1,6 +1,6 @@
 """The C++ host mirror (ndt_feature_graph_amd/host/*.h: lslgeneric::NDTMap / NDTMatcherD2D[_2D] and
 ndt_feature::NDTFeatureFuserHMT / NDTFeatureGraph over the C-ABI) compiles with plain g++ and behaves: without a GPU it
-fails loudly; with a GPU host_demo.cpp drives the graph front door over a trajectory, refines all links in batched
+fails loudly; with a GPU tests/native/host_demo.cpp drives the graph front door over a trajectory, refines all links in batched
 calls, and runs the reference's Newton loop (ndt_matcher_d2d_fusion.h:847-1121) RE-TYPED against the mirror -- one
 ndtgpu_derivatives call per evaluation -- landing on the device-resident matchFusion's pose."""
 import os
@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HOST = os.path.join(ROOT, "ndt_feature_graph_amd", "host")
+HOST = os.path.join(ROOT, "tests", "native")       # host_demo.cpp: the harness; the mirror it tests is ndt_feature_graph_amd/host/*.h
 
 
 def _build():
