@@ -89,63 +89,94 @@ def cpu_baseline_c(fixed_h, moving_h, T0, res, size_m, rng_lim, delta, nn, itr_m
 
 def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_lim):
     """BASELINE configs[3]: "ndt_offline_ndt_feature bag replay, ~5k nodes, all-pairs candidate edges sharded over 8 GPUs".
-    Synthetic replay (the bags are not in the reference): node poses along a trajectory inside one building, one node
-    map per pose (points / cell size of the headline config), candidate edges = all pairs in
-    NDTFeatureGraph::computeAllPossibleLinks order (ndt_feature_graph.cpp:395-405) or, with --gated, those the
-    reference's link gates keep (getValidLinks defaults, ndt_feature_graph_opt.cpp:49-52) on the odometry poses.
-    Every rank builds all node maps (replicated: a scan costs ~1 us of GPU time, cheaper than shipping cell maps), takes
-    its block-cyclic share of the edges (chunk 256), registers it in one device batch, and the edge transforms are
-    all-gathered at the end (the only collective).  Reported separately: nodes/s, edges/s, the gather."""
+    Synthetic replay (the bags are not in the reference): a trajectory with one node every 2 m (newNodeTranslDist,
+    ndt_graph_offline.cpp:301) through a floor plan of separate rooms (100 nodes per room on a serpentine path), every
+    node a FUSED node map -- `--scans-per-node` scans taken while the vehicle moves through the node's first metre, added one
+    after the other with ndtgpu_mapset_add_cloud (ray tracing + accumulate + finalise: what graph.cpp:273 really matches).
+    Candidate edges = all pairs in NDTFeatureGraph::computeAllPossibleLinks order (ndt_feature_graph.cpp:395-405) --
+    12 497 500 for 5000 nodes, most of them between rooms that share nothing: their registration ends at the first
+    evaluation -- or, with --gated, the pairs whose odometry poses lie within --gate-dist of each other and at least two
+    indices apart (the stand-in for the reference's FLIRT candidate matching + getValidLinks gates,
+    ndt_feature_graph_opt.cpp:49-52).  Every rank builds all node maps (replicated), registers its block-cyclic share of the
+    edges (chunk 256) in device batches of 2^20 and the edge results are all-gathered at the end (the only collective).
+    For the gated edges of rank 0 the per-link covariance and occupancy overlap of updateLinksUsingNDTRegistration
+    (graph.cpp:296-340) are timed too.  Reported separately: nodes/s, edges/s, covariance / overlap per edge, the gather."""
     from ndt_feature_graph_amd import distributed as D
-    n_nodes, NP, res = args.nodes, args.points, args.res
-    t = torch.linspace(0.0, 2.0 * np.pi, n_nodes + 1, dtype=torch.float64)[:-1]
-    poses = torch.stack([1.6 * torch.sin(t), 1.2 * torch.sin(2.0 * t + 0.3), 0.35 * torch.sin(3.0 * t)], dim=1)
-    seeds = torch.full((n_nodes,), 321, dtype=torch.int64, device=dev)
-    scans = synth.scan_2d(seeds, poses.to(dev), NP, chunk_bytes=2 << 30).contiguous()
-    node_T = synth.pose2d_to_T(poses).numpy()
+    n_nodes, res = args.nodes, args.res
+    S, NPn, per_room = args.scans_per_node, args.node_points, 100
+    q = np.arange(n_nodes) % per_room
+    room = np.arange(n_nodes) // per_room
+    col, row = q // 10, q % 10
+    row = np.where(col % 2 == 1, 9 - row, row)                       # serpentine: 2 m between consecutive nodes
+    lx, ly = -9.0 + 2.0 * col, -9.0 + 2.0 * row
+    yaw = np.where(col % 2 == 1, -np.pi / 2, np.pi / 2)
+    local = np.stack([lx, ly, yaw], axis=1)
+    world_xy = np.stack([80.0 * (room % 8) + lx, 80.0 * (room // 8) + ly], axis=1)
+    node_T = synth.pose2d_to_T(torch.as_tensor(np.concatenate([world_xy, yaw[:, None]], axis=1))).numpy()
     g = np.random.default_rng(11)
     odo_T = node_T.copy()
     odo_T[:, 0, 3] += g.normal(scale=0.03, size=n_nodes)
     odo_T[:, 1, 3] += g.normal(scale=0.03, size=n_nodes)
+    # the scans of every node, in its own frame (the vehicle drives 0.9 m / S per scan straight ahead inside a node)
+    seeds = torch.as_tensor(4000 + room, dtype=torch.int64, device=dev)
+    clouds = []
+    for k in range(S):
+        dx = 0.9 * k / max(1, S)
+        pk = local.copy()
+        pk[:, 0] += dx * np.cos(yaw); pk[:, 1] += dx * np.sin(yaw)
+        sc = synth.scan_2d(seeds, torch.as_tensor(pk, device=dev), NPn, noise_stream=k, chunk_bytes=2 << 30).contiguous()
+        sc[:, :, 0] += dx                                              # sensor frame -> node frame
+        clouds.append((sc, np.tile(np.array([[dx, 0.0, 0.0]]), (n_nodes, 1))))
     edges = D.all_pairs(n_nodes)
+    d_odo = np.linalg.norm(odo_T[edges[:, 0], :2, 3] - odo_T[edges[:, 1], :2, 3], axis=1)
+    gate = (d_odo <= args.gate_dist) & ((edges[:, 1] - edges[:, 0]) >= 2)
+    n_gated = int(gate.sum())
     if args.gated:
-        edges = edges[D.gate_links(edges, odo_T, max_dist=1.0, max_angle=0.2, min_idx_dist=2)]
+        edges = edges[gate]
+        gate = np.ones(len(edges), dtype=bool)
     n_edges = len(edges)
     mine = D.shard_edges(n_edges, rank, world, 256)
-    T0 = np.einsum("eij,ejk->eik", np.linalg.inv(odo_T[edges[mine, 0]]), odo_T[edges[mine, 1]])
+    T0 = np.einsum("eij,ejk->eik", np.linalg.inv(odo_T)[edges[mine, 0]], odo_T[edges[mine, 1]])
     T0_cm = torch.as_tensor(np.ascontiguousarray(T0.transpose(0, 2, 1)).reshape(-1, 16), device=dev)
     ti = torch.as_tensor(edges[mine, 0].astype(np.int32), device=dev)
     si = torch.as_tensor(edges[mine, 1].astype(np.int32), device=dev)
     pool = N.MapSet(res, [0, 0, 0], size_m, n_maps=n_nodes, max_cells=4096)
+    pool.enable_occupancy()
     T16 = T0_cm.clone()
     results = torch.zeros((len(mine), 64), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream()
+    CH = 1 << 20
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_pass(timed):
+    def one_pass():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record(st)
-        pool.build(scans, range_limit=rng_lim, stream=st)                          # phase A: node maps
+        pool.clear()                                                               # phase A: fused node maps
+        for k, (sc, org) in enumerate(clouds):
+            pool.add_cloud(sc, org, stream=st, **(dict(maxz=100.0, sensor_noise=0.1) if k == 0 else dict(maxz=25.0, sensor_noise=0.06)))
         ev[1].record(st)
         T16.copy_(T0_cm)
-        binding.match_batch_device(pool, ti, pool, si, T16, results, len(mine), stream=st, delta_score=1e-3)   # edge preset
+        for c0 in range(0, len(mine), CH):                                         # phase B: this rank's edges
+            c1 = min(len(mine), c0 + CH)
+            binding.match_batch_device(pool, ti[c0:c1], pool, si[c0:c1], T16[c0:c1], results[c0:c1], c1 - c0, stream=st, delta_score=1e-3)
         ev[2].record(st)
         gathered = D.gather_edge_results(T16, results, n_edges, rank, world, 256)   # phase D: the only collective
         ev[3].record(st)
         return ev, gathered
 
+    steps = args.steps if args.steps != 20 else 2
     barrier()
-    for _ in range(max(1, args.warmup)):
-        one_pass(False)
+    for _ in range(1 if args.warmup == 3 else max(1, args.warmup)):
+        one_pass()
     barrier()
     t0 = time.perf_counter()
     evs = []
-    for _ in range(args.steps):
-        ev, gathered = one_pass(True)
+    for _ in range(steps):
+        ev, gathered = one_pass()
         evs.append(ev)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -157,21 +188,42 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
     match_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
     gather_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
     r = gathered[1].cpu().numpy().view(binding.RESULT_DTYPE).reshape(-1)
-    out = {"metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)", "value": n_edges * args.steps / elapsed,
-           "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "configs[3]: graph replay, %d node maps (%d pts, %.2f m cells), %s candidate edges = %d, edge preset "
-                                  "(DELTA_SCORE 1e-3), block-cyclic shards of 256 edges over %d rank(s); one step = rebuild every node "
-                                  "map on every rank + register this rank's edges on prebuilt maps + all-gather of the edge results" % (
-                                      n_nodes, NP, res, "gated" if args.gated else "all-pairs", n_edges, world),
-                      "nodes": n_nodes, "edges": n_edges, "edges_this_rank": int(len(mine))},
-           "nodes_per_s_build": n_nodes / (build_ms * 1e-3), "edges_per_s_match": world * len(mine) / (match_ms * 1e-3),
+    Tg = gathered[0].cpu().numpy().reshape(-1, 4, 4).transpose(0, 2, 1)
+    cells = pool.num_cells_all()
+    # the gated edges: result quality + covariance + overlap (rank 0, host arrays like the reference's call sites)
+    gi = np.nonzero(gate)[0]
+    extra = {}
+    if rank == 0 and len(gi):
+        rel_true = np.einsum("eij,ejk->eik", np.linalg.inv(node_T)[edges[gi, 0]], node_T[edges[gi, 1]])
+        err = np.linalg.norm(Tg[gi][:, :2, 3] - rel_true[:, :2, 3], axis=1)
+        same_room = room[edges[gi, 0]] == room[edges[gi, 1]]
+        sub = gi[:200000]
+        tcov = _timed(torch, lambda: binding.covariance(pool, edges[sub, 0], pool, edges[sub, 1], Tg[sub]), reps=1, warm=1)
+        tovl = _timed(torch, lambda: binding.overlap_score(pool, edges[sub, 0], pool, edges[sub, 1], Tg[sub]), reps=1, warm=1)
+        extra = {"gated_edges": int(len(gi)), "gated_same_room_frac": float(same_room.mean()),
+                 "gated_converged_frac": float(r["converged"][gi].mean()), "gated_mean_iterations": float(r["iterations"][gi].mean()),
+                 "gated_median_translation_error_m": float(np.median(err)), "gated_err_below_5cm_frac": float((err < 0.05).mean()),
+                 "covariance_us_per_edge": 1e3 * tcov / len(sub), "overlap_us_per_edge": 1e3 * tovl / len(sub),
+                 "covariance_overlap_sample": int(len(sub))}
+    hist = np.bincount(np.minimum(r["iterations"], 32), minlength=33).tolist()
+    out = {"metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)", "value": n_edges * steps / elapsed,
+           "unit": "registrations/s", "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": 1e3 * elapsed / steps,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "configs[3]: graph replay, %d nodes 2 m apart through %d rooms, every node a fused map of %d scans x %d pts "
+                                  "(%.2f m cells), %s candidate edges = %d (edge preset DELTA_SCORE 1e-3), block-cyclic shards of 256 edges over "
+                                  "%d rank(s); one step = rebuild every node map on every rank (%d add_cloud calls) + register this rank's "
+                                  "edges on the node maps + all-gather of the edge results" % (
+                                      n_nodes, int(room.max()) + 1, S, NPn, res, "gated" if args.gated else "all-pairs", n_edges, world, S),
+                      "nodes": n_nodes, "edges": n_edges, "edges_this_rank": int(len(mine)), "edges_within_gate": n_gated,
+                      "gate_dist_m": args.gate_dist, "mean_cells_per_node_map": float(cells.mean())},
+           "nodes_per_s_build": n_nodes / (build_ms * 1e-3), "scans_per_s_fused": n_nodes * S / (build_ms * 1e-3),
+           "edges_per_s_match": len(mine) / (match_ms * 1e-3) * world,
            "phase_ms": {"build_all_nodes": build_ms, "match_my_edges": match_ms, "all_gather_edge_results": gather_ms},
            "gather_bytes_per_edge": 16 * 8 + 64, "converged_frac": float(r["converged"].mean()),
-           "mean_iterations": float(r["iterations"].mean()),
-           "note": "value counts edge registrations on prebuilt node maps (the unit the graph layer consumes, graph.cpp:273); a "
-                   "node map is built once per node per step, not per edge"}
+           "mean_iterations": float(r["iterations"].mean()), "iteration_histogram_0_to_32": hist,
+           "edges_without_any_pair_term": int((r["pair_terms_h"] == 0).sum()), "gated": extra,
+           "note": "value counts edge registrations on fused node maps (the unit the graph layer consumes, graph.cpp:273); a node map is "
+                   "built once per node per step, not per edge; edges_per_s_match scales one rank's rate by the world size"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -339,8 +391,11 @@ def main():
     ap.add_argument("--config", type=str, default="3", choices=["3", "4", "5", "fuse"],
                     help="3: BASELINE configs[2], the batch the metric is quoted on (default); 4: configs[3], the graph replay harness; "
                          "5: configs[4], 3D mode; fuse: the node-map path (add_cloud, link covariance and overlap)")
-    ap.add_argument("--nodes", type=int, default=1000, help="--config 4: node maps (5000 = the full config; 1000 by default)")
-    ap.add_argument("--gated", action="store_true", help="--config 4: only the edges the reference's link gates keep")
+    ap.add_argument("--nodes", type=int, default=5000, help="--config 4: node maps (5000 = the full config)")
+    ap.add_argument("--gated", action="store_true", help="--config 4: only the candidate edges within --gate-dist")
+    ap.add_argument("--gate-dist", type=float, default=6.0, help="--config 4: candidate gate on the odometry distance of two nodes [m]")
+    ap.add_argument("--scans-per-node", type=int, default=10, help="--config 4: scans fused into every node map")
+    ap.add_argument("--node-points", type=int, default=20000, help="--config 4: points per scan")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--buffers", type=int, default=3, help="pipeline depth (mapset pairs / streams)")
     ap.add_argument("--no-pipeline", action="store_true",

@@ -1,3 +1,3 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; ulimit -c 0; export PYTHONUNBUFFERED=1
-./tests/native/host_demo 2>&1 | tail -25
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+timeout 600 python bench.py --config 4 --nodes 1000 --gated 2>&1 | tail -2 | cut -c1-3000
+timeout 1200 python bench.py --config 4 2>&1 | tail -2 | cut -c1-3000
