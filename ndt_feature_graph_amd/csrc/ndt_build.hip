@@ -47,7 +47,7 @@
 #endif
 //        // sub-tiles per super-tile (one wavefront merge + flush per 2048 points)
 #define NDT_IDC 64           // entries of the per-wave slot -> id cache
-#define NDT_FLCAP 40         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 160 B)
+#define NDT_FLCAP 80         // records in the per-wave flush list (it reuses the tile buffer: 64*25*4 B / 80 B)
 #define NDT_QRUNS 16         // per-wave table of replaced runs, keyed by cell (power of two)
 #define NDT_EMPTY (-1)
 
@@ -117,27 +117,31 @@ NDT_D int get_or_assign(const BuildCtx &b, int slot)
     return expected;   // somebody else assigned it first
 }
 
-// One partial run {n, sum d (m), sum d d^T (m^2)} becomes a 20-double record in the per-wave flush list:
-// the sums are scaled to cell units * 2^s and split into integer-valued hi / lo doubles (see NdtAcc), so
-// that the fp64 atomic adds that consume the list are exact, hence order-independent.
-NDT_D void write_flush_record(const BuildCtx &b, double *rec, int *rec_id, int slot, double n, const double *sd,
+// rint(t) of a double |t| < 2^62 as a 64-bit integer (there is no fp64 -> int64 conversion instruction): the upper word
+// by floor(t 2^-32), the lower one from the exact remainder in [0, 2^32)
+NDT_D long long fixed_from_double(double t)
+{
+    double hi = floor(t * (1.0 / 4294967296.0));
+    double lo = rint(fma(-hi, 4294967296.0, t));            // exact remainder, rounded to an integer in [0, 2^32]
+    const bool carry = lo >= 4294967296.0;
+    lo = carry ? 0.0 : lo;
+    const long long h = (long long)(int)hi + (carry ? 1 : 0);
+    return (long long)((unsigned long long)h << 32) + (long long)(unsigned long long)(unsigned)lo;
+}
+
+// One partial run {n, sum d (m), sum d d^T (m^2)} becomes a 10-word record in the per-wave flush list: the sums are
+// scaled to cell units * 2^s and rounded to 64-bit integers (see NdtAcc), so that the integer atomic adds that consume
+// the list are exact, hence order-independent.
+NDT_D void write_flush_record(const BuildCtx &b, long long *rec, int *rec_id, int slot, double n, const double *sd,
                               const double *sdd)
 {
     int id = get_or_assign(b, slot);
     *rec_id = (id >= 0 && (uint32_t)id < b.cap) ? id : -1;
-    rec[0] = n;
+    rec[0] = (long long)(unsigned long long)(unsigned)n;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        double t = sd[k] * b.q1, hi = rint(t);
-        rec[1 + k] = hi;
-        rec[10 + k] = rint((t - hi) * 4294967296.0);
-    }
+    for (int k = 0; k < 3; k++) rec[1 + k] = fixed_from_double(sd[k] * b.q1);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        double t = sdd[k] * b.q2, hi = rint(t);
-        rec[4 + k] = hi;
-        rec[13 + k] = rint((t - hi) * 4294967296.0);
-    }
+    for (int k = 0; k < 6; k++) rec[4 + k] = fixed_from_double(sdd[k] * b.q2);
 }
 
 }  // namespace
@@ -166,7 +170,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     __shared__ __attribute__((aligned(16))) float s_tile[NDT_BUILD_WAVES * 64 * (STRIDE_DW ? LANE_DW : (NDT_PPL * 3 + 1))];
     constexpr int FLC = SCAT ? 64 : NDT_FLCAP;                       // records in a wave's flush list
     __shared__ int s_flid[NDT_BUILD_WAVES * FLC];
-    __shared__ double s_list[SCAT ? NDT_BUILD_WAVES * 64 * 20 : 1];
+    __shared__ long long s_list[SCAT ? NDT_BUILD_WAVES * 64 * 10 : 1];
     __shared__ double s_qval[NDT_BUILD_WAVES * 10 * NDT_QRUNS];
     __shared__ int s_qslot[NDT_BUILD_WAVES * NDT_QRUNS];
     __shared__ unsigned s_qcnt[NDT_BUILD_WAVES];
@@ -279,18 +283,18 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     // flush list: after the point loop the tile buffer is dead and holds the records of the partial
     // runs that must be added to their cells; ONE atomic instruction then serves up to 64 (record,
     // component) items, instead of 19 dependent single-lane atomics per run.
-    double *fl_val = SCAT ? s_list + awave * (64 * 20) : reinterpret_cast<double *>(mytile);
+    long long *fl_val = SCAT ? s_list + awave * (64 * 10) : reinterpret_cast<long long *>(mytile);
     int *fl_id = s_flid + awave * FLC;
     unsigned nfl = 0;   // wave-uniform
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
     auto drain_list = [&]() {
         ndt_wave_sync();                                  // the records were written by other lanes
-        const unsigned items = nfl * 20u;
+        const unsigned items = nfl * 10u;
         for (unsigned it = lane; it < items; it += 64u) {
-            unsigned e = it / 20u, k = it % 20u;
+            unsigned e = it / 10u, k = it % 10u;
             int id = fl_id[e];
-            if (k < 19u && id >= 0)
-                unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + id) + k, fl_val[e * 20u + k]);
+            if (id >= 0)
+                atomicAdd(reinterpret_cast<unsigned long long *>(bc.acc + id) + k, (unsigned long long)fl_val[e * 10u + k]);
         }
         ndt_wave_sync();                                  // the list may be overwritten now
         nfl = 0;
@@ -302,7 +306,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             const unsigned room = (unsigned)FLC - nfl;
             const unsigned rank = (unsigned)__popcll(m & lt_mask);
             const bool now = mine && ((m >> lane) & 1ull) && rank < room;
-            if (now) write_flush_record(bc, fl_val + (nfl + rank) * 20u, fl_id + nfl + rank, slot, n, sd3, se6);
+            if (now) write_flush_record(bc, fl_val + (nfl + rank) * 10u, fl_id + nfl + rank, slot, n, sd3, se6);
             const unsigned long long done = __ballot(now);
             nfl += (unsigned)__popcll(done);
             m &= ~done;
@@ -398,12 +402,12 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             if (placed) {
                 s_qcnt[wave] = 1u;
             } else {                             // table full (unordered cloud): add directly
-                double rec[20];
+                long long rec[10];
                 int rid;
                 write_flush_record(bc, rec, &rid, victim, vn, v3, v6);
                 if (rid >= 0)
-                    for (int k = 0; k < 19; k++)
-                        unsafeAtomicAdd(reinterpret_cast<double *>(bc.acc + rid) + k, rec[k]);
+                    for (int k = 0; k < 10; k++)
+                        atomicAdd(reinterpret_cast<unsigned long long *>(bc.acc + rid) + k, (unsigned long long)rec[k]);
             }
         };
         // A lane keeps the moments of TWO cells in registers (range noise on a wall that hugs a cell face makes its
@@ -666,10 +670,10 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             double dn = (double)n;
             double m[3];   // mean offset in cell units
 #pragma unroll
-            for (int k = 0; k < 3; k++) m[k] = ((a.s1[k] + a.l1[k] * (1.0 / 4294967296.0)) / dn) * IS1;
+            for (int k = 0; k < 3; k++) m[k] = ((double)a.s1[k] / dn) * IS1;
             double S[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) S[k] = (a.s2[k] + a.l2[k] * (1.0 / 4294967296.0)) * IS2;
+            for (int k = 0; k < 6; k++) S[k] = (double)a.s2[k] * IS2;
             double sc = res * res / (dn - 1.0);
             double C[3][3], V[3][3];
             C[0][0] = (S[0] - dn * m[0] * m[0]) * sc;
@@ -925,7 +929,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     long long t3 = __builtin_readcyclecounter();
     {
         unsigned long long *z = reinterpret_cast<unsigned long long *>(bc.acc);
-        for (unsigned k = tid; k < n_alloc * 20u; k += nthreads) z[k] = 0ull;
+        for (unsigned k = tid; k < n_alloc * 10u; k += nthreads) z[k] = 0ull;
     }
     if (tid == 0) {
         if (MODE != 3) ctr->n_cells = s_base;
@@ -988,16 +992,16 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
                             const double *range_origins_dev, int n_min, double eval_factor, int nice, hipStream_t stream)
 {
     if (count == 0) return hipSuccess;
-    // scales that keep every accumulator an exact integer below 2^53.  Even grid sizes: |u| <= 1/2
-    // (+ rounding), so N/2 * 2^s1 and N/4 * 2^s2 must stay below 2^52.  An odd size lets the reference's
-    // double->int truncation put offsets of up to 1.5 cells into index 0: bound |u| < 2 there.
+    // scales that keep every 64-bit accumulator below 2^62.  Even grid sizes: |u| <= 1/2 (+ rounding), so
+    // N/2 * 2^s1 and N/4 * 2^s2 must stay below 2^62.  An odd size lets the reference's double->int truncation put
+    // offsets of up to 1.5 cells into index 0: bound |u| < 2 there.
     int lg = 1;
     while ((1ull << lg) < (unsigned long long)(n_points ? n_points : 1)) lg++;
     const bool odd = (set.grid.size[0] | set.grid.size[1] | set.grid.size[2]) & 1;
-    int s1_shift = (odd ? 51 : 53) - lg;
-    int s2_shift = (odd ? 50 : 54) - lg;
-    if (s1_shift > 44) s1_shift = 44;
-    if (s2_shift > 44) s2_shift = 44;
+    int s1_shift = (odd ? 60 : 62) - lg;
+    int s2_shift = (odd ? 58 : 62) - lg;
+    if (s1_shift > 45) s1_shift = 45;
+    if (s2_shift > 45) s2_shift = 45;
     const int dbg = 0;   // reserved kernel argument
     const bool aligned4 = (((uintptr_t)xyz_dev | map_stride_bytes) & 3u) == 0;
     const int sdw = (stride_bytes == 12 && aligned4) ? 3 : (stride_bytes == 16 && aligned4) ? 4 : 0;
@@ -1072,9 +1076,9 @@ hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t cou
     int lg = 1;
     while ((1ull << lg) < (unsigned long long)(n_points ? n_points : 1)) lg++;
     const bool odd = (set.grid.size[0] | set.grid.size[1] | set.grid.size[2]) & 1;
-    int s1_shift = (odd ? 51 : 53) - lg, s2_shift = (odd ? 50 : 54) - lg;
-    if (s1_shift > 44) s1_shift = 44;
-    if (s2_shift > 44) s2_shift = 44;
+    int s1_shift = (odd ? 60 : 62) - lg, s2_shift = (odd ? 58 : 62) - lg;
+    if (s1_shift > 45) s1_shift = 45;
+    if (s2_shift > 45) s2_shift = 45;
     *s1_shift_out = s1_shift;
     *s2_shift_out = s2_shift;
     if (count == 0 || n_points == 0) return hipSuccess;

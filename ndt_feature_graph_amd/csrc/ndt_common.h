@@ -6,7 +6,7 @@
 //   wtable int32 [n_maps][slots]        build-time slot -> accumulator id (all -1 between builds)
 //   bitmap u32   [n_maps][slots/32]     build-time occupancy bits (all 0 between builds)
 //   cells  NdtCell [n_maps][max_cells]  80-byte records, Gaussian cells only, in slot order
-//   acc    NdtAcc  [n_maps][max_cells]  160-byte integer-valued fp64 moment accumulators (hi/lo)
+//   acc    NdtAcc  [n_maps][max_cells]  80-byte fixed-point (int64) moment accumulators
 //                                       (build scratch; all-zero between builds)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,20 +32,18 @@ struct alignas(16) NdtCell {   // 80 B: the algorithmic per-cell record (SURVEY 
 };
 static_assert(sizeof(NdtCell) == 80, "NdtCell must be 80 bytes");
 
-// Moment accumulators of u = (p - cell_origin)/res.  Each partial sum v handed to the accumulator is
-// split as  v * 2^s = hi + lo * 2^-32  with hi = rint(v 2^s), lo = rint((v 2^s - hi) 2^32): every
-// addend is an INTEGER-VALUED double and the scales keep every accumulator below 2^53, so the fp64
-// atomic additions are exact -- associative, order-independent, bit-reproducible -- using the native
-// global_atomic_add_f64 instead of emulated 64-bit integer arithmetic.  Resolution 2^-(s+32).
-struct alignas(16) NdtAcc {    // 160 B
-    double n;                  // point count
-    double s1[3];              // hi parts of sum u * 2^s1
-    double s2[6];              // hi parts of sum u_a u_b * 2^s2
-    double l1[3];              // lo parts (* 2^32)
-    double l2[6];
-    double pad;
+// Moment accumulators of u = (p - cell_origin)/res in 64-bit FIXED POINT: a partial sum v handed to the accumulator is
+// rounded once to rint(v * 2^s) and added with a 64-bit integer atomic -- exact, hence associative, order-independent
+// and bit-reproducible.  The scales keep every accumulator below 2^62 (s = 62 - log2 N for |u| <= 1/2, capped at 45):
+// resolution 2^-45 of a cell (squared) per partial run, two orders below what decides a rank-deficient cell
+// (NDT_DEGENERATE_REL * lambda_max ~ 1e-11 cell^2).  Ten atomics and 80 bytes per record (round 2: integer-valued
+// hi / lo doubles with fp64 atomics, nineteen atomics and 160 bytes).
+struct alignas(16) NdtAcc {    // 80 B
+    long long n;               // point count
+    long long s1[3];           // sum u     * 2^s1
+    long long s2[6];           // sum u u^T * 2^s2  (xx xy xz yy yz zz)
 };
-static_assert(sizeof(NdtAcc) == 160, "NdtAcc must be 160 bytes");
+static_assert(sizeof(NdtAcc) == 80, "NdtAcc must be 80 bytes");
 static_assert(sizeof(NdtAcc) >= sizeof(NdtCell), "the finaliser writes the cell record over its accumulator");
 
 struct NdtGrid {               // geometry shared by all maps of a set

@@ -290,9 +290,9 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
             const double dn = (double)n;
             double t2[3], S[6];   // sum of the new points' offsets from the cell origin [m], sum of their outer products [m^2]
 #pragma unroll
-            for (int k = 0; k < 3; k++) t2[k] = (a.s1[k] + a.l1[k] * (1.0 / 4294967296.0)) * IS1 * res;
+            for (int k = 0; k < 3; k++) t2[k] = (double)a.s1[k] * IS1 * res;
 #pragma unroll
-            for (int k = 0; k < 6; k++) S[k] = (a.s2[k] + a.l2[k] * (1.0 / 4294967296.0)) * IS2 * (res * res);
+            for (int k = 0; k < 6; k++) S[k] = (double)a.s2[k] * IS2 * (res * res);
             const double m2[3] = {t2[0] / dn, t2[1] / dn, t2[2] / dn};
             // c2 = sum (d - m2)(d - m2)^T
             double c2[6] = {S[0] - dn * m2[0] * m2[0], S[1] - dn * m2[0] * m2[1], S[2] - dn * m2[0] * m2[2],
@@ -457,7 +457,7 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
     // ---- 5. scratch back to its clean state, counters ---------------------------------------------------------------------
     {
         unsigned long long *z = reinterpret_cast<unsigned long long *>(acc);
-        for (unsigned k = tid; k < n_alloc * 20u; k += nthreads) z[k] = 0ull;
+        for (unsigned k = tid; k < n_alloc * 10u; k += nthreads) z[k] = 0ull;
     }
     if (tid == 0) {
         if (total_cells > cap) { total_cells = cap; ctr->overflow = 1u; }

@@ -79,6 +79,20 @@ struct ndtgpu_mapset {
         work_bytes = bytes;
         return NDTGPU_OK;
     }
+    // pinned host mirror of small staging blocks (poses, indices, results of a host-pointer matcher call): copies from /
+    // to pinned memory are truly asynchronous and skip the runtime's own bounce buffer
+    void *pin = nullptr;
+    size_t pin_bytes = 0;
+    ndtgpu_status ensure_pin(size_t bytes)
+    {
+        if (bytes <= pin_bytes) return NDTGPU_OK;
+        if (pin) (void)hipHostFree(pin);
+        pin = nullptr;
+        pin_bytes = 0;
+        HIP_TRY(hipHostMalloc(&pin, bytes, hipHostMallocDefault));
+        pin_bytes = bytes;
+        return NDTGPU_OK;
+    }
     ndtgpu_status ensure_stage(size_t bytes)
     {
         if (bytes <= stage_bytes) return NDTGPU_OK;
@@ -197,6 +211,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
 {
     if (!s) return NDTGPU_OK;
     (void)hipDeviceSynchronize();
+    if (s->pin) (void)hipHostFree(s->pin);
     if (s->v.table) (void)hipFree(s->v.table);
     if (s->v.rankmap) (void)hipFree(s->v.rankmap);
     if (s->v.wtable) (void)hipFree(s->v.wtable);
@@ -862,15 +877,35 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     if (n_pairs > (size_t)n_cu / 2) return NDTGPU_OK;
     const char *coop_env = getenv("NDTGPU_COOP");             // NDTGPU_COOP=0: persistent kernel above 8 pairs (A/B)
     if (coop_env && atoi(coop_env) == 0 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;
+    // One pinned host block mirrors the device staging block [T | results | target idx | source idx | Q], followed by the
+    // source maps' counters and the control words read back at the end: ONE copy in, the counters out, one wait; later one
+    // copy of poses + results and the control words out, one wait.  (Was: eight pageable copies and four waits -- a third of
+    // a single-pair call.)
+    const size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
+    const size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
+                 off_si = (off_ti + bI + 255) & ~(size_t)255, off_Q = (off_si + bI + 255) & ~(size_t)255;
+    const size_t total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
+    const size_t off_cs = (total + 255) & ~(size_t)255, off_ctrl = off_cs + n_pairs * sizeof(NdtMapCounters);
+    ndtgpu_status rc = ts->ensure_stage(total);
+    if (rc != NDTGPU_OK) return rc;
+    rc = ts->ensure_pin(off_ctrl + n_pairs * 16);
+    if (rc != NDTGPU_OK) return rc;
+    // an asynchronous launch of the persistent matcher (ndtgpu_match_batch_device on another stream) may still be using
+    // the work area of this target set: wait for it before the area is grown, cleared or handed to the launches below
+    if (ts->work_ev_valid) HIP_TRY(hipEventSynchronize(ts->work_ev));
+    char *base = (char *)ts->stage, *hp = (char *)ts->pin;
+    memcpy(hp, T16, bT);
+    memcpy(hp + off_ti, tidx, bI);
+    memcpy(hp + off_si, sidx, bI);
+    if (Q36) memcpy(hp + off_Q, Q36, n_pairs * 36 * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(base, hp, total, hipMemcpyHostToDevice, st));
     // source map sizes decide how many workgroups a registration can use
+    NdtMapCounters *cs = reinterpret_cast<NdtMapCounters *>(hp + off_cs);
+    for (size_t k = 0; k < n_pairs; k++)
+        HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     uint32_t max_cells = 0;
-    {
-        std::vector<NdtMapCounters> cs(n_pairs);
-        for (size_t k = 0; k < n_pairs; k++)
-            HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (size_t k = 0; k < n_pairs; k++) max_cells = std::max(max_cells, cs[k].n_cells);
-    }
+    for (size_t k = 0; k < n_pairs; k++) max_cells = std::max(max_cells, cs[k].n_cells);
     // 128 source cells per workgroup (16 per wave; fewer cells per workgroup stop paying: barrier + solver
     // latency dominate), at most one workgroup per CU.  Every registration uses ceil(its cells / 128) workgroups
     // whatever batch it is in; registrations that do not fit on the chip together run one after the other.
@@ -880,24 +915,9 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     if (groups > (unsigned)n_cu) groups = (unsigned)n_cu;
     if (groups < 1) groups = 1;
     if (groups == 1 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;      // persistent kernel instead
-
-    const size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
-    const size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
-                 off_si = (off_ti + bI + 255) & ~(size_t)255, off_Q = (off_si + bI + 255) & ~(size_t)255;
-    const size_t total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
-    ndtgpu_status rc = ts->ensure_stage(total);
-    if (rc != NDTGPU_OK) return rc;
-    // an asynchronous launch of the persistent matcher (ndtgpu_match_batch_device on another stream) may still be using
-    // the work area of this target set: wait for it before the area is grown, cleared or handed to the launches below
-    if (ts->work_ev_valid) HIP_TRY(hipEventSynchronize(ts->work_ev));
     const size_t stride = ndt_match_coop_work_bytes(groups);
     rc = ts->ensure_work(n_pairs * stride);
     if (rc != NDTGPU_OK) return rc;
-    char *base = (char *)ts->stage;
-    HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + off_ti, tidx, bI, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(base + off_si, sidx, bI, hipMemcpyHostToDevice, st));
-    if (Q36) HIP_TRY(hipMemcpyAsync(base + off_Q, Q36, n_pairs * 36 * sizeof(double), hipMemcpyHostToDevice, st));
     // Cooperative launches sized by the occupancy query: as many registrations per launch as fit on the chip together
     // (`groups` workgroups each), launch after launch on the same stream.  One cooperative launch at a time per
     // process: two of them (two host threads, two streams) could each hold part of the chip and wait for the rest.
@@ -916,7 +936,8 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     // from the previous call would stall the first barrier of this one)
     HIP_TRY(hipMemset2DAsync(ts->work, stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
     static std::mutex coop_mutex;
-    std::vector<unsigned> ctrl(n_pairs * 4);
+    const unsigned *ctrl = reinterpret_cast<const unsigned *>(hp + off_ctrl);
+    std::vector<double> Tin(T16, T16 + 16 * n_pairs);          // (the poses as they came in: a registration that has to be re-run)
     {
         std::lock_guard<std::mutex> coop_lock(coop_mutex);
         for (size_t b0 = 0; b0 < n_pairs; b0 += per_launch) {
@@ -926,23 +947,23 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
                                                  Q36 ? (const double *)(base + off_Q) : nullptr, groups, per_group, ts->work, st);
             if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: cooperative launch", e);
         }
-        HIP_TRY(hipMemcpy2DAsync(ctrl.data(), 16, ts->work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hp, base, off_R + bR, hipMemcpyDeviceToHost, st));                      // poses + results
+        HIP_TRY(hipMemcpy2DAsync(hp + off_ctrl, 16, ts->work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     ts->ev_valid[1] = false;          // (ndtgpu_last_kernel_ms(1): no persistent launch was timed by this call)
+    memcpy(T16, hp, bT);
+    memcpy(results, hp + off_R, bR);
     // A registration whose grid barrier gave up (it cannot with a co-resident grid; the bounded spin stays as a guard
     // against a foreign kernel holding CUs) is run again on the persistent kernel: the call does not fail.
     std::vector<size_t> bad;
     for (size_t k = 0; k < n_pairs; k++)
         if (ctrl[4 * k + 1]) bad.push_back(k);
-    std::vector<double> Tin;
     if (!bad.empty()) {
-        Tin.resize(16 * bad.size());
-        for (size_t j = 0; j < bad.size(); j++) memcpy(&Tin[16 * j], T16 + 16 * bad[j], 16 * sizeof(double));
+        std::vector<double> keep(16 * bad.size());
+        for (size_t j = 0; j < bad.size(); j++) memcpy(&keep[16 * j], &Tin[16 * bad[j]], 16 * sizeof(double));
+        Tin.swap(keep);
     }
-    HIP_TRY(hipMemcpyAsync(T16, base, bT, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(results, base + off_R, bR, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
     if (!bad.empty()) {
         std::vector<uint32_t> bt(bad.size()), bs(bad.size());
         std::vector<double> bQ;

@@ -11,6 +11,9 @@
 // Exit code 0 = every check passed.  Without a GPU: checks that the library fails loudly (NDTGPU_ERR_NO_DEVICE).
 #include "ndt_feature_graph_gpu.h"
 #include "ndt_map_msg_gpu.h"
+extern "C" {
+#include "../../oracle/ndt_oracle.h"      // test infrastructure only: the CPU restatement as checker
+}
 
 #include <cstdio>
 #include <random>
@@ -481,6 +484,42 @@ int main()
         pose_error(Ta, Tb, d, a);
         std::printf("E: message with %zu cells (%zu Gaussians); registration against the round-tripped map differs by %.2e m\n", msg.cells.size(), n_gauss, d);
         CHECK(d < 1e-9 && a < 1e-7, "round-tripped map registers differently: %g m %g rad", d, a);   // acos near 1: 1e-16 in R(0,0) is 1.5e-8 rad
+        // GPU map -> message -> ORACLE map (test infrastructure, oracle/ndt_oracle.h): the Gaussians the message carries give
+        // the CPU restatement the same derivatives as the GPU map gives the device path
+        {
+            std::vector<double> mean3, cov9;
+            for (const auto &c : msg.cells)
+                if (c.hasGaussian_) {
+                    mean3.push_back(c.mean_x); mean3.push_back(c.mean_y); mean3.push_back(c.mean_z);
+                    for (int k = 0; k < 9; k++) cov9.push_back(c.cov_matrix[k]);
+                }
+            const double cen[3] = {msg.x_cen, msg.y_cen, msg.z_cen}, ext[3] = {msg.x_size, msg.y_size, msg.z_size};
+            oracle_map *om = oracle_map_create(msg.x_cell_size, cen, ext);
+            CHECK(om && oracle_map_set_cells(om, mean3.data(), cov9.data(), mean3.size() / 3) == 0, "oracle map from the message");
+            std::vector<lslgeneric::NDTCell *> src = graph.getMap(0)->pseudoTransformNDT(graph.getNode(1).T.inverse() * graph.getNode(0).T);
+            std::vector<double> sm, sc;
+            for (auto *c : src) {
+                const Eigen::Vector3d mu = c->getMean();
+                const Eigen::Matrix3d C = c->getCov();
+                for (int a = 0; a < 3; a++) sm.push_back(mu(a));
+                for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sc.push_back(C(a, b));
+            }
+            double go[6], Ho[36];
+            const double so = oracle_derivatives(om, sm.data(), sc.data(), src.size(), 2, 1, 1.0, 0.05, go, Ho);
+            lslgeneric::NDTMatcherD2D md;
+            md.n_neighbours = 2;
+            Eigen::MatrixXd gg(6, 1), Hg(6, 6);
+            const double sg = md.derivativesNDT(src, *graph.getMap(1), gg, Hg, true);
+            double eg = 0, eh = 0, ng = 0, nh = 0;
+            for (int a = 0; a < 6; a++) {
+                eg = std::fmax(eg, std::fabs(gg(a, 0) - go[a])); ng = std::fmax(ng, std::fabs(go[a]));
+                for (int b = 0; b < 6; b++) { eh = std::fmax(eh, std::fabs(Hg(a, b) - Ho[a * 6 + b])); nh = std::fmax(nh, std::fabs(Ho[a * 6 + b])); }
+            }
+            std::printf("E: message -> oracle map: score %.6f vs %.6f on the GPU map, gradient off by %.1e (of %.1e), Hessian by %.1e (of %.1e)\n", so, sg, eg, ng, eh, nh);
+            CHECK(std::fabs(so - sg) < 1e-9 * std::fabs(so) && eg < 1e-9 * ng && eh < 1e-9 * nh && std::fabs(so) > 1.0, "oracle map from the message disagrees");
+            for (auto *c : src) delete c;
+            oracle_map_destroy(om);
+        }
         std::vector<float> o1 = graph.getMap(1)->getOccupancy(), o2 = back->getOccupancy();
         double worst = 0;
         for (size_t k = 0; k < o1.size(); k++)
