@@ -271,8 +271,10 @@ typedef struct ndtgpu_feat_pairs {
  * the feature maps with the (possibly negated) increment the first one left, and the step is the smaller of the two, the
  * larger one when either is 0 (fusion.h:1013-1023); the final score includes the feature score (fusion.h:1085-1096).
  * flags: bit 0 useSoftConstraints, bit 1 useTikhonovRegularization, bit 2 step_control_fusion.  With bit 2 set and bit 0
- * clear the reference runs the JOINT line search lineSearchMTFusion (fusion.h:390-793) instead: NOT built, rejected
- * with NDTGPU_ERR_INVALID.  `fevals` counts derivative evaluations of the NDT maps.  feat == NULL: ndtgpu_match_fusion_batch. */
+ * clear the reference runs the JOINT line search lineSearchMTFusion (fusion.h:1004-1006, 390-793) instead: one search
+ * on f_ndt(trial) + f_feat -- where, as written upstream, the feature maps are evaluated on the UN-stepped cells in every
+ * trial (fusion.h:619), so their score and gradient at the current pose enter as constants.  Restated as written.
+ * `fevals` counts derivative evaluations of the NDT maps.  feat == NULL: ndtgpu_match_fusion_batch. */
 ndtgpu_status ndtgpu_match_fusion_feat_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx,
                                              ndtgpu_mapset *source_set, const uint32_t *source_idx, double *T16,
                                              const double *Tcov36, const ndtgpu_feat_pairs *feat, size_t n_pairs,

@@ -782,6 +782,8 @@ NDT_D void feat_linesearch_and_apply(MatchSlot<QL> &S, const NdtMatchParamsDev &
     if (lane == 0) {
         st.step_ndt = st.step_size;
         st.fevals_saved = st.fevals;
+        st.ls_fconst = 0.0;
+        for (int a = 0; a < 6; a++) st.ls_gconst[a] = 0.0;
         // what survives of the NDT search: was its first trial (evaluated with its Hessian) accepted at full length?
         S.code = (st.reuse_sums ? 4 : 0) | (st.spec_ok ? 8 : 0);
         double dg0 = 0;
@@ -832,20 +834,31 @@ NDT_D void slot_step(MatchSlot<QL> &S, const NdtMatchParamsDev &prm)
         if (lane == 0) { st.reuse_sums = 0; S.code = linesearch_step(st, S.sums, prm); }
         ndt_wave_sync();
         if (S.code == NEXT_REQUEST_TRIAL) { if (lane == 0) mt_request_trial(st); return; }
-        feat_linesearch_and_apply(S, prm);                // the NDT search is over: st.step_size = step_size_ndt
+        if (st.ls_joint) {                                // lineSearchMTFusion: its step is the step
+            if (lane == 0) apply_step(st, prm);
+            ndt_wave_sync();
+        } else {
+            feat_linesearch_and_apply(S, prm);            // the NDT search is over: st.step_size = step_size_ndt
+        }
         if (!st.reuse_sums) return;
         phase = st.phase;
     }
     if (phase == PH_NEWTON) {
         feat_eval<true>(S.feat, S.n_feat, st.Teval, prm.lfd1, prm.lfd2, S.fsums);
         ndt_wave_sync();
-        if (lane == 0) S.code = newton_solve(st, S.sums, S.fsums, prm, S.ws);
+        if (lane == 0) {
+            if (st.ls_joint) {                            // the feature maps' share of lineSearchMTFusion's function
+                st.ls_fconst = S.fsums[0];
+                for (int a = 0; a < 6; a++) st.ls_gconst[a] = S.fsums[1 + a];
+            }
+            S.code = newton_solve(st, S.sums, S.fsums, prm, S.ws);
+        }
         ndt_wave_sync();
         const int next = S.code;
         if (next == NEXT_NONE) return;
         if (next == NEXT_REQUEST_TRIAL) { if (lane == 0) mt_request_trial(st); return; }
         // NEXT_APPLY_STEP: no step control (full step), or the NDT search gave its recovery step at once
-        if (!prm.step_control) { if (lane == 0) apply_step(st, prm); return; }
+        if (!prm.step_control || st.ls_joint) { if (lane == 0) apply_step(st, prm); return; }
         if (lane == 0) st.reuse_sums = 0;
         feat_linesearch_and_apply(S, prm);
     } else if (phase == PH_FINAL) {
@@ -1021,6 +1034,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                         S.feat = feat_cells + (size_t)f0 * 18;
                     }
                     S.st.use_feat = S.n_feat ? 1 : 0;
+                    S.st.ls_joint = (S.n_feat && (s_prm.fusion_flags & 4) && !(s_prm.fusion_flags & 1)) ? 1 : 0;
                     S.resumed = resumed ? 1 : 0;
                     S.session = atomicAdd(&s_session, 1u) + 1u;      // (a workgroup never sees 2^32 registrations)
                     S.with_h = S.st.with_h;

@@ -50,6 +50,11 @@ struct MatchState {
     // matchFusion feature / odometry-cell terms (fusion.h:858-871, 1013-1023): the feature maps' sums are added to the
     // NDT sums in the Newton system; the step is the smaller of the two line searches (NDT, then features)
     int use_feat;
+    // lineSearchMTFusion (fusion.h:390-793: useFeat, step_control_fusion, no soft constraint): ONE search on
+    // f_ndt(trial) + f_feat, where the feature maps are evaluated on the UN-stepped cells (fusion.h:619 passes sourceNDT_feat,
+    // not sourceNDTHere_feat): their score and gradient at the current pose are constants of the search
+    int ls_joint;
+    double ls_fconst, ls_gconst[6];
     double step_ndt;       // result of the NDT line search while the feature line search runs
     int fevals_saved, pad_feat;
     // matchFusion generalised Tikhonov regularisation (fusion.h:894-911): x0 = 2D pose vector of T Tinit^-1
@@ -507,7 +512,10 @@ NDT_HDN int newton_finish(MatchState &st, const double *sums, const NdtMatchPara
     // lineSearchMT: its initial derivativesNDT(nextNDT) equals this evaluation (same cells), so the
     // score and gradient are reused instead of being recomputed (fusion.h:444-453).  The step is decided by the
     // NDT-only line search on the NDT-only score.
-    return mt_start(st, sums[0], sums + 1);
+    double gls[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) gls[a] = sums[1 + a] + st.ls_gconst[a];        // (+ 0 unless lineSearchMTFusion)
+    return mt_start(st, sums[0] + st.ls_fconst, gls);
 }
 
 #if defined(NDT_SOLVER_STAGE_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -564,9 +572,9 @@ NDT_HDN int linesearch_step(MatchState &st, const double *sums, const NdtMatchPa
     const int maxfev = 40;
     MTState m = st.mt;
     st.fevals++;
-    double f = sums[0];
+    double f = sums[0] + st.ls_fconst;
     double dg = 0;
-    for (int a = 0; a < 6; a++) dg += st.incr[a] * sums[1 + a];
+    for (int a = 0; a < 6; a++) dg += st.incr[a] * (sums[1 + a] + st.ls_gconst[a]);
     m.nfev++;
     double ftest1 = m.finit + m.stp * m.dgtest;
     int info = 0;
@@ -627,6 +635,8 @@ NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchPa
     st.use_prior = Q36 != nullptr && (prm.fusion_flags & 1);
     st.use_tikhonov = Q36 != nullptr && (prm.fusion_flags & 2);
     st.use_feat = 0; st.step_ndt = 0.0; st.fevals_saved = 0; st.pad_feat = 0;     // (set by the caller that has feature maps)
+    st.ls_joint = 0; st.ls_fconst = 0.0;
+    for (int a = 0; a < 6; a++) st.ls_gconst[a] = 0.0;
     for (int a = 0; a < 6; a++) st.x0[a] = 0.0;
     for (int a = 0; a < 6; a++) st.pose_local[a] = 0.0;
     for (int a = 0; a < 36; a++) st.Q[a] = Q36 ? Q36[a] : 0.0;

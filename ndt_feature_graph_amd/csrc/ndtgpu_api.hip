@@ -1049,14 +1049,6 @@ ndtgpu_status ndtgpu_match_fusion_feat_batch(ndtgpu_mapset *ts, const uint32_t *
     if (!ts || !ss || (n_pairs && (!tidx || !sidx || !T16 || !results)))
         return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: bad argument");
     if (n_pairs == 0) return NDTGPU_OK;
-    // step_control_fusion (bit 2) only matters without the soft constraint (fusion.h:1004-1006): the JOINT line search
-    // lineSearchMTFusion (fusion.h:390-793) is not built
-    if ((flags & 4) && !(flags & 1)) {
-        bool any = false;
-        for (size_t k = 0; k < n_pairs && !any; k++) any = feat->offsets[k + 1] > feat->offsets[k];
-        if (any && to_dev(prm).step_control)
-            return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: step_control_fusion without useSoftConstraints selects lineSearchMTFusion, which is not built");
-    }
     for (size_t k = 0; k < n_pairs; k++) {
         if (tidx[k] >= ts->n_maps || sidx[k] >= ss->n_maps) return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: map index");
         if (feat->offsets[k + 1] < feat->offsets[k]) return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: offsets must not decrease");
@@ -1083,7 +1075,7 @@ ndtgpu_status ndtgpu_match_fusion_feat_batch(ndtgpu_mapset *ts, const uint32_t *
     HIP_TRY(hipStreamSynchronize(ts->last_stream));
     HIP_TRY(hipStreamSynchronize(ss->last_stream));
     NdtMatchParamsDev p = to_dev(prm);
-    p.fusion_flags = flags & 3;
+    p.fusion_flags = flags;          // bit 2 (step_control_fusion) selects lineSearchMTFusion when bit 0 is clear (fusion.h:1004)
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
     // (always the persistent matcher: the feature sums are evaluated inside its solver step)

@@ -218,7 +218,7 @@ def match_fusion(target, source, T0, Tcov, use_soft_constraints=True, tikhonov=F
                                            score=R.score, exit_code=R.exit_code)
 
 
-def match_fusion_feat(target, source, T0, Tcov, feat, use_soft_constraints=True, tikhonov=False, **kw):
+def match_fusion_feat(target, source, T0, Tcov, feat, use_soft_constraints=True, tikhonov=False, step_control_fusion=False, **kw):
     """ndt_feature::matchFusion with feature / odometry-cell maps: feat = (src_mean [k,3], src_cov [k,6], tgt_mean, tgt_cov)."""
     prm = dict(DEFAULT_PARAMS)
     prm.update(kw)
@@ -233,7 +233,7 @@ def match_fusion_feat(target, source, T0, Tcov, feat, use_soft_constraints=True,
                                            C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.POINTER(MatchResult)]
     rc = L.oracle_match_fusion_feat(target.h, source.h, _dp(Tc), C.byref(P), _dp(cov),
-                                    int(bool(use_soft_constraints)) | (2 if tikhonov else 0), k, _dp(sm), _dp(sc), _dp(tm), _dp(tc),
+                                    int(bool(use_soft_constraints)) | (2 if tikhonov else 0) | (4 if step_control_fusion else 0), k, _dp(sm), _dp(sc), _dp(tm), _dp(tc),
                                     C.byref(R))
     if rc:
         raise RuntimeError("oracle_match_fusion_feat rc=%d" % rc)

@@ -1390,6 +1390,54 @@ static double line_search_mt_feat(double incr[6], const ocell *tgt, const ocell 
     return oracle_mt_linesearch(lsf_phi, &ctx, score_init, dginit, NULL, NULL);
 }
 
+/* lineSearchMTFusion ([fusion.h]:390-793): ONE More-Thuente search on the sum of the NDT and the feature function.  As
+ * written upstream the feature maps are evaluated on the UN-stepped cells in every trial ([fusion.h]:619 passes
+ * sourceNDT_feat, not sourceNDTHere_feat): their score and gradient at the current pose are constants of the search.
+ * Restated as written, not "fixed". */
+typedef struct {
+    ls_ctx ndt;
+    double f_feat, g_feat[6];
+} lsj_ctx;
+
+static double lsj_phi(void *vctx, double stp, double *dg)
+{
+    lsj_ctx *c = (lsj_ctx *)vctx;
+    double pincr[6], ps[16], g[6], H[36];
+    for (int a = 0; a < 6; a++) pincr[a] = stp * c->ndt.incr[a];
+    oracle_pose_to_T(pincr, ps);
+    transform_cells(c->ndt.cells, c->ndt.scratch, c->ndt.n, ps);
+    double f = derivatives_cells(c->ndt.target, c->ndt.scratch, c->ndt.n, c->ndt.prm->n_neighbours, 0, c->ndt.prm->lfd1,
+                                 c->ndt.prm->lfd2, g, H);
+    (*c->ndt.fevals)++;
+    double d = 0;
+    for (int a = 0; a < 6; a++) d += c->ndt.incr[a] * (g[a] + c->g_feat[a]);
+    *dg = d;
+    return f + c->f_feat;
+}
+
+static double line_search_mt_fusion(double incr[6], const oracle_map *target, const ocell *cells, ocell *scratch, size_t n,
+                                    const ocell *ftgt, const ocell *fcells, size_t nf, const oracle_match_params *prm, int *fevals)
+{
+    double g[6], H[36], gf[6], Hf[36];
+    double score_init = derivatives_cells(target, cells, n, prm->n_neighbours, 0, prm->lfd1, prm->lfd2, g, H);
+    (*fevals)++;
+    const double ff = derivatives_feat(ftgt, fcells, nf, 0, prm->lfd1, prm->lfd2, gf, Hf);
+    score_init += ff;
+    double dginit = 0;
+    for (int a = 0; a < 6; a++) dginit += incr[a] * (g[a] + gf[a]);
+    if (dginit >= 0.0) {
+        for (int a = 0; a < 6; a++) incr[a] = -incr[a];
+        dginit = -dginit;
+        if (dginit >= 0.0) return 0.1; /* recoverystep */
+    }
+    lsj_ctx ctx;
+    ls_ctx nd = {target, cells, scratch, n, incr, prm, fevals};
+    ctx.ndt = nd;
+    ctx.f_feat = ff;
+    memcpy(ctx.g_feat, gf, sizeof gf);
+    return oracle_mt_linesearch(lsj_phi, &ctx, score_init, dginit, NULL, NULL);
+}
+
 /* Gauss-Jordan with partial pivoting: Eigen's Tcov.inverse() ([fusion.h]:845) */
 static int invert6(const double *A, double *inv)
 {
@@ -1460,8 +1508,8 @@ int oracle_match_fusion(const oracle_map *target, const oracle_map *source, doub
 
 /* ndt_feature::matchFusion with useFeat ([fusion.h]:797-1155): n_feat correspondences between sourceNDT_feat and
  * targetNDT_feat (cov6: xx xy xz yy yz zz).  flags: bit 0 useSoftConstraints, bit 1 useTikhonovRegularization.  The
- * separate line searches of [fusion.h]:1007-1023 (the joint lineSearchMTFusion of :1004-1006 is not restated: it runs
- * only with step_control_fusion and WITHOUT the soft constraint).  res->fevals counts NDT-map evaluations. */
+ * separate line searches of [fusion.h]:1007-1023, or (bit 2 step_control_fusion set, bit 0 clear) the joint
+ * lineSearchMTFusion of :1004-1006.  res->fevals counts NDT-map evaluations. */
 int oracle_match_fusion_feat(const oracle_map *target, const oracle_map *source, double T[16],
                              const oracle_match_params *prm, const double Tcov[36], int flags, size_t n_feat,
                              const double *src_mean, const double *src_cov6, const double *tgt_mean, const double *tgt_cov6,
@@ -1471,9 +1519,9 @@ int oracle_match_fusion_feat(const oracle_map *target, const oracle_map *source,
     feat_maps f = {n_feat, src_mean, src_cov6, tgt_mean, tgt_cov6};
     if (flags & 3) {
         if (!invert6(Tcov, Q)) return -2;
-        return match_common(target, source, T, prm, Q, flags & 3, &f, res);
+        return match_common(target, source, T, prm, Q, flags & 7, &f, res);
     }
-    return match_common(target, source, T, prm, NULL, 0, &f, res);
+    return match_common(target, source, T, prm, NULL, flags & 4, &f, res);
 }
 
 /* x0 = convertAffineToVector(forceEigenAffine3dTo2d(T * Tinit^-1))  ([fusion.h]:903-907, utils.h:30-68, 161-169) */
@@ -1510,6 +1558,7 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
     const int soft = Q && (flags & 1), tikhonov = Q && (flags & 2);
     const size_t nf = feat ? feat->n : 0;
     const int use_feat = nf > 0;
+    const int joint_ls = (flags & 4) && !soft;      /* useNDT && useFeat && step_control_fusion && !useSoftConstraints */
     double Tinit[16], x0[6] = {0, 0, 0, 0, 0, 0};
     int dofs[6], nd = 0;
     for (int a = 0; a < 6; a++)
@@ -1643,8 +1692,11 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
                 }
             }
             /* the line search sees only the active dofs' gradient through incr (inactive entries are 0) */
-            step_size = line_search_mt(incr, target, next, scratch, n, prm, &fevals);
-            if (use_feat) { /* [fusion.h]:1015-1023 */
+            if (use_feat && joint_ls) /* [fusion.h]:1004-1006 */
+                step_size = line_search_mt_fusion(incr, target, next, scratch, n, ftgt, fnext, nf, prm, &fevals);
+            else
+                step_size = line_search_mt(incr, target, next, scratch, n, prm, &fevals);
+            if (use_feat && !joint_ls) { /* [fusion.h]:1015-1023 */
                 double step_size_feat = line_search_mt_feat(incr, ftgt, fnext, fscratch, nf, prm);
                 if (step_size != 0. && step_size_feat != 0.) step_size = step_size < step_size_feat ? step_size : step_size_feat;
                 else step_size = step_size > step_size_feat ? step_size : step_size_feat;

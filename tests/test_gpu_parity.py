@@ -704,12 +704,15 @@ def _odom_cells(T_odom, odom_cov6, n=40):
     return sm, sc.copy(), tm, sc.copy()
 
 
-@pytest.mark.parametrize("soft,tikhonov", [(True, True), (True, False), (False, False)])
-def test_match_fusion_with_odometry_cells(N, O, soft, tikhonov):
+@pytest.mark.parametrize("soft,tikhonov,joint", [(True, True, True), (True, False, False), (False, False, False), (False, False, True),
+                                                 (False, True, True)])
+def test_match_fusion_with_odometry_cells(N, O, soft, tikhonov, joint):
     """matchFusion with useFeat / useOdom (the fuser's defaults): 40 odometry cell pairs with known correspondence
     (ndt_feature_fuser_hmt.cpp:322-334) whose NDTMatcherFeatureD2D sums join the NDT sums (fusion.h:858-871), a second
     line search over the feature maps and the smaller of the two steps (fusion.h:1013-1023), the feature score in the
-    final score (fusion.h:1087-1096).  HIP against the oracle: pose, iterations, exit, score; and the cells matter."""
+    final score (fusion.h:1087-1096); with step_control_fusion and without the soft constraint the joint
+    lineSearchMTFusion (fusion.h:1004-1006, 390-793, feature maps un-stepped as written at :619) instead.  HIP against
+    the oracle: pose, iterations, exit, score; and the cells matter."""
     from ndt_feature_graph_amd import binding
     seeds = list(range(31, 39))
     pr, tg, sr, om = _pair_maps(N, O, seeds, 20000, 0.5)
@@ -726,10 +729,12 @@ def test_match_fusion_with_odometry_cells(N, O, soft, tikhonov):
         feats.append(_odom_cells(Todo, odom_cov6, 40 if b != 3 else 7))
     feats[5] = tuple(a[:0] for a in feats[5])                  # a registration without cells in the same batch
     idx = np.arange(B)
-    Tb, rb = binding.match_fusion_feat_batch(tg, idx, sr, idx, T0, covs, feats, use_soft_constraints=soft, tikhonov=tikhonov)
+    Tb, rb = binding.match_fusion_feat_batch(tg, idx, sr, idx, T0, covs, feats, use_soft_constraints=soft, tikhonov=tikhonov,
+                                             step_control_fusion=joint)
     Tn, rn = N.match_fusion_batch(tg, idx, sr, idx, T0, covs, use_soft_constraints=soft, tikhonov=tikhonov)
     for b in range(B):
-        To, ro = O.binding.match_fusion_feat(om[b][0], om[b][1], T0[b], covs[b], feats[b], use_soft_constraints=soft, tikhonov=tikhonov)
+        To, ro = O.binding.match_fusion_feat(om[b][0], om[b][1], T0[b], covs[b], feats[b], use_soft_constraints=soft, tikhonov=tikhonov,
+                                             step_control_fusion=joint)
         dt, dr = pose_close(Tb[b], To)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
         assert rb["iterations"][b] == ro["iterations"] and bool(rb["converged"][b]) == ro["converged"], (b, rb["iterations"][b], ro["iterations"])
