@@ -159,14 +159,18 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         for k, (sc, org) in enumerate(clouds):
             pool.add_cloud(sc, org, stream=st, **(dict(maxz=100.0, sensor_noise=0.1) if k == 0 else dict(maxz=25.0, sensor_noise=0.06)))
         ev[1].record(st)
-        T16.copy_(T0_cm)
-        for c0 in range(0, len(mine), CH):                                         # phase B: this rank's edges
-            c1 = min(len(mine), c0 + CH)
-            binding.match_batch_device(pool, ti[c0:c1], pool, si[c0:c1], T16[c0:c1], results[c0:c1], c1 - c0, stream=st, delta_score=1e-3)
-        ev[2].record(st)
-        gathered = D.gather_edge_results(T16, results, n_edges, rank, world, 256)   # phase D: the only collective
+
+        def register(my_edges):                                                    # phase B: this rank's edges
+            assert len(my_edges) == len(mine)
+            T16.copy_(T0_cm)
+            for c0 in range(0, len(mine), CH):
+                c1 = min(len(mine), c0 + CH)
+                binding.match_batch_device(pool, ti[c0:c1], pool, si[c0:c1], T16[c0:c1], results[c0:c1], c1 - c0, stream=st, delta_score=1e-3)
+            ev[2].record(st)
+            return T16, results
+        _, Tg_, Rg_ = D.register_sharded(n_edges, rank, world, register, 256)      # phase D inside: the only collective
         ev[3].record(st)
-        return ev, gathered
+        return ev, (Tg_, Rg_)
 
     steps = args.steps if args.steps != 20 else 2
     barrier()

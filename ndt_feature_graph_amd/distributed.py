@@ -58,6 +58,18 @@ def gather_edge_results(T_local, res_local, n_edges, rank, world, chunk=256, gro
     return T, R
 
 
+def register_sharded(n_edges, rank, world, register_fn, chunk=256, group=None):
+    """One replay step of the multi-GPU path (bench.py --config 4 and tests/test_distributed.py run THIS function):
+    this rank's block-cyclic share of the edge list goes to register_fn(mine) -> (T [k,16] float64, res [k,64] uint8)
+    torch tensors on the process group's device -- the GPU matcher in bench.py, the CPU oracle under gloo in the tests --
+    and the results of all ranks are all-gathered back into edge order (the only collective).
+    Returns (mine, T [n_edges,16], res [n_edges,64])."""
+    mine = shard_edges(n_edges, rank, world, chunk)
+    T_local, res_local = register_fn(mine)
+    T, R = gather_edge_results(T_local, res_local, n_edges, rank, world, chunk, group)
+    return mine, T, R
+
+
 def all_pairs(n_nodes):
     """NDTFeatureGraph::computeAllPossibleLinks enumeration order (ndt_feature_graph.cpp:395-405)."""
     i, j = np.triu_indices(n_nodes, k=1)
