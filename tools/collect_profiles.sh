@@ -20,7 +20,12 @@ for c in 5 fuse; do
   python bench.py --config $c > gpurun_out/bench_c$c.log 2>&1
 done
 python bench.py > gpurun_out/bench_full.log 2>&1
+# summarise here (the raw traces and per-dispatch counter tables exceed what travels back), keep the small tables only
+python tools/summarize_profiles.py r03 gpurun_out/r03_profiles > gpurun_out/r03_summarize.log 2>&1
+python tools/kernel_resources.py > gpurun_out/r03_profiles/r03_kernel_resources.txt 2>&1
+for d in prof_kt prof_kt_serial prof_kt_5 prof_kt_fuse; do mkdir -p gpurun_out/r03_raw/$d; cp gpurun_out/$d/bench_kernel_stats.csv gpurun_out/r03_raw/$d/ 2>/dev/null; done
+rm -rf gpurun_out/prof_*
 tail -1 gpurun_out/bench_full.log | cut -c1-400
 tail -1 gpurun_out/bench_c5.log | cut -c1-400
 tail -1 gpurun_out/bench_cfuse.log | cut -c1-400
-find gpurun_out/prof_kt gpurun_out/prof_kt_serial gpurun_out/prof_kt_5 gpurun_out/prof_kt_fuse gpurun_out/prof_sq_fuse -name "*.csv" | head -20
+ls gpurun_out/r03_profiles; tail -3 gpurun_out/r03_summarize.log | cut -c1-300

@@ -4,7 +4,10 @@ usage: python tools/summarize_profiles.py r02"""
 import collections, csv, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+go = os.path.join(root, "gpurun_out")
+# (on the GPU box the summaries go under gpurun_out/ -- the only directory that travels back -- and are copied to profiles/ here)
+pr = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles")
+os.makedirs(pr, exist_ok=True)
 # kernel stats
 rows = list(csv.DictReader(open(os.path.join(go, "prof_kt", "bench_kernel_stats.csv"))))
 with open(os.path.join(pr, "%s_bench_kernel_stats.csv" % tag), "w", newline="") as f:
