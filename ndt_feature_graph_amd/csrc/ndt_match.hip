@@ -1314,7 +1314,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_eval_kernel(
 // Nothing goes back to the host between evaluations.  The launcher keeps gridDim.x <= number of CUs (one 512-thread
 // workgroup per CU is resident), the barrier spins with a bound and raises `abort` instead of hanging.
 struct NdtCoopCtrl {
-    unsigned top, abort, pad0, pad1;     // top: groups that completed a barrier, summed over all barriers so far
+    unsigned top, abort, leave, pad1;    // top: groups that completed a barrier, summed over all barriers so far;
+                                         // leave: workgroups that are through with the block (the last one zeroes it)
     rigid Teval;
     int with_h, done;
     alignas(64) unsigned grp[16 * 16];   // arrival counter of workgroup group i at grp[16 * i] (one 64-byte line each)
@@ -1433,6 +1434,17 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
             }
         }
     }
+    // The barrier counters only grow while a registration runs and must be zero when the next one starts: the last
+    // workgroup to leave (every other one has read the block for the last time) puts them back, so that the host does
+    // not have to clear the block before every call (a registration that gave up leaves it dirty; the host clears then).
+    if (threadIdx.x == 0) {
+        if (atomicAdd(&ctrl->leave, 1u) + 1u == G) {
+            const unsigned NG = G < 16u ? G : 16u;
+            for (unsigned i = 0; i < NG; i++) __hip_atomic_store(&ctrl->grp[16u * i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctrl->top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctrl->leave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (g == 0 && threadIdx.x == 0) {
         NdtMatchResultDev o;
         match_state_result(st, T16, o);
@@ -1474,12 +1486,17 @@ unsigned ndt_match_coop_capacity(int n_neighbours)
     return (unsigned)(per_cu * n_cu);
 }
 
-// ONE cooperative launch (hipLaunchCooperativeKernel: the runtime checks the grid against the occupancy and refuses
-// what cannot be co-resident) for pairs [pair_begin, pair_begin + pair_count).  The caller has cleared the control blocks.
+// ONE launch of the grid-barrier matcher for pairs [pair_begin, pair_begin + pair_count); the control blocks are zero.
+// The caller sizes the grid by the occupancy query (every workgroup that stays is resident) and lets one such launch
+// run at a time per process; with that a plain launch is as safe as hipLaunchCooperativeKernel, which adds 0.08 ms to
+// a call -- more for every other stream the process has (it goes through a queue of its own that is ordered against
+// all of them: 0.35 -> 0.43 ms with three idle streams, 0.58 ms inside bench.py; tools/latency_probe.py).  What the
+// runtime's check would add -- a foreign process holding CUs -- is covered by the barrier's bounded spin and the
+// caller's re-run.  `checked` != 0 (NDTGPU_COOP_API=1) uses the cooperative API.
 hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                                  const uint32_t *sidx_dev, double *T16_dev, size_t pair_begin, size_t pair_count,
                                  const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
-                                 unsigned n_groups, unsigned cells_per_group, void *work_dev, hipStream_t stream)
+                                 unsigned n_groups, unsigned cells_per_group, void *work_dev, int checked, hipStream_t stream)
 {
     size_t stride = ndt_match_coop_work_bytes(n_groups);
     NdtSetView ts = tset, ss = sset;
@@ -1488,6 +1505,20 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_de
     unsigned pb = (unsigned)pair_begin;
     void *args[] = {&ts, &tidx_dev, &ss, &sidx_dev, &T16_dev, &p, &res_dev, &Q36_dev, &work, &stride, &cells_per_group, &pb};
     const dim3 grid(n_groups, (unsigned)pair_count), block(NDT_MATCH_THREADS);
+    if (!checked) {
+#define NDT_LAUNCH_COOP(NN)                                                                                            \
+    hipLaunchKernelGGL(ndt_match_coop_kernel<NN>, grid, block, 0, stream, ts, tidx_dev, ss, sidx_dev, T16_dev, p, res_dev, \
+                       Q36_dev, work, stride, cells_per_group, pb)
+        switch (prm.n_neighbours) {
+        case 0: NDT_LAUNCH_COOP(0); break;
+        case 1: NDT_LAUNCH_COOP(1); break;
+        case 2: NDT_LAUNCH_COOP(2); break;
+        case 3: NDT_LAUNCH_COOP(3); break;
+        default: return hipErrorInvalidValue;
+        }
+#undef NDT_LAUNCH_COOP
+        return hipGetLastError();
+    }
     switch (prm.n_neighbours) {
     case 0: return hipLaunchCooperativeKernel((const void *)ndt_match_coop_kernel<0>, grid, block, args, 0, stream);
     case 1: return hipLaunchCooperativeKernel((const void *)ndt_match_coop_kernel<1>, grid, block, args, 0, stream);

@@ -79,6 +79,21 @@ struct ndtgpu_mapset {
         work_bytes = bytes;
         return NDTGPU_OK;
     }
+    // work area of the grid-barrier matcher (a control block + partial sums per registration); its kernels leave the
+    // control blocks zeroed, so a call only clears what it cannot know to be clean
+    void *coop_work = nullptr;
+    size_t coop_bytes = 0, coop_clean_stride = 0, coop_clean_upto = 0;
+    ndtgpu_status ensure_coop(size_t bytes)
+    {
+        if (bytes <= coop_bytes) return NDTGPU_OK;
+        if (coop_work) (void)hipFree(coop_work);
+        coop_work = nullptr;
+        coop_bytes = 0;
+        coop_clean_upto = 0;
+        HIP_TRY(hipMalloc(&coop_work, bytes));
+        coop_bytes = bytes;
+        return NDTGPU_OK;
+    }
     // pinned host mirror of small staging blocks (poses, indices, results of a host-pointer matcher call): copies from /
     // to pinned memory are truly asynchronous and skip the runtime's own bounce buffer
     void *pin = nullptr;
@@ -228,6 +243,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (s->v.cell_sel) (void)hipFree(s->v.cell_sel);
     if (s->stage) (void)hipFree(s->stage);
     if (s->work) (void)hipFree(s->work);
+    if (s->coop_work) (void)hipFree(s->coop_work);
     if (s->work_ev) (void)hipEventDestroy(s->work_ev);
     if (s->origins_dev) (void)hipFree(s->origins_dev);
     for (int k = 0; k < 4; k++)
@@ -890,40 +906,45 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     if (rc != NDTGPU_OK) return rc;
     rc = ts->ensure_pin(off_ctrl + n_pairs * 16);
     if (rc != NDTGPU_OK) return rc;
-    // an asynchronous launch of the persistent matcher (ndtgpu_match_batch_device on another stream) may still be using
-    // the work area of this target set: wait for it before the area is grown, cleared or handed to the launches below
-    if (ts->work_ev_valid) HIP_TRY(hipEventSynchronize(ts->work_ev));
     char *base = (char *)ts->stage, *hp = (char *)ts->pin;
     memcpy(hp, T16, bT);
     memcpy(hp + off_ti, tidx, bI);
     memcpy(hp + off_si, sidx, bI);
     if (Q36) memcpy(hp + off_Q, Q36, n_pairs * 36 * sizeof(double));
-    HIP_TRY(hipMemcpyAsync(base, hp, total, hipMemcpyHostToDevice, st));
-    // source map sizes decide how many workgroups a registration can use
-    NdtMapCounters *cs = reinterpret_cast<NdtMapCounters *>(hp + off_cs);
-    for (size_t k = 0; k < n_pairs; k++)
-        HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    uint32_t max_cells = 0;
-    for (size_t k = 0; k < n_pairs; k++) max_cells = std::max(max_cells, cs[k].n_cells);
     // 128 source cells per workgroup (16 per wave; fewer cells per workgroup stop paying: barrier + solver
     // latency dominate), at most one workgroup per CU.  Every registration uses ceil(its cells / 128) workgroups
-    // whatever batch it is in; registrations that do not fit on the chip together run one after the other.
+    // whatever batch it is in (the kernel works that out from the map; surplus workgroups of the grid leave at once);
+    // registrations that do not fit on the chip together run one after the other.
     const char *cpg = getenv("NDTGPU_COOP_CELLS");
     const unsigned per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 128u;
-    unsigned groups = (max_cells + per_group - 1u) / per_group;
-    if (groups > (unsigned)n_cu) groups = (unsigned)n_cu;
-    if (groups < 1) groups = 1;
-    if (groups == 1 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;      // persistent kernel instead
-    const size_t stride = ndt_match_coop_work_bytes(groups);
-    rc = ts->ensure_work(n_pairs * stride);
-    if (rc != NDTGPU_OK) return rc;
-    // Cooperative launches sized by the occupancy query: as many registrations per launch as fit on the chip together
-    // (`groups` workgroups each), launch after launch on the same stream.  One cooperative launch at a time per
-    // process: two of them (two host threads, two streams) could each hold part of the chip and wait for the rest.
     const unsigned capacity = ndt_match_coop_capacity(p.n_neighbours);
     if (capacity == 0) return NDTGPU_OK;                                          // no occupancy figure: persistent kernel instead
-    if (groups > capacity) groups = capacity;
+    // A few registrations whose LARGEST POSSIBLE grids (the source set's cell capacity) fit on the chip together are
+    // launched without asking the device how many cells the maps have: no read-back, no wait before the launch.
+    unsigned groups = (ss->v.grid.max_cells + per_group - 1u) / per_group;
+    if (groups < 1) groups = 1;
+    const bool blind = n_pairs <= NDTGPU_HOST_LOOP_MAX && (size_t)groups * n_pairs <= capacity;
+    HIP_TRY(hipMemcpyAsync(base, hp, total, hipMemcpyHostToDevice, st));
+    if (!blind) {
+        // source map sizes decide how many workgroups a registration can use
+        NdtMapCounters *cs = reinterpret_cast<NdtMapCounters *>(hp + off_cs);
+        for (size_t k = 0; k < n_pairs; k++)
+            HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t max_cells = 0;
+        for (size_t k = 0; k < n_pairs; k++) max_cells = std::max(max_cells, cs[k].n_cells);
+        groups = (max_cells + per_group - 1u) / per_group;
+        if (groups > (unsigned)n_cu) groups = (unsigned)n_cu;
+        if (groups < 1) groups = 1;
+        if (groups == 1 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;      // persistent kernel instead
+        if (groups > capacity) groups = capacity;
+    }
+    const size_t stride = ndt_match_coop_work_bytes(groups);
+    rc = ts->ensure_coop(n_pairs * stride);
+    if (rc != NDTGPU_OK) return rc;
+    // Launches sized by the occupancy query: as many registrations per launch as fit on the chip together (`groups`
+    // workgroups each), launch after launch on the same stream.  One such launch sequence at a time per process: two of
+    // them (two host threads, two streams) could each hold part of the chip and wait for the rest.
     const size_t per_launch = std::max<size_t>(1, capacity / groups);
     // The launches run one after the other: beyond a few of them the persistent kernel (every registration on its own
     // CU, all at once) is sooner done.  Measured with 12 k-cell 3D maps (96 workgroups each, 2 registrations per launch):
@@ -932,24 +953,35 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
         const size_t launches = (n_pairs + per_launch - 1) / per_launch;
         if (n_pairs > NDTGPU_HOST_LOOP_MAX && launches > std::max<size_t>(1, groups / 6)) return NDTGPU_OK;
     }
-    // the whole control block of every pair (barrier counters only grow during a launch sequence: a counter left over
-    // from the previous call would stall the first barrier of this one)
-    HIP_TRY(hipMemset2DAsync(ts->work, stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
+    const char *api_env = getenv("NDTGPU_COOP_API");          // NDTGPU_COOP_API=1: hipLaunchCooperativeKernel (checked by the runtime)
+    const int checked = (api_env && atoi(api_env) != 0) ? 1 : 0;
     static std::mutex coop_mutex;
     const unsigned *ctrl = reinterpret_cast<const unsigned *>(hp + off_ctrl);
     std::vector<double> Tin(T16, T16 + 16 * n_pairs);          // (the poses as they came in: a registration that has to be re-run)
     {
         std::lock_guard<std::mutex> coop_lock(coop_mutex);
+        // the control blocks must be zero (barrier counters only grow while a registration runs): the kernels leave them
+        // so, and only blocks this set has not seen finish cleanly at this stride are cleared
+        if (ts->coop_clean_stride != stride || ts->coop_clean_upto < n_pairs) {
+            HIP_TRY(hipMemset2DAsync(ts->coop_work, stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
+            ts->coop_clean_stride = stride;
+        }
+        const size_t clean_before = std::max(ts->coop_clean_upto, n_pairs);
+        ts->coop_clean_upto = 0;                                // (until this call is known to have ended cleanly)
         for (size_t b0 = 0; b0 < n_pairs; b0 += per_launch) {
             hipError_t e = ndt_launch_match_coop(ts->v, (const uint32_t *)(base + off_ti), ss->v, (const uint32_t *)(base + off_si),
                                                  (double *)base, b0, std::min(per_launch, n_pairs - b0), p,
                                                  reinterpret_cast<NdtMatchResultDev *>(base + off_R),
-                                                 Q36 ? (const double *)(base + off_Q) : nullptr, groups, per_group, ts->work, st);
-            if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: cooperative launch", e);
+                                                 Q36 ? (const double *)(base + off_Q) : nullptr, groups, per_group, ts->coop_work,
+                                                 checked, st);
+            if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: grid-barrier launch", e);
         }
         HIP_TRY(hipMemcpyAsync(hp, base, off_R + bR, hipMemcpyDeviceToHost, st));                      // poses + results
-        HIP_TRY(hipMemcpy2DAsync(hp + off_ctrl, 16, ts->work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpy2DAsync(hp + off_ctrl, 16, ts->coop_work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        bool any_bad = false;
+        for (size_t k = 0; k < n_pairs; k++) any_bad = any_bad || ctrl[4 * k + 1] != 0u;
+        ts->coop_clean_upto = any_bad ? 0 : clean_before;
     }
     ts->ev_valid[1] = false;          // (ndtgpu_last_kernel_ms(1): no persistent launch was timed by this call)
     memcpy(T16, hp, bT);

@@ -3,6 +3,8 @@
 Bars (BASELINE.json north_star): integer / index work bit-exact (cell set, point counts); cell
 statistics 1e-9 (fixed-point moments); derivatives 1e-9 relative; final pose within
 1e-4 m / 1e-4 rad of the CPU matcher on identical inputs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -460,6 +462,34 @@ def test_persistent_cooperative_and_host_driven_paths_agree(N, O, monkeypatch):
         To, ro = O.match_d2d(om[b][0], om[b][1], T0[b])
         dt, dr = pose_close(Ts, To)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD
+
+
+def test_grid_barrier_calls_leave_their_control_blocks_clean(N, O, monkeypatch):
+    """The grid-barrier matcher (small batches) zeroes its barrier counters when the last workgroup leaves, and the
+    host only clears blocks it has not seen finish cleanly at the same stride: calls of different sizes and shapes on
+    one map set, in any order, must each give the bits of their first run (a stale counter would stall or skip a
+    barrier); with the runtime-checked cooperative launch (NDTGPU_COOP_API=1) the same bits."""
+    pr, tg, sr, om = _pair_maps(N, O, list(range(1, 9)), 20000, 0.5, oracle_maps=False)
+    T0 = pr["T_init"].numpy()
+    first = {}
+    seq = [(0,), (0, 1, 2, 3, 4), (3,), tuple(range(8)), (0,), (5, 6), tuple(range(8)), (3,), (0, 1, 2, 3, 4), (5, 6)]
+    for rep, which in enumerate(seq + seq):
+        if rep == len(seq):
+            monkeypatch.setenv("NDTGPU_COOP_API", "1")
+        if rep == len(seq) + 4:
+            monkeypatch.setenv("NDTGPU_COOP_CELLS", "32")       # another stride on the same set ...
+        if rep == len(seq) + 6:
+            monkeypatch.delenv("NDTGPU_COOP_CELLS")              # ... and back
+        idx = np.array(which)
+        T, r = N.match_batch(tg, idx, sr, idx, T0[idx])
+        if os.environ.get("NDTGPU_COOP_CELLS"):
+            continue
+        if which in first:
+            assert np.array_equal(T, first[which][0]) and np.array_equal(r["iterations"], first[which][1])
+        else:
+            first[which] = (T.copy(), r["iterations"].copy())
+    for k in range(5):                                           # a pair's result ignores the batch it is in
+        assert np.array_equal(first[(0, 1, 2, 3, 4)][0][k], first[tuple(range(8))][0][k])
 
 
 def test_one_and_two_registrations_per_workgroup_agree(N, O, monkeypatch):

@@ -12,6 +12,21 @@ T0 = pr["T_init"][0].cpu().numpy()
 ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2, max_cells=4096)
 ms.profiling(True)
 st = torch.cuda.current_stream()
+keep = []
+if os.environ.get("LAT_STREAMS"):                      # other streams with finished work in the process, like bench.py's pipeline
+    for _ in range(int(os.environ["LAT_STREAMS"])):
+        q = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(q):
+            keep.append(torch.zeros(1024, device=dev) + 1)
+        keep.append(q)
+    torch.cuda.synchronize()
+if os.environ.get("LAT_MAPSETS"):                      # a large map set that was built once
+    big = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=int(os.environ["LAT_MAPSETS"]), max_cells=4096)
+    big.build(scans.repeat(int(os.environ["LAT_MAPSETS"]) // 2, 1, 1).contiguous(), range_limit=30.0, stream=st)
+    torch.cuda.synchronize()
+    keep.append(big)
+if os.environ.get("LAT_SLEEP"):
+    time.sleep(float(os.environ["LAT_SLEEP"]))        # an idle GPU first (clocks down), like bench.py's latency leg after the CPU baseline
 tb, tm, tt = [], [], []
 for k in range(30):
     torch.cuda.synchronize()
