@@ -214,7 +214,7 @@ ndtgpu_status ndtgpu_derivatives(ndtgpu_mapset *target, size_t target_map, const
  * Pair k matches target_set[target_idx[k]] (fixed) against source_set[source_idx[k]] (moving).
  * T16: HOST, n_pairs x 16 doubles, in: initial guess, out: result.  results: HOST, n_pairs.
  * The whole Newton / More-Thuente loop runs on the device: persistent workgroups pulling pairs from a ticket
- * counter when the batch fills the chip, one cooperative launch with several workgroups per registration when it
+ * counter when the batch fills the chip, one grid-barrier launch with several workgroups per registration when it
  * does not (<= 128 pairs; the one-link-at-a-time call of ndt_feature_graph.cpp:273 is n_pairs = 1).
  * Synchronous (returns after the results are on the host). */
 ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx, ndtgpu_mapset *source_set,
@@ -225,7 +225,7 @@ ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *targ
  * DEVICE uint32.  ONE launch of persistent workgroups, ALWAYS asynchronous on `stream`: no host synchronisation, safe
  * under stream capture; a registration's result does not depend on its batch.
  * Opt-in (environment NDTGPU_DEVICE_COOP=1, read per call): a small batch of LARGE maps (at least 1024 cells, few
- * enough pairs for a handful of cooperative launches) whose indices are sane is spread over several CUs per
+ * enough pairs for a handful of grid-barrier launches) whose indices are sane is spread over several CUs per
  * registration like ndtgpu_match_batch does -- an order of magnitude sooner done, same result to 1e-8 (another
  * summation order) -- but its indices and poses make a round trip through the host and the call then SYNCHRONISES
  * `stream` and the streams of the last builds of both sets.
