@@ -460,6 +460,11 @@ def main():
         b.T16 = T_init_cm.clone()
         b.results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
         b.stream = torch.cuda.Stream(device=dev)
+        # (measured and not kept: the matcher on a second stream of HIGHER priority than the builds, so that its 256
+        #  one-per-CU workgroups do not queue behind the 2048 small build workgroups of the next step: 366 k against 403 k
+        #  registrations/s, gpurun_out/r03A.log -- the builds then only get the CUs the matcher has left)
+        b.mstream = b.stream
+        b.match_done = None
         b.gathered = None
         if world > 1:
             b.gathered = [torch.empty((world * B, 16), dtype=torch.float64, device=dev),
@@ -470,28 +475,36 @@ def main():
     def step(ev=None):
         b = bufs[state["k"] % n_buf]
         state["k"] += 1
-        st = b.stream
+        st, mst = b.stream, b.mstream
         with torch.cuda.stream(st):
             if n_buf > 1 and state["match_started"] is not None:
                 st.wait_event(state["match_started"])
+            if mst is not st and b.match_done is not None:
+                st.wait_event(b.match_done)            # this buffer's maps are still being matched (step k - n_buf)
             marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if ev is not None else None
             if marks: marks[0].record(st)
             b.maps.build(both, range_limit=rng_lim, stream=st)
             if marks: marks[1].record(st); marks[2].record(st)
-            b.T16.copy_(T_init_cm)
             started = torch.cuda.Event()
             started.record(st)
             state["match_started"] = started
+        with torch.cuda.stream(mst):
+            if mst is not st:
+                mst.wait_event(started)
+            b.T16.copy_(T_init_cm)
             if marks:
                 marks.append(torch.cuda.Event(enable_timing=True))
-                marks[4].record(st)
-            binding.match_batch_device(b.maps, idx, b.maps, idx_src, b.T16, b.results, B, stream=st)
+                marks[4].record(mst)
+            binding.match_batch_device(b.maps, idx, b.maps, idx_src, b.T16, b.results, B, stream=mst)
             if marks:
-                marks[3].record(st)
+                marks[3].record(mst)
                 ev.append(marks)
             if world > 1:   # final gather of the edge transforms (the only collective on the path)
                 dist.all_gather_into_tensor(b.gathered[0], b.T16)
                 dist.all_gather_into_tensor(b.gathered[1], b.results)
+            if mst is not st:
+                b.match_done = torch.cuda.Event()
+                b.match_done.record(mst)
 
     def barrier():
         if world > 1:
@@ -714,483 +727,6 @@ def main():
             g.update({"cpu_1thread_ms": 1e3 * t_cpu, "speedup": t_cpu / (1e-3 * g["gpu_ms"]),
                       "cells": [int(r["n_target"]), int(r["n_source"])], "iterations": int(r["iterations"]), "dt_m": dt, "drot_rad": dr})
             lat[name] = g
-        out["single_pair_latency"] = lat
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
-
-
-def _timed(torch, fn, reps=5, warm=2):
-    """median wall time [ms] of fn() bracketed by device synchronisation"""
-    for _ in range(warm):
-        fn()
-    ts = []
-    for _ in range(reps):
-        torch.cuda.synchronize()
-        c0 = time.perf_counter()
-        fn()
-        torch.cuda.synchronize()
-        ts.append(1e3 * (time.perf_counter() - c0))
-    return float(np.median(ts))
-
-
-def config5(args, torch, N, binding, synth, dev):
-    """BASELINE configs[4]: 3D mode, 200 k-point Velodyne-style clouds, 0.25 m voxels, 6-DoF.  One pair through the
-    host-synchronous call (latency: the reference's call shape) and a batch of 64 sweeps = 32 pairs resident in HBM
-    (throughput).  Rooflines: the build against HBM (12 N + 80 M bytes per sweep), the matcher against the fp64 peak."""
-    res, size, rng, cap = 0.25, [100.0, 100.0, 10.0], 70.0, 120000
-    B = 32
-    pr = synth.pair_3d(torch.arange(1, B + 1, device=dev), device=dev)
-    sweeps = torch.cat([pr["fixed"], pr["moving"]]).contiguous()                  # [64, 200000, 3]
-    NP = int(sweeps.shape[1])
-    ms = N.MapSet(res, [0, 0, 0], size, n_maps=2 * B, max_cells=cap)
-    ms.profiling(True)
-    st = torch.cuda.current_stream()
-    Ti = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)
-    T16 = Ti.clone()
-    results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
-    ti = torch.arange(B, dtype=torch.int32, device=dev)
-    si = ti + B
-    build_ms = _timed(torch, lambda: ms.build(sweeps, range_limit=rng, stream=st))
-    cells = ms.num_cells_all().astype(np.float64)
-
-    def match():
-        T16.copy_(Ti)
-        binding.match_batch_device(ms, ti, ms, si, T16, results, B, stream=st)
-    match_ms = _timed(torch, match)
-    r = results.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
-    step_ms = _timed(torch, lambda: (ms.build(sweeps, range_limit=rng, stream=st), match()))
-    build_bytes = 2 * B * 12.0 * NP + 80.0 * cells.sum()
-    gflop = (130.0 * float(r["pair_terms_g"].sum()) + 610.0 * float(r["pair_terms_h"].sum())) / 1e9
-    # one pair, host-synchronous (cooperative launches: the registration is spread over the chip)
-    one = N.MapSet(res, [0, 0, 0], size, n_maps=2, max_cells=cap)
-    two = torch.stack([pr["fixed"][0], pr["moving"][0]]).contiguous()
-    T0 = pr["T_init"][0].cpu().numpy()
-    pair_ms = _timed(torch, lambda: (one.build(two, range_limit=rng, stream=st), N.match_d2d(one, 0, one, 1, T0)))
-    out = {"metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)", "value": B / (step_ms * 1e-3), "unit": "registrations/s",
-           "n_gpus": 1, "steps": 5, "warmup": 2, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "configs[4]: 3D mode, %d sweeps of %d points (64 rings), 0.25 m voxels, grid 100x100x10 m, range 70 m, "
-                                  "6-DoF D2D, n_neighbours 2; one step = build of the 64 sweeps + match of the 32 pairs (serial, one stream)" % (2 * B, NP),
-                      "mean_cells_per_map": float(cells.mean())},
-           "roofline": {"kernel": "ndt_build_kernel (MODE 1 accumulate + MODE 2/3 finalise, 64 sweeps)", "bound": "hbm",
-                        "achieved": build_bytes / build_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": build_bytes / build_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "algorithmic bytes 12 N + 80 M per sweep / wall time of the build call (three launches); atomic-rate "
-                                "bound: ~1 flush record per 6 points on ring-ordered sweeps (DESIGN.md 7)"},
-           "kernels": {"build_64_sweeps": {"ms": build_ms, "points_per_s": 2 * B * NP / (build_ms * 1e-3), "algorithmic_bytes": build_bytes},
-                       "match_32_pairs": {"ms": match_ms, "fp64_gflop": gflop, "fp64_tflops": gflop / match_ms,
-                                          "frac_of_fp64_peak": gflop / match_ms / 78.6, "mean_iterations": float(r["iterations"].mean()),
-                                          "converged_frac": float(r["converged"].mean()),
-                                          "note": "persistent matcher, one registration per workgroup slot: 32 registrations of ~12 k "
-                                                  "source cells on 32 CUs (a batch that cannot fill the chip)"}},
-           "single_pair": {"ms_build_x2_plus_match": pair_ms, "note": "host-synchronous ndtgpu_mapset_build + ndtgpu_match_d2d (cooperative launches)"}}
-    print(json.dumps(out))
-
-
-def config_fuse(args, torch, N, binding, synth, dev):
-    """The node-map path of SURVEY 8(f): ndtgpu_mapset_add_cloud (= NDTMap::addPointCloud + computeNDTCells: ray tracing,
-    accumulate, finalise) of 256 node maps with one 100 k-point cloud each, then the per-link work of the offline
-    refinement on 200 fused node maps (16 scans each): matcher, NDTMatcherD2D::covariance and overlapNDTOccupancyScore of
-    all 19 900 links.  Algorithmic bytes per add_cloud: 12 N (points) + 12 slots (occupancy + evidence) + 2 x 80 M (cells)."""
-    res, size, rng = args.res, [100.0, 100.0, 1.0], 30.0
-    NP, Bm = args.points, 256
-    poses = torch.zeros((Bm, 3), dtype=torch.float64)
-    poses[:, 0] = torch.linspace(-1.5, 1.5, Bm, dtype=torch.float64)
-    scans = synth.scan_2d(torch.full((Bm,), 77, dtype=torch.int64, device=dev), poses.to(dev), NP, chunk_bytes=2 << 30).contiguous()
-    ms = N.MapSet(res, [0, 0, 0], size, n_maps=Bm, max_cells=4096)
-    ms.enable_occupancy()
-    origins = np.concatenate([poses[:, :2].numpy(), np.zeros((Bm, 1))], axis=1)
-    st = torch.cuda.current_stream()
-
-    def add():
-        ms.clear()
-        ms.add_cloud(scans, origins, stream=st, maxz=100.0, sensor_noise=0.1)
-    add_ms = _timed(torch, add)
-    clear_ms = _timed(torch, lambda: ms.clear())
-    cells = ms.num_cells_all().astype(np.float64)
-    slots = int(size[0] / res) * int(size[1] / res) * max(1, int(size[2] / res))
-    add_bytes = Bm * (12.0 * NP + 12.0 * slots) + 2 * 80.0 * cells.sum()
-    # 200 fused node maps of 16 scans (20 k points each), all-pairs links
-    nn, ns, npts = 200, 16, 20000
-    nodes = N.MapSet(res, [0, 0, 0], size, n_maps=nn, max_cells=4096)
-    nodes.enable_occupancy()
-    t = torch.linspace(0.0, 2.0 * np.pi, nn + 1, dtype=torch.float64)[:-1]
-    node_pose = torch.stack([1.6 * torch.sin(t), 1.2 * torch.sin(2.0 * t + 0.3), 0.35 * torch.sin(3.0 * t)], dim=1)
-    node_T = synth.pose2d_to_T(node_pose).numpy()
-    c0 = time.perf_counter()
-    for k in range(ns):
-        p = node_pose.clone()
-        p[:, 0] += 0.01 * k * torch.cos(node_pose[:, 2]); p[:, 1] += 0.01 * k * torch.sin(node_pose[:, 2])
-        sc = synth.scan_2d(torch.full((nn,), 321, dtype=torch.int64, device=dev), p.to(dev), npts).contiguous()
-        # the cloud in the node frame: the scan frame is 1 cm x k ahead of the node frame
-        sc[:, :, 0] += 0.01 * k
-        org = np.tile(np.array([[0.01 * k, 0.0, 0.0]]), (nn, 1))
-        nodes.add_cloud(sc, org, stream=st, **(dict(maxz=100.0, sensor_noise=0.1) if k == 0 else dict(maxz=25.0, sensor_noise=0.06)))
-    torch.cuda.synchronize()
-    fuse_total_ms = 1e3 * (time.perf_counter() - c0)
-    iu = np.triu_indices(nn, 1)
-    ti, si = iu[0].astype(np.uint32), iu[1].astype(np.uint32)
-    T0 = np.einsum("eij,ejk->eik", np.linalg.inv(node_T[ti]), node_T[si])
-    n_links = len(ti)
-    holder = {}
-
-    def m():
-        holder["T"], holder["r"] = N.match_batch(nodes, ti, nodes, si, T0, delta_score=1e-3)
-    match_ms = _timed(torch, m, reps=3, warm=1)
-    cov_ms = _timed(torch, lambda: binding.covariance(nodes, ti, nodes, si, holder["T"]), reps=3, warm=1)
-    ovl_ms = _timed(torch, lambda: binding.overlap_score(nodes, ti, nodes, si, holder["T"]), reps=3, warm=1)
-    r = holder["r"]
-    mcells = nodes.num_cells_all().astype(np.float64)
-    gflop = (130.0 * float(r["pair_terms_g"].sum()) + 610.0 * float(r["pair_terms_h"].sum())) / 1e9
-    cov_bytes = n_links * 80.0 * 2 * mcells.mean()          # both cell maps of a link, once (they then live in L2)
-    ovl_bytes = n_links * 4.0 * slots * 2                   # the occupancy arrays of both maps
-    out = {"metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)", "value": n_links / (match_ms * 1e-3), "unit": "registrations/s",
-           "n_gpus": 1, "steps": 3, "warmup": 1, "ms_per_step": match_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "node-map path (SURVEY 8f): add_cloud of %d node maps x %d points; %d links of %d fused node maps (%d scans x %d "
-                                  "points each): matcher (edge preset), covariance, occupancy overlap; host arrays in and out" % (Bm, NP, n_links, nn, ns, npts),
-                      "mean_cells_fused_map": float(mcells.mean())},
-           "roofline": {"kernel": "ndtgpu_mapset_add_cloud = ndt_raytrace_kernel + ndt_build_kernel<.,1> + ndt_fuse_finalize_kernel", "bound": "hbm",
-                        "achieved": add_bytes / add_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": add_bytes / add_ms / 1e6 / HBM_PEAK_GBS,
-                        "traffic": None,
-                        "note": "algorithmic bytes (12 N + 12 slots) per map + 2 x 80 M / wall time of the call (three launches, includes the "
-                                "clear of the previous content: %.3f ms); the ray walk is VALU bound (~30 samples per beam, 3 exact cell "
-                                "indices per sample), profiles/r03_fuse_*" % clear_ms},
-           "kernels": {"add_cloud_256_maps": {"ms": add_ms, "us_per_scan": 1e3 * add_ms / Bm, "algorithmic_bytes": add_bytes},
-                       "fuse_200_nodes_16_scans": {"ms_total_incl_synthesis": fuse_total_ms},
-                       "match_links": {"ms": match_ms, "us_per_link": 1e3 * match_ms / n_links, "fp64_gflop": gflop,
-                                       "frac_of_fp64_peak": gflop / match_ms / 78.6, "converged_frac": float(r["converged"].mean()),
-                                       "mean_iterations": float(r["iterations"].mean())},
-                       "covariance_links": {"ms": cov_ms, "us_per_link": 1e3 * cov_ms / n_links, "algorithmic_bytes": cov_bytes,
-                                            "GBps": cov_bytes / cov_ms / 1e6},
-                       "overlap_links": {"ms": ovl_ms, "us_per_link": 1e3 * ovl_ms / n_links, "algorithmic_bytes": ovl_bytes,
-                                         "GBps": ovl_bytes / ovl_ms / 1e6, "frac_of_hbm_peak": ovl_bytes / ovl_ms / 1e6 / HBM_PEAK_GBS}}}
-    print(json.dumps(out))
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
-    ap.add_argument("--points", type=int, default=100000)
-    ap.add_argument("--res", type=float, default=0.5)
-    ap.add_argument("--cpu-sample", type=int, default=128, help="pairs timed on the CPU oracle (0 = skip): 6 passes of ~2 s")
-    ap.add_argument("--config", type=str, default="3", choices=["3", "4", "5", "fuse"],
-                    help="3: BASELINE configs[2], the batch the metric is quoted on (default); 4: configs[3], the graph replay harness; "
-                         "5: configs[4], 3D mode; fuse: the node-map path (add_cloud, link covariance and overlap)")
-    ap.add_argument("--nodes", type=int, default=5000, help="--config 4: node maps (5000 = the full config)")
-    ap.add_argument("--gated", action="store_true", help="--config 4: only the candidate edges within --gate-dist")
-    ap.add_argument("--gate-dist", type=float, default=6.0, help="--config 4: candidate gate on the odometry distance of two nodes [m]")
-    ap.add_argument("--scans-per-node", type=int, default=10, help="--config 4: scans fused into every node map")
-    ap.add_argument("--node-points", type=int, default=20000, help="--config 4: points per scan")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--buffers", type=int, default=3, help="pipeline depth (mapset pairs / streams)")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="one stream, one mapset pair: every step waits for the previous one (default: --buffers mapset pairs, the "
-                         "grid builds of step k+1 run on the CUs the matcher of step k has already left)")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    import ndt_feature_graph_amd as N
-    from ndt_feature_graph_amd import binding, synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available() or N.device_count() < 1:
-        raise RuntimeError("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    B, NP, res = args.pairs, args.points, args.res
-    size_m = [100.0, 100.0, 1.0]           # gustav_laser_tf.launch:16-18
-    rng_lim = 30.0                          # sensor_range, launch:22
-    if args.config == "4":
-        return config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_lim)
-    if args.config == "5":
-        return config5(args, torch, N, binding, synth, dev)
-    if args.config == "fuse":
-        return config_fuse(args, torch, N, binding, synth, dev)
-
-    # ---- synthetic batch, generated on the GPU, resident in HBM before the timed region -----
-    seeds = torch.arange(1 + rank * B, 1 + (rank + 1) * B, dtype=torch.int64, device=dev)
-    pr = synth.pair_2d(seeds, NP, device=dev, chunk_bytes=2 << 30)
-    # the 2B scans of a step sit in ONE tensor (fixed scans first): one build launch makes all 2B cell maps of one
-    # map set; registration i matches map i (target) against map B + i (source)
-    both = torch.cat([pr["fixed"], pr["moving"]]).contiguous()
-    pr["fixed"] = pr["moving"] = None
-    fixed, moving = both[:B], both[B:]
-    T_init_cm = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)     # column-major Affine3d
-    idx = torch.arange(B, dtype=torch.int32, device=dev)
-    idx_src = idx + B
-
-    # Two buffers (mapset pair + outputs + stream).  Steps alternate between them; the builds of step k+1 are
-    # released when the matcher of step k starts: its workgroups leave their CUs as soon as no registration is
-    # left to start (csrc/ndt_match.hip), so the next step's builds fill the CUs that the few long registrations
-    # of this step do not occupy.  Every step still does all of its work; results are identical to the serial run.
-    n_buf = 1 if args.no_pipeline else args.buffers
-
-    class Buf:
-        pass
-    bufs = []
-    for _ in range(n_buf):
-        b = Buf()
-        b.maps = N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * B, max_cells=4096)
-        b.T16 = T_init_cm.clone()
-        b.results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
-        b.stream = torch.cuda.Stream(device=dev)
-        b.gathered = None
-        if world > 1:
-            b.gathered = [torch.empty((world * B, 16), dtype=torch.float64, device=dev),
-                          torch.empty((world * B, 64), dtype=torch.uint8, device=dev)]
-        bufs.append(b)
-    state = {"k": 0, "match_started": None}
-
-    def step(ev=None):
-        b = bufs[state["k"] % n_buf]
-        state["k"] += 1
-        st = b.stream
-        with torch.cuda.stream(st):
-            if n_buf > 1 and state["match_started"] is not None:
-                st.wait_event(state["match_started"])
-            marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if ev is not None else None
-            if marks: marks[0].record(st)
-            b.maps.build(both, range_limit=rng_lim, stream=st)
-            if marks: marks[1].record(st); marks[2].record(st)
-            b.T16.copy_(T_init_cm)
-            started = torch.cuda.Event()
-            started.record(st)
-            state["match_started"] = started
-            if marks:
-                marks.append(torch.cuda.Event(enable_timing=True))
-                marks[4].record(st)
-            binding.match_batch_device(b.maps, idx, b.maps, idx_src, b.T16, b.results, B, stream=st)
-            if marks:
-                marks[3].record(st)
-                ev.append(marks)
-            if world > 1:   # final gather of the edge transforms (the only collective on the path)
-                dist.all_gather_into_tensor(b.gathered[0], b.T16)
-                dist.all_gather_into_tensor(b.gathered[1], b.results)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    # isolated kernel durations (one serial step, events inside the library), outside the timed region
-    for b in bufs[:1]:
-        b.maps.profiling(True)
-    for _ in range(n_buf):     # one serial step per buffer: code objects loaded, every buffer's pages touched
-        step(); barrier()
-        state["match_started"] = None
-    state["k"] = 0
-    step(); barrier()          # isolated kernel durations: a warm serial step on buffer 0
-    iso_build_ms = bufs[0].maps.last_kernel_ms(0)       # one launch: 2B scans
-    iso_match_ms = bufs[0].maps.last_kernel_ms(1)
-    for b in bufs[:1]:
-        b.maps.profiling(False)
-    state["k"] = 0
-    state["match_started"] = None
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    marks = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(marks)          # HIP events on the launch stream bracket every kernel of the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    k_build = [m[0].elapsed_time(m[1]) for m in marks]
-    k_match = [m[4].elapsed_time(m[3]) for m in marks]
-    last = bufs[(state["k"] - 1) % n_buf]
-    T16, results = last.T16, last.results
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * B * args.steps / elapsed
-
-    # ---- bookkeeping outside the timed region -------------------------------------------------
-    res_np = results.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
-    T_out = T16.cpu().numpy().reshape(B, 4, 4).transpose(0, 2, 1)
-    m_t, m_s = res_np["n_target"].astype(np.int64), res_np["n_source"].astype(np.int64)
-    build_ms = float(np.mean(k_build))                                 # per launch (2B scans)
-    match_ms = float(np.mean(k_match))
-    # algorithmic bytes (SURVEY.md 8d): build 12*N + 80*M per scan; match 80*(M_src+M_tgt) per pair
-    build_bytes = 2 * B * 12.0 * NP + 80.0 * float(m_t.sum() + m_s.sum())           # per launch
-    match_bytes = 80.0 * float(m_t.sum() + m_s.sum())
-    kern = {
-        "ndt_build_kernel": {"ms_per_launch": build_ms, "ms_isolated": iso_build_ms, "launches_per_step": 1,
-                             "scans_per_launch": 2 * B,
-                             "algorithmic_bytes": build_bytes, "GBps": build_bytes / build_ms / 1e6,
-                             "GBps_isolated": build_bytes / iso_build_ms / 1e6},
-        "ndt_match_kernel": {"ms_per_launch": match_ms, "ms_isolated": iso_match_ms, "launches_per_step": 1,
-                             "algorithmic_bytes": match_bytes,
-                             "GBps": match_bytes / match_ms / 1e6,
-                             # k-bar, E and the matcher's fp64 work (SURVEY.md 8d asks for them as measured outputs)
-                             "pair_terms_per_launch": int(res_np["pair_terms_g"].sum() + res_np["pair_terms_h"].sum()),
-                             "mean_neighbours_kbar": float((res_np["pair_terms_g"].sum() + res_np["pair_terms_h"].sum())
-                                                           / max(1, int((res_np["fevals"].astype(np.int64) * m_s).sum()))),
-                             "fp64_gflop_per_launch": (130.0 * float(res_np["pair_terms_g"].sum())
-                                                       + 610.0 * float(res_np["pair_terms_h"].sum())) / 1e9,
-                             "mean_iterations": float(res_np["iterations"].mean()),
-                             "mean_fevals": float(res_np["fevals"].mean()),
-                             "converged_frac": float(res_np["converged"].mean())},
-    }
-    mk = kern["ndt_match_kernel"]
-    mk["fp64_tflops"] = mk["fp64_gflop_per_launch"] / match_ms          # GFLOP / ms = TFLOP/s
-    mk["fp64_note"] = ("pair-term flops counted from csrc/ndt_match.hip: 130 per gradient term, 610 per Hessian term; "
-                       "MI355X fp64 vector peak 78.6 TFLOP/s (AMD datasheet) -> frac %.4f" % (mk["fp64_tflops"] / 78.6))
-    dominant = "ndt_build_kernel" if iso_build_ms >= iso_match_ms else "ndt_match_kernel"   # by time alone on the chip
-    dk = kern[dominant]
-    # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
-    # (tools/collect_profiles.sh -> profiles/rNN_pmc_traffic.json; FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
-    traffic = None
-    traffic_note = "no PMC summary for this library version under profiles/ (tools/collect_profiles.sh): traffic = null"
-    lib_version = binding.lib().ndtgpu_version().decode()
-    try:
-        if B == 1024 and NP == 100000:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-            # a summary taken with another binary says nothing about this one: refuse it
-            if pmc.get("lib_version") == lib_version:
-                for k in kern:
-                    kern[k]["pmc_hbm_bytes_per_launch"] = pmc["kernels"][k]["hbm_bytes_per_launch"]
-                traffic = pmc["kernels"][dominant]["hbm_bytes_per_launch"]
-                traffic_note = ("traffic = HBM bytes per launch from the rocprofv3 PMC passes of this library version committed as "
-                                "profiles/%s" % PMC_FILE)
-    except Exception:
-        traffic = None
-    note = ("achieved = algorithmic work per launch / HIP-event kernel duration over the timed region (events on the "
-            "launch stream; with the pipeline a kernel shares the chip with the other steps' kernels, *_isolated is the "
-            "kernel alone); " + traffic_note)
-    if dominant == "ndt_build_kernel":       # streaming pass over the points: HBM roof
-        roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                    "achieved_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6,
-                    "frac_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6 / HBM_PEAK_GBS, "note": note}
-    else:
-        # the matcher re-reads two cell maps that live in L2 ~1000 times: its roof is fp64 arithmetic (SURVEY.md 8d),
-        # 78.6 TFLOP/s on MI355X for matrix and vector fp64 alike.  Flops = the kernel's own pair-term counters x
-        # 130 (gradient term) / 610 (Hessian term), DESIGN.md 4.2.  kernels.ndt_match_kernel.GBps is the HBM view.
-        roofline = {"kernel": dominant, "bound": "fp64_valu", "achieved": mk["fp64_tflops"], "peak": 78.6, "unit": "TFLOP/s",
-                    "frac": mk["fp64_tflops"] / 78.6, "traffic": traffic,
-                    "achieved_isolated": mk["fp64_gflop_per_launch"] / mk["ms_isolated"],
-                    "frac_isolated": mk["fp64_gflop_per_launch"] / mk["ms_isolated"] / 78.6,
-                    "note": note + "; fp64 vector work (no MFMA instruction is issued: every pair term has its own 3x3 "
-                                   "inverse), counted against the fp64 peak"}
-
-    out = {
-        "metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)",
-        "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[2]: batch of %d independent 2D scan pairs per GPU, %d pts/scan, %.2f m cells, "
-                               "map 100x100x1 m, range 30 m, n_neighbours 2, ITR_MAX 30, DELTA_SCORE 1e-6, 6-DoF, "
-                               "grid build of both scans + D2D match per registration" % (B, NP, res),
-                   "pairs_per_gpu": B, "points_per_scan": NP, "cell_m": res,
-                   "pipeline": ("serial: one stream" if n_buf == 1 else
-                                "%d buffers / streams: builds of step k+1 start when the matcher of step k starts and run "
-                                "on the CUs its finished workgroups have left" % n_buf),
-                   "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2)},
-        "roofline": roofline, "kernels": kern,
-        # SURVEY.md 8d (config 4): node maps and edges are separate units when node maps are reused across edges
-        # north_star: scans/s and achieved HBM-bandwidth fraction (algorithmic bytes / time / 8 TB/s), per kernel
-        "scans_per_s": 2 * value,
-        "hbm_fraction": {k: {"timed_region": kern[k]["GBps"] / HBM_PEAK_GBS,
-                             "kernel_alone": kern[k]["algorithmic_bytes"] / kern[k]["ms_isolated"] / 1e6 / HBM_PEAK_GBS}
-                         for k in kern},
-        "nodes_per_s_build_only": world * 2 * B / (iso_build_ms * 1e-3),
-        "edges_per_s_match_only_prebuilt_maps": world * B / (iso_match_ms * 1e-3),
-    }
-
-    # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) ---------------------------
-    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
-        S = min(args.cpu_sample, B)
-        f_h, m_h = fixed[:S].cpu().numpy(), moving[:S].cpu().numpy()
-        Ti = pr["T_init"][:S].cpu().numpy()
-        one, omp, To = cpu_baseline_c(f_h, m_h, Ti, res, size_m, rng_lim, 1e-6, 2, 30)
-        max_dt = max_dr = 0.0
-        for b in range(S):
-            dt = float(np.linalg.norm(T_out[b][:3, 3] - To[b][:3, 3]))
-            dr = float(2 * np.arcsin(min(1.0, np.linalg.norm(T_out[b][:3, :3] - To[b][:3, :3]) / (2 * np.sqrt(2)))))
-            max_dt, max_dr = max(max_dt, dt), max(max_dr, dr)
-        model, nproc = cpu_info()
-        out["cpu_baseline"] = {"value": one["registrations_per_s"], "unit": "registrations/s", "cores": 1, "kind": "port",
-                               "sample": "first %d of the %d pairs (same inputs, same parameters): oracle/ndt_oracle.c through the C "
-                                         "driver oracle/cpu_baseline.c, gcc -O3 -march=native, taskset -c %d, 1 warm-up pass + median "
-                                         "of %d passes (%.2f s per pass, min %.2f / max %.2f)" % (
-                                             S, B, one["pinned_core"], one["reps"], one["median_pass_s"], one["min_pass_s"], one["max_pass_s"]),
-                               "cpu_model": model, "nproc": nproc,
-                               "all_cores": {"value": omp["registrations_per_s"], "unit": "registrations/s", "threads": omp["threads"],
-                                             "note": "OpenMP over the pairs of the same sample (whole registrations in parallel), median of "
-                                                     "%d passes; labelled figure, not the headline ratio" % omp["reps"]}}
-        out["parity"] = {"pairs_checked": S, "max_dt_m": max_dt, "max_drot_rad": max_dr,
-                         "tolerance": "1e-4 m / 1e-4 rad", "ok": bool(max_dt <= 1e-4 and max_dr <= 1e-4),
-                         "note": "the timing driver is built -march=native (FMA contraction allowed): its poses agree with the GPU to the "
-                                 "same bar as the strict oracle build the parity tests use"}
-        out["speedup_vs_cpu_1thread"] = value / one["registrations_per_s"]
-        out["speedup_vs_cpu_all_cores"] = value / omp["registrations_per_s"]
-        # ---- the boundary hands over HOST clouds (what the reference call sites do): PCIe-inclusive rate, measured ------
-        Bp = min(64, B)
-        hs = N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * Bp, max_cells=4096)
-        both = np.concatenate([fixed[:Bp].cpu().numpy(), moving[:Bp].cpu().numpy()])
-        Tp = pr["T_init"][:Bp].cpu().numpy()
-        best = 1e9
-        for _ in range(3):
-            torch.cuda.synchronize()
-            c0 = time.perf_counter()
-            hs.build(both, range_limit=rng_lim)                                  # H2D of the raw scans + build (synchronous)
-            N.match_batch(hs, np.arange(Bp), hs, np.arange(Bp) + Bp, Tp)         # H2D of poses, match, D2H of results
-            best = min(best, time.perf_counter() - c0)
-        out["pcie_inclusive"] = {"value": Bp / best, "unit": "registrations/s", "pairs": Bp,
-                                 "note": "host (pageable) clouds in, host poses out through ndtgpu_mapset_build_host + "
-                                         "ndtgpu_match_batch: %.1f MB H2D per registration; never the headline value" % (2 * NP * 12 / 1e6)}
-        del hs
-    # ---- single-pair latency of the other single-GPU configs (outside the timed region; rank 0, N=1) ---
-    if rank == 0 and world == 1 and not args.no_cpu:
-        import oracle as O
-
-        def one_pair(fx, mv, T0, res_, size_, rng_, cap):
-            ms = N.MapSet(res_, [0, 0, 0], size_, n_maps=2, max_cells=cap)
-            scans = torch.stack([fx, mv]).contiguous()
-            times = []
-            for _ in range(24):
-                torch.cuda.synchronize()
-                c0 = time.perf_counter()
-                ms.build(scans, range_limit=rng_, stream=torch.cuda.current_stream())
-                T, r = N.match_d2d(ms, 0, ms, 1, T0)
-                times.append(time.perf_counter() - c0)
-            times = sorted(times[3:])                      # the first calls load code objects and size the staging buffers
-            best = times[len(times) // 2]                  # median of 21 (a minimum would hide a slow repeat call)
-            f_h, m_h = fx.cpu().numpy(), mv.cpu().numpy()
-            c0 = time.perf_counter()
-            ot = O.OracleMap(res_, [0, 0, 0], size_); ot.load_points(f_h, rng_); ot.compute_cells()
-            os_ = O.OracleMap(res_, [0, 0, 0], size_); os_.load_points(m_h, rng_); os_.compute_cells()
-            To, ro = O.match_d2d(ot, os_, T0)
-            t_cpu = time.perf_counter() - c0
-            dt = float(np.linalg.norm(T[:3, 3] - To[:3, 3]))
-            dr = float(2 * np.arcsin(min(1.0, np.linalg.norm(T[:3, :3] - To[:3, :3]) / (2 * np.sqrt(2)))))
-            return {"gpu_ms": 1e3 * best, "gpu_ms_min_max": [1e3 * times[0], 1e3 * times[-1]], "cpu_1thread_ms": 1e3 * t_cpu, "speedup": t_cpu / best,
-                    "cells": [int(r["n_target"]), int(r["n_source"])], "iterations": int(r["iterations"]),
-                    "dt_m": dt, "drot_rad": dr}
-
-        lat = {}
-        lat["configs[1] single 2D pair, %d pts, %.2f m cells (build x2 + match, host-synchronous call)" % (NP, res)] = \
-            one_pair(fixed[0], moving[0], pr["T_init"][0].cpu().numpy(), res, size_m, rng_lim, 4096)
-        p3 = synth.pair_3d(torch.tensor([1], device=dev), device=dev)
-        lat["configs[4] single 3D pair, 200000 pts, 0.25 m voxels, 100x100x10 m, 6-DoF"] = \
-            one_pair(p3["fixed"][0], p3["moving"][0], p3["T_init"][0].cpu().numpy(), 0.25, [100.0, 100.0, 10.0], 70.0, 120000)
         out["single_pair_latency"] = lat
     if rank == 0:
         print(json.dumps(out))
