@@ -426,9 +426,14 @@ NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double
 //   registration this evaluation belongs to: when the wave's last evaluation had the same key and group and no mean
 //   has left its cell since (the small steps of a line search), PROBE is skipped and the list is used again.
 // On return every hit of the group has been summed into w.acc.
-template <int NN, bool WITH_H, int QL>
+// SEG: the 64 lanes (cells) of the group are cut into segments of `seg_lanes` lanes -- the chunks of the grid-barrier
+// matcher -- and every segment gets its own hit list, its own pass over the pair terms and its own row of wave totals
+// (seg_rows + segment * seg_stride; the accumulators are zero again afterwards): TRANSFORM and PROBE run once for all 64
+// cells, while the sums of a segment are bit for bit those of a group that holds that segment's cells alone.
+template <int NN, bool WITH_H, int QL, bool SEG = false>
 NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int base, int stride, int end,
-                      const rigid &T, double lfd1, double lfd2, unsigned cache_key)
+                      const rigid &T, double lfd1, double lfd2, unsigned cache_key, unsigned seg_lanes = 64u,
+                      double *seg_rows = nullptr, unsigned seg_stride = 0u)
 {
     constexpr int W = 2 * NN + 1;
     constexpr int NDT_QL = QL;
@@ -500,19 +505,10 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
             cnt += (unsigned)__popc(bits[q]);
         }
     }
-    unsigned total = hc.count, my_off = 0u;
-    if (!reuse) {
-        const unsigned incl = wave_incl_scan_u32(cnt);
-        total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-        my_off = incl - cnt;
-    }
-    NDT_PROF_T(1)
-    // the list is materialised NDT_QL hits at a time (one pass unless the neighbourhoods are dense 3D ones)
-#pragma unroll 1
-    for (unsigned p0 = 0; p0 < total; p0 += (unsigned)NDT_QL) {
-        const unsigned p1 = min(total, p0 + (unsigned)NDT_QL);
-        if (!reuse && my_off < p1 && my_off + cnt > p0) {
-            unsigned gi = my_off;
+    // entries [p0, p1) of a hit list in which this lane's `cnt_l` hits start at `off_l` go to the queue
+    auto fill = [&](unsigned off_l, unsigned cnt_l, unsigned p0, unsigned p1) __attribute__((always_inline)) {
+        if (!reuse && cnt_l != 0u && off_l < p1 && off_l + cnt_l > p0) {
+            unsigned gi = off_l;
             if (flat) {
 #pragma unroll 1
                 for (int q = 0; q < W; q++) {
@@ -539,12 +535,79 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
                 }
             }
         }
-        ndt_wave_sync();                             // list entries and tile columns were written by other lanes
-        NDT_PROF_T(2)
-        term_list<WITH_H>(w, tg, lfd1, lfd2, p1 - p0);
-        NDT_PROF_T(3)
-        ndt_wave_sync();                             // the next pass (or group) overwrites the list and the tile
+    };
+    // the list is materialised NDT_QL hits at a time (one pass unless the neighbourhoods are dense 3D ones), each
+    // pass followed by its pair terms
+    auto run_list = [&](unsigned off_l, unsigned cnt_l, unsigned total_l) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (unsigned p0 = 0; p0 < total_l; p0 += (unsigned)NDT_QL) {
+            const unsigned p1 = min(total_l, p0 + (unsigned)NDT_QL);
+            fill(off_l, cnt_l, p0, p1);
+            ndt_wave_sync();                             // list entries and tile columns were written by other lanes
+            NDT_PROF_T(2)
+            term_list<WITH_H>(w, tg, lfd1, lfd2, p1 - p0);
+            NDT_PROF_T(3)
+            ndt_wave_sync();                             // the next pass (or group) overwrites the list and the tile
+        }
+    };
+    unsigned total = hc.count, my_off = 0u;
+    if constexpr (SEG) {
+        constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3;
+        NDT_PROF_T(1)
+        const unsigned incl = wave_incl_scan_u32(cnt);
+        const unsigned total_all = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        const unsigned off_all = incl - cnt;
+        const unsigned long long have = __ballot(vi);
+        const unsigned n_seg = have ? (63u - (unsigned)__builtin_clzll(have)) / seg_lanes + 1u : 0u;   // segments that hold cells
+        // list offset at which segment x starts (x == n_seg: the end of the list)
+        auto seg_off = [&](unsigned x) -> unsigned {
+            return x * seg_lanes < 64u && x < n_seg ? (unsigned)__builtin_amdgcn_readlane((int)off_all, (int)(x * seg_lanes)) : total_all;
+        };
+        auto emit_row = [&](unsigned sg) __attribute__((always_inline)) {
+            const double tot = wave_totals<WITH_H>(w);
+            double *row = seg_rows + sg * seg_stride;
+            if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) row[lane >> SH] = tot;
+            if (lane == 0) row[28] = (double)w.terms;
+            w.terms = 0;
+#pragma unroll
+            for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
+        };
+#pragma unroll 1
+        for (unsigned sg = 0; sg < n_seg;) {
+            const unsigned o0 = seg_off(sg);
+            unsigned e = sg + 1u;
+            while (e < n_seg && seg_off(e + 1u) - o0 <= (unsigned)NDT_QL) e++;     // whole segments that fit into the list together
+            const unsigned o1 = seg_off(e);
+            const bool in = lane >= sg * seg_lanes && lane < e * seg_lanes;
+            const unsigned cnt_s = in ? cnt : 0u, off_s = in ? off_all - o0 : 0u;
+            if (o1 - o0 > (unsigned)NDT_QL) {             // one segment with more hits than the list holds: its own passes
+                run_list(off_s, cnt_s, o1 - o0);
+                emit_row(sg);
+            } else {                                      // ONE pass of window fetches for all of them, then their terms in turn
+                fill(off_s, cnt_s, 0u, o1 - o0);
+                ndt_wave_sync();
+                uint32_t *const q0 = w.myq;
+#pragma unroll 1
+                for (unsigned x = sg; x < e; x++) {
+                    const unsigned a = seg_off(x), b = seg_off(x + 1u);
+                    w.myq = q0 + (a - o0);
+                    term_list<WITH_H>(w, tg, lfd1, lfd2, b - a);
+                    emit_row(x);
+                }
+                w.myq = q0;
+                ndt_wave_sync();
+            }
+            sg = e;
+        }
+        return;
     }
+    if (!reuse) {
+        const unsigned incl = wave_incl_scan_u32(cnt);
+        total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        my_off = incl - cnt;
+    }
+    NDT_PROF_T(1)
+    run_list(my_off, cnt, total);
     if (lane == 0 && !reuse) {
         HitCache nc;
         nc.key = total <= (unsigned)NDT_QL ? cache_key : 0u;
@@ -618,6 +681,45 @@ NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &
 #ifdef NDT_MATCH_PROF
     if (tid == NDT_PROF_TID) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long *)&g_prof[k + (WITH_H ? 8 : 0)], (unsigned long long)w.prof[k]); atomicAdd((unsigned long long *)&g_prof[5 + (WITH_H ? 8 : 0)], 1ull); }
 #endif
+}
+
+// The same for up to 64 / seg_lanes CHUNKS of 8 * seg_lanes source cells at once (msrc <= 512 cells, one group of 64
+// cells per share, a chunk = seg_lanes lanes of it): TRANSFORM and PROBE use all 64 lanes, every chunk gets its own sums.
+// Row `c` of `out` (32 doubles, as sh.sums) is bit for bit what eval_derivs yields for chunk c alone.  Ends with a barrier.
+template <int NN, bool WITH_H>
+NDT_D void eval_chunks(const MapView &tg, gcell_ptr src, int msrc, const rigid &T, double lfd1, double lfd2,
+                       EvalShared<NDT_MATCH_WAVES> &sh, unsigned seg_lanes, double *rows, double *out, unsigned n_out)
+{
+    constexpr int NACC = WaveEval<WITH_H>::NACC, QL = EvalShared<NDT_MATCH_WAVES>::QL;
+    const unsigned tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const unsigned n_seg = ((unsigned)msrc + 8u * seg_lanes - 1u) / (8u * seg_lanes);
+    WaveEval<WITH_H> w;
+    wave_eval_init<NDT_MATCH_WAVES, WITH_H>(w, sh);
+    {
+        const unsigned v = wave;                      // 8 waves, 8 shares
+        w.myq = sh.queue + v * QL;
+        w.mycell = sh.cell + v * (3 * 64);
+        w.cache = sh.cache + v;
+        w.terms = 0;
+#pragma unroll
+        for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
+        // a share whose lanes hold no cell of a chunk (the tail of the range) must still deliver a row of zeros for it
+        for (unsigned sg = 0; sg < n_seg; sg++)
+            if ((tid & 63u) < 32u) rows[(sg * NDT_VW + v) * 32 + (tid & 63u)] = 0.0;
+        ndt_wave_sync();
+        eval_group<NN, WITH_H, QL, true>(w, tg, src, (int)v, NDT_VW, msrc, T, lfd1, lfd2, 0u, seg_lanes, rows + v * 32, NDT_VW * 32);
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < n_out * 32u; i += NDT_MATCH_THREADS) {      // (n_out >= n_seg: chunks without cells get zeros)
+        const unsigned sg = i >> 5, k = i & 31u;
+        if (k < (unsigned)NACC || k == 28u) {
+            double a = 0;
+            if (sg < n_seg)
+                for (int q = 0; q < NDT_VW; q++) a += rows[(sg * NDT_VW + q) * 32 + k];
+            out[sg * 32 + k] = a;
+        }
+    }
+    __syncthreads();
 }
 
 }  // namespace
@@ -1321,7 +1423,7 @@ struct NdtCoopCtrl {
     alignas(64) unsigned grp[16 * 16];   // arrival counter of workgroup group i at grp[16 * i] (one 64-byte line each)
 };
 static_assert(sizeof(NdtCoopCtrl) % 64 == 0, "control block keeps the partials aligned");
-size_t ndt_match_coop_work_bytes(size_t n_groups) { return sizeof(NdtCoopCtrl) + n_groups * 32 * sizeof(double); }   // multiple of 64
+size_t ndt_match_coop_work_bytes(size_t n_chunks) { return sizeof(NdtCoopCtrl) + n_chunks * 32 * sizeof(double); }   // multiple of 64
 size_t ndt_match_coop_ctrl_bytes() { return sizeof(NdtCoopCtrl); }   // what a launch sequence must find zeroed
 
 // Grid barrier number `epoch` (1, 2, ...).  Arrivals on ONE counter serialise at the L2 (~50-100 ns each: 30 us for
@@ -1362,10 +1464,12 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     __shared__ NdtMatchParamsDev s_prm;     // the solver takes the parameters by reference: LDS, not a private copy
     __shared__ rigid s_T;
     __shared__ int s_with_h, s_done;
+    __shared__ long long s_cnt[5];          // clocks: evaluations, solver, barriers; pair terms: gradient-only, with Hessian
+    __shared__ double s_rows[8 * NDT_VW * 32];      // eval_chunks: up to 8 chunks x 8 shares x 32 sums
 
-    // blockIdx.y = registration: its gridDim.x workgroups have their own control block and barrier.  The launch is a
-    // cooperative one sized by the occupancy query: every workgroup of the grid is resident, so no barrier can wait
-    // for a workgroup that has not started.
+    // blockIdx.y = registration: its gridDim.x workgroups have their own control block and barrier.  The caller sizes
+    // the grid by the occupancy query and lets one such launch run at a time: every workgroup that stays is resident,
+    // so no barrier can wait for a workgroup that has not started.
     const unsigned pair = pair_begin + blockIdx.y;
     char *work_mem = work_all + (size_t)pair * work_stride;
     double *T16 = T16_all + (size_t)pair * 16;
@@ -1373,17 +1477,43 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     const double *Q36 = Q36_all ? Q36_all + (size_t)pair * 36 : nullptr;
     NdtCoopCtrl *ctrl = reinterpret_cast<NdtCoopCtrl *>(work_mem);
     double *partials = reinterpret_cast<double *>(work_mem + sizeof(NdtCoopCtrl));
-    const MapView tg = map_view(tset, tidx[pair]);
-    const MapView sv = map_view(sset, sidx[pair]);
-    // the number of workgroups of a registration depends on its own source map only (a pair's result does not
-    // depend on the batch it is in); the launch grid is sized for the largest map, surplus workgroups leave
+    // the indices and the maps may come from device memory the host never saw: check them here (like the persistent kernel)
+    const uint32_t ti = tidx[pair], si = sidx[pair];
+    const bool bad_index = ti >= tset.n_maps || si >= sset.n_maps;
+    const bool truncated = !bad_index && (tset.counters[ti].overflow != 0u || sset.counters[si].overflow != 0u);
+    if (bad_index || truncated) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {              // (converged = 0; the pose is left untouched)
+            NdtMatchResultDev o;
+            o.converged = 0; o.iterations = 0; o.fevals = 0;
+            o.exit_code = bad_index ? -2 : -3;                  // -2 map index out of range, -3 a map needed more cells than max_cells
+            o.score = 0.0; o.n_source = 0; o.n_target = 0;
+            o.cycles_eval = 0; o.cycles_solver = 0; o.pair_terms_g = 0; o.pair_terms_h = 0;
+            *res = o;
+        }
+        return;
+    }
+    const MapView tg = map_view(tset, ti);
+    const MapView sv = map_view(sset, si);
+    // The source cells are cut into NC CHUNKS of (about) cells_per_group cells -- a property of the map alone -- and every
+    // chunk has its own row of partial sums; the rows are added in chunk order.  The G workgroups that the grid has for
+    // this registration deal the chunks among themselves (workgroup g: chunks g, g + G, ...): one chunk each when a
+    // single registration has the chip, a dozen each when 32 registrations of 12 k cells share it.  The result does not
+    // depend on G, i.e. not on the batch a registration is in.  Surplus workgroups leave at once.
     const unsigned g = blockIdx.x;
-    const unsigned G = min(gridDim.x, max(1u, ((unsigned)sv.n_cells + cells_per_group - 1u) / cells_per_group));
+    const unsigned NC = max(1u, ((unsigned)sv.n_cells + cells_per_group - 1u) / cells_per_group);
+    // chunks of equal length, a multiple of 8 cells (a chunk is then a whole number of lanes in each of the 8 shares)
+    const int per = (((sv.n_cells + (int)NC - 1) / (int)NC) + 7) & ~7;
+    // fewer workgroups than chunks: a workgroup takes CH chunks at a time through ONE pass of up to 64 cells per wave
+    // (eval_chunks; with 16 cells per wave TRANSFORM and PROBE would run at a quarter of their width)
+    const unsigned seg_lanes = (unsigned)per / 8u;
+    const bool packed = gridDim.x < NC && seg_lanes >= 8u && seg_lanes <= 32u;
+    const unsigned CH = packed ? 64u / seg_lanes : 1u;       // <= 8
+    const unsigned NQ = (NC + CH - 1u) / CH;                     // passes of CH chunks
+    const unsigned G = min(gridDim.x, NQ);
     if (g >= G) return;
-    const int per = (sv.n_cells + (int)G - 1) / (int)G;
-    const int begin = min(sv.n_cells, (int)g * per), count = min(sv.n_cells - begin, per);
     unsigned target = 0;
-    long long terms_g = 0, terms_h = 0;
+    // (profiling counters of workgroup 0 in LDS: as registers they are live across the whole loop and get spilled)
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
 
     if (threadIdx.x == 0) s_prm = prm;
     __syncthreads();
@@ -1391,31 +1521,54 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         match_state_init(st, T16, s_prm, Q36);
         ctrl->Teval = st.Teval; ctrl->with_h = st.with_h; ctrl->done = st.done;
     }
-    long long cyc_eval = 0, cyc_solver = 0, cyc_bar = 0;
+    // a barrier that gave up (a foreign process holding CUs: bounded spin): the registration reports exit code -4 and
+    // leaves the pose as it came in; the host-pointer entries run it again on the persistent kernel
+    auto gave_up = [&]() {
+        if (g == 0 && threadIdx.x == 0) {
+            NdtMatchResultDev o;
+            o.converged = 0; o.iterations = 0; o.fevals = 0; o.exit_code = -4;
+            o.score = 0.0; o.n_source = sv.n_cells; o.n_target = tg.n_cells;
+            o.cycles_eval = 0; o.cycles_solver = 0; o.pair_terms_g = 0; o.pair_terms_h = 0;
+            *res = o;
+        }
+    };
     for (;;) {
         long long b0 = __builtin_readcyclecounter();
-        if (!coop_barrier(ctrl, target, G)) return;               // the request is published
-        cyc_bar += (long long)__builtin_readcyclecounter() - b0;
+        if (!coop_barrier(ctrl, target, G)) { gave_up(); return; }   // the request is published
+        if (threadIdx.x == 0) s_cnt[2] += (long long)__builtin_readcyclecounter() - b0;
         if (threadIdx.x == 0) { s_T = ctrl->Teval; s_with_h = ctrl->with_h; s_done = ctrl->done; }
         __syncthreads();
         if (s_done) break;
         const rigid Te = s_T;
         long long c0 = __builtin_readcyclecounter();
-        if (s_with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
-        else eval_derivs<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
-        if (threadIdx.x < 32) { partials[g * 32 + threadIdx.x] = sh.sums[threadIdx.x]; __threadfence(); }
+#pragma unroll 1
+        for (unsigned q = g; q < NQ; q += G) {
+            const unsigned c = q * CH;
+            const int begin = min(sv.n_cells, (int)c * per), count = min(sv.n_cells - begin, (int)CH * per);
+            if (packed) {
+                if (s_with_h) eval_chunks<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, partials + c * 32, min(CH, NC - c));
+                else eval_chunks<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, partials + c * 32, min(CH, NC - c));
+            } else {
+                if (s_with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
+                else eval_derivs<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
+                if (threadIdx.x < 32) partials[c * 32 + threadIdx.x] = sh.sums[threadIdx.x];
+            }
+        }
+        if (threadIdx.x < (packed ? CH * 32u : 32u)) __threadfence();      // (the waves that wrote rows)
         long long c1 = __builtin_readcyclecounter();
-        cyc_eval += c1 - c0;
-        if (!coop_barrier(ctrl, target, G)) return;               // all partials are in memory
-        cyc_bar += (long long)__builtin_readcyclecounter() - c1;
+        if (threadIdx.x == 0) s_cnt[0] += c1 - c0;
+        if (!coop_barrier(ctrl, target, G)) { gave_up(); return; }   // all partials are in memory
+        if (threadIdx.x == 0) s_cnt[2] += (long long)__builtin_readcyclecounter() - c1;
         if (g == 0) {
-            // 16 x 32 threads: thread (r, k) adds value k of workgroups r, r + 16, ... (loads of different threads
-            // overlap: a single lane walking all G rows pays G dependent L2 round trips); the 16 rows are then
+            // 16 x 32 threads: thread (r, k) adds value k of chunks r, r + 16, ... (loads of different threads
+            // overlap: a single lane walking all NC rows pays NC dependent L2 round trips); the 16 rows are then
             // added in order.  Fixed order: deterministic.
             {
-                const unsigned k = threadIdx.x & 31u, r = threadIdx.x >> 5;
+                unsigned t = threadIdx.x;
+                asm volatile("" : "+v"(t));           // (recomputed here: hoisted out of the loop the shift is kept in a spilled register)
+                const unsigned k = t & 31u, r = t >> 5;
                 double a = 0;
-                for (unsigned w = r; w < G; w += 16u) a += partials[w * 32 + k];
+                for (unsigned w = r; w < NC; w += 16u) a += partials[w * 32 + k];
                 sh.src[r * 32 + k] = a;                    // the source tile buffer is free between evaluations
             }
             __syncthreads();
@@ -1427,10 +1580,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
             __syncthreads();
             if (threadIdx.x == 0) {
                 long long d0 = __builtin_readcyclecounter();
-                if (s_with_h) terms_h += (long long)sh.sums[28]; else terms_g += (long long)sh.sums[28];
+                s_cnt[s_with_h ? 4 : 3] += (long long)sh.sums[28];
                 match_state_step(st, sh.sums, s_prm, s_ws);
                 ctrl->Teval = st.Teval; ctrl->with_h = st.with_h; ctrl->done = st.done;
-                cyc_solver += (long long)__builtin_readcyclecounter() - d0;
+                s_cnt[1] += (long long)__builtin_readcyclecounter() - d0;
             }
         }
     }
@@ -1450,15 +1603,13 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         match_state_result(st, T16, o);
         o.n_source = sv.n_cells;
         o.n_target = tg.n_cells;
-        o.cycles_eval = cyc_eval;          // workgroup 0: its share of the evaluations
-        o.cycles_solver = cyc_solver;
+        o.cycles_eval = s_cnt[0];          // workgroup 0: its share of the evaluations
+        o.cycles_solver = s_cnt[1];
 #ifdef NDT_COOP_PROF
-        o.cycles_eval = cyc_bar;           // profiling build: time at the grid barriers instead
-#else
-        (void)cyc_bar;
+        o.cycles_eval = s_cnt[2];          // profiling build: time at the grid barriers instead
 #endif
-        o.pair_terms_g = terms_g;
-        o.pair_terms_h = terms_h;
+        o.pair_terms_g = s_cnt[3];
+        o.pair_terms_h = s_cnt[4];
         *res = o;
     }
 }
@@ -1496,9 +1647,10 @@ unsigned ndt_match_coop_capacity(int n_neighbours)
 hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                                  const uint32_t *sidx_dev, double *T16_dev, size_t pair_begin, size_t pair_count,
                                  const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
-                                 unsigned n_groups, unsigned cells_per_group, void *work_dev, int checked, hipStream_t stream)
+                                 unsigned n_groups, unsigned cells_per_group, void *work_dev, size_t work_stride, int checked,
+                                 hipStream_t stream)
 {
-    size_t stride = ndt_match_coop_work_bytes(n_groups);
+    size_t stride = work_stride;        // per registration: a control block + one row of partial sums per chunk
     NdtSetView ts = tset, ss = sset;
     NdtMatchParamsDev p = prm;
     char *work = (char *)work_dev;

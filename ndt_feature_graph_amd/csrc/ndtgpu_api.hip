@@ -83,7 +83,8 @@ struct ndtgpu_mapset {
     // control blocks zeroed, so a call only clears what it cannot know to be clean
     void *coop_work = nullptr;
     size_t coop_bytes = 0, coop_clean_stride = 0, coop_clean_upto = 0;
-    ndtgpu_status ensure_coop(size_t bytes)
+    ndtgpu_status ensure_coop(size_t bytes);     // (defined below: waits for the last grid-barrier launch before it frees)
+    ndtgpu_status ensure_coop_impl(size_t bytes)
     {
         if (bytes <= coop_bytes) return NDTGPU_OK;
         if (coop_work) (void)hipFree(coop_work);
@@ -675,6 +676,63 @@ static NdtMatchParamsDev to_dev(const ndtgpu_match_params *p)
 
 static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result layouts must agree");
 
+// ---- the grid-barrier matcher (csrc/ndt_match.hip ndt_match_coop_kernel): several workgroups per registration ---------
+// One such launch at a time on the device: two of them could each hold part of the chip and wait for the rest.  Every
+// launch waits (on its stream, not on the host) for the event of the one before it.
+static std::mutex g_coop_mutex;
+static hipEvent_t g_coop_ev = nullptr;
+static bool g_coop_ev_valid = false;
+
+ndtgpu_status ndtgpu_mapset::ensure_coop(size_t bytes)
+{
+    if (bytes > coop_bytes && g_coop_ev_valid) HIP_TRY(hipEventSynchronize(g_coop_ev));   // an asynchronous launch may still use the area
+    return ensure_coop_impl(bytes);
+}
+
+struct CoopPlan {
+    unsigned groups, per_group;   // workgroups per registration in the grid; source cells per chunk
+    size_t stride;                // bytes of work area per registration
+    int checked;                  // launch through hipLaunchCooperativeKernel
+};
+
+// The grid of a batch: every registration gets the same number of workgroups, as many as fit on the chip together
+// (occupancy query), at most one per chunk of the largest map the source set can hold.  No look at the maps: the kernel
+// cuts a registration into chunks by its own cell count and surplus workgroups leave at once.  False: the batch does not
+// fit (more registrations than resident workgroups).
+static bool coop_plan(const ndtgpu_mapset *ss, size_t n_pairs, const NdtMatchParamsDev &p, CoopPlan &pl)
+{
+    const unsigned capacity = ndt_match_coop_capacity(p.n_neighbours);
+    if (capacity == 0 || n_pairs == 0 || n_pairs > capacity) return false;
+    // 128 source cells per chunk (16 per wave; fewer stop paying: barrier + solver latency dominate)
+    const char *cpg = getenv("NDTGPU_COOP_CELLS");
+    pl.per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 128u;
+    const unsigned n_chunks = std::max(1u, (ss->v.grid.max_cells + pl.per_group - 1u) / pl.per_group);
+    pl.groups = std::max<unsigned>(1u, std::min<size_t>(n_chunks, capacity / n_pairs));
+    pl.stride = ndt_match_coop_work_bytes(n_chunks);
+    const char *api_env = getenv("NDTGPU_COOP_API");          // NDTGPU_COOP_API=1: hipLaunchCooperativeKernel (checked by the runtime)
+    pl.checked = (api_env && atoi(api_env) != 0) ? 1 : 0;
+    return true;
+}
+
+// Enqueues ONE launch for the whole batch on `st` behind the previous grid-barrier launch of the process (g_coop_mutex held).
+static ndtgpu_status coop_enqueue(ndtgpu_mapset *ts, ndtgpu_mapset *ss, const uint32_t *tidx_dev, const uint32_t *sidx_dev,
+                                  double *T16_dev, NdtMatchResultDev *res_dev, const double *Q36_dev, size_t n_pairs,
+                                  const NdtMatchParamsDev &p, const CoopPlan &pl, bool clear, bool record, hipStream_t st)
+{
+    if (g_coop_ev_valid) HIP_TRY(hipStreamWaitEvent(st, g_coop_ev, 0));
+    // the control blocks must be zero (barrier counters only grow while a registration runs); the kernels leave them so
+    if (clear) HIP_TRY(hipMemset2DAsync(ts->coop_work, pl.stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
+    hipError_t e = ndt_launch_match_coop(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, 0, n_pairs, p, res_dev, Q36_dev, pl.groups,
+                                         pl.per_group, ts->coop_work, pl.stride, pl.checked, st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: grid-barrier launch", e);
+    if (record) {     // (a caller that waits for its launch under the mutex leaves nothing for later launches to wait for)
+        if (!g_coop_ev) HIP_TRY(hipEventCreateWithFlags(&g_coop_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g_coop_ev, st));
+        g_coop_ev_valid = true;
+    }
+    return NDTGPU_OK;
+}
+
 // The persistent matcher on device-resident arguments: asynchronous on `stream`.
 static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_dev, ndtgpu_mapset *ss, const uint32_t *sidx_dev,
                                        double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &p,
@@ -732,57 +790,29 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
     p.fusion_flags = 0;
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
-    // Opt-in (NDTGPU_DEVICE_COOP=1): a batch that cannot fill the chip (one persistent workgroup per registration would
-    // leave most CUs idle) takes the cooperative launches of the host-pointer API when its indices are sane and its maps
-    // are large enough to be split: poses and indices make a round trip through the host (a few hundred bytes per
-    // registration) and the call SYNCHRONISES.  By default this entry never synchronises.
+    // A batch that cannot fill the chip with one persistent workgroup per registration (at most half as many pairs as
+    // CUs) on maps large enough to be split (a source set that holds >= 1024 cells per map): the grid-barrier matcher,
+    // as many workgroups per registration as fit on the chip together -- ONE asynchronous launch that reads indices and
+    // poses where they are, ordered behind the previous launch of its kind by an event.  NDTGPU_DEVICE_COOP=0 keeps such
+    // batches on the persistent kernel; so does a stream that is being captured (the event is not part of the capture).
     {
         hipStream_t st = (hipStream_t)stream;
         int dev = 0, n_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
         const char *dc_env = getenv("NDTGPU_DEVICE_COOP");
-        const char *coop_env = (dc_env && atoi(dc_env) != 0) ? "1" : "0";
-        if (n_pairs > 0 && n_pairs <= (size_t)n_cu / 2 && !(coop_env && atoi(coop_env) == 0)) {
-            std::vector<uint32_t> ti(n_pairs), si(n_pairs);
-            HIP_TRY(hipStreamSynchronize(ts->last_stream));      // the map counters read below come from the builds
-            HIP_TRY(hipStreamSynchronize(ss->last_stream));
-            HIP_TRY(hipMemcpyAsync(ti.data(), tidx_dev, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(si.data(), sidx_dev, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            bool sane = true;
-            for (size_t k = 0; k < n_pairs && sane; k++) sane = ti[k] < ts->n_maps && si[k] < ss->n_maps;
-            uint32_t max_cells = 0;
-            if (sane) {
-                std::vector<NdtMapCounters> ct(n_pairs), cs(n_pairs);
-                for (size_t k = 0; k < n_pairs; k++) {
-                    HIP_TRY(hipMemcpyAsync(&ct[k], ts->v.counters + ti[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + si[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
-                }
-                HIP_TRY(hipStreamSynchronize(st));
-                for (size_t k = 0; k < n_pairs && sane; k++) {
-                    sane = ct[k].overflow == 0u && cs[k].overflow == 0u;
-                    max_cells = std::max(max_cells, cs[k].n_cells);
-                }
-            }
-            // (maps of at least 1024 cells: there a registration gains an order of magnitude from 8+ workgroups; smaller
-            //  maps stay on the persistent kernel, whose result for a registration never depends on its batch)
-            if (sane && max_cells >= 1024u) {
-                std::vector<double> T(n_pairs * 16);
-                std::vector<ndtgpu_match_result> r(n_pairs);
-                HIP_TRY(hipMemcpyAsync(T.data(), T16_dev, n_pairs * 16 * sizeof(double), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                if (ts->work_ev_valid) HIP_TRY(hipEventSynchronize(ts->work_ev));   // an earlier launch may still use the work area
-                bool done = false;
-                ndtgpu_status crc = match_coop(ts, ti.data(), ss, si.data(), T.data(), n_pairs, p, nullptr, r.data(), st, &done);
-                if (crc != NDTGPU_OK) return crc;
-                if (done) {
-                    HIP_TRY(hipMemcpyAsync(T16_dev, T.data(), n_pairs * 16 * sizeof(double), hipMemcpyHostToDevice, st));
-                    HIP_TRY(hipMemcpyAsync(results_dev, r.data(), n_pairs * sizeof(ndtgpu_match_result), hipMemcpyHostToDevice, st));
-                    HIP_TRY(hipStreamSynchronize(st));
-                    return NDTGPU_OK;
-                }
-            }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        CoopPlan pl;
+        if (n_pairs > 0 && n_pairs <= (size_t)n_cu / 2 && ss->v.grid.max_cells >= 1024u && !(dc_env && atoi(dc_env) == 0) &&
+            hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone && coop_plan(ss, n_pairs, p, pl)) {
+            std::lock_guard<std::mutex> coop_lock(g_coop_mutex);
+            ndtgpu_status rc = ts->ensure_coop(n_pairs * pl.stride);
+            if (rc != NDTGPU_OK) return rc;
+            ts->coop_clean_stride = pl.stride;
+            ts->coop_clean_upto = 0;                            // (nobody will look how this launch ended: the next call clears)
+            ts->ev_valid[1] = false;
+            return coop_enqueue(ts, ss, tidx_dev, sidx_dev, T16_dev, reinterpret_cast<NdtMatchResultDev *>(results_dev), nullptr,
+                                n_pairs, p, pl, true, true, st);
         }
     }
     return match_device_core(ts, tidx_dev, ss, sidx_dev, T16_dev, n_pairs, p, results_dev, nullptr, (hipStream_t)stream);
@@ -878,10 +908,8 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
     return NDTGPU_OK;
 }
 
-// Batches that cannot fill the chip with one workgroup per registration: cooperative launches, n_groups workgroups
-// per registration (csrc/ndt_match.hip ndt_match_coop_kernel): the group evaluates, its workgroup 0 solves, no
-// host round trip per evaluation.  Returns NDTGPU_OK with *done = false when one workgroup per registration is
-// the better shape (the caller then uses the persistent kernel).
+// Host-pointer batches that cannot fill the chip with one workgroup per registration (the reference's one-link-at-a-time
+// call is the extreme case).  Returns NDTGPU_OK with *done = false when the persistent kernel is the better shape.
 static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                 double *T16, size_t n_pairs, const NdtMatchParamsDev &p, const double *Q36,
                                 ndtgpu_match_result *results, hipStream_t st, bool *done)
@@ -893,15 +921,16 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     if (n_pairs > (size_t)n_cu / 2) return NDTGPU_OK;
     const char *coop_env = getenv("NDTGPU_COOP");             // NDTGPU_COOP=0: persistent kernel above 8 pairs (A/B)
     if (coop_env && atoi(coop_env) == 0 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;
+    CoopPlan pl;
+    if (!coop_plan(ss, n_pairs, p, pl)) return NDTGPU_OK;
     // One pinned host block mirrors the device staging block [T | results | target idx | source idx | Q], followed by the
-    // source maps' counters and the control words read back at the end: ONE copy in, the counters out, one wait; later one
-    // copy of poses + results and the control words out, one wait.  (Was: eight pageable copies and four waits -- a third of
-    // a single-pair call.)
+    // control words read back at the end: one copy in, the launch, one copy of poses + results and the control words out,
+    // ONE wait.  (Round 2: eight pageable copies and four waits -- a third of a single-pair call.)
     const size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), bI = n_pairs * sizeof(uint32_t);
     const size_t off_R = (bT + 255) & ~(size_t)255, off_ti = (off_R + bR + 255) & ~(size_t)255,
                  off_si = (off_ti + bI + 255) & ~(size_t)255, off_Q = (off_si + bI + 255) & ~(size_t)255;
     const size_t total = off_Q + (Q36 ? n_pairs * 36 * sizeof(double) : 0);
-    const size_t off_cs = (total + 255) & ~(size_t)255, off_ctrl = off_cs + n_pairs * sizeof(NdtMapCounters);
+    const size_t off_ctrl = (total + 255) & ~(size_t)255;
     ndtgpu_status rc = ts->ensure_stage(total);
     if (rc != NDTGPU_OK) return rc;
     rc = ts->ensure_pin(off_ctrl + n_pairs * 16);
@@ -911,74 +940,26 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     memcpy(hp + off_ti, tidx, bI);
     memcpy(hp + off_si, sidx, bI);
     if (Q36) memcpy(hp + off_Q, Q36, n_pairs * 36 * sizeof(double));
-    // 128 source cells per workgroup (16 per wave; fewer cells per workgroup stop paying: barrier + solver
-    // latency dominate), at most one workgroup per CU.  Every registration uses ceil(its cells / 128) workgroups
-    // whatever batch it is in (the kernel works that out from the map; surplus workgroups of the grid leave at once);
-    // registrations that do not fit on the chip together run one after the other.
-    const char *cpg = getenv("NDTGPU_COOP_CELLS");
-    const unsigned per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 128u;
-    const unsigned capacity = ndt_match_coop_capacity(p.n_neighbours);
-    if (capacity == 0) return NDTGPU_OK;                                          // no occupancy figure: persistent kernel instead
-    // A few registrations whose LARGEST POSSIBLE grids (the source set's cell capacity) fit on the chip together are
-    // launched without asking the device how many cells the maps have: no read-back, no wait before the launch.
-    unsigned groups = (ss->v.grid.max_cells + per_group - 1u) / per_group;
-    if (groups < 1) groups = 1;
-    const bool blind = n_pairs <= NDTGPU_HOST_LOOP_MAX && (size_t)groups * n_pairs <= capacity;
-    HIP_TRY(hipMemcpyAsync(base, hp, total, hipMemcpyHostToDevice, st));
-    if (!blind) {
-        // source map sizes decide how many workgroups a registration can use
-        NdtMapCounters *cs = reinterpret_cast<NdtMapCounters *>(hp + off_cs);
-        for (size_t k = 0; k < n_pairs; k++)
-            HIP_TRY(hipMemcpyAsync(&cs[k], ss->v.counters + sidx[k], sizeof(NdtMapCounters), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        uint32_t max_cells = 0;
-        for (size_t k = 0; k < n_pairs; k++) max_cells = std::max(max_cells, cs[k].n_cells);
-        groups = (max_cells + per_group - 1u) / per_group;
-        if (groups > (unsigned)n_cu) groups = (unsigned)n_cu;
-        if (groups < 1) groups = 1;
-        if (groups == 1 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;      // persistent kernel instead
-        if (groups > capacity) groups = capacity;
-    }
-    const size_t stride = ndt_match_coop_work_bytes(groups);
-    rc = ts->ensure_coop(n_pairs * stride);
-    if (rc != NDTGPU_OK) return rc;
-    // Launches sized by the occupancy query: as many registrations per launch as fit on the chip together (`groups`
-    // workgroups each), launch after launch on the same stream.  One such launch sequence at a time per process: two of
-    // them (two host threads, two streams) could each hold part of the chip and wait for the rest.
-    const size_t per_launch = std::max<size_t>(1, capacity / groups);
-    // The launches run one after the other: beyond a few of them the persistent kernel (every registration on its own
-    // CU, all at once) is sooner done.  Measured with 12 k-cell 3D maps (96 workgroups each, 2 registrations per launch):
-    // 32 pairs 25.7 ms against 33.2 ms, 64 pairs 51 ms against 33.5 ms; 2D maps (3 workgroups each): one launch only.
-    {
-        const size_t launches = (n_pairs + per_launch - 1) / per_launch;
-        if (n_pairs > NDTGPU_HOST_LOOP_MAX && launches > std::max<size_t>(1, groups / 6)) return NDTGPU_OK;
-    }
-    const char *api_env = getenv("NDTGPU_COOP_API");          // NDTGPU_COOP_API=1: hipLaunchCooperativeKernel (checked by the runtime)
-    const int checked = (api_env && atoi(api_env) != 0) ? 1 : 0;
-    static std::mutex coop_mutex;
     const unsigned *ctrl = reinterpret_cast<const unsigned *>(hp + off_ctrl);
     std::vector<double> Tin(T16, T16 + 16 * n_pairs);          // (the poses as they came in: a registration that has to be re-run)
     {
-        std::lock_guard<std::mutex> coop_lock(coop_mutex);
-        // the control blocks must be zero (barrier counters only grow while a registration runs): the kernels leave them
-        // so, and only blocks this set has not seen finish cleanly at this stride are cleared
-        if (ts->coop_clean_stride != stride || ts->coop_clean_upto < n_pairs) {
-            HIP_TRY(hipMemset2DAsync(ts->coop_work, stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
-            ts->coop_clean_stride = stride;
-        }
-        const size_t clean_before = std::max(ts->coop_clean_upto, n_pairs);
+        std::lock_guard<std::mutex> coop_lock(g_coop_mutex);
+        rc = ts->ensure_coop(n_pairs * pl.stride);
+        if (rc != NDTGPU_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(base, hp, total, hipMemcpyHostToDevice, st));
+        // only blocks this set has not seen finish cleanly at this stride are cleared
+        const bool clear = ts->coop_clean_stride != pl.stride || ts->coop_clean_upto < n_pairs;
+        const size_t clean_before = clear ? n_pairs : ts->coop_clean_upto;
+        ts->coop_clean_stride = pl.stride;
         ts->coop_clean_upto = 0;                                // (until this call is known to have ended cleanly)
-        for (size_t b0 = 0; b0 < n_pairs; b0 += per_launch) {
-            hipError_t e = ndt_launch_match_coop(ts->v, (const uint32_t *)(base + off_ti), ss->v, (const uint32_t *)(base + off_si),
-                                                 (double *)base, b0, std::min(per_launch, n_pairs - b0), p,
-                                                 reinterpret_cast<NdtMatchResultDev *>(base + off_R),
-                                                 Q36 ? (const double *)(base + off_Q) : nullptr, groups, per_group, ts->coop_work,
-                                                 checked, st);
-            if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: grid-barrier launch", e);
-        }
+        rc = coop_enqueue(ts, ss, (const uint32_t *)(base + off_ti), (const uint32_t *)(base + off_si), (double *)base,
+                          reinterpret_cast<NdtMatchResultDev *>(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr,
+                          n_pairs, p, pl, clear, false, st);
+        if (rc != NDTGPU_OK) return rc;
         HIP_TRY(hipMemcpyAsync(hp, base, off_R + bR, hipMemcpyDeviceToHost, st));                      // poses + results
-        HIP_TRY(hipMemcpy2DAsync(hp + off_ctrl, 16, ts->coop_work, stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpy2DAsync(hp + off_ctrl, 16, ts->coop_work, pl.stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        g_coop_ev_valid = false;          // (this stream waited for the last asynchronous launch, and is drained now)
         bool any_bad = false;
         for (size_t k = 0; k < n_pairs; k++) any_bad = any_bad || ctrl[4 * k + 1] != 0u;
         ts->coop_clean_upto = any_bad ? 0 : clean_before;

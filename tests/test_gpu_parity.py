@@ -492,6 +492,27 @@ def test_grid_barrier_calls_leave_their_control_blocks_clean(N, O, monkeypatch):
         assert np.array_equal(first[(0, 1, 2, 3, 4)][0][k], first[tuple(range(8))][0][k])
 
 
+def test_grid_barrier_result_does_not_depend_on_the_batch(N, O):
+    """The grid-barrier matcher cuts the source cells of a registration into chunks of 128 cells -- a property of the map --
+    and adds the chunks' sums in chunk order.  Alone on the chip a registration has one workgroup per chunk; in a batch
+    of 64 a workgroup takes four chunks at a time through one pass of 64 cells per wave (eval_chunks), each chunk still
+    summed on its own: the bits must not change.  One pair against the oracle."""
+    pr, tg, sr, om = _pair_maps(N, O, list(range(1, 7)), 60000, 0.25)
+    T0 = pr["T_init"].numpy()
+    assert min(sr.num_cells(k) for k in range(6)) > 4 * 128            # more chunks than workgroups per pair below
+    idx = np.arange(64) % 6
+    Tb, rb = N.match_batch(tg, idx, sr, idx, T0[idx])                  # 64 pairs: 4 workgroups each, packed passes
+    for k in range(6):
+        T1, r1 = N.match_d2d(tg, k, sr, k, T0[k])                      # alone: a workgroup per chunk
+        for j in range(k, 64, 6):
+            assert np.array_equal(Tb[j], T1) and rb["iterations"][j] == r1["iterations"] and rb["fevals"][j] == r1["fevals"]
+    Td, rd = N.match_batch(tg, idx[:12], sr, idx[:12], T0[idx[:12]])   # 12 pairs: 21 workgroups each, one chunk per pass
+    assert np.array_equal(Td, Tb[:12])
+    To, ro = O.match_d2d(om[2][0], om[2][1], T0[2])
+    dt, dr = pose_close(Tb[2], To)
+    assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD and rb["iterations"][2] == ro["iterations"]
+
+
 def test_one_and_two_registrations_per_workgroup_agree(N, O, monkeypatch):
     """The persistent matcher keeps two registrations in flight per workgroup and its waves take the eight shares of
     their evaluations in whatever order they come free (NDTGPU_SLOTS=1: one registration per workgroup).  Shares,
