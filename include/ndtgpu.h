@@ -87,7 +87,8 @@ typedef struct {
     int32_t iterations; /* itr_ctr at exit */
     int32_t fevals;     /* derivativesNDT evaluations */
     int32_t exit_code;  /* 0 step<delta, 1 gradient vanished, 2 wrong direction, 3 iteration cap;
-                         * not run (device-pointer batches): -2 map index out of range, -3 a map overflowed max_cells */
+                         * not run (device-pointer batches): -2 map index out of range, -3 a map overflowed max_cells,
+                         * -4 the grid barrier of a small batch gave up (foreign work held CUs for seconds) */
     double score;       /* score at the returned pose */
     int32_t n_source;   /* Gaussian cells in the source map */
     int32_t n_target;
@@ -215,20 +216,23 @@ ndtgpu_status ndtgpu_derivatives(ndtgpu_mapset *target, size_t target_map, const
  * T16: HOST, n_pairs x 16 doubles, in: initial guess, out: result.  results: HOST, n_pairs.
  * The whole Newton / More-Thuente loop runs on the device: persistent workgroups pulling pairs from a ticket
  * counter when the batch fills the chip, one grid-barrier launch with several workgroups per registration when it
- * does not (<= 128 pairs; the one-link-at-a-time call of ndt_feature_graph.cpp:273 is n_pairs = 1).
+ * does not (<= 8 pairs, or <= 128 pairs of large maps; the one-link-at-a-time call of ndt_feature_graph.cpp:273 is
+ * n_pairs = 1).
  * Synchronous (returns after the results are on the host). */
 ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx, ndtgpu_mapset *source_set,
                                  const uint32_t *source_idx, double *T16, size_t n_pairs,
                                  const ndtgpu_match_params *prm, ndtgpu_match_result *results,
                                  ndtgpu_stream stream);
 /* device-resident variant for pipelines: T16_dev / results_dev are DEVICE buffers, idx arrays
- * DEVICE uint32.  ONE launch of persistent workgroups, ALWAYS asynchronous on `stream`: no host synchronisation, safe
- * under stream capture; a registration's result does not depend on its batch.
- * Opt-in (environment NDTGPU_DEVICE_COOP=1, read per call): a small batch of LARGE maps (at least 1024 cells, few
- * enough pairs for a handful of grid-barrier launches) whose indices are sane is spread over several CUs per
- * registration like ndtgpu_match_batch does -- an order of magnitude sooner done, same result to 1e-8 (another
- * summation order) -- but its indices and poses make a round trip through the host and the call then SYNCHRONISES
- * `stream` and the streams of the last builds of both sets.
+ * DEVICE uint32.  ONE launch, ALWAYS asynchronous on `stream`: no host synchronisation.
+ * Batches that fill the chip (and every batch on sets of small maps): persistent workgroups that pull pairs from a
+ * ticket counter; safe under stream capture.  At most half as many pairs as CUs on a source set with room for >= 16384
+ * cells per map (3D maps): the grid-barrier matcher, as many workgroups per registration as fit on the chip together
+ * (32 pairs of 12 k-cell maps: 10.7 instead of 65 ms) -- ordered behind the previous launch of its kind, on whatever
+ * stream, by an event (not while `stream` is being captured: the persistent kernel then).  Environment
+ * NDTGPU_DEVICE_COOP=0 (read per call) keeps every batch on the persistent kernel.  Either way a registration's result
+ * does not depend on its batch; the two shapes agree to 1e-8 (another summation order).  A grid barrier that gives up
+ * (a foreign process holding CUs for seconds) reports exit_code -4, converged = 0 and leaves the pose untouched.
  * The indices are range-checked on the device and a map whose build overflowed max_cells is refused: such a pair gets
  * converged = 0 and exit_code -2 / -3, its pose stays untouched.  The work area (ticket counters, parked solver
  * states) belongs to the TARGET set: calls on different streams with the same target set -- through this entry or the

@@ -679,6 +679,7 @@ static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result 
 // ---- the grid-barrier matcher (csrc/ndt_match.hip ndt_match_coop_kernel): several workgroups per registration ---------
 // One such launch at a time on the device: two of them could each hold part of the chip and wait for the rest.  Every
 // launch waits (on its stream, not on the host) for the event of the one before it.
+#define NDTGPU_COOP_MIN_SET_CELLS 16384u   // source sets with room for fewer cells per map hold small (2D) maps
 static std::mutex g_coop_mutex;
 static hipEvent_t g_coop_ev = nullptr;
 static bool g_coop_ev_valid = false;
@@ -791,7 +792,7 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
     // A batch that cannot fill the chip with one persistent workgroup per registration (at most half as many pairs as
-    // CUs) on maps large enough to be split (a source set that holds >= 1024 cells per map): the grid-barrier matcher,
+    // CUs) on maps large enough to be split (a source set that holds >= 16 k cells per map): the grid-barrier matcher,
     // as many workgroups per registration as fit on the chip together -- ONE asynchronous launch that reads indices and
     // poses where they are, ordered behind the previous launch of its kind by an event.  NDTGPU_DEVICE_COOP=0 keeps such
     // batches on the persistent kernel; so does a stream that is being captured (the event is not part of the capture).
@@ -803,7 +804,7 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
         const char *dc_env = getenv("NDTGPU_DEVICE_COOP");
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         CoopPlan pl;
-        if (n_pairs > 0 && n_pairs <= (size_t)n_cu / 2 && ss->v.grid.max_cells >= 1024u && !(dc_env && atoi(dc_env) == 0) &&
+        if (n_pairs > 0 && n_pairs <= (size_t)n_cu / 2 && ss->v.grid.max_cells >= NDTGPU_COOP_MIN_SET_CELLS && !(dc_env && atoi(dc_env) == 0) &&
             hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone && coop_plan(ss, n_pairs, p, pl)) {
             std::lock_guard<std::mutex> coop_lock(g_coop_mutex);
             ndtgpu_status rc = ts->ensure_coop(n_pairs * pl.stride);
@@ -919,8 +920,13 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
         n_cu = 256;
     if (n_pairs > (size_t)n_cu / 2) return NDTGPU_OK;
-    const char *coop_env = getenv("NDTGPU_COOP");             // NDTGPU_COOP=0: persistent kernel above 8 pairs (A/B)
+    const char *coop_env = getenv("NDTGPU_COOP");             // NDTGPU_COOP=0: persistent kernel above 8 pairs, =1: never (A/B)
     if (coop_env && atoi(coop_env) == 0 && n_pairs > NDTGPU_HOST_LOOP_MAX) return NDTGPU_OK;
+    // More than a handful of registrations on a set of small maps (fewer than 16 k cells per map, i.e. 2D scans: four
+    // chunks each): one CU per registration is as fast or faster (2D, 100 k points: 16 / 64 / 128 pairs 1.47 / 1.59 / 2.39 ms
+    // here against 1.46 / 1.47 / 1.48 ms on the persistent kernel; 12 k-cell 3D maps: 4.9 / 12.8 ms against 46 ms).
+    // (NDTGPU_COOP=1 takes the grid-barrier matcher regardless)
+    if (n_pairs > NDTGPU_HOST_LOOP_MAX && ss->v.grid.max_cells < NDTGPU_COOP_MIN_SET_CELLS && !(coop_env && atoi(coop_env) == 1)) return NDTGPU_OK;
     CoopPlan pl;
     if (!coop_plan(ss, n_pairs, p, pl)) return NDTGPU_OK;
     // One pinned host block mirrors the device staging block [T | results | target idx | source idx | Q], followed by the

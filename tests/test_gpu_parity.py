@@ -441,8 +441,9 @@ def test_persistent_cooperative_and_host_driven_paths_agree(N, O, monkeypatch):
     idx = np.arange(12)
     monkeypatch.setenv("NDTGPU_COOP", "0")
     Tb, rb = N.match_batch(tg, idx, sr, idx, T0)                 # persistent kernel
+    monkeypatch.setenv("NDTGPU_COOP", "1")
+    Tc, rc = N.match_batch(tg, idx, sr, idx, T0)                 # one grid-barrier launch, a few workgroups per pair
     monkeypatch.delenv("NDTGPU_COOP")
-    Tc, rc = N.match_batch(tg, idx, sr, idx, T0)                 # one cooperative launch, a few workgroups per pair
     # (another summation order: agreement to rounding of the sums, far inside the 1e-4 m / rad of the metric)
     assert np.max(np.abs(Tc - Tb)) < 1e-8 and np.array_equal(rc["iterations"], rb["iterations"])
     for b in (0, 5, 11):
@@ -492,11 +493,12 @@ def test_grid_barrier_calls_leave_their_control_blocks_clean(N, O, monkeypatch):
         assert np.array_equal(first[(0, 1, 2, 3, 4)][0][k], first[tuple(range(8))][0][k])
 
 
-def test_grid_barrier_result_does_not_depend_on_the_batch(N, O):
+def test_grid_barrier_result_does_not_depend_on_the_batch(N, O, monkeypatch):
     """The grid-barrier matcher cuts the source cells of a registration into chunks of 128 cells -- a property of the map --
     and adds the chunks' sums in chunk order.  Alone on the chip a registration has one workgroup per chunk; in a batch
     of 64 a workgroup takes four chunks at a time through one pass of 64 cells per wave (eval_chunks), each chunk still
     summed on its own: the bits must not change.  One pair against the oracle."""
+    monkeypatch.setenv("NDTGPU_COOP", "1")      # (sets of small maps would take the persistent kernel beyond 8 pairs)
     pr, tg, sr, om = _pair_maps(N, O, list(range(1, 7)), 60000, 0.25)
     T0 = pr["T_init"].numpy()
     assert min(sr.num_cells(k) for k in range(6)) > 4 * 128            # more chunks than workgroups per pair below
@@ -830,9 +832,10 @@ def test_device_pointer_batch_checks_indices_and_overflow(N):
 
 
 def test_device_pointer_small_batch_of_large_maps(N, monkeypatch):
-    """Opt-in (NDTGPU_DEVICE_COOP=1): ndtgpu_match_batch_device spreads a small batch of large maps over several CUs per
-    registration (cooperative launches, host round trip of the poses: the call then synchronises) instead of one CU
-    each: same answer as the always-asynchronous default (persistent kernel) to 1e-8."""
+    """ndtgpu_match_batch_device spreads a small batch of large maps over several CUs per registration (the grid-barrier
+    matcher: one asynchronous launch behind an event that orders such launches on the device) instead of one CU each
+    (NDTGPU_DEVICE_COOP=0: persistent kernel): same answer to 1e-8.  Two such calls on two streams without a wait in
+    between, and a bad index in the batch, behave as on the persistent kernel."""
     import torch
     from ndt_feature_graph_amd import binding, synth
     dev = torch.device("cuda", 0)
@@ -854,8 +857,27 @@ def test_device_pointer_small_batch_of_large_maps(N, monkeypatch):
         out[coop] = (T16.cpu().numpy(), res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(2).copy())
     assert np.max(np.abs(out["1"][0] - out["0"][0])) < 1e-8
     assert np.array_equal(out["1"][1]["iterations"], out["0"][1]["iterations"]) and np.all(out["1"][1]["converged"] == 1)
-    # the cooperative launches use many workgroups per registration: far fewer shader clocks on the critical path
+    # the grid-barrier launch uses many workgroups per registration: far fewer shader clocks on the critical path
     assert out["1"][1]["cycles_eval"].max() * 4 < out["0"][1]["cycles_eval"].max()
+    # two launches in flight on two streams (they must not hold parts of the chip and wait for each other), one with a
+    # bad index: its pose stays, exit code -2; everybody else gets the bits of the sequential run
+    monkeypatch.setenv("NDTGPU_DEVICE_COOP", "1")
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    Ta, Tb = T0.clone(), T0.clone()
+    ra = torch.zeros((2, 64), dtype=torch.uint8, device=dev)
+    rb = torch.zeros((2, 64), dtype=torch.uint8, device=dev)
+    si_bad = torch.tensor([2, 99], dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        Ta.copy_(T0); Tb.copy_(T0)
+        torch.cuda.synchronize()
+        binding.match_batch_device(ms, ti, ms, si, Ta, ra, 2, stream=s1)
+        binding.match_batch_device(ms, ti, ms, si_bad, Tb, rb, 2, stream=s2)
+        torch.cuda.synchronize()
+        assert np.array_equal(Ta.cpu().numpy(), out["1"][0])
+        rbn = rb.cpu().numpy().view(binding.RESULT_DTYPE).reshape(2)
+        assert np.array_equal(Tb.cpu().numpy()[0], out["1"][0][0]) and rbn["exit_code"][1] == -2 and rbn["converged"][1] == 0
+        assert np.array_equal(Tb.cpu().numpy()[1], T0.cpu().numpy()[1])
 
 
 def test_config4_replay_small(N, O):
