@@ -165,6 +165,13 @@ hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, co
 hipError_t ndt_launch_covariance(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                                  const uint32_t *sidx_dev, const double *T16_dev, size_t n_links, int n_neighbours,
                                  double lfd1, double lfd2, int mode, double *cov36_dev, int *status_dev, hipStream_t stream);
+size_t ndt_match_pool_ctrl_bytes();
+size_t ndt_match_pool_head_bytes();
+size_t ndt_match_pool_pair_bytes(size_t n_chunks);
+hipError_t ndt_launch_match_pool(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
+                                 const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
+                                 NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups,
+                                 unsigned cells_per_group, void *work_dev, size_t pair_stride, hipStream_t stream);
 struct rigid;
 hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,
                            int n_neighbours, int with_h, double lfd1, double lfd2, unsigned n_groups, double *partials_dev,

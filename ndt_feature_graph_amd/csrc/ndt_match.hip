@@ -1680,6 +1680,298 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_de
     }
 }
 
+// ---- the task-pool matcher: batches that cannot fill the chip with one workgroup per registration ---------------------
+// One EVALUATION of one registration is a set of TASKS (one chunk of ~128 source cells each, or four chunks through one
+// pass of 64 cells per wave when there are more tasks than workgroups); any workgroup takes any open task of any
+// registration (a 64-bit ticket per registration: evaluation number << 32 | tasks drawn), writes the chunks' rows of partial
+// sums and counts the task as delivered.  The workgroup that delivers the LAST task of an evaluation adds the rows in chunk
+// order, runs the solver step (state in global memory between steps, ~1.5 KB) and publishes the next evaluation, or the
+// result.  No barrier between workgroups and nothing that needs them resident together: a launch cannot deadlock, needs no
+// occupancy-sized grid and no ordering against other launches; registrations that run long get the workgroups the others
+// leave.  Chunks are a property of the map and rows are added in chunk order: a registration's result does not depend on
+// who computed what, nor on the batch -- bit for bit.
+struct alignas(64) NdtPoolPair {
+    unsigned long long ticket;          // (evaluation << 32) | tasks drawn; evaluation 0: nothing published (yet / any more)
+    unsigned n_tasks, done_tasks;       // tasks of an evaluation (fixed per registration); delivered in the current one
+    int with_h;
+    unsigned chunks_per_task, n_chunks, per;   // the cut of this registration's source cells
+    rigid Teval;                        // pose of the open evaluation
+    long long cnt[4];                   // clocks in evaluations (all workgroups) and solver steps; pair terms g / h
+    MatchState st;                      // solver state between steps
+};
+struct alignas(64) NdtPoolCtrl {
+    unsigned finished, abort, leave, pad;
+};
+size_t ndt_match_pool_ctrl_bytes() { return sizeof(NdtPoolCtrl); }
+size_t ndt_match_pool_head_bytes() { return sizeof(NdtPoolPair); }          // per registration: what a launch must find zeroed
+size_t ndt_match_pool_pair_bytes(size_t n_chunks) { return sizeof(NdtPoolPair) + n_chunks * 32 * sizeof(double); }
+
+template <int NN>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
+    NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
+    double *__restrict__ T16_all, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res_all,
+    const double *__restrict__ Q36_all, char *__restrict__ work, size_t pair_stride, unsigned cells_per_group,
+    unsigned n_pairs)
+{
+    __shared__ EvalShared<NDT_MATCH_WAVES> sh;
+    __shared__ MatchState st;
+    __shared__ NewtonWs s_ws;
+    __shared__ NdtMatchParamsDev s_prm;     // the solver takes the parameters by reference: LDS, not a private copy
+    __shared__ rigid s_T;
+    __shared__ double s_rows[4 * NDT_VW * 32];      // eval_chunks: up to 4 chunks x 8 shares x 32 sums
+    __shared__ double s_out[4 * 32];                // ... and their sums over the shares
+    __shared__ unsigned s_task[9];          // pair, task, with_h, code, last, evaluation, chunks, chunks per task, cells per chunk
+    __shared__ unsigned s_nt[64];           // tasks per evaluation of the first 64 registrations (0: not seen yet)
+    __shared__ long long s_clk;
+    enum { POOL_TASK = 0, POOL_NONE = 1, POOL_EXIT = 2 };
+    const unsigned tid = threadIdx.x;
+    NdtPoolCtrl *ctl = reinterpret_cast<NdtPoolCtrl *>(work);
+    auto pair_at = [&](unsigned p) { return reinterpret_cast<NdtPoolPair *>(work + sizeof(NdtPoolCtrl) + (size_t)p * pair_stride); };
+    auto rows_of = [&](unsigned p) { return reinterpret_cast<double *>(work + sizeof(NdtPoolCtrl) + (size_t)p * pair_stride + sizeof(NdtPoolPair)); };
+    auto aload = [](const unsigned *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // Everything workgroups hand to each other (request, rows, solver state) is LOADED with system-scope accesses, which
+    // bypass the L1 and the XCD's L2, and stored write-through; a producer's stores are complete (vmcnt 0, at the
+    // workgroup barrier) before its thread 0 touches the ticket / counter the consumer polls.  No cache-maintenance fence
+    // anywhere (1.7 - 3.5 us each, MI355X_MICROARCH.md): the maps stay in L1 / L2 from task to task.
+    auto ld64 = [](const void *q) { return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto st64 = [](void *q, unsigned long long v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(q), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto ld32 = [](const void *q) { return __hip_atomic_load(reinterpret_cast<const unsigned *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto st32 = [](void *q, unsigned v) { __hip_atomic_store(reinterpret_cast<unsigned *>(q), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto ldd = [&](const double *q) { return __builtin_bit_cast(double, ld64(q)); };
+    auto std_ = [&](double *q, double v) { st64(q, __builtin_bit_cast(unsigned long long, v)); };
+    constexpr unsigned ST_WORDS = (unsigned)(sizeof(MatchState) / sizeof(unsigned long long));
+    static_assert(sizeof(MatchState) % sizeof(unsigned long long) == 0, "MatchState is copied as 64-bit words");
+    auto refuse = [&](unsigned pair, int code) {                // (converged = 0; the pose is left untouched)
+        NdtMatchResultDev o;
+        o.converged = 0; o.iterations = 0; o.fevals = 0; o.exit_code = code;
+        o.score = 0.0; o.n_source = 0; o.n_target = 0;
+        o.cycles_eval = 0; o.cycles_solver = 0; o.pair_terms_g = 0; o.pair_terms_h = 0;
+        res_all[pair] = o;
+    };
+    auto finish_pair = [&](NdtPoolPair *P, unsigned pair) {     // thread 0, solver state in `st`
+        NdtMatchResultDev o;
+        match_state_result(st, T16_all + (size_t)pair * 16, o);
+        o.n_source = (int)sset.counters[sidx[pair]].n_cells;
+        o.n_target = (int)tset.counters[tidx[pair]].n_cells;
+        o.cycles_eval = (long long)ld64(&P->cnt[0]); o.cycles_solver = (long long)ld64(&P->cnt[1]);
+        o.pair_terms_g = (long long)ld64(&P->cnt[2]); o.pair_terms_h = (long long)ld64(&P->cnt[3]);
+        res_all[pair] = o;
+        __threadfence();                // (once per registration: pose and result leave this XCD's L2 before the launch can end)
+        atomicAdd(&ctl->finished, 1u);
+    };
+    if (tid == 0) s_prm = prm;
+    if (tid < 64) s_nt[tid] = 0u;
+    __syncthreads();
+
+    // ---- open the registrations (pair p by workgroup p mod gridDim.x) -------------------------------------------------
+    for (unsigned pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        if (tid == 0) {
+            NdtPoolPair *P = pair_at(pair);
+            // the indices and the maps may come from device memory the host never saw: check them here
+            const uint32_t ti = tidx[pair], si = sidx[pair];
+            const bool bad_index = ti >= tset.n_maps || si >= sset.n_maps;
+            const bool truncated = !bad_index && (tset.counters[ti].overflow != 0u || sset.counters[si].overflow != 0u);
+            if (bad_index || truncated) {
+                refuse(pair, bad_index ? -2 : -3);          // -2 map index out of range, -3 a map needed more cells than max_cells
+                atomicAdd(&ctl->finished, 1u);
+            } else {
+                refuse(pair, -4);                           // (what stays if the launch gives up before this one is finished)
+                __threadfence();                            // (... written through before any other workgroup can finish the pair)
+                match_state_init(st, T16_all + (size_t)pair * 16, s_prm, Q36_all ? Q36_all + (size_t)pair * 36 : nullptr);
+                if (st.done) {                               // parameters the solver rejects
+                    for (int i = 0; i < 4; i++) st64(&P->cnt[i], 0ull);
+                    finish_pair(P, pair);
+                } else {
+                    // chunks of equal length, a multiple of 8 cells (a chunk is then a whole number of lanes in each of the
+                    // 8 shares); four of them per task when the batch has more tasks than the launch has workgroups
+                    const unsigned n = sset.counters[si].n_cells;
+                    const unsigned NC = max(1u, (n + cells_per_group - 1u) / cells_per_group);
+                    const unsigned per = (((n + NC - 1u) / NC) + 7u) & ~7u;
+                    const unsigned seg_lanes = per / 8u;
+                    const bool packed = (size_t)n_pairs * NC > gridDim.x && seg_lanes >= 8u && seg_lanes <= 32u;
+                    const unsigned CH = packed ? min(4u, 64u / seg_lanes) : 1u;
+                    st32(&P->n_chunks, NC); st32(&P->per, per); st32(&P->chunks_per_task, CH);
+                    st32(&P->n_tasks, (NC + CH - 1u) / CH);
+                    st32(&P->done_tasks, 0u);
+                    st32(&P->with_h, (unsigned)st.with_h);
+                    for (int i = 0; i < 9; i++) std_(&P->Teval.r[i], st.Teval.r[i]);
+                    for (int i = 0; i < 3; i++) std_(&P->Teval.t[i], st.Teval.t[i]);
+                    for (int i = 0; i < 4; i++) st64(&P->cnt[i], 0ull);
+                    for (unsigned i = 0; i < ST_WORDS; i++)
+                        st64(reinterpret_cast<unsigned long long *>(&P->st) + i, reinterpret_cast<const unsigned long long *>(&st)[i]);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&P->ticket, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- take tasks until every registration is finished --------------------------------------------------------------
+    unsigned home = blockIdx.x % n_pairs, idle = 0;
+    for (;;) {
+        if (tid == 0) {
+            unsigned code = POOL_NONE;
+            // (one load per registration and poll: the ticket; the end of the launch is looked for when nothing is open)
+            for (unsigned k = 0; k < n_pairs && code == POOL_NONE; k++) {
+                const unsigned q = home + k < n_pairs ? home + k : home + k - n_pairs;
+                NdtPoolPair *P = pair_at(q);
+                unsigned long long t = __hip_atomic_load(&P->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((t >> 32) == 0ull) continue;
+                unsigned nt = n_pairs <= 64u ? s_nt[q] : 0u;              // tasks per evaluation: fixed once published
+                if (nt == 0u) { nt = aload(&P->n_tasks); if (n_pairs <= 64u) s_nt[q] = nt; }
+                if ((unsigned)t >= nt) continue;
+                t = __hip_atomic_fetch_add(&P->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((t >> 32) != 0ull && (unsigned)t < nt) {
+                    s_task[0] = q; s_task[1] = (unsigned)t; s_task[5] = (unsigned)(t >> 32);
+                    s_task[2] = ld32(&P->with_h);
+                    for (int i = 0; i < 9; i++) s_T.r[i] = ldd(&P->Teval.r[i]);
+                    for (int i = 0; i < 3; i++) s_T.t[i] = ldd(&P->Teval.t[i]);
+                    s_task[6] = ld32(&P->n_chunks); s_task[7] = ld32(&P->chunks_per_task); s_task[8] = ld32(&P->per);
+                    code = POOL_TASK;
+                    home = q;                                                 // (look here first next time)
+                }
+            }
+            if (code == POOL_NONE && (aload(&ctl->finished) >= n_pairs || aload(&ctl->abort) != 0u)) code = POOL_EXIT;
+            if (code == POOL_NONE) {
+                // nothing open: somebody is in a solver step (or everything left is being evaluated).  ~10 s of this
+                // means a bug, not a wait: raise the abort word instead of hanging the device
+                if (++idle > (1u << 23)) { __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); code = POOL_EXIT; }
+            } else {
+                idle = 0;
+            }
+            s_task[3] = code;
+        }
+        __syncthreads();
+        const unsigned code = s_task[3];
+        if (code == POOL_EXIT) break;
+        if (code == POOL_NONE) { __builtin_amdgcn_s_sleep(8); __syncthreads(); continue; }
+        // (what a task needs lives in LDS and is read again after the evaluation: as registers across it, it is spilled)
+        if (tid == 0) s_clk = (long long)__builtin_readcyclecounter();
+        {
+            const unsigned pair = s_task[0], task = s_task[1];
+            const bool with_h = s_task[2] != 0u;
+            double *rows = rows_of(pair);
+            const MapView tg = map_view(tset, tidx[pair]);
+            const MapView sv = map_view(sset, sidx[pair]);
+            const unsigned NC = s_task[6], CH = s_task[7];
+            const int per = (int)s_task[8];
+            const rigid Te = s_T;
+            const unsigned c = task * CH;
+            const int begin = min(sv.n_cells, (int)c * per), count = min(sv.n_cells - begin, (int)CH * per);
+            if (CH > 1u) {
+                const unsigned seg_lanes = (unsigned)per / 8u;
+                const unsigned n_out = min(CH, NC - c);
+                if (with_h) eval_chunks<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, s_out, n_out);
+                else eval_chunks<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, s_out, n_out);
+                if (tid < n_out * 32u) std_(rows + c * 32 + tid, s_out[tid]);
+            } else {
+                if (with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
+                else eval_derivs<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
+                if (tid < 32) std_(rows + c * 32 + tid, sh.sums[tid]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the rows are in memory before the task counts as delivered
+        }
+        __syncthreads();
+        const unsigned pair = s_task[0];
+        const bool with_h = s_task[2] != 0u;
+        NdtPoolPair *P = pair_at(pair);
+        double *rows = rows_of(pair);
+        const unsigned NC = s_task[6], n_tasks = (NC + s_task[7] - 1u) / s_task[7];
+        if (tid == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&P->cnt[0]), (unsigned long long)((long long)__builtin_readcyclecounter() - s_clk));
+            const unsigned d = __hip_atomic_fetch_add(&P->done_tasks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_task[4] = d + 1u == n_tasks ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_task[4] == 0u) continue;
+        // ---- the last task of the evaluation: add the rows, run the solver step, publish ---------------------------------
+        {
+            // 16 x 32 threads: thread (r, k) adds value k of chunks r, r + 16, ...; the 16 rows are then added in order
+            unsigned t = tid;
+            asm volatile("" : "+v"(t));
+            const unsigned k = t & 31u, r = t >> 5;
+            double a = 0;
+            for (unsigned w = r; w < NC; w += 16u) a += ldd(rows + w * 32 + k);
+            sh.src[r * 32 + k] = a;                        // the source tile buffer is free between evaluations
+        }
+        {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&P->st);
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&st);
+            for (unsigned i = tid; i < ST_WORDS; i += NDT_MATCH_THREADS) dst[i] = ld64(src + i);
+        }
+        __syncthreads();
+        if (tid < 29) {
+            double a = 0;
+            for (unsigned r = 0; r < 16u; r++) a += sh.src[r * 32 + tid];
+            sh.sums[tid] = a;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long d0 = __builtin_readcyclecounter();
+            st64(&P->cnt[with_h ? 3 : 2], ld64(&P->cnt[with_h ? 3 : 2]) + (unsigned long long)(long long)sh.sums[28]);
+            match_state_step(st, sh.sums, s_prm, s_ws);
+            st64(&P->cnt[1], ld64(&P->cnt[1]) + (unsigned long long)((long long)__builtin_readcyclecounter() - d0));
+        }
+        __syncthreads();
+        if (st.done) {
+            if (tid == 0) finish_pair(P, pair);
+        } else {
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&P->st);
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&st);
+            for (unsigned i = tid; i < ST_WORDS; i += NDT_MATCH_THREADS) st64(dst + i, src[i]);
+            if (tid < 9) std_(&P->Teval.r[tid], st.Teval.r[tid]);
+            else if (tid < 12) std_(&P->Teval.t[tid - 9], st.Teval.t[tid - 9]);
+            else if (tid == 12) st32(&P->with_h, (unsigned)st.with_h);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(&P->done_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&P->ticket, (unsigned long long)(s_task[5] + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+    // The tickets must read "nothing published" when the next launch starts: the last workgroup to leave puts the
+    // headers back (a launch that gave up leaves them dirty; the host clears then).
+    if (tid == 0 && aload(&ctl->abort) == 0u) {
+        if (atomicAdd(&ctl->leave, 1u) + 1u == gridDim.x) {
+            for (unsigned p = 0; p < n_pairs; p++) {
+                NdtPoolPair *P = pair_at(p);
+                __hip_atomic_store(&P->ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&P->n_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&P->done_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(&ctl->finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->leave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// One launch for the whole batch; `work` = a control block + per registration a header and one row per chunk the source
+// set can hold (ndt_match_pool_pair_bytes); headers and control block zero.
+hipError_t ndt_launch_match_pool(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
+                                 const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
+                                 NdtMatchResultDev *res_dev, const double *Q36_dev, unsigned n_groups,
+                                 unsigned cells_per_group, void *work_dev, size_t pair_stride, hipStream_t stream)
+{
+    char *work = (char *)work_dev;
+    const dim3 grid(n_groups), block(NDT_MATCH_THREADS);
+#define NDT_LAUNCH_POOL(NN)                                                                                            \
+    hipLaunchKernelGGL(ndt_match_pool_kernel<NN>, grid, block, 0, stream, tset, tidx_dev, sset, sidx_dev, T16_dev, prm,  \
+                       res_dev, Q36_dev, work, pair_stride, cells_per_group, (unsigned)n_pairs)
+    switch (prm.n_neighbours) {
+    case 0: NDT_LAUNCH_POOL(0); break;
+    case 1: NDT_LAUNCH_POOL(1); break;
+    case 2: NDT_LAUNCH_POOL(2); break;
+    case 3: NDT_LAUNCH_POOL(3); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef NDT_LAUNCH_POOL
+    return hipGetLastError();
+}
+
 hipError_t ndt_launch_eval(const NdtSetView &tset, size_t tmap, const NdtSetView &sset, size_t smap, const rigid &T,
                            int n_neighbours, int with_h, double lfd1, double lfd2, unsigned n_groups, double *partials_dev,
                            hipStream_t stream)

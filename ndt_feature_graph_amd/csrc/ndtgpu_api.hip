@@ -679,6 +679,7 @@ static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result 
 // ---- the grid-barrier matcher (csrc/ndt_match.hip ndt_match_coop_kernel): several workgroups per registration ---------
 // One such launch at a time on the device: two of them could each hold part of the chip and wait for the rest.  Every
 // launch waits (on its stream, not on the host) for the event of the one before it.
+#define NDTGPU_HOST_LOOP_MAX 8             // up to this many registrations per call: the latency shapes (grid barrier / host loop)
 #define NDTGPU_COOP_MIN_SET_CELLS 16384u   // source sets with room for fewer cells per map hold small (2D) maps
 static std::mutex g_coop_mutex;
 static hipEvent_t g_coop_ev = nullptr;
@@ -691,9 +692,10 @@ ndtgpu_status ndtgpu_mapset::ensure_coop(size_t bytes)
 }
 
 struct CoopPlan {
-    unsigned groups, per_group;   // workgroups per registration in the grid; source cells per chunk
+    unsigned groups, per_group;   // workgroups per registration in the grid (task pool: of the launch); source cells per chunk
     size_t stride;                // bytes of work area per registration
     int checked;                  // launch through hipLaunchCooperativeKernel
+    bool pool;                    // the task-pool kernel (default) instead of the grid-barrier kernel (NDTGPU_POOL=0)
 };
 
 // The grid of a batch: every registration gets the same number of workgroups, as many as fit on the chip together
@@ -708,8 +710,20 @@ static bool coop_plan(const ndtgpu_mapset *ss, size_t n_pairs, const NdtMatchPar
     const char *cpg = getenv("NDTGPU_COOP_CELLS");
     pl.per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 128u;
     const unsigned n_chunks = std::max(1u, (ss->v.grid.max_cells + pl.per_group - 1u) / pl.per_group);
-    pl.groups = std::max<unsigned>(1u, std::min<size_t>(n_chunks, capacity / n_pairs));
-    pl.stride = ndt_match_coop_work_bytes(n_chunks);
+    // Up to 8 registrations: the grid-barrier kernel (static teams, the solver state stays in one workgroup's LDS: 12 k-cell
+    // 3D maps, 1 / 4 / 8 pairs 1.63 / 2.30 / 3.01 ms against 1.94 / 2.57 / 3.14 ms).  More: the task pool (any workgroup
+    // takes any task of any registration, the long registrations get the workgroups the others leave: 16 / 32 pairs
+    // 5.6 / 6.9 ms against 7.2 / 10.7 ms).  Same chunks, same order of sums: the same bits.  NDTGPU_POOL=0 / 1 forces one.
+    const char *pool_env = getenv("NDTGPU_POOL");
+    pl.pool = pool_env ? atoi(pool_env) != 0 : n_pairs > NDTGPU_HOST_LOOP_MAX;
+    if (pl.pool) {
+        // any workgroup takes any task of any registration: as many workgroups as the chip holds, or as there can be tasks
+        pl.groups = (unsigned)std::max<size_t>(1, std::min<size_t>(capacity, n_pairs * (size_t)n_chunks));
+        pl.stride = ndt_match_pool_pair_bytes(n_chunks);
+    } else {
+        pl.groups = std::max<unsigned>(1u, std::min<size_t>(n_chunks, capacity / n_pairs));
+        pl.stride = ndt_match_coop_work_bytes(n_chunks);
+    }
     const char *api_env = getenv("NDTGPU_COOP_API");          // NDTGPU_COOP_API=1: hipLaunchCooperativeKernel (checked by the runtime)
     pl.checked = (api_env && atoi(api_env) != 0) ? 1 : 0;
     return true;
@@ -722,9 +736,19 @@ static ndtgpu_status coop_enqueue(ndtgpu_mapset *ts, ndtgpu_mapset *ss, const ui
 {
     if (g_coop_ev_valid) HIP_TRY(hipStreamWaitEvent(st, g_coop_ev, 0));
     // the control blocks must be zero (barrier counters only grow while a registration runs); the kernels leave them so
-    if (clear) HIP_TRY(hipMemset2DAsync(ts->coop_work, pl.stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
-    hipError_t e = ndt_launch_match_coop(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, 0, n_pairs, p, res_dev, Q36_dev, pl.groups,
-                                         pl.per_group, ts->coop_work, pl.stride, pl.checked, st);
+    hipError_t e;
+    if (pl.pool) {
+        if (clear) {
+            HIP_TRY(hipMemsetAsync(ts->coop_work, 0, ndt_match_pool_ctrl_bytes(), st));
+            HIP_TRY(hipMemset2DAsync((char *)ts->coop_work + ndt_match_pool_ctrl_bytes(), pl.stride, 0, ndt_match_pool_head_bytes(), n_pairs, st));
+        }
+        e = ndt_launch_match_pool(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, n_pairs, p, res_dev, Q36_dev, pl.groups, pl.per_group,
+                                  ts->coop_work, pl.stride, st);
+    } else {
+        if (clear) HIP_TRY(hipMemset2DAsync(ts->coop_work, pl.stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
+        e = ndt_launch_match_coop(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, 0, n_pairs, p, res_dev, Q36_dev, pl.groups,
+                                  pl.per_group, ts->coop_work, pl.stride, pl.checked, st);
+    }
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: grid-barrier launch", e);
     if (record) {     // (a caller that waits for its launch under the mutex leaves nothing for later launches to wait for)
         if (!g_coop_ev) HIP_TRY(hipEventCreateWithFlags(&g_coop_ev, hipEventDisableTiming));
@@ -807,7 +831,7 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
         if (n_pairs > 0 && n_pairs <= (size_t)n_cu / 2 && ss->v.grid.max_cells >= NDTGPU_COOP_MIN_SET_CELLS && !(dc_env && atoi(dc_env) == 0) &&
             hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone && coop_plan(ss, n_pairs, p, pl)) {
             std::lock_guard<std::mutex> coop_lock(g_coop_mutex);
-            ndtgpu_status rc = ts->ensure_coop(n_pairs * pl.stride);
+            ndtgpu_status rc = ts->ensure_coop(n_pairs * pl.stride + (pl.pool ? ndt_match_pool_ctrl_bytes() : 0));
             if (rc != NDTGPU_OK) return rc;
             ts->coop_clean_stride = pl.stride;
             ts->coop_clean_upto = 0;                            // (nobody will look how this launch ended: the next call clears)
@@ -859,7 +883,6 @@ static ndtgpu_status match_persistent_host(ndtgpu_mapset *ts, const uint32_t *ti
 // Small batches: the host runs the Newton / More-Thuente state machine (the same ndt_solver.h code the
 // persistent kernel runs on the device) and every derivative evaluation is one multi-workgroup kernel,
 // so a single registration uses the whole chip instead of one CU.  Used below NDTGPU_HOST_LOOP_MAX pairs.
-#define NDTGPU_HOST_LOOP_MAX 8
 static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_mapset *ss, const uint32_t *sidx,
                                        double *T16, size_t n_pairs, const NdtMatchParamsDev &p, const double *Q36,
                                        ndtgpu_match_result *results, hipStream_t st)
@@ -950,7 +973,7 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     std::vector<double> Tin(T16, T16 + 16 * n_pairs);          // (the poses as they came in: a registration that has to be re-run)
     {
         std::lock_guard<std::mutex> coop_lock(g_coop_mutex);
-        rc = ts->ensure_coop(n_pairs * pl.stride);
+        rc = ts->ensure_coop(n_pairs * pl.stride + (pl.pool ? ndt_match_pool_ctrl_bytes() : 0));
         if (rc != NDTGPU_OK) return rc;
         HIP_TRY(hipMemcpyAsync(base, hp, total, hipMemcpyHostToDevice, st));
         // only blocks this set has not seen finish cleanly at this stride are cleared
@@ -963,9 +986,14 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
                           n_pairs, p, pl, clear, false, st);
         if (rc != NDTGPU_OK) return rc;
         HIP_TRY(hipMemcpyAsync(hp, base, off_R + bR, hipMemcpyDeviceToHost, st));                      // poses + results
-        HIP_TRY(hipMemcpy2DAsync(hp + off_ctrl, 16, ts->coop_work, pl.stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
+        if (!pl.pool) HIP_TRY(hipMemcpy2DAsync(hp + off_ctrl, 16, ts->coop_work, pl.stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         g_coop_ev_valid = false;          // (this stream waited for the last asynchronous launch, and is drained now)
+        if (pl.pool) {                    // a registration the launch gave up on reports exit code -4 (the kernel's opening mark)
+            const ndtgpu_match_result *hr = reinterpret_cast<const ndtgpu_match_result *>(hp + off_R);
+            unsigned *cw = reinterpret_cast<unsigned *>(hp + off_ctrl);
+            for (size_t k = 0; k < n_pairs; k++) { cw[4 * k] = 0u; cw[4 * k + 1] = hr[k].exit_code == -4 ? 1u : 0u; }
+        }
         bool any_bad = false;
         for (size_t k = 0; k < n_pairs; k++) any_bad = any_bad || ctrl[4 * k + 1] != 0u;
         ts->coop_clean_upto = any_bad ? 0 : clean_before;
