@@ -227,12 +227,13 @@ ndtgpu_status ndtgpu_match_batch(ndtgpu_mapset *target_set, const uint32_t *targ
  * DEVICE uint32.  ONE launch, ALWAYS asynchronous on `stream`: no host synchronisation.
  * Batches that fill the chip (and every batch on sets of small maps): persistent workgroups that pull pairs from a
  * ticket counter; safe under stream capture.  At most half as many pairs as CUs on a source set with room for >= 16384
- * cells per map (3D maps): the grid-barrier matcher, as many workgroups per registration as fit on the chip together
- * (32 pairs of 12 k-cell maps: 10.7 instead of 65 ms) -- ordered behind the previous launch of its kind, on whatever
- * stream, by an event (not while `stream` is being captured: the persistent kernel then).  Environment
+ * cells per map (3D maps): several workgroups per registration -- static teams at a grid barrier up to 8 pairs, beyond
+ * that a pool of (registration, evaluation, chunk) tasks that any workgroup serves (32 pairs of 12 k-cell maps: 7 instead
+ * of 65 ms) -- ordered behind the previous launch of its kind, on whatever stream, by an event (not while `stream` is
+ * being captured: the persistent kernel then).  Environment
  * NDTGPU_DEVICE_COOP=0 (read per call) keeps every batch on the persistent kernel.  Either way a registration's result
- * does not depend on its batch; the two shapes agree to 1e-8 (another summation order).  A grid barrier that gives up
- * (a foreign process holding CUs for seconds) reports exit_code -4, converged = 0 and leaves the pose untouched.
+ * does not depend on its batch; the shapes agree to 1e-8 (another summation order).  A launch that gives up (a grid
+ * barrier starved by a foreign process for seconds) reports exit_code -4, converged = 0 and leaves the pose untouched.
  * The indices are range-checked on the device and a map whose build overflowed max_cells is refused: such a pair gets
  * converged = 0 and exit_code -2 / -3, its pose stays untouched.  The work area (ticket counters, parked solver
  * states) belongs to the TARGET set: calls on different streams with the same target set -- through this entry or the
