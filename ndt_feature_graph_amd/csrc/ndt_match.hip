@@ -650,7 +650,9 @@ NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &
                        double lfd2, EvalShared<NW> &sh, unsigned cache_key = 0u)
 {
     constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3, QL = EvalShared<NW>::QL;
-    const unsigned tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));       // (opaque: LDS addresses derived from it stay inside this call, see eval_chunks)
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
     WaveEval<WITH_H> w;
     wave_eval_init<NW, WITH_H>(w, sh);
     // cells are dealt to the shares in turn (cell i -> share i mod 8): cells are ranked in slot order, so a contiguous
@@ -691,7 +693,9 @@ NDT_D void eval_chunks(const MapView &tg, gcell_ptr src, int msrc, const rigid &
                        EvalShared<NDT_MATCH_WAVES> &sh, unsigned seg_lanes, double *rows, double *out, unsigned n_out)
 {
     constexpr int NACC = WaveEval<WITH_H>::NACC, QL = EvalShared<NDT_MATCH_WAVES>::QL;
-    const unsigned tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));       // (opaque: LDS addresses derived from it stay inside this call instead of living, spilled, in the caller's loop)
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned n_seg = ((unsigned)msrc + 8u * seg_lanes - 1u) / (8u * seg_lanes);
     WaveEval<WITH_H> w;
     wave_eval_init<NDT_MATCH_WAVES, WITH_H>(w, sh);
@@ -1762,11 +1766,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
     constexpr unsigned ST_WORDS = (unsigned)(sizeof(MatchState) / sizeof(unsigned long long));
     static_assert(sizeof(MatchState) % sizeof(unsigned long long) == 0, "MatchState is copied as 64-bit words");
     auto refuse = [&](unsigned pair, int code) {                // (converged = 0; the pose is left untouched)
-        NdtMatchResultDev o;
-        o.converged = 0; o.iterations = 0; o.fevals = 0; o.exit_code = code;
-        o.score = 0.0; o.n_source = 0; o.n_target = 0;
-        o.cycles_eval = 0; o.cycles_solver = 0; o.pair_terms_g = 0; o.pair_terms_h = 0;
-        res_all[pair] = o;
+        NdtMatchResultDev *o = res_all + pair;
+        o->converged = 0; o->iterations = 0; o->fevals = 0; o->exit_code = code;
+        o->score = 0.0; o->n_source = 0; o->n_target = 0;
+        o->cycles_eval = 0; o->cycles_solver = 0; o->pair_terms_g = 0; o->pair_terms_h = 0;
     };
     auto finish_pair = [&](NdtPoolPair *P, unsigned pair) {     // thread 0, solver state in `st`
         NdtMatchResultDev o;
@@ -1867,7 +1870,9 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         if (code == POOL_EXIT) break;
         if (code == POOL_NONE) { __builtin_amdgcn_s_sleep(8); __syncthreads(); continue; }
         // (what a task needs lives in LDS and is read again after the evaluation: as registers across it, it is spilled)
-        if (tid == 0) s_clk = (long long)__builtin_readcyclecounter();
+        unsigned tt = threadIdx.x;
+        asm volatile("" : "+v"(tt));
+        if (tt == 0) s_clk = (long long)__builtin_readcyclecounter();
         {
             const unsigned pair = s_task[0], task = s_task[1];
             const bool with_h = s_task[2] != 0u;
@@ -1884,11 +1889,11 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
                 const unsigned n_out = min(CH, NC - c);
                 if (with_h) eval_chunks<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, s_out, n_out);
                 else eval_chunks<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, s_out, n_out);
-                if (tid < n_out * 32u) std_(rows + c * 32 + tid, s_out[tid]);
+                if (tt < n_out * 32u) std_(rows + c * 32 + tt, s_out[tt]);
             } else {
                 if (with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
                 else eval_derivs<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
-                if (tid < 32) std_(rows + c * 32 + tid, sh.sums[tid]);
+                if (tt < 32) std_(rows + c * 32 + tt, sh.sums[tt]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the rows are in memory before the task counts as delivered
         }
@@ -1898,7 +1903,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         NdtPoolPair *P = pair_at(pair);
         double *rows = rows_of(pair);
         const unsigned NC = s_task[6], n_tasks = (NC + s_task[7] - 1u) / s_task[7];
-        if (tid == 0) {
+        if (tt == 0) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&P->cnt[0]), (unsigned long long)((long long)__builtin_readcyclecounter() - s_clk));
             const unsigned d = __hip_atomic_fetch_add(&P->done_tasks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_task[4] = d + 1u == n_tasks ? 1u : 0u;
@@ -1906,11 +1911,13 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         __syncthreads();
         if (s_task[4] == 0u) continue;
         // ---- the last task of the evaluation: add the rows, run the solver step, publish ---------------------------------
+        // (the thread index is read again here, opaquely: what is derived from it -- LDS addresses, row and word indices --
+        //  would otherwise be hoisted out of the loop into registers that live across the evaluations, and be spilled)
+        unsigned ft = threadIdx.x;
+        asm volatile("" : "+v"(ft));
         {
             // 16 x 32 threads: thread (r, k) adds value k of chunks r, r + 16, ...; the 16 rows are then added in order
-            unsigned t = tid;
-            asm volatile("" : "+v"(t));
-            const unsigned k = t & 31u, r = t >> 5;
+            const unsigned k = ft & 31u, r = ft >> 5;
             double a = 0;
             for (unsigned w = r; w < NC; w += 16u) a += ldd(rows + w * 32 + k);
             sh.src[r * 32 + k] = a;                        // the source tile buffer is free between evaluations
@@ -1918,16 +1925,16 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         {
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&P->st);
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(&st);
-            for (unsigned i = tid; i < ST_WORDS; i += NDT_MATCH_THREADS) dst[i] = ld64(src + i);
+            for (unsigned i = ft; i < ST_WORDS; i += NDT_MATCH_THREADS) dst[i] = ld64(src + i);
         }
         __syncthreads();
-        if (tid < 29) {
+        if (ft < 29) {
             double a = 0;
-            for (unsigned r = 0; r < 16u; r++) a += sh.src[r * 32 + tid];
-            sh.sums[tid] = a;
+            for (unsigned r = 0; r < 16u; r++) a += sh.src[r * 32 + ft];
+            sh.sums[ft] = a;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (ft == 0) {
             long long d0 = __builtin_readcyclecounter();
             st64(&P->cnt[with_h ? 3 : 2], ld64(&P->cnt[with_h ? 3 : 2]) + (unsigned long long)(long long)sh.sums[28]);
             match_state_step(st, sh.sums, s_prm, s_ws);
@@ -1935,17 +1942,17 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         }
         __syncthreads();
         if (st.done) {
-            if (tid == 0) finish_pair(P, pair);
+            if (ft == 0) finish_pair(P, pair);
         } else {
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(&P->st);
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&st);
-            for (unsigned i = tid; i < ST_WORDS; i += NDT_MATCH_THREADS) st64(dst + i, src[i]);
-            if (tid < 9) std_(&P->Teval.r[tid], st.Teval.r[tid]);
-            else if (tid < 12) std_(&P->Teval.t[tid - 9], st.Teval.t[tid - 9]);
-            else if (tid == 12) st32(&P->with_h, (unsigned)st.with_h);
+            for (unsigned i = ft; i < ST_WORDS; i += NDT_MATCH_THREADS) st64(dst + i, src[i]);
+            if (ft < 9) std_(&P->Teval.r[ft], st.Teval.r[ft]);
+            else if (ft < 12) std_(&P->Teval.t[ft - 9], st.Teval.t[ft - 9]);
+            else if (ft == 12) st32(&P->with_h, (unsigned)st.with_h);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) {
+            if (ft == 0) {
                 __hip_atomic_store(&P->done_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_store(&P->ticket, (unsigned long long)(s_task[5] + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
