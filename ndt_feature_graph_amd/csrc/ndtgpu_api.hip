@@ -719,6 +719,8 @@ static bool coop_plan(const ndtgpu_mapset *ss, size_t n_pairs, const NdtMatchPar
     if (pl.pool) {
         // any workgroup takes any task of any registration: as many workgroups as the chip holds, or as there can be tasks
         pl.groups = (unsigned)std::max<size_t>(1, std::min<size_t>(capacity, n_pairs * (size_t)n_chunks));
+        const char *pg = getenv("NDTGPU_POOL_GROUPS");                        // (experiments: workgroups of the launch)
+        if (pg && atoi(pg) > 0) pl.groups = (unsigned)atoi(pg);
         pl.stride = ndt_match_pool_pair_bytes(n_chunks);
     } else {
         pl.groups = std::max<unsigned>(1u, std::min<size_t>(n_chunks, capacity / n_pairs));

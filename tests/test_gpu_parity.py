@@ -496,17 +496,17 @@ def test_grid_barrier_calls_leave_their_control_blocks_clean(N, O, monkeypatch):
 def test_grid_barrier_result_does_not_depend_on_the_batch(N, O, monkeypatch):
     """The grid-barrier matcher cuts the source cells of a registration into chunks of 128 cells -- a property of the map --
     and adds the chunks' sums in chunk order.  Alone on the chip a registration has one workgroup per chunk; in a batch
-    of 64 a workgroup takes four chunks at a time through one pass of 64 cells per wave (eval_chunks), each chunk still
+    of 72 a workgroup takes four chunks at a time through one pass of 64 cells per wave (eval_chunks), each chunk still
     summed on its own: the bits must not change.  One pair against the oracle."""
     monkeypatch.setenv("NDTGPU_COOP", "1")      # (sets of small maps would take the persistent kernel beyond 8 pairs)
     pr, tg, sr, om = _pair_maps(N, O, list(range(1, 7)), 60000, 0.25)
     T0 = pr["T_init"].numpy()
     assert min(sr.num_cells(k) for k in range(6)) > 4 * 128            # more chunks than workgroups per pair below
-    idx = np.arange(64) % 6
-    Tb, rb = N.match_batch(tg, idx, sr, idx, T0[idx])                  # 64 pairs: 4 workgroups each, packed passes
+    idx = np.arange(72) % 6
+    Tb, rb = N.match_batch(tg, idx, sr, idx, T0[idx])                  # 72 pairs: four chunks per task
     for k in range(6):
         T1, r1 = N.match_d2d(tg, k, sr, k, T0[k])                      # alone: a workgroup per chunk
-        for j in range(k, 64, 6):
+        for j in range(k, 72, 6):
             assert np.array_equal(Tb[j], T1) and rb["iterations"][j] == r1["iterations"] and rb["fevals"][j] == r1["fevals"]
     Td, rd = N.match_batch(tg, idx[:12], sr, idx[:12], T0[idx[:12]])   # 12 pairs: one chunk per task
     assert np.array_equal(Td, Tb[:12])
@@ -678,7 +678,7 @@ def test_config5_3d_small(N, O):
     assert pose_close(T, pr["T_gt"][0].numpy())[0] < 0.05
 
 
-def test_match_fusion_soft_constraint_parity(N, O):
+def test_match_fusion_soft_constraint_parity(N, O, monkeypatch):
     """ndt_feature::matchFusion (NDT + odometry soft constraint x^T Tcov^-1 x), the scan-to-map call of
     NDTFeatureFuserHMT::update (fuser_hmt.cpp:356): HIP vs oracle, both execution paths."""
     pr, tg, sr, om = _pair_maps(N, O, list(range(1, 11)), 20000, 0.5)
@@ -697,10 +697,19 @@ def test_match_fusion_soft_constraint_parity(N, O):
         dt, dr = pose_close(Tb[b], To)
         assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
         assert abs(rb["score"][b] - ro["score"]) < 1e-6 * abs(ro["score"])
-    Ts, rs = N.match_fusion_batch(tg, idx[:3], sr, idx[:3], T0[:3], covs[:3])    # host-driven path
+    Ts, rs = N.match_fusion_batch(tg, idx[:3], sr, idx[:3], T0[:3], covs[:3])    # grid-barrier kernel (<= 8 pairs)
     for b in range(3):
         dt, dr = pose_close(Ts[b], Tb[b])
         assert dt < 1e-9 and dr < 1e-9
+    # the prior through the grid-barrier kernel and through the task pool (forced for these small maps): the same bits
+    monkeypatch.setenv("NDTGPU_COOP", "1")
+    out = {}
+    for pool in ("0", "1"):
+        monkeypatch.setenv("NDTGPU_POOL", pool)
+        out[pool] = N.match_fusion_batch(tg, idx, sr, idx, T0, covs)
+    monkeypatch.delenv("NDTGPU_COOP"); monkeypatch.delenv("NDTGPU_POOL")
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1]["fevals"], out["1"][1]["fevals"])
+    assert np.array_equal(out["0"][0][:3], Ts) and max(pose_close(out["1"][0][b], Tb[b])[0] for b in range(B)) < 1e-8
     # the prior matters: results differ from the plain matcher, and switching it off gives the plain matcher
     Tp, _ = N.match_batch(tg, idx, sr, idx, T0)
     assert max(pose_close(Tp[b], Tb[b])[0] for b in range(B)) > 1e-5
