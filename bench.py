@@ -234,6 +234,21 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         dist.destroy_process_group()
 
 
+def _masked_stream(torch, dev, first_cu, n_cus, n_cu_dev):
+    """A HIP stream whose kernels only run on CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    words = (n_cu_dev + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for cu in range(first_cu, first_cu + n_cus):
+        mask[cu // 32] |= 1 << (cu % 32)
+    h = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(words), mask)
+    if rc != 0 or not h.value:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 def _timed(torch, fn, reps=5, warm=2):
     """median wall time [ms] of fn() bracketed by device synchronisation"""
     for _ in range(warm):
@@ -405,6 +420,8 @@ def main():
     ap.add_argument("--node-points", type=int, default=20000, help="--config 4: points per scan")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--buffers", type=int, default=3, help="pipeline depth (mapset pairs / streams)")
+    ap.add_argument("--cu-split", type=int, default=0, help="CUs given to the build streams (hipExtStreamCreateWithCUMask), the "
+                    "matcher streams get the rest; 0: every stream sees the whole chip")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one stream, one mapset pair: every step waits for the previous one (default: --buffers mapset pairs, the "
                          "grid builds of step k+1 run on the CUs the matcher of step k has already left)")
@@ -453,6 +470,9 @@ def main():
     # left to start (csrc/ndt_match.hip), so the next step's builds fill the CUs that the few long registrations
     # of this step do not occupy.  Every step still does all of its work; results are identical to the serial run.
     n_buf = 1 if args.no_pipeline else args.buffers
+    n_cu_dev = torch.cuda.get_device_properties(dev).multi_processor_count
+    if args.cu_split > 0 and n_buf > 1:
+        os.environ["NDTGPU_MATCH_GROUPS"] = str(n_cu_dev - args.cu_split)
 
     class Buf:
         pass
@@ -467,6 +487,11 @@ def main():
         #  one-per-CU workgroups do not queue behind the 2048 small build workgroups of the next step: 366 k against 403 k
         #  registrations/s, gpurun_out/r03A.log -- the builds then only get the CUs the matcher has left)
         b.mstream = b.stream
+        if args.cu_split > 0 and n_buf > 1:
+            # builds on the first `cu_split` CUs, matchers on the rest: the matcher's one-per-CU workgroups never wait for a CU
+            # to drain its small build workgroups, and the builds never lose CUs to a matcher's tail
+            b.stream = _masked_stream(torch, dev, 0, args.cu_split, n_cu_dev)
+            b.mstream = _masked_stream(torch, dev, args.cu_split, n_cu_dev - args.cu_split, n_cu_dev)
         b.match_done = None
         b.gathered = None
         if world > 1:

@@ -779,7 +779,11 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
     const int park_iters = park_env ? atoi(park_env) : 6;
     const char *slots_env = getenv("NDTGPU_SLOTS");
     const int slots = (slots_env && atoi(slots_env) == 1) ? 1 : 2;
-    const unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
+    unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
+    // (a stream that owns only part of the chip -- hipExtStreamCreateWithCUMask, bench.py --cu-split -- wants one workgroup
+    //  per CU it has, not per CU of the device)
+    const char *grp_env = getenv("NDTGPU_MATCH_GROUPS");
+    if (grp_env && atoi(grp_env) > 0) n_groups = std::min<unsigned>(n_groups, (unsigned)atoi(grp_env));
     const char *dbl_env = getenv("NDTGPU_DOUBLE_THRESH");
     const unsigned double_thresh = dbl_env ? (unsigned)atoi(dbl_env) : n_groups;
     // The work area (ticket counters, parked solver states) belongs to the target set: a launch on another stream
