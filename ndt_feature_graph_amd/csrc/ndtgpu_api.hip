@@ -58,6 +58,31 @@ struct ndtgpu_mapset {
     size_t stage_bytes = 0;
     double *origins_dev = nullptr;
     size_t origins_cap = 0;
+    hipEvent_t origins_ev = nullptr;   // recorded after the last launch that reads origins_dev (it may be on another stream)
+    bool origins_ev_valid = false;
+    // room for `n` doubles in origins_dev, ordered behind its last reader: `st` waits for that launch before the buffer is
+    // overwritten (or the host does, before it is replaced)
+    ndtgpu_status origins_reserve(size_t n, hipStream_t st)
+    {
+        if (origins_cap < n) {
+            if (origins_ev_valid) HIP_TRY(hipEventSynchronize(origins_ev));
+            if (origins_dev) (void)hipFree(origins_dev);
+            origins_dev = nullptr;
+            origins_cap = 0;
+            HIP_TRY(hipMalloc((void **)&origins_dev, n * sizeof(double)));
+            origins_cap = n;
+        } else if (origins_ev_valid) {
+            HIP_TRY(hipStreamWaitEvent(st, origins_ev, 0));
+        }
+        return NDTGPU_OK;
+    }
+    ndtgpu_status origins_used(hipStream_t st)
+    {
+        if (!origins_ev) HIP_TRY(hipEventCreateWithFlags(&origins_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(origins_ev, st));
+        origins_ev_valid = true;
+        return NDTGPU_OK;
+    }
     // matcher work area: ticket counters, parked list, parked solver states
     void *work = nullptr;
     size_t work_bytes = 0;
@@ -247,6 +272,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (s->coop_work) (void)hipFree(s->coop_work);
     if (s->work_ev) (void)hipEventDestroy(s->work_ev);
     if (s->origins_dev) (void)hipFree(s->origins_dev);
+    if (s->origins_ev) (void)hipEventDestroy(s->origins_ev);
     for (int k = 0; k < 4; k++)
         if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     delete s;
@@ -285,13 +311,8 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
     hipStream_t st = (hipStream_t)stream;
     const double *orig_dev = nullptr;
     if (range_origins && count) {
-        if (s->origins_cap < count * 3) {
-            if (s->origins_dev) (void)hipFree(s->origins_dev);
-            s->origins_dev = nullptr;
-            s->origins_cap = 0;
-            HIP_TRY(hipMalloc((void **)&s->origins_dev, count * 3 * sizeof(double)));
-            s->origins_cap = count * 3;
-        }
+        ndtgpu_status orc = s->origins_reserve(count * 3, st);
+        if (orc != NDTGPU_OK) return orc;
         HIP_TRY(hipMemcpyAsync(s->origins_dev, range_origins, count * 3 * sizeof(double), hipMemcpyHostToDevice, st));
         orig_dev = s->origins_dev;
     }
@@ -303,6 +324,7 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
                          orig_dev, cp.n_min, cp.eval_factor, s->nice_range(first, count), st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: launch", e);
     if (s->profiling) { HIP_TRY(hipEventRecord(s->ev[1], st)); s->ev_valid[0] = true; }
+    if (orig_dev) return s->origins_used(st);
     return NDTGPU_OK;
 }
 
@@ -556,12 +578,9 @@ ndtgpu_status ndtgpu_mapset_add_cloud(ndtgpu_mapset *s, size_t first, size_t cou
     if (prm) fp = *prm;
     if (!(fp.occupancy_limit > 0)) return fail(NDTGPU_ERR_INVALID, "add_cloud: occupancy_limit must be positive");
     hipStream_t st = (hipStream_t)stream;
-    if (s->origins_cap < count * 3) {
-        if (s->origins_dev) (void)hipFree(s->origins_dev);
-        s->origins_dev = nullptr;
-        s->origins_cap = 0;
-        HIP_TRY(hipMalloc((void **)&s->origins_dev, count * 3 * sizeof(double)));
-        s->origins_cap = count * 3;
+    {
+        ndtgpu_status orc = s->origins_reserve(count * 3, st);
+        if (orc != NDTGPU_OK) return orc;
     }
     HIP_TRY(hipMemcpyAsync(s->origins_dev, origins, count * 3 * sizeof(double), hipMemcpyHostToDevice, st));
     s->last_stream = st;
@@ -571,7 +590,7 @@ ndtgpu_status ndtgpu_mapset_add_cloud(ndtgpu_mapset *s, size_t first, size_t cou
     hipError_t e = ndt_launch_fuse(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, s->origins_dev, p,
                                    s->nice_range(first, count), st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "add_cloud: launch", e);
-    return NDTGPU_OK;
+    return s->origins_used(st);
 }
 
 ndtgpu_status ndtgpu_mapset_add_cloud_host(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,

@@ -230,6 +230,18 @@ public:
             loadPointCloud(pc);
             return;
         }
+        // Upstream a second addPointCloud before computeNDTCells adds its points and evidence to the same cells.  Here the
+        // two calls are ONE device update (ray walk + moments + Gaussians) made at computeNDTCells: a second cloud from the
+        // same origin with the same arguments joins the first; anything else would have to be dropped -- refuse it instead.
+        if (pending_kind_ == PENDING_ADD && !pending_.empty()) {
+            const bool same = origin_[0] == origin(0) && origin_[1] == origin(1) && origin_[2] == origin(2) && add_maxz_ == maxz &&
+                              add_noise_ == sensor_noise && add_occ_limit_ == occupancy_limit;
+            if (!same)
+                throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTMap::addPointCloud: a cloud from another origin (or with other arguments) is "
+                                                             "pending; call computeNDTCells between the two");
+            pending_.insert(pending_.end(), pc.points.begin(), pc.points.end());
+            return;
+        }
         for (int a = 0; a < 3; a++) origin_[a] = origin(a);
         pending_.assign(pc.points.begin(), pc.points.end());
         pending_kind_ = PENDING_ADD;
