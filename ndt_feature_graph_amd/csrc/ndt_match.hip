@@ -1481,10 +1481,12 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     auto st64 = [](void *q, unsigned long long v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(q), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     auto ldd = [&](const double *q) { return __builtin_bit_cast(double, ld64(q)); };
     auto std_ = [&](double *q, double v) { st64(q, __builtin_bit_cast(unsigned long long, v)); };
-    auto publish = [&](NdtCoopCtrl *c) {                    // workgroup 0, thread 0: the next request
-        for (int i = 0; i < 9; i++) std_(&c->Teval.r[i], st.Teval.r[i]);
-        for (int i = 0; i < 3; i++) std_(&c->Teval.t[i], st.Teval.t[i]);
-        st64(&c->with_h, (unsigned long long)(unsigned)st.with_h | ((unsigned long long)(unsigned)st.done << 32));
+    auto publish = [&](NdtCoopCtrl *c) {                    // workgroup 0, after a barrier of its threads: the next request,
+        unsigned t = threadIdx.x;                           // one store per lane (thirteen from one lane cost 2 us more)
+        asm volatile("" : "+v"(t));                         // (opaque: the addresses are not worth registers across the loop)
+        if (t < 9) std_(&c->Teval.r[t], st.Teval.r[t]);
+        else if (t < 12) std_(&c->Teval.t[t - 9], st.Teval.t[t - 9]);
+        else if (t == 12) st64(&c->with_h, (unsigned long long)(unsigned)st.with_h | ((unsigned long long)(unsigned)st.done << 32));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     const unsigned pair = pair_begin + blockIdx.y;
@@ -1534,8 +1536,9 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
 
     if (threadIdx.x == 0) s_prm = prm;
     __syncthreads();
-    if (g == 0 && threadIdx.x == 0) {
-        match_state_init(st, T16, s_prm, Q36);
+    if (g == 0) {
+        if (threadIdx.x == 0) match_state_init(st, T16, s_prm, Q36);
+        __syncthreads();
         publish(ctrl);
     }
     // a barrier that gave up (a foreign process holding CUs: bounded spin): the registration reports exit code -4 and
@@ -1606,9 +1609,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
                 long long d0 = __builtin_readcyclecounter();
                 s_cnt[s_with_h ? 4 : 3] += (long long)sh.sums[28];
                 match_state_step(st, sh.sums, s_prm, s_ws);
-                publish(ctrl);
                 s_cnt[1] += (long long)__builtin_readcyclecounter() - d0;
             }
+            __syncthreads();
+            publish(ctrl);
         }
     }
     // The barrier counters only grow while a registration runs and must be zero when the next one starts: the last
