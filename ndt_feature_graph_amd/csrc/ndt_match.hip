@@ -1776,6 +1776,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         o->cycles_eval = 0; o->cycles_solver = 0; o->pair_terms_g = 0; o->pair_terms_h = 0;
     };
     auto finish_pair = [&](NdtPoolPair *P, unsigned pair) {     // thread 0, solver state in `st`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (this thread's own counter updates are in memory before it reads them)
         NdtMatchResultDev o;
         match_state_result(st, T16_all + (size_t)pair * 16, o);
         o.n_source = (int)sset.counters[sidx[pair]].n_cells;
