@@ -988,7 +988,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
     const double *__restrict__ feat_cells /* 18 doubles per correspondence */,
     unsigned n_pairs, int park_iters, unsigned double_thresh, char *__restrict__ work_mem)
 {
-    constexpr int QL = 1024;
+    constexpr int QL = R >= 3 ? 512 : 1024;     // (three slots: half the hit list per share; longer lists take two passes)
     typedef MatchSlot<QL> Slot;
     __shared__ Slot slots[R];
     __shared__ double w_src[NDT_MATCH_WAVES * 9 * 64];   // per wave: the transformed source tile, one column per lane
@@ -2029,13 +2029,16 @@ hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, co
                             int slots, unsigned double_thresh, void *work_dev, hipStream_t stream)
 {
     if (n_pairs == 0) return hipSuccess;
-    if (slots != 1 && slots != 2) return hipErrorInvalidValue;
+    if (slots < 1 || slots > 3) return hipErrorInvalidValue;
     // ticket counters and the parked list start at zero
     hipError_t e = hipMemsetAsync(work_dev, 0, sizeof(NdtMatchWork) + (n_pairs + (size_t)n_groups * slots + 1) * sizeof(unsigned), stream);
     if (e != hipSuccess) return e;
 #define NDT_LAUNCH_MATCH(NN)                                                                                         \
     do {                                                                                                             \
-        if (slots == 2)                                                                                              \
+        if (slots == 3)                                                                                              \
+            hipLaunchKernelGGL((ndt_match_kernel<NN, 3>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev, sset, \
+                               sidx_dev, T16_dev, prm, res_dev, Q36_dev, feat_off_dev, feat_cells_dev, (unsigned)n_pairs, park_iters, double_thresh, (char *)work_dev); \
+        else if (slots == 2)                                                                                         \
             hipLaunchKernelGGL((ndt_match_kernel<NN, 2>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, tset, tidx_dev, sset, \
                                sidx_dev, T16_dev, prm, res_dev, Q36_dev, feat_off_dev, feat_cells_dev, (unsigned)n_pairs, park_iters, double_thresh, (char *)work_dev); \
         else                                                                                                         \

@@ -797,7 +797,7 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
     const char *park_env = getenv("NDTGPU_PARK_ITERS");       // read per call: tests switch it
     const int park_iters = park_env ? atoi(park_env) : 6;
     const char *slots_env = getenv("NDTGPU_SLOTS");
-    const int slots = (slots_env && atoi(slots_env) == 1) ? 1 : 2;
+    const int slots = (slots_env && atoi(slots_env) >= 1 && atoi(slots_env) <= 3) ? atoi(slots_env) : 2;
     unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
     // (a stream that owns only part of the chip -- hipExtStreamCreateWithCUMask, bench.py --cu-split -- wants one workgroup
     //  per CU it has, not per CU of the device)
