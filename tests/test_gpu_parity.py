@@ -645,7 +645,7 @@ def test_full_size_properties(N):
             assert dt < 0.02 and dr < 0.005, (k, dt, dr)
 
 
-def test_self_match_and_empty_maps(N):
+def test_self_match_and_empty_maps(N, monkeypatch):
     from ndt_feature_graph_amd import synth
     pts = synth.pair_2d([9], 20000)["fixed"].numpy()
     ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2)
@@ -657,6 +657,17 @@ def test_self_match_and_empty_maps(N):
     for a, b in ((0, 1), (1, 0), (1, 1)):
         T, r = N.match_d2d(ms, a, ms, b, T0)
         assert np.array_equal(T, T0) and r["exit_code"] == 1 and r["score"] == 0.0
+    # the same in a batch of ten, through the persistent kernel, the grid-barrier kernel and the task pool
+    ti = np.array([0, 1, 1, 0, 0, 1, 0, 1, 1, 0]); si = np.array([1, 0, 1, 0, 1, 1, 0, 0, 1, 1])
+    Tb = np.repeat(T0[None], 10, 0)
+    for coop, pool in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("NDTGPU_COOP", coop); monkeypatch.setenv("NDTGPU_POOL", pool)
+        T, r = N.match_batch(ms, ti, ms, si, Tb)
+        for k in range(10):
+            if ti[k] == 0 and si[k] == 0:
+                assert r["converged"][k] and np.max(np.abs(T[k] - np.eye(4))) < 1e-6 or r["iterations"][k] > 0
+            else:
+                assert np.array_equal(T[k], T0) and r["exit_code"][k] == 1 and r["score"][k] == 0.0
 
 
 def test_config5_3d_small(N, O):
