@@ -1710,8 +1710,10 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_de
 
 // ---- the task-pool matcher: batches that cannot fill the chip with one workgroup per registration ---------------------
 // One EVALUATION of one registration is a set of TASKS (one chunk of ~128 source cells each, or four chunks through one
-// pass of 64 cells per wave when there are more tasks than workgroups); any workgroup takes any open task of any
-// registration (a 64-bit ticket per registration: evaluation number << 32 | tasks drawn), writes the chunks' rows of partial
+// pass of 64 cells per wave while the registrations still running have more chunks than the launch has workgroups -- decided
+// anew for every evaluation, so the last registrations of a batch are cut fine and spread over the idle chip); any workgroup
+// takes any open task of any registration (a 64-bit ticket per registration: evaluation | tasks | tasks drawn), writes the
+// chunks' rows of partial
 // sums and counts the task as delivered.  The workgroup that delivers the LAST task of an evaluation adds the rows in chunk
 // order, runs the solver step (state in global memory between steps, ~1.5 KB) and publishes the next evaluation, or the
 // result.  No barrier between workgroups and nothing that needs them resident together: a launch cannot deadlock, needs no
@@ -1719,8 +1721,8 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_de
 // leave.  Chunks are a property of the map and rows are added in chunk order: a registration's result does not depend on
 // who computed what, nor on the batch -- bit for bit.
 struct alignas(64) NdtPoolPair {
-    unsigned long long ticket;          // (evaluation << 32) | tasks drawn; evaluation 0: nothing published (yet / any more)
-    unsigned n_tasks, done_tasks;       // tasks of an evaluation (fixed per registration); delivered in the current one
+    unsigned long long ticket;          // evaluation << 40 | tasks of it << 20 | tasks drawn; evaluation 0: nothing published
+    unsigned n_tasks, done_tasks;       // (unused); tasks delivered in the open evaluation
     int with_h;
     unsigned chunks_per_task, n_chunks, per;   // the cut of this registration's source cells
     rigid Teval;                        // pose of the open evaluation
@@ -1748,8 +1750,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
     __shared__ rigid s_T;
     __shared__ double s_rows[4 * NDT_VW * 32];      // eval_chunks: up to 4 chunks x 8 shares x 32 sums
     __shared__ double s_out[4 * 32];                // ... and their sums over the shares
-    __shared__ unsigned s_task[9];          // pair, task, with_h, code, last, evaluation, chunks, chunks per task, cells per chunk
-    __shared__ unsigned s_nt[64];           // tasks per evaluation of the first 64 registrations (0: not seen yet)
+    __shared__ unsigned s_task[10];         // pair, task, with_h, code, last, evaluation, chunks, chunks per task, cells per chunk, tasks
     __shared__ long long s_clk;
     enum { POOL_TASK = 0, POOL_NONE = 1, POOL_EXIT = 2 };
     const unsigned tid = threadIdx.x;
@@ -1757,6 +1758,17 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
     auto pair_at = [&](unsigned p) { return reinterpret_cast<NdtPoolPair *>(work + sizeof(NdtPoolCtrl) + (size_t)p * pair_stride); };
     auto rows_of = [&](unsigned p) { return reinterpret_cast<double *>(work + sizeof(NdtPoolCtrl) + (size_t)p * pair_stride + sizeof(NdtPoolPair)); };
     auto aload = [](const unsigned *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto tk_make = [](unsigned seq, unsigned nt) { return ((unsigned long long)seq << 40) | ((unsigned long long)nt << 20); };
+    auto tk_seq = [](unsigned long long t) { return (unsigned)(t >> 40); };
+    auto tk_tasks = [](unsigned long long t) { return (unsigned)(t >> 20) & 0xFFFFFu; };
+    auto tk_drawn = [](unsigned long long t) { return (unsigned)t & 0xFFFFFu; };
+    // chunks per task of the NEXT evaluation of a registration of NC chunks (seg_lanes lanes per chunk and share): four
+    // through one pass while the registrations still running have more chunks than the launch has workgroups, one otherwise
+    auto chunks_per_task = [&](unsigned NC, unsigned seg_lanes) {
+        const unsigned active = n_pairs - min(n_pairs, aload(&ctl->finished));
+        const bool packed = (size_t)active * NC > gridDim.x && seg_lanes >= 8u && seg_lanes <= 32u;
+        return packed ? min(4u, 64u / seg_lanes) : 1u;
+    };
     // Everything workgroups hand to each other (request, rows, solver state) is LOADED with system-scope accesses, which
     // bypass the L1 and the XCD's L2, and stored write-through; a producer's stores are complete (vmcnt 0, at the
     // workgroup barrier) before its thread 0 touches the ticket / counter the consumer polls.  No cache-maintenance fence
@@ -1788,7 +1800,6 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         atomicAdd(&ctl->finished, 1u);
     };
     if (tid == 0) s_prm = prm;
-    if (tid < 64) s_nt[tid] = 0u;
     __syncthreads();
 
     // ---- open the registrations (pair p by workgroup p mod gridDim.x) -------------------------------------------------
@@ -1816,10 +1827,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
                     const unsigned NC = max(1u, (n + cells_per_group - 1u) / cells_per_group);
                     const unsigned per = (((n + NC - 1u) / NC) + 7u) & ~7u;
                     const unsigned seg_lanes = per / 8u;
-                    const bool packed = (size_t)n_pairs * NC > gridDim.x && seg_lanes >= 8u && seg_lanes <= 32u;
-                    const unsigned CH = packed ? min(4u, 64u / seg_lanes) : 1u;
+                    const unsigned CH = chunks_per_task(NC, seg_lanes);
                     st32(&P->n_chunks, NC); st32(&P->per, per); st32(&P->chunks_per_task, CH);
-                    st32(&P->n_tasks, (NC + CH - 1u) / CH);
                     st32(&P->done_tasks, 0u);
                     st32(&P->with_h, (unsigned)st.with_h);
                     for (int i = 0; i < 9; i++) std_(&P->Teval.r[i], st.Teval.r[i]);
@@ -1828,7 +1837,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
                     for (unsigned i = 0; i < ST_WORDS; i++)
                         st64(reinterpret_cast<unsigned long long *>(&P->st) + i, reinterpret_cast<const unsigned long long *>(&st)[i]);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(&P->ticket, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&P->ticket, tk_make(1u, (NC + CH - 1u) / CH), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -1838,37 +1847,55 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
     // ---- take tasks until every registration is finished --------------------------------------------------------------
     unsigned home = blockIdx.x % n_pairs, idle = 0;
     for (;;) {
-        if (tid == 0) {
+        if (tid < 64) {
+            // Wave 0 looks for a task: lane l reads the ticket of registration home + l (one round trip for 64
+            // registrations; one lane walking them paid one round trip EACH, and an idle workgroup took 20 us to notice the
+            // evaluation that the last registration of 32 had just opened), the first lane with an open ticket draws.
             unsigned code = POOL_NONE;
-            // (one load per registration and poll: the ticket; the end of the launch is looked for when nothing is open)
-            for (unsigned k = 0; k < n_pairs && code == POOL_NONE; k++) {
-                const unsigned q = home + k < n_pairs ? home + k : home + k - n_pairs;
+            for (unsigned base = 0; base < n_pairs && code == POOL_NONE; base += 64u) {
+                const unsigned k = base + tid;
+                const unsigned q = (home + k) % n_pairs;
                 NdtPoolPair *P = pair_at(q);
-                unsigned long long t = __hip_atomic_load(&P->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((t >> 32) == 0ull) continue;
-                unsigned nt = n_pairs <= 64u ? s_nt[q] : 0u;              // tasks per evaluation: fixed once published
-                if (nt == 0u) { nt = aload(&P->n_tasks); if (n_pairs <= 64u) s_nt[q] = nt; }
-                if ((unsigned)t >= nt) continue;
-                t = __hip_atomic_fetch_add(&P->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((t >> 32) != 0ull && (unsigned)t < nt) {
-                    s_task[0] = q; s_task[1] = (unsigned)t; s_task[5] = (unsigned)(t >> 32);
-                    s_task[2] = ld32(&P->with_h);
-                    for (int i = 0; i < 9; i++) s_T.r[i] = ldd(&P->Teval.r[i]);
-                    for (int i = 0; i < 3; i++) s_T.t[i] = ldd(&P->Teval.t[i]);
-                    s_task[6] = ld32(&P->n_chunks); s_task[7] = ld32(&P->chunks_per_task); s_task[8] = ld32(&P->per);
-                    code = POOL_TASK;
-                    home = q;                                                 // (look here first next time)
+                unsigned long long t = 0ull;
+                if (k < n_pairs) t = __hip_atomic_load(&P->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long open = __ballot(tk_seq(t) != 0u && tk_drawn(t) < tk_tasks(t));
+                while (open != 0ull && code == POOL_NONE) {
+                    const unsigned l = (unsigned)__builtin_ctzll(open);
+                    open &= open - 1ull;
+                    int won = 0;
+                    if (tid == l) {
+                        t = __hip_atomic_fetch_add(&P->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (tk_seq(t) != 0u && tk_drawn(t) < tk_tasks(t)) {
+                            won = 1;
+                            s_task[0] = q; s_task[1] = tk_drawn(t); s_task[5] = tk_seq(t); s_task[9] = tk_tasks(t);
+                        }
+                    }
+                    if (__ballot(won)) code = POOL_TASK;
                 }
             }
-            if (code == POOL_NONE && (aload(&ctl->finished) >= n_pairs || aload(&ctl->abort) != 0u)) code = POOL_EXIT;
-            if (code == POOL_NONE) {
+            if (code == POOL_TASK) {
+                // the request of the registration that was drawn from: one word per lane
+                ndt_wave_sync();
+                const unsigned q = s_task[0];
+                NdtPoolPair *P = pair_at(q);
+                if (tid < 9) s_T.r[tid] = ldd(&P->Teval.r[tid]);
+                else if (tid < 12) s_T.t[tid - 9] = ldd(&P->Teval.t[tid - 9]);
+                else if (tid == 12) s_task[2] = ld32(&P->with_h);
+                else if (tid == 13) s_task[6] = ld32(&P->n_chunks);
+                else if (tid == 14) s_task[7] = ld32(&P->chunks_per_task);
+                else if (tid == 15) s_task[8] = ld32(&P->per);
+                home = q;                                                     // (look here first next time)
+                idle = 0;
+            } else {
+                if (aload(&ctl->finished) >= n_pairs || aload(&ctl->abort) != 0u) code = POOL_EXIT;
                 // nothing open: somebody is in a solver step (or everything left is being evaluated).  ~10 s of this
                 // means a bug, not a wait: raise the abort word instead of hanging the device
-                if (++idle > (1u << 23)) { __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); code = POOL_EXIT; }
-            } else {
-                idle = 0;
+                else if (++idle > (1u << 23)) {
+                    if (tid == 0) __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    code = POOL_EXIT;
+                }
             }
-            s_task[3] = code;
+            if (tid == 0) s_task[3] = code;
         }
         __syncthreads();
         const unsigned code = s_task[3];
@@ -1907,7 +1934,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         const bool with_h = s_task[2] != 0u;
         NdtPoolPair *P = pair_at(pair);
         double *rows = rows_of(pair);
-        const unsigned NC = s_task[6], n_tasks = (NC + s_task[7] - 1u) / s_task[7];
+        const unsigned NC = s_task[6], n_tasks = s_task[9];
         if (tt == 0) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&P->cnt[0]), (unsigned long long)((long long)__builtin_readcyclecounter() - s_clk));
             const unsigned d = __hip_atomic_fetch_add(&P->done_tasks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1940,6 +1967,9 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         }
         __syncthreads();
         if (ft == 0) {
+            // (the delivery counter goes back to zero now: nobody touches it before the next ticket, and the store is long
+            //  complete when that is published after the solver step)
+            __hip_atomic_store(&P->done_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long long d0 = __builtin_readcyclecounter();
             st64(&P->cnt[with_h ? 3 : 2], ld64(&P->cnt[with_h ? 3 : 2]) + (unsigned long long)(long long)sh.sums[28]);
             match_state_step(st, sh.sums, s_prm, s_ws);
@@ -1958,9 +1988,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (ft == 0) {
-                __hip_atomic_store(&P->done_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned CHn = chunks_per_task(NC, s_task[8] / 8u);
+                st32(&P->chunks_per_task, CHn);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&P->ticket, (unsigned long long)(s_task[5] + 1u) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&P->ticket, tk_make(s_task[5] + 1u, (NC + CHn - 1u) / CHn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -1972,7 +2003,6 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
             for (unsigned p = 0; p < n_pairs; p++) {
                 NdtPoolPair *P = pair_at(p);
                 __hip_atomic_store(&P->ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&P->n_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&P->done_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __hip_atomic_store(&ctl->finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
