@@ -430,7 +430,7 @@ NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double
 // matcher -- and every segment gets its own hit list, its own pass over the pair terms and its own row of wave totals
 // (seg_rows + segment * seg_stride; the accumulators are zero again afterwards): TRANSFORM and PROBE run once for all 64
 // cells, while the sums of a segment are bit for bit those of a group that holds that segment's cells alone.
-template <int NN, bool WITH_H, int QL, bool SEG = false>
+template <int NN, bool WITH_H, int QL, bool SEG = false, bool KEEP_RUNS = false>
 NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int base, int stride, int end,
                       const rigid &T, double lfd1, double lfd2, unsigned cache_key, unsigned seg_lanes = 64u,
                       double *seg_rows = nullptr, unsigned seg_stride = 0u)
@@ -495,54 +495,104 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
     };
     uint2 *win = w.mywin + lane;
     unsigned cnt = 0;
-#pragma unroll 1
-    for (int outer = 0; outer < (reuse ? 0 : flat ? 1 : W); outer++) {
-        unsigned bits[W], id0[W];
-        windows(outer, bits, id0);
+    // thick maps (W x W runs of <= W bits per lane): the decoded runs stay in REGISTERS, (bits << 24 | first cell rank), for
+    // the pass that fills the hit list -- fetching and decoding them a second time there was a third of a 3D evaluation
+    // (16 k of 48 k clocks per 512 cells, tools/evalloop3d.py).  The largest neighbourhood (7 x 7 runs) fetches twice.
+    // (KEEP_RUNS: the kernels that serve large maps; the persistent matcher of the 2D batches has no registers to spare)
+    constexpr bool KEEP = KEEP_RUNS && W <= 5;
+    unsigned pk[KEEP ? W * W : 1];
 #pragma unroll
-        for (int q = 0; q < W; q++) {
-            if (flat) win[q * 64] = make_uint2(bits[q], id0[q]);   // (the other form reads its windows again below)
-            cnt += (unsigned)__popc(bits[q]);
+    for (int i = 0; i < (KEEP ? W * W : 1); i++) pk[i] = 0u;
+    if (!reuse) {
+        if (flat) {
+            unsigned bits[W], id0[W];
+            windows(0, bits, id0);
+#pragma unroll
+            for (int q = 0; q < W; q++) {
+                win[q * 64] = make_uint2(bits[q], id0[q]);
+                cnt += (unsigned)__popc(bits[q]);
+            }
+        } else if constexpr (KEEP) {
+#pragma unroll
+            for (int outer = 0; outer < W; outer++) {
+                unsigned bits[W], id0[W];
+                windows(outer, bits, id0);
+#pragma unroll
+                for (int q = 0; q < W; q++) {
+                    pk[outer * W + q] = (bits[q] << 24) | (id0[q] & 0xFFFFFFu);
+                    cnt += (unsigned)__popc(bits[q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);       // (one round of 2 W loads at a time: all W rounds in flight need 100 registers)
+            }
+        } else {
+#pragma unroll 1
+            for (int outer = 0; outer < W; outer++) {
+                unsigned bits[W], id0[W];
+                windows(outer, bits, id0);
+#pragma unroll
+                for (int q = 0; q < W; q++) cnt += (unsigned)__popc(bits[q]);
+            }
         }
     }
-    // entries [p0, p1) of a hit list in which this lane's `cnt_l` hits start at `off_l` go to the queue
+    // entries [p0, p1) of a hit list in which this lane's `cnt_l` hits start at `off_l` go to the queue.  FROM_REGS: the
+    // runs of a thick map come from the registers the count pass left them in (only the FIRST fill of a group may: the
+    // registers must not live across the pair terms); otherwise they are fetched and decoded again.
+    auto put_run = [&](unsigned b_, unsigned id, unsigned &gi, unsigned p0, unsigned p1) __attribute__((always_inline)) {
+        while (b_) {
+            if (gi >= p0 && gi < p1) w.myq[gi - p0] = (lane << 24) | id;
+            gi += 1u; id += 1u; b_ &= b_ - 1u;
+        }
+    };
+    auto fill_flat = [&](unsigned &gi, unsigned p0, unsigned p1) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int q = 0; q < W; q++) {
+            const uint2 v = win[q * 64];
+            put_run(v.x, v.y, gi, p0, p1);
+        }
+    };
+    auto fill_regs = [&](unsigned off_l, unsigned cnt_l, unsigned p0, unsigned p1) __attribute__((always_inline)) {
+        if (!reuse && cnt_l != 0u && off_l < p1 && off_l + cnt_l > p0) {
+            unsigned gi = off_l;
+            if (flat) {
+                fill_flat(gi, p0, p1);
+            } else if constexpr (KEEP) {
+#pragma unroll
+                for (int i = 0; i < W * W; i++) put_run(pk[i] >> 24, pk[i] & 0xFFFFFFu, gi, p0, p1);
+            } else {                                      // (no registers kept: fetch and decode again)
+#pragma unroll 1
+                for (int outer = 0; outer < W; outer++) {
+                    unsigned bits[W], id0[W];
+                    windows(outer, bits, id0);
+#pragma unroll
+                    for (int q = 0; q < W; q++) put_run(bits[q], id0[q], gi, p0, p1);
+                }
+            }
+        }
+    };
     auto fill = [&](unsigned off_l, unsigned cnt_l, unsigned p0, unsigned p1) __attribute__((always_inline)) {
         if (!reuse && cnt_l != 0u && off_l < p1 && off_l + cnt_l > p0) {
             unsigned gi = off_l;
             if (flat) {
-#pragma unroll 1
-                for (int q = 0; q < W; q++) {
-                    const uint2 v = win[q * 64];
-                    unsigned bits = v.x, id = v.y;
-                    while (bits) {
-                        if (gi >= p0 && gi < p1) w.myq[gi - p0] = (lane << 24) | id;
-                        gi += 1u; id += 1u; bits &= bits - 1u;
-                    }
-                }
+                fill_flat(gi, p0, p1);
             } else {
 #pragma unroll 1
                 for (int outer = 0; outer < W; outer++) {
                     unsigned bits[W], id0[W];
                     windows(outer, bits, id0);
 #pragma unroll
-                    for (int q = 0; q < W; q++) {
-                        unsigned b_ = bits[q], id = id0[q];
-                        while (b_) {
-                            if (gi >= p0 && gi < p1) w.myq[gi - p0] = (lane << 24) | id;
-                            gi += 1u; id += 1u; b_ &= b_ - 1u;
-                        }
-                    }
+                    for (int q = 0; q < W; q++) put_run(bits[q], id0[q], gi, p0, p1);
                 }
             }
         }
     };
     // the list is materialised NDT_QL hits at a time (one pass unless the neighbourhoods are dense 3D ones), each
     // pass followed by its pair terms
-    auto run_list = [&](unsigned off_l, unsigned cnt_l, unsigned total_l) __attribute__((always_inline)) {
+    // (`filled`: the list already holds its first -- then only -- pass)
+    auto run_list = [&](unsigned off_l, unsigned cnt_l, unsigned total_l, bool filled) __attribute__((always_inline)) {
 #pragma unroll 1
         for (unsigned p0 = 0; p0 < total_l; p0 += (unsigned)NDT_QL) {
             const unsigned p1 = min(total_l, p0 + (unsigned)NDT_QL);
-            fill(off_l, cnt_l, p0, p1);
+            if (!(filled && p0 == 0u)) fill(off_l, cnt_l, p0, p1);
             ndt_wave_sync();                             // list entries and tile columns were written by other lanes
             NDT_PROF_T(2)
             term_list<WITH_H>(w, tg, lfd1, lfd2, p1 - p0);
@@ -572,29 +622,38 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
 #pragma unroll
             for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
         };
+        // the terms of segments [sg, e), whose hits are in the list from offset o0 on: every segment on its own
+        auto seg_terms = [&](unsigned sg, unsigned e, unsigned o0) __attribute__((always_inline)) {
+            uint32_t *const q0 = w.myq;
+#pragma unroll 1
+            for (unsigned x = sg; x < e; x++) {
+                const unsigned a = seg_off(x), b = seg_off(x + 1u);
+                w.myq = q0 + (a - o0);
+                term_list<WITH_H>(w, tg, lfd1, lfd2, b - a);
+                emit_row(x);
+            }
+            w.myq = q0;
+        };
+        // the usual case: ONE fill, from the registers, for all segments -- before the loop, so that the registers are dead
+        // when the pair terms start
+        const bool all_in = total_all <= (unsigned)NDT_QL;
+        if (all_in) fill_regs(off_all, cnt, 0u, total_all);
 #pragma unroll 1
         for (unsigned sg = 0; sg < n_seg;) {
             const unsigned o0 = seg_off(sg);
             unsigned e = sg + 1u;
-            while (e < n_seg && seg_off(e + 1u) - o0 <= (unsigned)NDT_QL) e++;     // whole segments that fit into the list together
+            if (all_in) e = n_seg;
+            else while (e < n_seg && seg_off(e + 1u) - o0 <= (unsigned)NDT_QL) e++;   // whole segments that fit into the list together
             const unsigned o1 = seg_off(e);
             const bool in = lane >= sg * seg_lanes && lane < e * seg_lanes;
             const unsigned cnt_s = in ? cnt : 0u, off_s = in ? off_all - o0 : 0u;
             if (o1 - o0 > (unsigned)NDT_QL) {             // one segment with more hits than the list holds: its own passes
-                run_list(off_s, cnt_s, o1 - o0);
+                run_list(off_s, cnt_s, o1 - o0, false);
                 emit_row(sg);
-            } else {                                      // ONE pass of window fetches for all of them, then their terms in turn
-                fill(off_s, cnt_s, 0u, o1 - o0);
+            } else {                                      // one pass of window fetches for all of them, then their terms in turn
+                if (!all_in) fill(off_s, cnt_s, 0u, o1 - o0);
                 ndt_wave_sync();
-                uint32_t *const q0 = w.myq;
-#pragma unroll 1
-                for (unsigned x = sg; x < e; x++) {
-                    const unsigned a = seg_off(x), b = seg_off(x + 1u);
-                    w.myq = q0 + (a - o0);
-                    term_list<WITH_H>(w, tg, lfd1, lfd2, b - a);
-                    emit_row(x);
-                }
-                w.myq = q0;
+                seg_terms(sg, e, o0);
                 ndt_wave_sync();
             }
             sg = e;
@@ -607,7 +666,9 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
         my_off = incl - cnt;
     }
     NDT_PROF_T(1)
-    run_list(my_off, cnt, total);
+    const bool one_pass = total <= (unsigned)NDT_QL;      // the usual case: one fill, from the registers (dead after it)
+    if (one_pass) fill_regs(my_off, cnt, 0u, total);
+    run_list(my_off, cnt, total, one_pass);
     if (lane == 0 && !reuse) {
         HitCache nc;
         nc.key = total <= (unsigned)NDT_QL ? cache_key : 0u;
@@ -667,7 +728,7 @@ NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &
 #pragma unroll
         for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
         for (int base = (int)v; base < msrc; base += 64 * NDT_VW)
-            eval_group<NN, WITH_H, QL>(w, tg, src, base, NDT_VW, msrc, T, lfd1, lfd2, key);
+            eval_group<NN, WITH_H, QL, false, true>(w, tg, src, base, NDT_VW, msrc, T, lfd1, lfd2, key);
         const double tot = wave_totals<WITH_H>(w);
         if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) sh.part[v * 32 + (lane >> SH)] = tot;
         if (lane == 0) sh.part[v * 32 + 28] = (double)w.terms;
@@ -711,7 +772,7 @@ NDT_D void eval_chunks(const MapView &tg, gcell_ptr src, int msrc, const rigid &
         for (unsigned sg = 0; sg < n_seg; sg++)
             if ((tid & 63u) < 32u) rows[(sg * NDT_VW + v) * 32 + (tid & 63u)] = 0.0;
         ndt_wave_sync();
-        eval_group<NN, WITH_H, QL, true>(w, tg, src, (int)v, NDT_VW, msrc, T, lfd1, lfd2, 0u, seg_lanes, rows + v * 32, NDT_VW * 32);
+        eval_group<NN, WITH_H, QL, true, true>(w, tg, src, (int)v, NDT_VW, msrc, T, lfd1, lfd2, 0u, seg_lanes, rows + v * 32, NDT_VW * 32);
     }
     __syncthreads();
     for (unsigned i = tid; i < n_out * 32u; i += NDT_MATCH_THREADS) {      // (n_out >= n_seg: chunks without cells get zeros)
