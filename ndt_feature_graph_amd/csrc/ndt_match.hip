@@ -513,16 +513,41 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
                 cnt += (unsigned)__popc(bits[q]);
             }
         } else if constexpr (KEEP) {
-#pragma unroll
-            for (int outer = 0; outer < W; outer++) {
-                unsigned bits[W], id0[W];
-                windows(outer, bits, id0);
+            // two rounds of 2 W loads in flight: round k + 1 is issued before round k is decoded (all W rounds at once would
+            // need 100 registers; one at a time pays W dependent round trips)
+            uint2 wa[2][W], wb[2][W];
+            unsigned shf[2][W];
+            int len[2][W];
+            auto issue = [&](int outer, int slot) __attribute__((always_inline)) {
+                const int xx = ix + outer - NN;
+                const bool xok = vi && xx >= 0 && xx < tg.sx && zlo <= zhi;
 #pragma unroll
                 for (int q = 0; q < W; q++) {
-                    pk[outer * W + q] = (bits[q] << 24) | (id0[q] & 0xFFFFFFu);
-                    cnt += (unsigned)__popc(bits[q]);
+                    const int yy = iy - NN + q;
+                    const bool ok = xok && yy >= 0 && yy < tg.sy;
+                    const unsigned s0 = ok ? (unsigned)((xx * tg.sy + yy) * tg.sz + zlo) : 0u;
+                    len[slot][q] = ok ? zhi - zlo + 1 : 0;
+                    shf[slot][q] = s0 & 31u;
+                    const unsigned long long ra = rmw[s0 >> 5], rb = rmw[(s0 >> 5) + 1u];
+                    wa[slot][q] = make_uint2((unsigned)ra, (unsigned)(ra >> 32));
+                    wb[slot][q] = make_uint2((unsigned)rb, (unsigned)(rb >> 32));
                 }
-                __builtin_amdgcn_sched_barrier(0);       // (one round of 2 W loads at a time: all W rounds in flight need 100 registers)
+            };
+            issue(0, 0);
+#pragma unroll
+            for (int outer = 0; outer < W; outer++) {
+                const int cur = outer & 1;
+                if (outer + 1 < W) issue(outer + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < W; q++) {
+                    const unsigned bits = __builtin_amdgcn_alignbit(wb[cur][q].x, wa[cur][q].x, shf[cur][q]) & ((1u << len[cur][q]) - 1u);
+                    const unsigned lowa = wa[cur][q].x >> shf[cur][q];          // the window's part of the first word
+                    const unsigned id0 = lowa ? wa[cur][q].y + (unsigned)__popc(wa[cur][q].x & ((1u << shf[cur][q]) - 1u)) : wb[cur][q].y;
+                    pk[outer * W + q] = (bits << 24) | (id0 & 0xFFFFFFu);
+                    cnt += (unsigned)__popc(bits);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll 1
