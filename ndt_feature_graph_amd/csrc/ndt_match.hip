@@ -322,6 +322,7 @@ __device__ long long g_tl[4 * NDT_TL_PAIRS + 1024 + 8];
 #endif
 #ifdef NDT_MATCH_PROF   // experiments: section clocks of wave 0 (src+transform, probe, pop, term, reduce)
 __device__ long long g_prof[16];   // [0..5]: gradient-only evaluations (5 sections + count), [8..13]: with Hessian
+__device__ long long g_wave[16];   // eval_derivs: per wave, clocks until it reaches the final barrier [0..7], its pair terms [8..15]
 #ifndef NDT_PROF_TID
 #define NDT_PROF_TID 0
 #endif
@@ -333,7 +334,7 @@ template <bool WITH_H>
 struct WaveEval {
     static constexpr int NACC = WITH_H ? 28 : 7;
 #ifdef NDT_MATCH_PROF
-    long long prof[6], pt;
+    long long prof[6], pt, pt0;
 #endif
     double acc[NACC];
     double *mysrc;
@@ -727,7 +728,7 @@ NDT_D void wave_eval_init(WaveEval<WITH_H> &w, EvalShared<NW> &sh)
     w.terms = 0;
 #ifdef NDT_MATCH_PROF
     for (int k = 0; k < 6; k++) w.prof[k] = 0;
-    w.pt = clock64();
+    w.pt = clock64(); w.pt0 = w.pt;
 #endif
 }
 
@@ -772,6 +773,9 @@ NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &
         const double tot = wave_totals<WITH_H>(w);
         if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) sh.part[v * 32 + (lane >> SH)] = tot;
         if (lane == 0) sh.part[v * 32 + 28] = (double)w.terms;
+#ifdef NDT_MATCH_PROF
+        if (lane == 0) { atomicAdd((unsigned long long *)&g_wave[v & 7u], (unsigned long long)(clock64() - w.pt0)); atomicAdd((unsigned long long *)&g_wave[8u + (v & 7u)], (unsigned long long)w.terms); }
+#endif
     }
     __syncthreads();
     if (tid < (unsigned)NACC || tid == 28u) {
@@ -920,7 +924,7 @@ NDT_D void run_share(MatchSlot<QL> &S, unsigned v, double *wsrc, uint2 *wwin, do
     w.terms = 0;
 #ifdef NDT_MATCH_PROF
     for (int k = 0; k < 6; k++) w.prof[k] = 0;
-    w.pt = clock64();
+    w.pt = clock64(); w.pt0 = w.pt;
 #endif
 #pragma unroll
     for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
@@ -2266,6 +2270,16 @@ extern "C" int ndtgpu_debug_solver_prof(long long out[16], int reset)
     if (reset) {
         long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_solver_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+extern "C" int ndtgpu_debug_wave_prof(long long out[16], int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave), 16 * sizeof(long long)) != hipSuccess) return -1;
+    if (reset) {
+        long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave), z, sizeof z) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -22,12 +22,17 @@ L.ndtgpu_debug_prof.argtypes = [C.POINTER(C.c_longlong), C.c_int]
 P = binding.MatchParams(); L.ndtgpu_default_match_params(C.byref(P))
 n_it = 20
 prof = np.zeros(16, dtype=np.int64)
+wavep = np.zeros(16, dtype=np.int64)
+L.ndtgpu_debug_wave_prof.argtypes = [C.POINTER(C.c_longlong), C.c_int]
 for with_h in (0, 1):
     L.ndtgpu_debug_prof(prof.ctypes.data_as(C.POINTER(C.c_longlong)), 1)
+    L.ndtgpu_debug_wave_prof(wavep.ctypes.data_as(C.POINTER(C.c_longlong)), 1)
     rc = L.ndtgpu_debug_eval_loop(ms.h, 0, ms.h, 1, T.ctypes.data_as(C.POINTER(C.c_double)), with_h, n_it, 0, 1, P.lfd1, P.lfd2,
                                   out.ctypes.data_as(C.POINTER(C.c_longlong)))
     assert rc == 0, rc
     L.ndtgpu_debug_prof(prof.ctypes.data_as(C.POINTER(C.c_longlong)), 0)
+    L.ndtgpu_debug_wave_prof(wavep.ctypes.data_as(C.POINTER(C.c_longlong)), 0)
+    print("   per share: k clocks until the final barrier", np.round(wavep[:8] / n_it / 1e3).astype(int), " k pair terms", np.round(wavep[8:] / n_it / 1e3, 1))
     p = prof[8:14] if with_h else prof[0:6]
     per = out[0] / n_it
     passes = (out[2] + 511) // 512
