@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_HERE, "libndtgpu.so")
-_SOURCES = ["ndt_build.hip", "ndt_match.hip", "ndt_fuse.hip", "ndtgpu_api.hip"]
+_SOURCES = ["ndt_build.hip", "ndt_build_flat.hip", "ndt_match.hip", "ndt_fuse.hip", "ndtgpu_api.hip"]
 
 STATUS = {0: "OK", -1: "ERR_INVALID", -2: "ERR_HIP", -3: "ERR_NO_DEVICE", -4: "ERR_CAPACITY", -5: "ERR_ALLOC"}
 
@@ -28,7 +28,10 @@ def library_path():
 # per-source flags.  ndt_match.hip: the solver's pivoted LDL^T picks one of several statically indexed register swaps; with
 # common-code sinking the optimiser merges those branches into ONE swap with computed indices, and the register array
 # goes to the stack (the only private segment the matcher kernels would have).
-_SOURCE_FLAGS = {"ndt_match.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
+# ndt_build_flat.hip: the same pass merges the two symmetric "replace run A / run B" branches into one that works through a
+# POINTER to the run's scalar state, which then lives in scratch memory instead of scalar registers.
+_SOURCE_FLAGS = {"ndt_match.hip": ["-mllvm", "-simplifycfg-sink-common=false"],
+                 "ndt_build_flat.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 
 def build_library(force=False, verbose=False):
@@ -44,7 +47,9 @@ def build_library(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     extra = os.environ.get("NDTGPU_BUILD_FLAGS", "").split()      # experiments only (-DNDT_MATCH_PROF ...)
-    objdir = os.path.join(_HERE, "build")
+    # one object directory per output library: concurrent builds of variants (tools/build_variant.sh) do not share objects
+    tag = os.path.splitext(os.path.basename(so))[0]
+    objdir = os.path.join(_HERE, "build") if so == _SO else os.path.join(_HERE, "build", tag)
     os.makedirs(objdir, exist_ok=True)
     # (spills never go to AGPRs: with AGPRs in use the matcher kernel would not keep 256 architectural VGPRs at two
     #  waves per SIMD)
@@ -57,11 +62,13 @@ def build_library(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         jobs.append((subprocess.Popen(cmd), cmd, obj))
-    objs = []
-    for proc, cmd, obj in jobs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    objs, failed = [], None
+    for proc, cmd, obj in jobs:                 # every compile job is reaped, also after a failure
+        if proc.wait() != 0 and failed is None:
+            failed = (proc.returncode, cmd)
         objs.append(obj)
+    if failed:
+        raise subprocess.CalledProcessError(*failed)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", so + ".tmp"]
     if verbose:
         print(" ".join(link))

@@ -33,6 +33,8 @@
 //     accumulators) to its clean state: no memset is ever issued between builds.
 //   HBM algorithmic bytes per scan: 12*N (points) + 80*M (cell records)  (SURVEY.md 8d).
 #include "ndt_math.h"
+#include "ndt_binning.h"
+#include "ndt_wave.h"
 #include <cstdlib>
 
 #define NDT_BUILD_THREADS 256
@@ -54,19 +56,6 @@
 namespace {
 
 constexpr int ndt_gcd(int a, int b) { return b == 0 ? a : ndt_gcd(b, a % b); }
-
-// inclusive scan over the 64 lanes in the vector ALU (DPP row shifts, then the two row broadcasts): no LDS round trips
-NDT_D unsigned wave_incl_scan(unsigned v)
-{
-    int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
-    return (unsigned)x;
-}
 
 struct BuildCtx {
     int32_t *wtable;      // work table: slot -> accumulator id while building, EMPTY otherwise
@@ -117,18 +106,6 @@ NDT_D int get_or_assign(const BuildCtx &b, int slot)
     return expected;   // somebody else assigned it first
 }
 
-// rint(t) of a double |t| < 2^62 as a 64-bit integer (there is no fp64 -> int64 conversion instruction): the upper word
-// by floor(t 2^-32), the lower one from the exact remainder in [0, 2^32)
-NDT_D long long fixed_from_double(double t)
-{
-    double hi = floor(t * (1.0 / 4294967296.0));
-    double lo = rint(fma(-hi, 4294967296.0, t));            // exact remainder, rounded to an integer in [0, 2^32]
-    const bool carry = lo >= 4294967296.0;
-    lo = carry ? 0.0 : lo;
-    const long long h = (long long)(int)hi + (carry ? 1 : 0);
-    return (long long)((unsigned long long)h << 32) + (long long)(unsigned long long)(unsigned)lo;
-}
-
 // One partial run {n, sum d (m), sum d d^T (m^2)} becomes a 10-word record in the per-wave flush list: the sums are
 // scaled to cell units * 2^s and rounded to 64-bit integers (see NdtAcc), so that the integer atomic adds that consume
 // the list are exact, hence order-independent.
@@ -139,9 +116,9 @@ NDT_D void write_flush_record(const BuildCtx &b, long long *rec, int *rec_id, in
     *rec_id = (id >= 0 && (uint32_t)id < b.cap) ? id : -1;
     rec[0] = (long long)(unsigned long long)(unsigned)n;
 #pragma unroll
-    for (int k = 0; k < 3; k++) rec[1 + k] = fixed_from_double(sd[k] * b.q1);
+    for (int k = 0; k < 3; k++) rec[1 + k] = ndt_fixed_from_double(sd[k] * b.q1);
 #pragma unroll
-    for (int k = 0; k < 6; k++) rec[4 + k] = fixed_from_double(sdd[k] * b.q2);
+    for (int k = 0; k < 6; k++) rec[4 + k] = ndt_fixed_from_double(sdd[k] * b.q2);
 }
 
 }  // namespace
@@ -189,7 +166,6 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     const unsigned map = first + map_local;
     const NdtGrid g = set.grid;
     const uint32_t cap = g.max_cells;
-    int32_t *table = set.table + (size_t)map * g.slots;
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     const unsigned bm_words = (unsigned)((g.slots + 31) >> 5);
     NdtCell *cells = set.cells + (size_t)map * cap;          // a (re)build always lands in the first cell array
@@ -214,33 +190,14 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     double ox = 0, oy = 0, oz = 0;
     if (range_origins) { ox = range_origins[map_local * 3]; oy = range_origins[map_local * 3 + 1]; oz = range_origins[map_local * 3 + 2]; }
     const char *pts = xyz + (size_t)map_local * map_stride_bytes;
-    const float inv32 = (float)inv_res;
-    // fast-path constants: idx = floor(p*inv + k), k = 0.5 + size/2 - c*inv.  Only for EVEN sizes (size/2
-    // integral); with an odd size the reference's double->int truncation makes the index formula
-    // non-monotone, so every point takes the exact path then (force_exact).
-    const bool force_exact = ((g.size[0] | g.size[1] | g.size[2]) & 1) != 0;
-    const float kx32 = (float)(0.5 + hx - cx * inv_res), ky32 = (float)(0.5 + hy - cy * inv_res),
-                kz32 = (float)(0.5 + hz - cz * inv_res);
-    const float ox32 = (float)ox, oy32 = (float)oy, oz32 = (float)oz;
     // `nice` grids (the launcher checked it for every map of the launch): res and every cell origin c + (k - size/2) res
     // are fp32 numbers.  Then origin32 = fma(k, res32, c0) is exact, and so is the fp32 difference p - origin32 (the point
     // lies within a cell of its origin, and |origin| >= res or origin == 0: the difference needs no more bits than p has):
     // the offset of a point from its cell origin costs three fp32 operations instead of five fp64 ones per axis.
     const float res32 = (float)res;
     const float c0x32 = (float)(cx - hx * res), c0y32 = (float)(cy - hy * res), c0z32 = (float)(cz - hz * res);
-    const float r2 = (float)(range_limit * range_limit);
-    const float r2eff = range_limit > 0 ? r2 : __builtin_inff();
-    const float r2band = range_limit > 0 ? 1e-3f * r2 : -1.0f;
-    // fp32 error of v = fma(p, inv32, k32) against (p - c)/res + 0.5 + size/2 for a point in or next to the grid:
-    // inv32, k32 and the fma each round once (2^-24 relative), |p/res| <= |v| + |k|  =>  |error| <= 1.2e-7 (|v| + |k|),
-    // |v| <= size + 1.  Points whose fraction is within twice that bound of a cell face take the exact path; a
-    // point further outside the grid is out of bounds on either path (error < 1 cell up to 2^23 cells, above
-    // that the float -> int conversion saturates).
-    const float kmax = fmaxf(fmaxf(fabsf(kx32), fabsf(ky32)), fabsf(kz32));
-    const float smax = (float)max(max(g.size[0], g.size[1]), g.size[2]) + 1.0f;
-    const float face_guard = 2.4e-7f * (smax + kmax);
-    // fast path: |frac - 0.5| <= frac_lim on every axis; odd sizes / absurd centres: exact path for every point
-    const float frac_lim = (force_exact || !(face_guard < 0.25f)) ? -1.0f : 0.5f - face_guard;
+    NdtBinner bn;                       // point -> cell (csrc/ndt_binning.h)
+    bn.init(g, cx, cy, cz, ox, oy, oz, range_limit, z_max32);
 
     // ---------------- phase 0: forget the previous content of the slot -> rank table -------------
     if (MODE != 1 && MODE != 3) {
@@ -248,7 +205,6 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
         if (old > cap) old = cap;
         for (unsigned i = fin_part * nthreads + tid; i < old; i += nthreads * fin_parts) {
             const uint32_t sl = cells_prev[i].slot;
-            table[sl] = NDT_EMPTY;
             rankmap[sl >> 5].x = 0u;
         }
         if (MODE == 0 && tid == 0) ctr->overflow = 0;
@@ -316,49 +272,6 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     // parallel: nothing in the point loop waits for global memory
     double *q_val = s_qval + awave * (10 * NDT_QRUNS);
     int *q_slot = s_qslot + awave * NDT_QRUNS;
-    const unsigned gsx = (unsigned)g.size[0], gsy = (unsigned)g.size[1], gsz = (unsigned)g.size[2];
-    // fp32 fast path of one point -> cell index.  Every test is false for a NaN (NaN points are skipped, like padding);
-    // an Inf passes the range test when no range is set and is then out of the grid.  Returns true when the
-    // reference's fp64 formulas must decide (bin_exact): the point is within the fp32 error bound of a cell face or
-    // of the range sphere (frac_lim < 0 sends every point there: odd grid sizes, absurd centres).
-    // (the cell index leaves as the three floats floor() made: the offset arithmetic wants them as floats again)
-    auto bin_fast = [&](float fx, float fy, float fz, float &gx, float &gy, float &gz, int &slot) -> bool {
-        const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
-        const float dd = dx * dx + dy * dy + dz * dz;
-        const bool okz = fz <= z_max32;                                 // addPointCloud's maxz (+inf otherwise)
-        const bool okr = (dd <= r2eff) & okz;                           // r2eff = +inf without a range limit
-        const bool near_r = fabsf(dd - r2) < r2band;                    // r2band < 0 without a range limit
-        // v = (p - c)/res + 0.5 + size/2 in one fma per axis; the integer part is the cell index
-        const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
-        const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
-        const float tx = fabsf((vx - flx) - 0.5f), ty = fabsf((vy - fly) - 0.5f), tz = fabsf((vz - flz) - 0.5f);
-        const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
-        gx = flx; gy = fly; gz = flz;
-        const bool inb = ((unsigned)ix < gsx) & ((unsigned)iy < gsy) & ((unsigned)iz < gsz);
-        const int sl = (int)(((unsigned)ix * gsy + (unsigned)iy) * gsz + (unsigned)iz);
-        slot = (okr & inb) ? sl : -1;
-        return (okr | (near_r & okz)) & (near_r | !(fmaxf(fmaxf(tx, ty), tz) <= frac_lim));
-    };
-    // ... and the reference's own formulas for those few points
-    auto bin_exact = [&](float fx, float fy, float fz, float &gx, float &gy, float &gz, int &slot) {
-        int ix = (int)gx, iy = (int)gy, iz = (int)gz;
-        const float dx = fx - ox32, dy = fy - oy32, dz = fz - oz32;
-        const float dd = dx * dx + dy * dy + dz * dz;
-        const bool okz = fz <= z_max32;
-        bool ok = (dd <= r2eff) & okz;
-        if (fabsf(dd - r2) < r2band) {
-#pragma clang fp contract(off)
-            double ex = (double)fx - ox, ey = (double)fy - oy, ez = (double)fz - oz;
-            ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit) && okz;
-        }
-        const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
-        if (!(fabsf((vx - floorf(vx)) - 0.5f) <= frac_lim)) ix = lazygrid_index((double)fx, cx, res, g.size[0]);
-        if (!(fabsf((vy - floorf(vy)) - 0.5f) <= frac_lim)) iy = lazygrid_index((double)fy, cy, res, g.size[1]);
-        if (!(fabsf((vz - floorf(vz)) - 0.5f) <= frac_lim)) iz = lazygrid_index((double)fz, cz, res, g.size[2]);
-        slot = (ok && (unsigned)ix < gsx && (unsigned)iy < gsy && (unsigned)iz < gsz)
-                   ? (int)(((unsigned)ix * gsy + (unsigned)iy) * gsz + (unsigned)iz) : -1;
-        gx = (float)ix; gy = (float)iy; gz = (float)iz;           // (only cells of the grid matter: exact below 2^24)
-    };
     for (unsigned tile = tile_begin; tile < tile_end;) {
         const unsigned R = min((unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
         const unsigned p0 = tile * NDT_TILE;                              // its first point
@@ -551,11 +464,11 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             load_point(r, j + 1, bx, by, bz);
             float agx, agy, agz, bgx, bgy, bgz;
             int aslot, bslot;
-            const bool na = bin_fast(ax, ay, az, agx, agy, agz, aslot);
-            const bool nb = bin_fast(bx, by, bz, bgx, bgy, bgz, bslot);
+            const bool na = bn.fast(ax, ay, az, agx, agy, agz, aslot);
+            const bool nb = bn.fast(bx, by, bz, bgx, bgy, bgz, bslot);
             if (__ballot(na | nb)) {
-                if (na) bin_exact(ax, ay, az, agx, agy, agz, aslot);
-                if (nb) bin_exact(bx, by, bz, bgx, bgy, bgz, bslot);
+                if (na) bn.exact(ax, ay, az, agx, agy, agz, aslot);
+                if (nb) bn.exact(bx, by, bz, bgx, bgy, bgz, bslot);
             }
             add_point(ax, ay, az, agx, agy, agz, aslot);
             add_point(bx, by, bz, bgx, bgy, bgz, bslot);
@@ -647,13 +560,6 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     const double IS1 = ldexp(1.0, -s1_shift), IS2 = ldexp(1.0, -s2_shift);
     for (unsigned id = fin_part * nthreads + tid; MODE != 3 && id < n_alloc; id += nthreads * fin_parts) {
         NdtAcc a = bc.acc[id];
-        NdtCell c;
-        c.n = 0;
-        c.slot = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) c.mean[k] = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) c.cov[k] = 0;
         unsigned long long n = (unsigned long long)a.n;
         binned += (unsigned)n;               // points that reached a cell (the others were NaN, out of range / grid)
         if (set.occ && n > 0) {
@@ -662,61 +568,10 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             const float o = (float)((double)n * NDT_LOGODD_OCC);
             set.occ[(size_t)map * g.slots + bc.acc_slot[id]] = o > 255.0f ? 255.0f : o;
         }
-        if (n >= 2 && n >= (unsigned long long)n_min) {
-            unsigned slot = bc.acc_slot[id];
-            int iz = slot % g.size[2];
-            int iy = (slot / g.size[2]) % g.size[1];
-            int ix = slot / (g.size[2] * g.size[1]);
-            double dn = (double)n;
-            double m[3];   // mean offset in cell units
-#pragma unroll
-            for (int k = 0; k < 3; k++) m[k] = ((double)a.s1[k] / dn) * IS1;
-            double S[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) S[k] = (double)a.s2[k] * IS2;
-            double sc = res * res / (dn - 1.0);
-            double C[3][3], V[3][3];
-            C[0][0] = (S[0] - dn * m[0] * m[0]) * sc;
-            C[0][1] = (S[1] - dn * m[0] * m[1]) * sc;
-            C[0][2] = (S[2] - dn * m[0] * m[2]) * sc;
-            C[1][1] = (S[3] - dn * m[1] * m[1]) * sc;
-            C[1][2] = (S[4] - dn * m[1] * m[2]) * sc;
-            C[2][2] = (S[5] - dn * m[2] * m[2]) * sc;
-            C[1][0] = C[0][1]; C[2][0] = C[0][2]; C[2][1] = C[1][2];
-            double E[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int q2 = 0; q2 < 3; q2++) E[r][q2] = C[r][q2];
-            jacobi_static<3, true>(E, V);
-            double ev[3] = {E[0][0], E[1][1], E[2][2]};
-            double mx = dmax3(ev[0], ev[1], ev[2]), mn = dmin3(ev[0], ev[1], ev[2]);
-            // NDTCell::rescaleCovariance
-            if (mx > 0 && mn > NDT_DEGENERATE_REL * mx) {
-                bool recalc = false;
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    if (mx > ev[k] * eval_factor) { ev[k] = mx / eval_factor; recalc = true; }
-                if (recalc) {
-#pragma unroll
-                    for (int r = 0; r < 3; r++)
-#pragma unroll
-                        for (int q2 = r; q2 < 3; q2++) {
-                            double s = 0;
-#pragma unroll
-                            for (int k = 0; k < 3; k++) s += V[r][k] * ev[k] * V[q2][k];
-                            C[r][q2] = s;
-                        }
-                }
-                c.mean[0] = cx + (ix - hx) * res + m[0] * res;
-                c.mean[1] = cy + (iy - hy) * res + m[1] * res;
-                c.mean[2] = cz + (iz - hz) * res + m[2] * res;
-                c.cov[0] = C[0][0]; c.cov[1] = C[0][1]; c.cov[2] = C[0][2];
-                c.cov[3] = C[1][1]; c.cov[4] = C[1][2]; c.cov[5] = C[2][2];
-                c.n = (uint32_t)n;
-                c.slot = slot;
-            }
-        }
+        const unsigned slot = n ? bc.acc_slot[id] : 0u;
+        const int iz = slot % g.size[2], iy = (slot / g.size[2]) % g.size[1], ix = slot / (g.size[2] * g.size[1]);
+        const double centre[3] = {cx + (ix - hx) * res, cy + (iy - hy) * res, cz + (iz - hz) * res};
+        const NdtCell c = ndt_gaussian_from_moments(a, slot, centre, res, n_min, eval_factor, IS1, IS2);
         *reinterpret_cast<NdtCell *>(tmp_base + id) = c;
         // a touched cell without a Gaussian leaves the occupancy bitmap here, so that phase C finds exactly the
         // Gaussian cells in it (n == 0: an id wasted by an allocation race, it has no slot)
@@ -803,7 +658,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
 #pragma unroll
             for (unsigned k = 0; k < WPL; k++) cnt += (unsigned)__popc((ovf && bits[k]) ? valid_bits(w0 + k, bits[k]) : bits[k]);
         }
-        unsigned incl = wave_incl_scan(cnt);
+        unsigned incl = ndt_wave_incl_scan(cnt);
         if (lane == 63) s_wave_cnt[wave] = incl;
     }
     __syncthreads();
@@ -848,7 +703,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             unsigned cnt = 0;
 #pragma unroll
             for (unsigned k = 0; k < WPL; k++) cnt += (unsigned)__popc(bits[k]);
-            const unsigned incl = wave_incl_scan(cnt);
+            const unsigned incl = ndt_wave_incl_scan(cnt);
             unsigned before = running + incl - cnt;
             running += __shfl(incl, 63, 64);
 #pragma unroll
@@ -871,7 +726,6 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             const unsigned slot = __hip_atomic_load(&cells[r].slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int id = bc.wtable[slot];
             cells[r] = *reinterpret_cast<const NdtCell *>(tmp_base + id);
-            table[slot] = (int)r;
             bc.wtable[slot] = NDT_EMPTY;                          // work table back to its clean state
         }
     } else
@@ -887,7 +741,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             vmask[k] = (ovf && bits[k]) ? valid_bits(w0 + k, bits[k]) : bits[k];
             cnt += (unsigned)__popc(vmask[k]);
         }
-        unsigned incl = wave_incl_scan(cnt);
+        unsigned incl = ndt_wave_incl_scan(cnt);
         unsigned before = running + incl - cnt;
         running += __shfl(incl, 63, 64);
 #pragma unroll
@@ -900,7 +754,6 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
                 int id = bc.wtable[slot];
                 if (vk & (1u << bit)) {
                     cells[before] = *reinterpret_cast<const NdtCell *>(tmp_base + id);
-                    table[slot] = (int)before;
                     before++;
                 }
                 bc.wtable[slot] = NDT_EMPTY;      // work table back to its clean state
@@ -949,14 +802,12 @@ extern "C" __global__ void ndt_install_cells_kernel(NdtSetView set, unsigned map
                                                     unsigned n_cells)
 {
     const NdtGrid g = set.grid;
-    int32_t *table = set.table + (size_t)map * g.slots;
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     NdtCell *cells = set.cells + (size_t)map * g.max_cells;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_cells) {
         NdtCell c = src[i];
         cells[i] = c;
-        table[c.slot] = (int)i;
         atomicOr(&rankmap[c.slot >> 5].x, 1u << (c.slot & 31u));
         if (i == 0 || (src[i - 1].slot >> 5) != (c.slot >> 5)) rankmap[c.slot >> 5].y = i;   // sorted by slot
     }
@@ -1012,6 +863,15 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         parts = (unsigned)(1024 / count);
         if (parts > n_tiles / 4) parts = n_tiles / 4;
         if (parts < 1) parts = 1;
+    }
+    // batches of planar scans on a grid whose cell centres are fp32 numbers: the wave-uniform kernel of
+    // csrc/ndt_build_flat.hip (NDTGPU_FLAT=0: never, 2: also for the few-maps case, one workgroup per map)
+    {
+        const char *fe = getenv("NDTGPU_FLAT");
+        const int flat_mode = fe ? atoi(fe) : 1;
+        if (flat_mode && (parts == 1 || flat_mode == 2) && ndt_build_flat_ok(set.grid, nice, sdw))
+            return ndt_launch_build_flat(set, first, count, xyz_dev, n_points, sdw, map_stride_bytes, range_limit,
+                                         range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, stream);
     }
     // thick grids hold 3D sweeps, whose consecutive points change cell every few points: replaced runs go to the wide
     // flush list (SCAT).  Flat grids hold planar scans, whose points stay in a cell for hundreds of points.
@@ -1116,10 +976,7 @@ hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t cou
 hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const NdtCell *cells_dev, size_t n_cells,
                                     hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(set.table + map * (size_t)set.grid.slots, 0xFF,
-                                  (size_t)set.grid.slots * sizeof(int32_t), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(set.rankmap + map * ndt_rm_stride(set.grid), 0, ndt_rm_stride(set.grid) * sizeof(uint2), stream);
+    hipError_t e = hipMemsetAsync(set.rankmap + map * ndt_rm_stride(set.grid), 0, ndt_rm_stride(set.grid) * sizeof(uint2), stream);
     if (e != hipSuccess) return e;
     unsigned blocks = (unsigned)((n_cells + 255) / 256);
     if (blocks == 0) blocks = 1;

@@ -1,8 +1,9 @@
 // ndt_common.h -- shared host/device types of the MI355X NDT front-end (product code).
 //
 // Data layout in HBM (DESIGN.md "Layout"):
-//   table  int32 [n_maps][slots]        dense LazyGrid slot -> cell rank (-1 = no Gaussian);
-//                                       slot = (ix*sy + iy)*sz + iz, like dataArray[x][y][z]
+//   rankmap uint2 [n_maps][slots/32+1]  per 32 LazyGrid slots {bit per Gaussian cell, rank of the word's first one};
+//                                       slot = (ix*sy + iy)*sz + iz, like dataArray[x][y][z].  Slot -> cell rank is
+//                                       ndt_rank_of(): there is no dense per-slot table (round 4 removed it)
 //   wtable int32 [n_maps][slots]        build-time slot -> accumulator id (all -1 between builds)
 //   bitmap u32   [n_maps][slots/32]     build-time occupancy bits (all 0 between builds)
 //   cells  NdtCell [n_maps][max_cells]  80-byte records, Gaussian cells only, in slot order
@@ -66,9 +67,9 @@ struct NdtMapCounters {        // per map, device resident
 struct NdtSetView {            // what kernels see of a mapset
     NdtGrid grid;
     uint32_t n_maps;
-    int32_t *table;            // [n_maps][slots]      slot -> cell rank, -1 = no Gaussian
     uint2 *rankmap;            // [n_maps][rm_stride]  per 32 slots: {.x = Gaussian-cell bits, .y = rank of the word's
-                               //                      first Gaussian cell (valid when .x != 0)}: what the matcher probes
+                               //                      first Gaussian cell (valid when .x != 0)}: what the matcher probes,
+                               //                      and the only slot -> rank index (ndt_rank_of)
     int32_t *wtable;           // [n_maps][slots]      build scratch
     uint32_t *bitmap;          // [n_maps][(slots+31)/32] build scratch
     NdtCell *cells;            // [n_maps][max_cells]
@@ -105,6 +106,22 @@ static __device__ __forceinline__ void ndt_wave_sync()
 }
 #endif
 
+// rank of the Gaussian cell in `slot` (cells are ranked in slot order), -1 when the slot holds none: NDTMap::getCellAtPoint
+// on a rank-map word -- one 8-byte read of a 20 KB structure instead of a 4-byte read of a 320 KB one
+static inline __host__ __device__ int ndt_rank_in_word(uint2 w, unsigned bit)
+{
+    if (!((w.x >> bit) & 1u)) return -1;
+#ifdef __HIP_DEVICE_COMPILE__
+    return (int)(w.y + (unsigned)__popc(w.x & ((1u << bit) - 1u)));
+#else
+    return (int)(w.y + (unsigned)__builtin_popcount(w.x & ((1u << bit) - 1u)));
+#endif
+}
+static inline __host__ __device__ int ndt_rank_of(const uint2 *rankmap, unsigned slot)
+{
+    return ndt_rank_in_word(rankmap[slot >> 5], slot & 31u);
+}
+
 // words per map of NdtSetView::rankmap (+1: a probe window may read one word past its first)
 static inline __host__ __device__ size_t ndt_rm_stride(const NdtGrid &g) { return (size_t)((g.slots + 31) / 32) + 1; }
 
@@ -126,6 +143,11 @@ struct NdtMatchResultDev {     // mirrors ndtgpu_match_result
 hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                             size_t stride_bytes, size_t map_stride_bytes, double range_limit,
                             const double *range_origins_dev, int n_min, double eval_factor, int nice, hipStream_t stream);
+// the batch kernel for flat grids (csrc/ndt_build_flat.hip); ndt_launch_build hands over when ndt_build_flat_ok
+bool ndt_build_flat_ok(const NdtGrid &g, int nice, int sdw);
+hipError_t ndt_launch_build_flat(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                                 int sdw, size_t map_stride_bytes, double range_limit, const double *range_origins_dev,
+                                 int n_min, double eval_factor, int s1_shift, int s2_shift, hipStream_t stream);
 // accumulate only (phase A of the build: points -> per-cell moment accumulators), z_max: points above it are dropped
 hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t count, const void *xyz_dev, size_t n_points,
                                  size_t stride_bytes, size_t map_stride_bytes, double range_limit,

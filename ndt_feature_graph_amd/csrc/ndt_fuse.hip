@@ -21,7 +21,7 @@
 //                            (N, N mean, (N-1) cov) with saturation at maxnumpoints; rescaleCovariance); old Gaussians
 //                            whose occupancy fell to <= 0 disappear; all Gaussian cells are ranked in slot order into the
 //                            map's OTHER cell array (the old one is read while the new one is written) together with the
-//                            slot -> rank table and the rank bitmap the matcher probes.
+//                            rank map the matcher probes.
 // Deviation from the reference, restated by the test suite's CPU checker in its `order_free` mode: the reference processes beam
 // after beam, so a cell that loses its Gaussian half way through a cloud is treated as empty by the remaining beams,
 // and it accumulates in float.  Here every beam sees the cells as they were when the call started.
@@ -32,6 +32,7 @@
 // Gaussian update of a cell -- 110 registers, 292 bytes of scratch per lane)
 #define NDT_FIN2_THREADS 512
 #define NDT_EMPTY (-1)
+#define NDT_DROPPED (-2)   // work-table marker inside ndt_fuse_finalize_kernel: an old Gaussian that this update dropped
 
 namespace {
 
@@ -149,7 +150,7 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
     if (N <= 2) N = 0;
     const double sx = dx / (double)(float)N, sy = dy / (double)(float)N, sz = dz / (double)(float)N;
     const double cx = set.centres[map * 3], cy = set.centres[map * 3 + 1], cz = set.centres[map * 3 + 2];
-    const int32_t *table = set.table + (size_t)map * g.slots;
+    const uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     const NdtCell *cells = ndt_cells_of(set, map, set.cell_sel[map]);
     long long *delta = set.occ_delta + (size_t)map * g.slots;
     int iox = 0, ioy = 0, ioz = 0;                    // idxo = idyo = idzo = 0 like upstream
@@ -190,7 +191,7 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
                 iox = ix; ioy = iy; ioz = iz;
                 if ((unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] && (unsigned)iz < (unsigned)g.size[2]) {
                     const int sl = (ix * g.size[1] + iy) * g.size[2] + iz;
-                    const int r = table[sl];
+                    const int r = ndt_rank_of(rankmap, (unsigned)sl);
                     float upd = -0.2f;                // seen empty, no Gaussian to argue with
                     bool ok = true;
                     if (r >= 0) {
@@ -230,7 +231,6 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
     const unsigned map = first + blockIdx.x;
     const NdtGrid g = set.grid;
     const uint32_t cap = g.max_cells;
-    int32_t *table = set.table + (size_t)map * g.slots;
     int32_t *wtable = set.wtable + (size_t)map * g.slots;
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     uint32_t *bitmap = set.bitmap + (size_t)map * ((g.slots + 31) >> 5);
@@ -279,7 +279,7 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
         binned += (unsigned)n;
         if (n > 0) {
             const unsigned slot = acc_slot[id];
-            const int old_rank = table[slot];
+            const int old_rank = ndt_rank_of(rankmap, slot);        // (the rank map still describes the old cells)
             const bool had = old_rank >= 0 && occ[slot] > 0.0f;      // a Gaussian the beams did not take away
             // occupancy += n log(0.6 / 0.4), clamped
             float o = occ[slot] + (float)((double)n * NDT_LOGODD_OCC);
@@ -371,10 +371,10 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
                 }
             }
             if (c.n == 0) {
-                // touched, no Gaussian: the cell leaves the bitmap, its slot the work table and the rank table
+                // touched, no Gaussian: the cell leaves the bitmap and its slot the work table; an old Gaussian that is
+                // dropped here keeps a marker there until step 3 has passed it
                 __hip_atomic_fetch_and(&bitmap[slot >> 5], ~(1u << (slot & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wtable[slot] = NDT_EMPTY;
-                if (old_rank >= 0) table[slot] = NDT_EMPTY;
+                wtable[slot] = old_rank >= 0 ? NDT_DROPPED : NDT_EMPTY;
             }
         }
         *reinterpret_cast<NdtCell *>(acc + id) = c;    // the record waits in its own accumulator
@@ -385,12 +385,11 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
     // ---- 3. Gaussians that received no points: they stay while their occupancy is positive -------------------------
     for (unsigned r = tid; r < n_old; r += nthreads) {
         const unsigned slot = cells_old[r].slot;
-        rankmap[slot >> 5].x = 0u;                     // the rank bitmap is rebuilt below
-        if (wtable[slot] != NDT_EMPTY) continue;       // touched: decided above (a stale EMPTY cannot be read:
-                                                       // this workgroup's L1 was invalidated after the accumulation)
-        if (table[slot] != (int)r) continue;           // (touched and dropped above)
+        const int wt = wtable[slot];                   // (a stale EMPTY cannot be read: this workgroup's L1 was
+                                                       // invalidated after the accumulation)
+        if (wt == NDT_DROPPED) { wtable[slot] = NDT_EMPTY; continue; }   // touched and dropped above
+        if (wt != NDT_EMPTY) continue;                 // touched: decided above
         if (occ[slot] > 0.0f) __hip_atomic_fetch_or(&bitmap[slot >> 5], 1u << (slot & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else table[slot] = NDT_EMPTY;
     }
     __syncthreads();
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // bitmap atomics are performed at the memory side
@@ -428,25 +427,23 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
     for (unsigned step = wb; step < we; step += 64u) {
         const unsigned w = step + lane;
         const unsigned bits = (w < we) ? bitmap[w] : 0u;
-        if (!__ballot(bits != 0u)) continue;
+        const uint2 old = (w < we) ? rankmap[w] : make_uint2(0u, 0u);   // the old cells of this word: bits and first rank
+        if (!__ballot((bits | old.x) != 0u)) continue;
         const unsigned vmask = (ovf && bits) ? valid_bits(w, bits) : bits;
         const unsigned cnt = (unsigned)__popc(vmask);
         const unsigned incl = fuse_wave_incl_scan(cnt);
         unsigned before = running + incl - cnt;
         running += __shfl(incl, 63, 64);
-        if (vmask) rankmap[w] = make_uint2(vmask, before);
+        if (vmask | old.x) rankmap[w] = make_uint2(vmask, before);
         for (unsigned b = bits; b; b &= b - 1u) {
             const int bit = __ffs((int)b) - 1;
             const unsigned slot = w * 32u + (unsigned)bit;
             const int id = wtable[slot];
             if (vmask & (1u << bit)) {
-                NdtCell c = (id == NDT_EMPTY) ? cells_old[table[slot]] : *reinterpret_cast<const NdtCell *>(acc + id);
+                NdtCell c = (id == NDT_EMPTY) ? cells_old[ndt_rank_in_word(old, (unsigned)bit)] : *reinterpret_cast<const NdtCell *>(acc + id);
                 c.slot = slot;
                 if (before < cap) cells_new[before] = c;
-                table[slot] = (int)before;
                 before++;
-            } else {
-                table[slot] = NDT_EMPTY;
             }
             wtable[slot] = NDT_EMPTY;
         }
@@ -529,8 +526,8 @@ extern "C" __global__ __launch_bounds__(256) void ndt_overlap_kernel(
 
 // ndt_feature::discardCell(map, pt) (utils.h:229-236; fuser_hmt.cpp:229-232): the cells that hold the given points lose
 // their Gaussian.  One workgroup; the surviving cells are compacted in place in rank order (a cell never moves up, and a
-// chunk of 1024 records is read completely before any of it is rewritten), then the rank table and the rank bitmap are
-// rebuilt for the map.
+// chunk of 1024 records is read completely before any of it is rewritten), then the first ranks of the rank map's words
+// are rewritten (its bits were cleared while marking).
 extern "C" __global__ __launch_bounds__(NDT_FUSE_THREADS) void ndt_discard_kernel(NdtSetView set, unsigned map,
                                                                                   const float *__restrict__ xyz, unsigned n_pts)
 {
@@ -538,20 +535,19 @@ extern "C" __global__ __launch_bounds__(NDT_FUSE_THREADS) void ndt_discard_kerne
     __shared__ unsigned s_base;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const NdtGrid g = set.grid;
-    int32_t *table = set.table + (size_t)map * g.slots;
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     NdtCell *cells = ndt_cells_of(set, map, set.cell_sel ? set.cell_sel[map] : 0u);
     NdtMapCounters *ctr = set.counters + map;
     const unsigned n_old = ctr->n_cells > g.max_cells ? g.max_cells : ctr->n_cells;
     const double cx = set.centres[map * 3], cy = set.centres[map * 3 + 1], cz = set.centres[map * 3 + 2];
-    // 1. mark: table[slot] = -2 for the cells that hold a point (NDTMap::getCellAtPoint)
+    // 1. mark: the cells that hold a point (NDTMap::getCellAtPoint) leave the rank map's bits
     for (unsigned i = tid; i < n_pts; i += NDT_FUSE_THREADS) {
         const int ix = lazygrid_index((double)xyz[3 * i], cx, g.res, g.size[0]);
         const int iy = lazygrid_index((double)xyz[3 * i + 1], cy, g.res, g.size[1]);
         const int iz = lazygrid_index((double)xyz[3 * i + 2], cz, g.res, g.size[2]);
         if ((unsigned)ix >= (unsigned)g.size[0] || (unsigned)iy >= (unsigned)g.size[1] || (unsigned)iz >= (unsigned)g.size[2]) continue;
         const int slot = (ix * g.size[1] + iy) * g.size[2] + iz;
-        if (table[slot] >= 0) table[slot] = -2;
+        atomicAnd(&rankmap[slot >> 5].x, ~(1u << (slot & 31)));
     }
     if (tid == 0) s_base = 0;
     __syncthreads();
@@ -562,9 +558,7 @@ extern "C" __global__ __launch_bounds__(NDT_FUSE_THREADS) void ndt_discard_kerne
         bool keep = false;
         if (r < n_old) {
             c = cells[r];
-            rankmap[c.slot >> 5].x = 0u;                    // rebuilt below
-            keep = table[c.slot] != -2;
-            if (!keep) table[c.slot] = NDT_EMPTY;
+            keep = ((__hip_atomic_load(&rankmap[c.slot >> 5].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (c.slot & 31u)) & 1u) != 0u;
         }
         const unsigned long long m = __ballot(keep);
         const unsigned before = (unsigned)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64u - lane))));
@@ -574,7 +568,6 @@ extern "C" __global__ __launch_bounds__(NDT_FUSE_THREADS) void ndt_discard_kerne
         for (unsigned k = 0; k < wave; k++) off += s_wave[k];
         if (keep) {
             cells[off + before] = c;
-            table[c.slot] = (int)(off + before);
         }
         __syncthreads();
         if (tid == 0) {
@@ -585,10 +578,9 @@ extern "C" __global__ __launch_bounds__(NDT_FUSE_THREADS) void ndt_discard_kerne
         __syncthreads();
     }
     const unsigned n_new = s_base;
-    // 3. rank bitmap: a bit per Gaussian cell, the rank of the first one of every 32-slot word
+    // 3. rank map: the bits are those that survived step 1; the rank of the first cell of every 32-slot word
     for (unsigned r = tid; r < n_new; r += NDT_FUSE_THREADS) {
         const unsigned slot = cells[r].slot;
-        atomicOr(&rankmap[slot >> 5].x, 1u << (slot & 31u));
         if (r == 0 || (cells[r - 1].slot >> 5) != (slot >> 5)) rankmap[slot >> 5].y = r;
     }
     if (tid == 0) ctr->n_cells = n_new;

@@ -29,6 +29,7 @@
 //   * no atomics in the sums, fixed summation order -> run-to-run identical.
 //   * MFMA is not used: nothing here is a dense contraction (3x3 / 6x6 per-pair expressions).
 #include "ndt_math.h"
+#include "ndt_wave.h"
 #ifdef NDT_MATCH_PROF
 __device__ long long g_solver_prof[16];
 #define NDT_SOLVER_STAGE_PROF
@@ -74,69 +75,7 @@ NDT_D double wave_sum_d(double v)
     return v;
 }
 
-// Sum of N (power of two) per-lane values over the 64 lanes of a wave, all N at once: a butterfly that halves the
-// number of values a lane carries at every step (the lane keeps the half selected by its lane bit and receives
-// the partner's copy of it), then finishes the single remaining value over the unused low lane bits.
-// 2N - 1 exchanges instead of 6N, and the association order is the one of the plain xor tree
-// v += shfl_xor(v, 32), 16, ..., 1 -- the result is bit-identical to it.  Lane l ends with the total of value
-// l >> (6 - log2 N).  Lane bits 5 and 4 use gfx950's v_permlane32_swap / v_permlane16_swap (no LDS, no selects).
-NDT_D double pl_swap_add(double a, double b, bool rows16)
-{
-    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
-    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
-    if (rows16) {
-        auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-        auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-        return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-    }
-    auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
-}
-
-// value of lane (l ^ O) for O = 1, 2, 4, 8 in the vector ALU: quad permutes for 1 and 2; lane ^ 4 is the half-row mirror
-// (^ 7) of the quad reversal (^ 3), lane ^ 8 the row mirror (^ 15) of the half-row mirror (^ 7).  No LDS round trip.
-template <int O>
-NDT_D double xor_lane(double x)
-{
-    static_assert(O == 1 || O == 2 || O == 4 || O == 8, "within a row of 16 lanes");
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    if constexpr (O == 1) {
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true);
-    } else if constexpr (O == 2) {
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, true);
-    } else if constexpr (O == 4) {
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0x1B, 0xf, 0xf, true);    // quad_perm [3,2,1,0]
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0x1B, 0xf, 0xf, true);
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, true);   // row_half_mirror
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, true);
-    } else {
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, true);   // row_half_mirror
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, true);
-        lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, true);   // row_mirror
-        hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, true);
-    }
-    return __hiloint2double(hi, lo);
-}
-
-template <int N, int HALF, int O>
-NDT_D void wave_sum_step(double (&v)[N], unsigned lane)
-{
-#pragma unroll
-    for (int k = 0; k < HALF; k++) {
-        if constexpr (O >= 16) {
-            v[k] = pl_swap_add(v[k], v[k + HALF], O == 16);
-        } else {
-            const bool up = (lane & (unsigned)O) != 0;
-            const double keep = up ? v[k + HALF] : v[k], send = up ? v[k] : v[k + HALF];
-            v[k] = keep + xor_lane<O>(send);
-        }
-    }
-    if constexpr (HALF > 1) wave_sum_step<N, HALF / 2, O / 2>(v, lane);   // static indices only: v stays in registers
-}
-
+// (pl_swap_add, xor_lane, wave_sum_step: csrc/ndt_wave.h)
 template <int N>
 NDT_D double wave_sum_all(double (&v)[N])
 {
@@ -1380,7 +1319,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
     const unsigned link = blockIdx.x, tid = threadIdx.x, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6)), lane = tid & 63u;
     const MapView tg = map_view(tset, tidx[link]);
     const MapView sv = map_view(sset, sidx[link]);
-    const int32_t *table = tset.table + (size_t)tidx[link] * tset.grid.slots;
+    const uint2 *trank = tset.rankmap + (size_t)tidx[link] * ndt_rm_stride(tset.grid);
     if (tid == 0) {
         const double *Tm = T16 + (size_t)link * 16;
         for (int r = 0; r < 3; r++) {
@@ -1404,7 +1343,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_covariance_kernel(
         const int ix = lazygrid_index(m.x, tg.cx, tg.res, tg.sx), iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy),
                   iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
         if ((unsigned)ix >= (unsigned)tg.sx || (unsigned)iy >= (unsigned)tg.sy || (unsigned)iz >= (unsigned)tg.sz) continue;
-        const int r = table[(ix * tg.sy + iy) * tg.sz + iz];
+        const int r = ndt_rank_of(trank, (unsigned)((ix * tg.sy + iy) * tg.sz + iz));
         if (r < 0) continue;
         gcell_ptr tc = tg.cells + r;
         const d3 x = m - d3{tc->mean[0], tc->mean[1], tc->mean[2]};

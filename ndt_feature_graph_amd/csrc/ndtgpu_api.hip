@@ -221,7 +221,6 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
         ndtgpu_mapset_destroy(s);                                                  \
         return fail(NDTGPU_ERR_ALLOC, "mapset_create: hipMalloc " #ptr, e);        \
     }
-    ALLOC(s->v.table, n_maps * (size_t)g.slots * sizeof(int32_t));
     ALLOC(s->v.rankmap, n_maps * ndt_rm_stride(g) * sizeof(uint2));
     ALLOC(s->v.wtable, n_maps * (size_t)g.slots * sizeof(int32_t));
     ALLOC(s->v.bitmap, n_maps * (size_t)((g.slots + 31) / 32) * sizeof(uint32_t));
@@ -232,8 +231,7 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
     ALLOC(s->v.counters, n_maps * sizeof(NdtMapCounters));
     ALLOC(s->v.centres, n_maps * 3 * sizeof(double));
 #undef ALLOC
-    if ((e = hipMemset(s->v.table, 0xFF, n_maps * (size_t)g.slots * sizeof(int32_t))) != hipSuccess ||
-        (e = hipMemset(s->v.rankmap, 0, n_maps * ndt_rm_stride(g) * sizeof(uint2))) != hipSuccess ||
+    if ((e = hipMemset(s->v.rankmap, 0, n_maps * ndt_rm_stride(g) * sizeof(uint2))) != hipSuccess ||
         (e = hipMemset(s->v.wtable, 0xFF, n_maps * (size_t)g.slots * sizeof(int32_t))) != hipSuccess ||
         (e = hipMemset(s->v.bitmap, 0, n_maps * (size_t)((g.slots + 31) / 32) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemset(s->v.acc, 0, n_maps * (size_t)cap * sizeof(NdtAcc))) != hipSuccess ||
@@ -253,7 +251,6 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (!s) return NDTGPU_OK;
     (void)hipDeviceSynchronize();
     if (s->pin) (void)hipHostFree(s->pin);
-    if (s->v.table) (void)hipFree(s->v.table);
     if (s->v.rankmap) (void)hipFree(s->v.rankmap);
     if (s->v.wtable) (void)hipFree(s->v.wtable);
     if (s->v.bitmap) (void)hipFree(s->v.bitmap);
@@ -616,7 +613,6 @@ ndtgpu_status ndtgpu_mapset_clear(ndtgpu_mapset *s, size_t first, size_t count)
     HIP_TRY(hipStreamSynchronize(s->last_stream));
     const NdtGrid &g = s->v.grid;
     const size_t slots = (size_t)g.slots;
-    HIP_TRY(hipMemset(s->v.table + first * slots, 0xFF, count * slots * sizeof(int32_t)));
     HIP_TRY(hipMemset(s->v.rankmap + first * ndt_rm_stride(g), 0, count * ndt_rm_stride(g) * sizeof(uint2)));
     HIP_TRY(hipMemset(s->v.counters + first, 0, count * sizeof(NdtMapCounters)));
     if (s->v.occ) {
