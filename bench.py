@@ -93,14 +93,19 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
     ndt_graph_offline.cpp:301) through a floor plan of separate rooms (100 nodes per room on a serpentine path), every
     node a FUSED node map -- `--scans-per-node` scans taken while the vehicle moves through the node's first metre, added one
     after the other with ndtgpu_mapset_add_cloud (ray tracing + accumulate + finalise: what graph.cpp:273 really matches).
-    Candidate edges = all pairs in NDTFeatureGraph::computeAllPossibleLinks order (ndt_feature_graph.cpp:395-405) --
-    12 497 500 for 5000 nodes, most of them between rooms that share nothing: their registration ends at the first
-    evaluation -- or, with --gated, the pairs whose odometry poses lie within --gate-dist of each other and at least two
-    indices apart (the stand-in for the reference's FLIRT candidate matching + getValidLinks gates,
-    ndt_feature_graph_opt.cpp:49-52).  Every rank builds all node maps (replicated), registers its block-cyclic share of the
-    edges (chunk 256) in device batches of 2^20 and the edge results are all-gathered at the end (the only collective).
-    For the gated edges of rank 0 the per-link covariance and occupancy overlap of updateLinksUsingNDTRegistration
-    (graph.cpp:296-340) are timed too.  Reported separately: nodes/s, edges/s, covariance / overlap per edge, the gather."""
+    One step, as SURVEY.md 8(e) lays it out:
+      A. node maps built data-parallel: node k on rank k mod world (its scans exist on that rank only);
+      B. ONE all-gather of the packed cell records (cells + occupancies; ndtgpu_mapset_pack_cells_device / _unpack): every
+         rank then holds every node map;
+      C. the candidate edges, dealt block-cyclically (chunk 256), registered on the node maps with the edge preset;
+      D. the final all-gather of the edge results.
+    The candidate edges that are TIMED (and are `value`) are the GATED ones: pairs whose odometry poses lie within
+    --gate-dist of each other and at least two indices apart -- the stand-in for the reference's FLIRT candidate matching +
+    getValidLinks gates (ndt_feature_graph_opt.cpp:49-52, :131-160).  All 12 497 500 pairs of computeAllPossibleLinks
+    (ndt_feature_graph.cpp:395-405) are registered once more outside the timed region and reported as a labelled extra:
+    98 % of them join rooms that share nothing and end at their first evaluation, so their rate says little.
+    --all-pairs makes them the timed workload instead.  For the gated edges of rank 0 the per-link covariance and occupancy
+    overlap of updateLinksUsingNDTRegistration (graph.cpp:296-340) are timed too."""
     from ndt_feature_graph_amd import distributed as D
     n_nodes, res = args.nodes, args.res
     S, NPn, per_room = args.scans_per_node, args.node_points, 100
@@ -117,70 +122,100 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
     odo_T = node_T.copy()
     odo_T[:, 0, 3] += g.normal(scale=0.03, size=n_nodes)
     odo_T[:, 1, 3] += g.normal(scale=0.03, size=n_nodes)
-    # the scans of every node, in its own frame (the vehicle drives 0.9 m / S per scan straight ahead inside a node)
-    seeds = torch.as_tensor(4000 + room, dtype=torch.int64, device=dev)
+    # phase A input: the scans of THIS rank's nodes, in the node frame (the vehicle drives 0.9 m / S per scan straight ahead)
+    my_nodes = D.shard_nodes(n_nodes, rank, world)
+    n_local = len(my_nodes)
+    seeds = torch.as_tensor(4000 + room[my_nodes], dtype=torch.int64, device=dev)
     clouds = []
     for k in range(S):
         dx = 0.9 * k / max(1, S)
-        pk = local.copy()
-        pk[:, 0] += dx * np.cos(yaw); pk[:, 1] += dx * np.sin(yaw)
+        pk = local[my_nodes].copy()
+        pk[:, 0] += dx * np.cos(yaw[my_nodes]); pk[:, 1] += dx * np.sin(yaw[my_nodes])
         sc = synth.scan_2d(seeds, torch.as_tensor(pk, device=dev), NPn, noise_stream=k, chunk_bytes=2 << 30).contiguous()
         sc[:, :, 0] += dx                                              # sensor frame -> node frame
-        clouds.append((sc, np.tile(np.array([[dx, 0.0, 0.0]]), (n_nodes, 1))))
-    edges = D.all_pairs(n_nodes)
-    d_odo = np.linalg.norm(odo_T[edges[:, 0], :2, 3] - odo_T[edges[:, 1], :2, 3], axis=1)
-    gate = (d_odo <= args.gate_dist) & ((edges[:, 1] - edges[:, 0]) >= 2)
-    n_gated = int(gate.sum())
-    if args.gated:
-        edges = edges[gate]
-        gate = np.ones(len(edges), dtype=bool)
+        clouds.append((sc, np.tile(np.array([[dx, 0.0, 0.0]]), (n_local, 1))))
+    all_edges = D.all_pairs(n_nodes)
+    d_odo = np.linalg.norm(odo_T[all_edges[:, 0], :2, 3] - odo_T[all_edges[:, 1], :2, 3], axis=1)
+    gate_all = (d_odo <= args.gate_dist) & ((all_edges[:, 1] - all_edges[:, 0]) >= 2)
+    n_gated = int(gate_all.sum())
+    timed_all_pairs = bool(args.all_pairs)
+    edges = all_edges if timed_all_pairs else all_edges[gate_all]
+    gate = gate_all if timed_all_pairs else np.ones(len(edges), dtype=bool)
     n_edges = len(edges)
-    mine = D.shard_edges(n_edges, rank, world, 256)
-    T0 = np.einsum("eij,ejk->eik", np.linalg.inv(odo_T)[edges[mine, 0]], odo_T[edges[mine, 1]])
-    T0_cm = torch.as_tensor(np.ascontiguousarray(T0.transpose(0, 2, 1)).reshape(-1, 16), device=dev)
-    ti = torch.as_tensor(edges[mine, 0].astype(np.int32), device=dev)
-    si = torch.as_tensor(edges[mine, 1].astype(np.int32), device=dev)
-    pool = N.MapSet(res, [0, 0, 0], size_m, n_maps=n_nodes, max_cells=4096)
-    pool.enable_occupancy()
-    T16 = T0_cm.clone()
-    results = torch.zeros((len(mine), 64), dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream()
     CH = 1 << 20
+    local_set = N.MapSet(res, [0, 0, 0], size_m, n_maps=max(1, n_local), max_cells=4096)
+    local_set.enable_occupancy()
+    pool = N.MapSet(res, [0, 0, 0], size_m, n_maps=n_nodes, max_cells=4096)
+    pool.enable_occupancy()
+
+    def build_local():
+        local_set.clear()
+        for k, (sc, org) in enumerate(clouds):
+            local_set.add_cloud(sc, org, stream=st, **(dict(maxz=100.0, sensor_noise=0.1) if k == 0 else dict(maxz=25.0, sensor_noise=0.06)))
+
+    # the record size is a configuration value like max_cells: the largest node map of this replay, rounded up (one untimed
+    # build; a map with more cells would be cut and flagged, and refused by the matcher like an overflowing build)
+    build_local()
+    cap_local = int(local_set.num_cells_all()[:n_local].max()) if n_local else 0
+    capt = torch.tensor([cap_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(capt, op=dist.ReduceOp.MAX)
+    cells_cap = min(4096, (int(capt.item()) * 5 // 4 + 63) // 64 * 64)
+    stride = local_set.pack_bytes(cells_cap, True)
+    packed = torch.zeros((max(1, (n_nodes + world - 1) // world), stride), dtype=torch.uint8, device=dev)
+
+    class Edges:
+        def __init__(self, e):
+            self.e = e
+            self.mine = D.shard_edges(len(e), rank, world, 256)
+            T0 = np.einsum("eij,ejk->eik", np.linalg.inv(odo_T)[e[self.mine, 0]], odo_T[e[self.mine, 1]])
+            self.T0_cm = torch.as_tensor(np.ascontiguousarray(T0.transpose(0, 2, 1)).reshape(-1, 16), device=dev)
+            self.ti = torch.as_tensor(e[self.mine, 0].astype(np.int32), device=dev)
+            self.si = torch.as_tensor(e[self.mine, 1].astype(np.int32), device=dev)
+            self.T16 = self.T0_cm.clone()
+            self.results = torch.zeros((len(self.mine), 64), dtype=torch.uint8, device=dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_pass():
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    def one_pass(E, rebuild=True):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)
-        pool.clear()                                                               # phase A: fused node maps
-        for k, (sc, org) in enumerate(clouds):
-            pool.add_cloud(sc, org, stream=st, **(dict(maxz=100.0, sensor_noise=0.1) if k == 0 else dict(maxz=25.0, sensor_noise=0.06)))
+        if rebuild:
+            build_local()                                                            # phase A: this rank's node maps
         ev[1].record(st)
+        if rebuild:
+            local_set.pack_cells(packed, 0, n_local, cells_cap=cells_cap, with_occupancy=True, stream=st)   # phase B
+            allrec = D.exchange_node_maps(packed[:n_local], n_nodes, rank, world)
+            pool.unpack_cells(allrec, 0, n_nodes, with_occupancy=True, stream=st)
+        ev[2].record(st)
 
-        def register(my_edges):                                                    # phase B: this rank's edges
-            assert len(my_edges) == len(mine)
-            T16.copy_(T0_cm)
-            for c0 in range(0, len(mine), CH):
-                c1 = min(len(mine), c0 + CH)
-                binding.match_batch_device(pool, ti[c0:c1], pool, si[c0:c1], T16[c0:c1], results[c0:c1], c1 - c0, stream=st, delta_score=1e-3)
-            ev[2].record(st)
-            return T16, results
-        _, Tg_, Rg_ = D.register_sharded(n_edges, rank, world, register, 256)      # phase D inside: the only collective
-        ev[3].record(st)
+        def register(my_edges):                                                      # phase C: this rank's edges
+            assert len(my_edges) == len(E.mine)
+            E.T16.copy_(E.T0_cm)
+            for c0 in range(0, len(E.mine), CH):
+                c1 = min(len(E.mine), c0 + CH)
+                binding.match_batch_device(pool, E.ti[c0:c1], pool, E.si[c0:c1], E.T16[c0:c1], E.results[c0:c1], c1 - c0,
+                                           stream=st, delta_score=1e-3)
+            ev[3].record(st)
+            return E.T16, E.results
+        _, Tg_, Rg_ = D.register_sharded(len(E.e), rank, world, register, 256)       # phase D inside: the only collective
+        ev[4].record(st)
         return ev, (Tg_, Rg_)
 
-    steps = args.steps if args.steps != 20 else 2
+    E = Edges(edges)
+    steps = args.steps if args.steps != 20 else 3
     barrier()
     for _ in range(1 if args.warmup == 3 else max(1, args.warmup)):
-        one_pass()
+        one_pass(E)
     barrier()
     t0 = time.perf_counter()
     evs = []
     for _ in range(steps):
-        ev, gathered = one_pass()
+        ev, gathered = one_pass(E)
         evs.append(ev)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -189,8 +224,9 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     build_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    match_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
-    gather_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
+    exch_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    match_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
+    gather_ms = float(np.mean([e[3].elapsed_time(e[4]) for e in evs]))
     r = gathered[1].cpu().numpy().view(binding.RESULT_DTYPE).reshape(-1)
     Tg = gathered[0].cpu().numpy().reshape(-1, 4, 4).transpose(0, 2, 1)
     cells = pool.num_cells_all()
@@ -210,24 +246,54 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
                  "covariance_us_per_edge": 1e3 * tcov / len(sub), "overlap_us_per_edge": 1e3 * tovl / len(sub),
                  "covariance_overlap_sample": int(len(sub))}
     hist = np.bincount(np.minimum(r["iterations"], 32), minlength=33).tolist()
-    out = {"metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)", "value": n_edges * steps / elapsed,
+    # the labelled extra: all pairs once (node maps as they stand), outside the timed region
+    all_extra = None
+    if not timed_all_pairs and not args.no_all_pairs:
+        EA = Edges(all_edges)
+        one_pass(EA, rebuild=False); barrier()
+        tA = time.perf_counter()
+        evA, gA = one_pass(EA, rebuild=False)
+        barrier()
+        tA = time.perf_counter() - tA
+        rA = gA[1].cpu().numpy().view(binding.RESULT_DTYPE).reshape(-1)
+        all_extra = {"edges": int(len(all_edges)), "match_and_gather_ms": 1e3 * tA,
+                     "edge_registrations_per_s": len(all_edges) / tA,
+                     "edges_without_any_pair_term": int((rA["pair_terms_h"] == 0).sum()),
+                     "edges_with_pair_terms": int((rA["pair_terms_h"] > 0).sum()),
+                     "note": "all 12.5 M pairs of computeAllPossibleLinks on the node maps of the last step; an edge between rooms "
+                             "that share no cell ends at its first evaluation -- this rate is not comparable with `value`"}
+        del EA
+    what = "all-pairs" if timed_all_pairs else "gated"
+    model = D.phase_model(build_ms * world, match_ms * world, n_nodes, stride, n_edges) if world == 1 else None
+    out = {"metric": "NDT graph-edge registrations/sec on fused node maps (%d scans x %d pts per node, %.2f m cells), %s candidate edges"
+                     % (S, NPn, res, what),
+           "value": n_edges * steps / elapsed,
            "unit": "registrations/s", "n_gpus": world, "steps": steps, "warmup": 1, "ms_per_step": 1e3 * elapsed / steps,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "configs[3]: graph replay, %d nodes 2 m apart through %d rooms, every node a fused map of %d scans x %d pts "
-                                  "(%.2f m cells), %s candidate edges = %d (edge preset DELTA_SCORE 1e-3), block-cyclic shards of 256 edges over "
-                                  "%d rank(s); one step = rebuild every node map on every rank (%d add_cloud calls) + register this rank's "
-                                  "edges on the node maps + all-gather of the edge results" % (
-                                      n_nodes, int(room.max()) + 1, S, NPn, res, "gated" if args.gated else "all-pairs", n_edges, world, S),
-                      "nodes": n_nodes, "edges": n_edges, "edges_this_rank": int(len(mine)), "edges_within_gate": n_gated,
-                      "gate_dist_m": args.gate_dist, "mean_cells_per_node_map": float(cells.mean())},
-           "nodes_per_s_build": n_nodes / (build_ms * 1e-3), "scans_per_s_fused": n_nodes * S / (build_ms * 1e-3),
-           "edges_per_s_match": len(mine) / (match_ms * 1e-3) * world,
-           "phase_ms": {"build_all_nodes": build_ms, "match_my_edges": match_ms, "all_gather_edge_results": gather_ms},
+                                  "(%.2f m cells); one step = A. build the node maps k %% world == rank (%d add_cloud calls), B. pack + ONE "
+                                  "all-gather + unpack of the cell records (%d B per node: %d cells + occupancies), C. register this rank's "
+                                  "block-cyclic share (chunk 256) of the %d %s candidate edges with the edge preset (DELTA_SCORE 1e-3), "
+                                  "D. all-gather of the edge results; %d rank(s)" % (
+                                      n_nodes, int(room.max()) + 1, S, NPn, res, S, stride, cells_cap, n_edges, what, world),
+                      "nodes": n_nodes, "nodes_this_rank": int(n_local), "edges": n_edges, "edges_this_rank": int(len(E.mine)),
+                      "edges_within_gate": n_gated, "gate_dist_m": args.gate_dist, "mean_cells_per_node_map": float(cells.mean()),
+                      "record_bytes_per_node": int(stride), "cells_cap": int(cells_cap)},
+           "nodes_per_s_build": n_nodes / (build_ms * 1e-3) if world == 1 else n_local * world / (build_ms * 1e-3),
+           "scans_per_s_fused": n_local * world * S / (build_ms * 1e-3),
+           "edges_per_s_match": len(E.mine) / (match_ms * 1e-3) * world,
+           "phase_ms": {"A_build_my_nodes": build_ms, "B_pack_allgather_unpack": exch_ms, "C_match_my_edges": match_ms,
+                        "D_all_gather_edge_results": gather_ms},
+           "phase_model_1_to_8_gpus": model,
+           "phase_model_note": "from this one-rank run: builds and registrations divide by the world size, the exchange is an all-gather "
+                               "of the node records over point-to-point xGMI (7 links x ~153 GB/s per GPU); a model, no 8-GPU node "
+                               "was available (distributed.phase_model)",
            "gather_bytes_per_edge": 16 * 8 + 64, "converged_frac": float(r["converged"].mean()),
            "mean_iterations": float(r["iterations"].mean()), "iteration_histogram_0_to_32": hist,
-           "edges_without_any_pair_term": int((r["pair_terms_h"] == 0).sum()), "gated": extra,
-           "note": "value counts edge registrations on fused node maps (the unit the graph layer consumes, graph.cpp:273); a node map is "
-                   "built once per node per step, not per edge; edges_per_s_match scales one rank's rate by the world size"}
+           "edges_without_any_pair_term": int((r["pair_terms_h"] == 0).sum()), "gated": extra, "all_pairs_extra": all_extra,
+           "note": "value counts registrations of the %s candidate edges on fused node maps (the unit the graph layer consumes, "
+                   "graph.cpp:273) per second of whole steps (node builds + exchange + registrations + gather); a node map is built "
+                   "once per node per step, not per edge" % what}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -414,7 +480,9 @@ def main():
                     help="3: BASELINE configs[2], the batch the metric is quoted on (default); 4: configs[3], the graph replay harness; "
                          "5: configs[4], 3D mode; fuse: the node-map path (add_cloud, link covariance and overlap)")
     ap.add_argument("--nodes", type=int, default=5000, help="--config 4: node maps (5000 = the full config)")
-    ap.add_argument("--gated", action="store_true", help="--config 4: only the candidate edges within --gate-dist")
+    ap.add_argument("--gated", action="store_true", help="--config 4: (default since round 4) time the candidate edges within --gate-dist")
+    ap.add_argument("--all-pairs", action="store_true", help="--config 4: time all pairs of computeAllPossibleLinks instead of the gated ones")
+    ap.add_argument("--no-all-pairs", action="store_true", help="--config 4: skip the untimed all-pairs extra")
     ap.add_argument("--gate-dist", type=float, default=6.0, help="--config 4: candidate gate on the odometry distance of two nodes [m]")
     ap.add_argument("--scans-per-node", type=int, default=10, help="--config 4: scans fused into every node map")
     ap.add_argument("--node-points", type=int, default=20000, help="--config 4: points per scan")

@@ -243,6 +243,11 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *target_set, const uint32_
                                         ndtgpu_mapset *source_set, const uint32_t *source_idx_dev,
                                         double *T16_dev, size_t n_pairs, const ndtgpu_match_params *prm,
                                         ndtgpu_match_result *results_dev, ndtgpu_stream stream);
+/* The persistent kernel's safety valve: a wave that finds no work for ~2 s raises a word in the target set's work area
+ * and every workgroup leaves; registrations that were never drawn then keep whatever results_dev held.  The
+ * host-pointer entries read the word themselves (NDTGPU_ERR_HIP); after a device batch the caller asks here (waits for
+ * the set's last stream).  No counterpart in the reference: graph.cpp:347-353 is a serial host loop. */
+ndtgpu_status ndtgpu_match_aborted(ndtgpu_mapset *target_set, int *aborted);
 /* ndt_feature::matchFusion(target, source, <empty feature maps>, T, Tcov, useInitialGuess, useNDT = true,
  * useFeat = false, step_control, ITR_MAX, n_neighbours, DELTA_SCORE, useSoftConstraints, ...,
  * useTikhonovRegularization = false)  (ndt_matcher_d2d_fusion.h:797-1155; call site
@@ -297,6 +302,31 @@ ndtgpu_status ndtgpu_covariance_batch(ndtgpu_mapset *target_set, const uint32_t 
                                       const uint32_t *source_idx, const double *T16, size_t n_links,
                                       const ndtgpu_match_params *prm, int mode, double *cov36, int32_t *singular,
                                       ndtgpu_stream stream);
+/* ---- exchange records of cell maps (multi-GPU graph replay, SURVEY.md 8e phases A-B) --------------------------------
+ * With the node maps of a replay built data-parallel (node k on rank k mod world), every rank needs every node map before
+ * it refines its share of the links: ndt_feature_graph.cpp:273 reads nodes_[ref].map and nodes_[mov].map (the loop
+ * :347-353; candidate enumeration :395-405; caller ndt_feature_graph_opt.cpp:131-160).  pack writes ONE fixed-stride
+ * record per map into a DEVICE buffer -- what one all_gather then moves --, unpack installs records into maps of a set
+ * with the same grid geometry (cells, rank map, counters; occupancies when both sides carry them): an unpacked map is
+ * indistinguishable from the packed one (same matcher bits).  Record = ndtgpu_packed_header, cells_cap cell records
+ * (80 bytes each, the first n_cells valid, in LazyGrid slot order), then cells-per-grid floats when with_occupancy
+ * (NDTCell::occ of every cell, for overlapNDTOccupancyScore, ndt_feature_node.h:213-252).  A map with more cells than
+ * cells_cap is cut and flagged (flags bit 0), as is one that overflowed max_cells where it was built.  Asynchronous on
+ * `stream`; no counterpart in the reference, whose graph lives in one process. */
+typedef struct ndtgpu_packed_header { uint32_t n_cells, flags, n_dropped, cells_cap; } ndtgpu_packed_header;
+typedef struct ndtgpu_cell_record {            /* 80 bytes */
+    double mean[3];
+    double cov[6];                             /* xx xy xz yy yz zz */
+    uint32_t n;                                /* points behind the Gaussian */
+    uint32_t slot;                             /* (ix * size_y + iy) * size_z + iz */
+} ndtgpu_cell_record;
+size_t ndtgpu_mapset_pack_bytes(const ndtgpu_mapset *set, uint32_t cells_cap, int with_occupancy);   /* bytes per record */
+ndtgpu_status ndtgpu_mapset_pack_cells_device(ndtgpu_mapset *set, size_t first, size_t count, void *buf_dev,
+                                              size_t record_stride_bytes, uint32_t cells_cap, int with_occupancy,
+                                              ndtgpu_stream stream);
+ndtgpu_status ndtgpu_mapset_unpack_cells_device(ndtgpu_mapset *set, size_t first, size_t count, const void *buf_dev,
+                                                size_t record_stride_bytes, int with_occupancy, ndtgpu_stream stream);
+
 /* single pair convenience == graph.cpp:273 */
 ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *target_set, size_t target_map, ndtgpu_mapset *source_set,
                                size_t source_map, double T16[16], const ndtgpu_match_params *prm,

@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_HERE, "libndtgpu.so")
-_SOURCES = ["ndt_build.hip", "ndt_build_flat.hip", "ndt_match.hip", "ndt_fuse.hip", "ndtgpu_api.hip"]
+_SOURCES = ["ndt_build.hip", "ndt_build_flat.hip", "ndt_match.hip", "ndt_fuse.hip", "ndt_pack.hip", "ndtgpu_api.hip"]
 
 STATUS = {0: "OK", -1: "ERR_INVALID", -2: "ERR_HIP", -3: "ERR_NO_DEVICE", -4: "ERR_CAPACITY", -5: "ERR_ALLOC"}
 
@@ -118,7 +118,8 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_enable_occupancy", "ndtgpu_default_fuse_params", "ndtgpu_mapset_add_cloud",
            "ndtgpu_mapset_add_cloud_host", "ndtgpu_mapset_clear", "ndtgpu_mapset_export_occupancy",
            "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch", "ndtgpu_mapset_discard_cells", "ndtgpu_mapset_import_occupancy",
-           "ndtgpu_match_fusion_feat_batch"]
+           "ndtgpu_match_fusion_feat_batch", "ndtgpu_match_aborted", "ndtgpu_mapset_pack_bytes",
+           "ndtgpu_mapset_pack_cells_device", "ndtgpu_mapset_unpack_cells_device"]
 
 _lib = None
 
@@ -178,6 +179,11 @@ def lib():
     L.ndtgpu_mapset_import_occupancy.argtypes = [vp, C.c_size_t, C.POINTER(C.c_float)]
     L.ndtgpu_mapset_discard_cells.argtypes = [vp, C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
     L.ndtgpu_covariance_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, C.POINTER(MatchParams), C.c_int, dp, i32p, vp]
+    L.ndtgpu_match_aborted.argtypes = [vp, i32p]
+    L.ndtgpu_mapset_pack_bytes.restype = C.c_size_t
+    L.ndtgpu_mapset_pack_bytes.argtypes = [vp, C.c_uint32, C.c_int]
+    L.ndtgpu_mapset_pack_cells_device.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_int, vp]
+    L.ndtgpu_mapset_unpack_cells_device.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
     _lib = L
     return L
 
@@ -327,6 +333,31 @@ class MapSet:
         _check(lib().ndtgpu_mapset_export_occupancy(self.h, int(i), out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def pack_bytes(self, cells_cap, with_occupancy=False):
+        return int(lib().ndtgpu_mapset_pack_bytes(self.h, int(cells_cap), int(bool(with_occupancy))))
+
+    def pack_cells(self, buf, first=0, count=None, cells_cap=None, with_occupancy=False, stream=None):
+        """Exchange records of maps [first, first+count) into the torch CUDA uint8 tensor buf [count, stride]
+        (ndtgpu_mapset_pack_cells_device; asynchronous)."""
+        import torch
+        count = self.n_maps - first if count is None else count
+        cap = self.info()["max_cells"] if cells_cap is None else cells_cap
+        assert buf.dtype == torch.uint8 and buf.is_cuda and buf.is_contiguous() and buf.shape[0] >= count
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        _check(lib().ndtgpu_mapset_pack_cells_device(self.h, int(first), int(count), C.c_void_p(buf.data_ptr()), int(buf.stride(0)),
+                                                     int(cap), int(bool(with_occupancy)), _stream_ptr(stream)))
+
+    def unpack_cells(self, buf, first=0, count=None, with_occupancy=False, stream=None):
+        """Installs exchange records (ndtgpu_mapset_unpack_cells_device; asynchronous)."""
+        import torch
+        count = buf.shape[0] if count is None else count
+        assert buf.dtype == torch.uint8 and buf.is_cuda and buf.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        _check(lib().ndtgpu_mapset_unpack_cells_device(self.h, int(first), int(count), C.c_void_p(buf.data_ptr()), int(buf.stride(0)),
+                                                       int(bool(with_occupancy)), _stream_ptr(stream)))
+
     def profiling(self, on=True):
         _check(lib().ndtgpu_profiling_enable(self.h, int(bool(on))))
 
@@ -441,6 +472,13 @@ def match_fusion_feat_batch(target_set, target_idx, source_set, source_idx, T, T
                                             si.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(Tc), _dp(cov), C.byref(fp), n,
                                             C.byref(p), flags, C.c_void_p(res.ctypes.data), _stream_ptr(stream)))
     return np.transpose(Tc, (0, 2, 1)).copy(), res
+
+
+def match_aborted(target_set):
+    """True when the last persistent matcher launch on this target set gave up (waits for that launch)."""
+    a = C.c_int32()
+    _check(lib().ndtgpu_match_aborted(target_set.h, C.byref(a)))
+    return bool(a.value)
 
 
 def match_batch_device(target_set, tidx_dev, source_set, sidx_dev, T16_dev, results_dev, n_pairs, stream=None, **params):

@@ -803,7 +803,7 @@ NDT_D void eval_chunks(const MapView &tg, gcell_ptr src, int msrc, const rigid &
 struct NdtMatchWork {
     unsigned fresh, reserve, head;
     unsigned abort;        // a wave that found nothing to do for about a second raises it and everybody leaves (guard against
-                           // a scheduling bug hanging the device; ndt_match_aborted())
+                           // a scheduling bug hanging the device; ndtgpu_match_aborted())
 };
 struct NdtParkedState {
     MatchState st;

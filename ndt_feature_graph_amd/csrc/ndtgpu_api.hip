@@ -53,6 +53,7 @@ struct ndtgpu_mapset {
         return 1;
     }
     hipStream_t last_stream = nullptr;
+    hipStream_t last_match_stream = nullptr;   // stream of the last persistent matcher launch with this set as target
     // staging buffers reused across calls
     void *stage = nullptr;
     size_t stage_bytes = 0;
@@ -697,8 +698,18 @@ static_assert(sizeof(NdtMatchResultDev) == sizeof(ndtgpu_match_result), "result 
 #define NDTGPU_HOST_LOOP_MAX 8             // up to this many registrations per call: the latency shapes (grid barrier / host loop)
 #define NDTGPU_COOP_MIN_SET_CELLS 16384u   // source sets with room for fewer cells per map hold small (2D) maps
 static std::mutex g_coop_mutex;
-static hipEvent_t g_coop_ev = nullptr;
-static bool g_coop_ev_valid = false;
+// (per device: an event belongs to the device it was created on, and launches on one device need not wait for another's)
+#define NDTGPU_MAX_DEVICES 64
+static hipEvent_t g_coop_ev_dev[NDTGPU_MAX_DEVICES] = {};
+static bool g_coop_ev_valid_dev[NDTGPU_MAX_DEVICES] = {};
+static int coop_dev()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d % NDTGPU_MAX_DEVICES;
+}
+#define g_coop_ev g_coop_ev_dev[coop_dev()]
+#define g_coop_ev_valid g_coop_ev_valid_dev[coop_dev()]
 
 ndtgpu_status ndtgpu_mapset::ensure_coop(size_t bytes)
 {
@@ -782,6 +793,7 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
                                        const unsigned *feat_off_dev = nullptr, const double *feat_cells_dev = nullptr)
 {
     if (n_pairs == 0) return NDTGPU_OK;
+    ts->last_match_stream = st;
     // persistent workgroups, one per CU (8 waves x 256 VGPRs), each with `slots` registrations in flight whose evaluation
     // shares its waves take in turn (csrc/ndt_match.hip); pairs are pulled from a ticket counter.
     // NDTGPU_PARK_ITERS: iterations after which a long registration yields to a fresh pair.  NDTGPU_SLOTS=1: one
@@ -898,6 +910,54 @@ static ndtgpu_status match_persistent_host(ndtgpu_mapset *ts, const uint32_t *ti
     HIP_TRY(hipMemcpyAsync(&aborted, (char *)ts->work + ndt_match_abort_offset(), sizeof aborted, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (aborted) return fail(NDTGPU_ERR_HIP, "match: the persistent matcher gave up (a wave found no work for ~1 s)");
+    return NDTGPU_OK;
+}
+
+static_assert(sizeof(ndtgpu_cell_record) == sizeof(NdtCell) && offsetof(ndtgpu_cell_record, slot) == offsetof(NdtCell, slot) &&
+              offsetof(ndtgpu_cell_record, cov) == offsetof(NdtCell, cov), "the exchange record is the device cell record");
+
+size_t ndtgpu_mapset_pack_bytes(const ndtgpu_mapset *s, uint32_t cells_cap, int with_occupancy)
+{
+    if (!s) return 0;
+    size_t b = sizeof(ndtgpu_packed_header) + (size_t)cells_cap * sizeof(NdtCell);
+    if (with_occupancy) b += (size_t)s->v.grid.slots * sizeof(float);
+    return (b + 15u) & ~(size_t)15u;
+}
+
+ndtgpu_status ndtgpu_mapset_pack_cells_device(ndtgpu_mapset *s, size_t first, size_t count, void *buf_dev, size_t stride,
+                                              uint32_t cells_cap, int with_occupancy, ndtgpu_stream stream)
+{
+    if (!s || first + count > s->n_maps || (count && !buf_dev) || ((uintptr_t)buf_dev & 15u) || (stride & 15u) ||
+        stride < ndtgpu_mapset_pack_bytes(s, cells_cap, with_occupancy))
+        return fail(NDTGPU_ERR_INVALID, "pack_cells: bad argument (16-byte aligned buffer, stride >= ndtgpu_mapset_pack_bytes)");
+    if (with_occupancy && !s->v.occ) return fail(NDTGPU_ERR_INVALID, "pack_cells: the set carries no occupancies");
+    hipError_t e = ndt_launch_pack(s->v, first, count, buf_dev, stride, cells_cap, with_occupancy ? 1 : 0, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "pack_cells: launch", e);
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_unpack_cells_device(ndtgpu_mapset *s, size_t first, size_t count, const void *buf_dev, size_t stride,
+                                                int with_occupancy, ndtgpu_stream stream)
+{
+    if (!s || first + count > s->n_maps || (count && !buf_dev) || ((uintptr_t)buf_dev & 15u) || (stride & 15u) ||
+        stride < sizeof(ndtgpu_packed_header))
+        return fail(NDTGPU_ERR_INVALID, "unpack_cells: bad argument");
+    if (with_occupancy && !s->v.occ) return fail(NDTGPU_ERR_INVALID, "unpack_cells: call ndtgpu_mapset_enable_occupancy first");
+    s->last_stream = (hipStream_t)stream;
+    hipError_t e = ndt_launch_unpack(s->v, first, count, buf_dev, stride, with_occupancy ? 1 : 0, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "unpack_cells: launch", e);
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_match_aborted(ndtgpu_mapset *ts, int *aborted)
+{
+    if (!ts || !aborted) return fail(NDTGPU_ERR_INVALID, "match_aborted: bad argument");
+    *aborted = 0;
+    if (!ts->work) return NDTGPU_OK;                     // no persistent launch has used this set as a target
+    HIP_TRY(hipStreamSynchronize(ts->last_match_stream));
+    unsigned w = 0;
+    HIP_TRY(hipMemcpy(&w, (char *)ts->work + ndt_match_abort_offset(), sizeof w, hipMemcpyDeviceToHost));
+    *aborted = w != 0u;
     return NDTGPU_OK;
 }
 
@@ -1111,9 +1171,9 @@ ndtgpu_status ndtgpu_match_fusion_feat_batch(ndtgpu_mapset *ts, const uint32_t *
                                              const ndtgpu_match_params *prm, int flags, ndtgpu_match_result *results,
                                              ndtgpu_stream stream)
 {
-    if (!feat || !feat->offsets)
-        return ndtgpu_match_fusion_batch(ts, tidx, ss, sidx, T16, Tcov36, n_pairs, prm, flags & 3, results, stream);
     if (flags < 0 || flags > 7) return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: flags is a 3-bit set");
+    if (!feat || !feat->offsets)   // no feature maps: bit 2 (the joint line search of the feature maps) has nothing to act on
+        return ndtgpu_match_fusion_batch(ts, tidx, ss, sidx, T16, Tcov36, n_pairs, prm, flags & 3, results, stream);
     if (!ts || !ss || (n_pairs && (!tidx || !sidx || !T16 || !results)))
         return fail(NDTGPU_ERR_INVALID, "match_fusion_feat: bad argument");
     if (n_pairs == 0) return NDTGPU_OK;

@@ -4,8 +4,11 @@ The path shards naturally: every NDTFeatureGraph::updateLinkUsingNDTRegistration
 node maps and writes its own link (ndt_feature_graph.cpp:260-345; the loop :347-353 carries no
 state), so there is NO data-path collective.  One process per GPU:
 
-  * node maps are rebuilt on every rank (replicated build: 100 k points -> ~4 us of GPU time per
-    scan, cheaper than shipping cell maps over xGMI and it removes the all-gather of phase B);
+  * node maps are built data-parallel, node k on rank k mod world (SURVEY.md 8e phase A), packed into fixed-stride
+    exchange records on the device (ndtgpu_mapset_pack_cells_device: the Gaussian cells in slot order + the occupancy of
+    every cell) and all-gathered ONCE (phase B); every rank unpacks all of them (cells, rank map, counters).  A fused node
+    map costs ~28 us of GPU time (ten ray-traced scans): replicating that on 8 ranks capped the replay at 3.5x;
+    plain one-scan maps (configs 1-3, 5) need no exchange at all -- each rank builds the scans of its own pairs;
   * the edge list (identical on all ranks) is dealt block-cyclically, `chunk` edges at a time,
     because iteration counts vary per edge;
   * the only collective is the FINAL all-gather of the edge results {T 16 f64, result 64 B}
@@ -68,6 +71,102 @@ def register_sharded(n_edges, rank, world, register_fn, chunk=256, group=None):
     T_local, res_local = register_fn(mine)
     T, R = gather_edge_results(T_local, res_local, n_edges, rank, world, chunk, group)
     return mine, T, R
+
+
+def shard_nodes(n_nodes, rank, world):
+    """Nodes whose maps rank `rank` builds: k with k % world == rank (SURVEY.md 8e phase A)."""
+    return np.arange(rank, n_nodes, max(1, world), dtype=np.int64)
+
+
+def records_to_node_order(gathered, n_nodes, world):
+    """The all-gathered records [world * n_max, stride] (rank-major, every rank's share padded to n_max = ceil(n / world))
+    in NODE order [n_nodes, stride]: record i of rank r is node i * world + r."""
+    n_max = (n_nodes + world - 1) // world
+    stride = gathered.shape[1]
+    return gathered.view(world, n_max, stride).transpose(0, 1).reshape(world * n_max, stride)[:n_nodes].contiguous()
+
+
+def exchange_node_maps(packed_local, n_nodes, rank, world, group=None):
+    """Phase B: ONE all-gather of the exchange records.  packed_local: torch uint8 [n_local, stride], record i = node
+    rank + i * world (ndtgpu_mapset_pack_cells_device on GPUs; any producer of the same layout in the CPU tests).
+    Returns uint8 [n_nodes, stride] in NODE order on every rank -- what ndtgpu_mapset_unpack_cells_device installs with
+    one call."""
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return packed_local[:n_nodes]
+    n_max = (n_nodes + world - 1) // world
+    stride = packed_local.shape[1]
+    mine = packed_local
+    if mine.shape[0] != n_max:                              # the last ranks hold one node less: pad to equal shares
+        pad = torch.zeros((n_max, stride), dtype=torch.uint8, device=packed_local.device)
+        pad[:mine.shape[0]] = mine
+        mine = pad
+    gathered = torch.empty((world * n_max, stride), dtype=torch.uint8, device=packed_local.device)
+    dist.all_gather_into_tensor(gathered, mine.contiguous(), group=group)
+    return records_to_node_order(gathered, n_nodes, world)
+
+
+# the exchange record of include/ndtgpu.h (ndtgpu_packed_header + ndtgpu_cell_record) as NumPy dtypes: host-side views of
+# packed buffers (tests, tools); the device side is csrc/ndt_pack.hip
+PACKED_HEADER_DTYPE = np.dtype([("n_cells", "<u4"), ("flags", "<u4"), ("n_dropped", "<u4"), ("cells_cap", "<u4")])
+PACKED_CELL_DTYPE = np.dtype([("mean", "<f8", (3,)), ("cov", "<f8", (6,)), ("n", "<u4"), ("slot", "<u4")])
+assert PACKED_HEADER_DTYPE.itemsize == 16 and PACKED_CELL_DTYPE.itemsize == 80
+
+
+def record_bytes(cells_cap, slots=0):
+    """ndtgpu_mapset_pack_bytes: bytes of one record (slots > 0: with the occupancy of every cell)."""
+    return (16 + 80 * int(cells_cap) + 4 * int(slots) + 15) // 16 * 16
+
+
+def record_from_cells(mean, cov, idx, npts, cells_per_axis, cells_cap, n_dropped=0):
+    """One exchange record (uint8 [record_bytes]) from exported cells: mean [n,3], cov [n,3,3], idx [n,3] LazyGrid indices,
+    npts [n]; the cells are put in slot order like the device's."""
+    sx, sy, sz = (int(v) for v in cells_per_axis)
+    idx = np.asarray(idx, dtype=np.int64).reshape(-1, 3)
+    slot = (idx[:, 0] * sy + idx[:, 1]) * sz + idx[:, 2]
+    order = np.argsort(slot, kind="stable")
+    n = min(len(order), int(cells_cap))
+    rec = np.zeros(record_bytes(cells_cap), dtype=np.uint8)
+    h = rec[:16].view(PACKED_HEADER_DTYPE)
+    h["n_cells"], h["flags"], h["n_dropped"], h["cells_cap"] = n, (1 if len(order) > cells_cap else 0), n_dropped, cells_cap
+    c = rec[16:16 + 80 * int(cells_cap)].view(PACKED_CELL_DTYPE)
+    cov = np.asarray(cov, dtype=np.float64).reshape(-1, 3, 3)
+    o = order[:n]
+    c["mean"][:n] = np.asarray(mean, dtype=np.float64).reshape(-1, 3)[o]
+    c["cov"][:n] = np.stack([cov[o, 0, 0], cov[o, 0, 1], cov[o, 0, 2], cov[o, 1, 1], cov[o, 1, 2], cov[o, 2, 2]], axis=1)
+    c["n"][:n] = np.asarray(npts).reshape(-1)[o]
+    c["slot"][:n] = slot[o]
+    return rec
+
+
+def cells_from_record(rec):
+    """(mean [n,3], cov [n,3,3], slot [n], npts [n], flags) of one exchange record."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1)
+    h = rec[:16].view(PACKED_HEADER_DTYPE)[0]
+    n, cap = int(h["n_cells"]), int(h["cells_cap"])
+    c = rec[16:16 + 80 * cap].view(PACKED_CELL_DTYPE)[:n]
+    v = c["cov"]
+    cov = np.stack([v[:, 0], v[:, 1], v[:, 2], v[:, 1], v[:, 3], v[:, 4], v[:, 2], v[:, 4], v[:, 5]], axis=1).reshape(-1, 3, 3)
+    return c["mean"].copy(), cov, c["slot"].copy(), c["n"].copy(), int(h["flags"])
+
+
+def phase_model(build_all_ms, match_all_ms, n_nodes, record_bytes, n_edges, worlds=(1, 2, 4, 8), link_GBps=153.0, links=7):
+    """Per-phase time model of one replay step on `world` GPUs of one node, from the one-rank measurements: node builds
+    and edge registrations divide by world; the exchange is an all-gather of n_nodes records over point-to-point xGMI
+    (each rank sends its share to the other world - 1 ranks over its own links, ~153 GB/s per link), the final gather one of
+    192 B per edge.  A model, not a measurement: no multi-GPU node was available to any round."""
+    out = {}
+    for w in worlds:
+        per_rank_out = record_bytes * n_nodes / w * (w - 1)          # bytes a rank puts on its links
+        bw = link_GBps * 1e9 * min(links, max(1, w - 1))
+        gather_ms = 0.0 if w == 1 else 1e3 * per_rank_out / bw
+        edge_ms = 0.0 if w == 1 else 1e3 * (192.0 * n_edges / w * (w - 1)) / bw
+        total = build_all_ms / w + gather_ms + match_all_ms / w + edge_ms
+        out[str(w)] = {"build_ms": build_all_ms / w, "exchange_ms": gather_ms, "match_ms": match_all_ms / w,
+                       "edge_gather_ms": edge_ms, "step_ms": total,
+                       "speedup": (build_all_ms + match_all_ms) / total}
+    return out
 
 
 def all_pairs(n_nodes):

@@ -1,6 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo processes shard an edge list block-cyclically, register
-their share (the CPU oracle stands in for the GPU matcher -- tests may use it as the checker),
-all-gather the edge results and must reproduce the single-process answer exactly."""
+"""N>1 path on CPU: world_size-2 gloo processes build their share of the node maps (node k on rank k mod world), exchange
+them as the device's packed records with ONE all-gather, shard the edge list block-cyclically, register their share (the
+CPU oracle stands in for the GPU builder and matcher -- tests may use it as the checker), all-gather the edge results and
+must reproduce the single-process answer exactly."""
 import os
 import socket
 import sys
@@ -42,12 +43,25 @@ def _worker(rank, world, port, out_dir):
     from ndt_feature_graph_amd import distributed as D, synth
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_nodes, chunk = 5, 2
-    # node k = scan of room seed 77 from a pose 0.25 m further along x (replicated build on every rank)
+    # node k = scan of room seed 77 from a pose 0.25 m further along x.  Phase A: this rank builds nodes k % world == rank;
+    # phase B: their cells travel as the exchange records of include/ndtgpu.h through ONE all-gather; every rank installs
+    # all of them (bench.py --config 4 does the same with ndtgpu_mapset_pack_cells_device / _unpack_cells_device)
     poses = np.array([[0.25 * k, 0.05 * k, 0.01 * k] for k in range(n_nodes)])
     scans = synth.scan_2d([77] * n_nodes, poses, 3000).numpy()
+    cap, grid = 512, (100, 100, 1)
+    recs = []
+    for k in D.shard_nodes(n_nodes, rank, world):
+        m = O.OracleMap(1.0, [0, 0, 0], [100, 100, 1]); m.load_points(scans[k], 30.0); m.compute_cells()
+        recs.append(D.record_from_cells(*m.export_cells(), grid, cap))
+    packed = torch.from_numpy(np.stack(recs)) if recs else torch.zeros((0, D.record_bytes(cap)), dtype=torch.uint8)
+    allrec = D.exchange_node_maps(packed, n_nodes, rank, world).numpy()
+    assert allrec.shape == (n_nodes, D.record_bytes(cap))
     maps = []
     for k in range(n_nodes):
-        m = O.OracleMap(1.0, [0, 0, 0], [100, 100, 1]); m.load_points(scans[k], 30.0); m.compute_cells()
+        mean, cov, slot, npts, flags = D.cells_from_record(allrec[k])
+        assert flags == 0 and np.all(np.diff(slot.astype(np.int64)) > 0)            # slot order, nothing cut
+        m = O.OracleMap(1.0, [0, 0, 0], [100, 100, 1]); m.set_cells(mean, cov)
+        assert m.num_cells() == len(slot)
         maps.append(m)
     edges = D.all_pairs(n_nodes)
     node_T = synth.pose2d_to_T(poses).numpy()

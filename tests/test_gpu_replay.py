@@ -1,0 +1,224 @@
+"""configs[3] at the survey's CI size on FUSED node maps (-m gpu): 500 nodes 2 m apart through five rooms, every node a
+map fused from several ray-traced scans (what ndt_feature_graph.cpp:273 really registers), built data-parallel the way
+bench.py --config 4 does it on several ranks -- node k in the set of "rank" k mod world --, exchanged as packed cell
+records (ndtgpu_mapset_pack_cells_device -> the reordering of distributed.exchange_node_maps -> _unpack_cells_device) and
+registered: the gated candidate edges (ndt_feature_graph_opt.cpp:49-52, :131-160) and ALL pairs of
+computeAllPossibleLinks (ndt_feature_graph.cpp:395-405).  300 sampled edges against the CPU oracle: pose, iterations,
+covariance (graph.cpp:296-298), occupancy overlap (graph.cpp:338-340; ndt_feature_node.h:213-252)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4       # north_star: output pose per pair within 1e-4 m / 1e-4 rad of the CPU matcher
+POSE_TOL_RAD = 1e-4
+DET_FIELDS = ("converged", "iterations", "fevals", "exit_code", "score", "n_source", "n_target", "pair_terms_g", "pair_terms_h")
+
+
+@pytest.fixture(scope="module")
+def N():
+    import ndt_feature_graph_amd as N
+    if N.device_count() < 1:
+        pytest.fail("no HIP device visible: the HIP path cannot run (there is no CPU fallback)")
+    return N
+
+
+@pytest.fixture(scope="module")
+def O():
+    import oracle
+    return oracle
+
+
+def pose_close(Ta, Tb):
+    dt = float(np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]))
+    dr = float(2.0 * np.arcsin(min(1.0, np.linalg.norm(Ta[:3, :3] - Tb[:3, :3]) / (2.0 * np.sqrt(2.0)))))
+    return dt, dr
+
+
+def replay_layout(n_nodes, per_room=100):
+    """The trajectory of bench.py --config 4: 100 nodes per room on a serpentine path, 2 m between consecutive nodes."""
+    q = np.arange(n_nodes) % per_room
+    room = np.arange(n_nodes) // per_room
+    col, row = q // 10, q % 10
+    row = np.where(col % 2 == 1, 9 - row, row)
+    lx, ly = -9.0 + 2.0 * col, -9.0 + 2.0 * row
+    yaw = np.where(col % 2 == 1, -np.pi / 2, np.pi / 2)
+    world_xy = np.stack([80.0 * (room % 8) + lx, 80.0 * (room // 8) + ly], axis=1)
+    return room, np.stack([lx, ly, yaw], axis=1), np.concatenate([world_xy, yaw[:, None]], axis=1)
+
+
+def test_replay_500_fused_nodes_sharded_build_and_exchange(N, O):
+    import torch
+    from ndt_feature_graph_amd import binding, distributed as D, synth
+    dev = torch.device("cuda", 0)
+    n_nodes, S, n_pts, res, size = 500, 3, 6000, 0.5, [100.0, 100.0, 1.0]
+    room, local, world_pose = replay_layout(n_nodes)
+    node_T = synth.pose2d_to_T(torch.as_tensor(world_pose)).numpy()
+    g = np.random.default_rng(11)
+    odo_T = node_T.copy()
+    odo_T[:, 0, 3] += g.normal(scale=0.03, size=n_nodes)
+    odo_T[:, 1, 3] += g.normal(scale=0.03, size=n_nodes)
+    seeds = torch.as_tensor(4000 + room, dtype=torch.int64, device=dev)
+    clouds = []
+    for k in range(S):
+        dx = 0.9 * k / S
+        pk = local.copy()
+        pk[:, 0] += dx * np.cos(local[:, 2]); pk[:, 1] += dx * np.sin(local[:, 2])
+        sc = synth.scan_2d(seeds, torch.as_tensor(pk, device=dev), n_pts, noise_stream=k).contiguous()
+        sc[:, :, 0] += dx                                              # sensor frame -> node frame
+        clouds.append((sc, np.tile(np.array([[dx, 0.0, 0.0]]), (n_nodes, 1))))
+    fuse_kw = [dict(maxz=100.0, sensor_noise=0.1)] + [dict(maxz=25.0, sensor_noise=0.06)] * (S - 1)
+
+    # the reference for the exchange: every node map built in ONE set
+    direct = N.MapSet(res, [0, 0, 0], size, n_maps=n_nodes, max_cells=2048)
+    direct.enable_occupancy()
+    for (sc, org), kw in zip(clouds, fuse_kw):
+        direct.add_cloud(sc, org, **kw)
+    cells_per_map = direct.num_cells_all()
+    assert cells_per_map.min() > 5 and cells_per_map.mean() > 100
+
+    # phases A + B as on `world` ranks: node k is built in the set of rank k % world, packed there, the records are
+    # gathered (rank-major, padded to equal shares) and put into node order, ONE unpack installs them all
+    world = 4
+    cells_cap = (int(cells_per_map.max()) * 5 // 4 + 63) // 64 * 64
+    n_max = (n_nodes + world - 1) // world
+    stride = direct.pack_bytes(cells_cap, True)
+    assert stride == D.record_bytes(cells_cap, 200 * 200 * 2)
+    gathered = torch.zeros((world, n_max, stride), dtype=torch.uint8, device=dev)
+    locs = []
+    for rank in range(world):
+        mine = D.shard_nodes(n_nodes, rank, world)
+        loc = N.MapSet(res, [0, 0, 0], size, n_maps=len(mine), max_cells=2048)
+        loc.enable_occupancy()
+        sel = torch.as_tensor(mine, device=dev)
+        for (sc, org), kw in zip(clouds, fuse_kw):
+            loc.add_cloud(sc[sel].contiguous(), org[mine], **kw)
+        buf = torch.zeros((len(mine), stride), dtype=torch.uint8, device=dev)
+        loc.pack_cells(buf, 0, len(mine), cells_cap=cells_cap, with_occupancy=True)
+        gathered[rank, :len(mine)] = buf
+        torch.cuda.synchronize()
+        locs.append(loc)
+    allrec = D.records_to_node_order(gathered.view(world * n_max, stride), n_nodes, world)
+    pool = N.MapSet(res, [0, 0, 0], size, n_maps=n_nodes, max_cells=2048)
+    pool.enable_occupancy()
+    pool.unpack_cells(allrec, 0, n_nodes, with_occupancy=True)
+    # a record on the host reads like the exported map of the rank that built it
+    for k in (0, 137, 499):
+        mean, cov, slot, npts, flags = D.cells_from_record(allrec[k].cpu().numpy())
+        em, ec, ei, en = locs[k % world].export_cells(k // world)
+        assert flags == 2 and np.array_equal(mean, em) and np.array_equal(cov, ec) and np.array_equal(npts, en)
+        assert np.array_equal(slot, (ei[:, 0] * 200 + ei[:, 1]) * 2 + ei[:, 2])
+    # an unpacked map is the packed map: cells, counters, occupancies (and the matcher's bits: test_pack_... below)
+    assert np.array_equal(pool.num_cells_all(), cells_per_map)
+    for k in (3, 250, 498, 499):
+        for x, y in zip(pool.export_cells(k), locs[k % world].export_cells(k // world)):
+            assert np.array_equal(x, y)
+        assert np.array_equal(pool.occupancy(k), locs[k % world].occupancy(k // world))
+        # against the same node built in the 500-map set: the same cells and point counts; the moments may differ in
+        # their last bits (a set of 125 maps cuts a scan into other chunks than a set of 500: other partial sums)
+        a, b = pool.export_cells(k), direct.export_cells(k)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert np.max(np.abs(a[0] - b[0])) < 1e-12 and np.max(np.abs(a[1] - b[1])) < 1e-12
+
+    # phase C: gated candidates and all pairs, dealt block-cyclically to 8 shards, reassembled in edge order
+    edges = D.all_pairs(n_nodes)
+    assert len(edges) == 124750
+    d_odo = np.linalg.norm(odo_T[edges[:, 0], :2, 3] - odo_T[edges[:, 1], :2, 3], axis=1)
+    gate = (d_odo <= 6.0) & ((edges[:, 1] - edges[:, 0]) >= 2)
+    T0 = np.einsum("eij,ejk->eik", np.linalg.inv(odo_T)[edges[:, 0]], odo_T[edges[:, 1]])
+    T_all = np.zeros((len(edges), 4, 4))
+    r_all = None
+    for rank in range(8):
+        mine = D.shard_edges(len(edges), rank, 8, 256)
+        Tm, rm = N.match_batch(pool, edges[mine, 0], pool, edges[mine, 1], T0[mine], delta_score=1e-3)   # "edge" preset
+        if r_all is None:
+            r_all = np.zeros(len(edges), dtype=rm.dtype)
+        T_all[mine], r_all[mine] = Tm, rm
+    gi = np.nonzero(gate)[0]
+    assert 3000 < len(gi) < 6000
+    Tg, rg = N.match_batch(pool, edges[gi, 0], pool, edges[gi, 1], T0[gi], delta_score=1e-3)     # the gated edges on their own
+    assert np.array_equal(Tg, T_all[gi])
+    for f in DET_FIELDS:
+        assert np.array_equal(rg[f], r_all[f][gi]), f
+    Td, rd = N.match_batch(direct, edges[gi, 0], direct, edges[gi, 1], T0[gi], delta_score=1e-3)  # on the maps built in one set
+    assert np.max(np.abs(Td - Tg)) < 1e-7 and np.mean(rd["iterations"] == rg["iterations"]) > 0.99
+    assert r_all["converged"][gi].mean() > 0.98
+    gt = np.einsum("eij,ejk->eik", np.linalg.inv(node_T)[edges[gi, 0]], node_T[edges[gi, 1]])
+    err = np.linalg.norm(Tg[:, :2, 3] - gt[:, :2, 3], axis=1)
+    assert np.median(err) < 0.02
+    # edges between rooms share no cell: they end at the first evaluation, untouched
+    far = room[edges[:, 0]] != room[edges[:, 1]]
+    assert np.all(r_all["pair_terms_h"][far] == 0) and np.array_equal(T_all[far], T0[far])
+
+    # per-link outputs of updateLinksUsingNDTRegistration on the gated edges
+    cov, sing = N.covariance(pool, edges[gi, 0], pool, edges[gi, 1], Tg)
+    score, nb = N.overlap_score(pool, edges[gi, 0], pool, edges[gi, 1], Tg)
+    assert sing.mean() < 0.05            # (a few node maps of this small replay hold a dozen cells: singular Hessians)
+
+    # 300 sampled edges against the oracle: the gated ones of three anchor stretches (60 fused oracle maps), the rest others
+    anchors = np.concatenate([np.arange(20, 40), np.arange(150, 170), np.arange(420, 440)])
+    in_a = np.isin(edges[:, 0], anchors) & np.isin(edges[:, 1], anchors)
+    cand_g = np.nonzero(gate & in_a)[0]
+    cand_o = np.nonzero(~gate & in_a)[0]
+    n_g = min(240, len(cand_g))
+    sample = np.concatenate([g.choice(cand_g, n_g, replace=False), g.choice(cand_o, 300 - n_g, replace=False)])
+    assert len(sample) == 300 and n_g >= 150
+    scans_h = [(sc[torch.as_tensor(anchors, device=dev)].cpu().numpy(), org[anchors]) for sc, org in clouds]
+    omaps = {}
+    for a, k in enumerate(anchors):
+        om = O.OracleMap(res, [0, 0, 0], size)
+        for (sc, org), kw in zip(scans_h, fuse_kw):
+            om.add_point_cloud(org[a], sc[a], maxz=kw["maxz"], sensor_noise=kw["sensor_noise"], order_free=True)
+            om.compute_cells_full()
+        assert om.num_cells() == cells_per_map[k]
+        omaps[int(k)] = om
+    pos = {int(e): q for q, e in enumerate(gi)}
+    for e in sample:
+        i, j = (int(v) for v in edges[e])
+        To, ro = O.match_d2d(omaps[i], omaps[j], T0[e], delta_score=1e-3)
+        dt, dr = pose_close(T_all[e], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (e, dt, dr)
+        assert r_all["iterations"][e] == ro["iterations"] and bool(r_all["converged"][e]) == ro["converged"], e
+        if e in pos:
+            q = pos[e]
+            if sing[q]:
+                continue
+            co = O.covariance(omaps[i], omaps[j], Tg[q])
+            scale = np.abs(co).max()
+            assert scale > 0 and np.max(np.abs(cov[q] - co)) < 1e-6 * scale, (e, np.max(np.abs(cov[q] - co)) / scale)
+            so, nbo = O.overlap_score(omaps[i], omaps[j], Tg[q])
+            assert nb[q] == nbo and abs(score[q] - so) < 1e-6 * max(so, 1e-3), (e, nb[q], nbo, score[q], so)
+
+
+def test_pack_flags_a_map_that_does_not_fit(N):
+    """A record with room for fewer cells than the map holds is cut and flagged; the unpacked map is refused by the
+    matcher like a map whose build overflowed max_cells (exit code -3), never silently matched with missing cells."""
+    import torch
+    from ndt_feature_graph_amd import distributed as D, synth
+    dev = torch.device("cuda", 0)
+    pr = synth.pair_2d([5], 20000)
+    ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2, max_cells=1024)
+    ms.build(np.stack([pr["fixed"][0].numpy(), pr["moving"][0].numpy()]), range_limit=30.0)
+    n0 = ms.num_cells(0)
+    assert n0 > 64
+    buf = torch.zeros((2, ms.pack_bytes(64, False)), dtype=torch.uint8, device=dev)
+    ms.pack_cells(buf, 0, 2, cells_cap=64)
+    torch.cuda.synchronize()
+    _, _, slot, _, flags = D.cells_from_record(buf[0].cpu().numpy())
+    assert flags & 1 and len(slot) == 64
+    dst = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=2, max_cells=1024)
+    dst.unpack_cells(buf, 0, 2)
+    with pytest.raises(N.NdtGpuError):
+        dst.num_cells(0)                                   # ERR_CAPACITY, like an overflowing build
+    T, r = N.match_batch(dst, [0], dst, [1], pr["T_init"].numpy()[:1])
+    assert r["exit_code"][0] == -3 and not r["converged"][0]
+    # with room for all cells the round trip is exact
+    buf2 = torch.zeros((2, ms.pack_bytes(1024, False)), dtype=torch.uint8, device=dev)
+    ms.pack_cells(buf2, 0, 2, cells_cap=1024)
+    dst.unpack_cells(buf2, 0, 2)
+    for k in range(2):
+        for x, y in zip(dst.export_cells(k), ms.export_cells(k)):
+            assert np.array_equal(x, y)
+    Ta, ra = N.match_batch(ms, [0], ms, [1], pr["T_init"].numpy()[:1])
+    Tb, rb = N.match_batch(dst, [0], dst, [1], pr["T_init"].numpy()[:1])
+    assert np.array_equal(Ta, Tb) and ra["iterations"][0] == rb["iterations"][0]
