@@ -300,6 +300,78 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         dist.destroy_process_group()
 
 
+def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_cpu):
+    """The headline configuration (100 k points, 0.5 m cells, fuser preset) on the DENSE scene of synth.room_2d -- ~2 k Gaussian
+    cells per map, the size SURVEY.md 8(a, d) gives a 2D map, against ~370 in the plain room the headline runs on: the same two
+    launches per step (all maps, all registrations), serial on one stream, fewer pairs (the scene generator is the slow
+    part).  Returns the labelled `dense_scene` object: registrations/s, kernel times, roofline of the dominant kernel, parity
+    and a CPU baseline on a small sample."""
+    B, NP, res = args.dense_pairs, args.points, args.res
+    seeds = torch.arange(1, B + 1, dtype=torch.int64, device=dev)
+    pr = synth.pair_2d(seeds, NP, device=dev, chunk_bytes=1 << 30, scene="dense")
+    both = torch.cat([pr["fixed"], pr["moving"]]).contiguous()
+    T_init_cm = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)
+    idx = torch.arange(B, dtype=torch.int32, device=dev)
+    idx_src = idx + B
+    ms = N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * B, max_cells=4096)
+    ms.profiling(True)
+    T16 = T_init_cm.clone()
+    results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream()
+
+    def step():
+        ms.build(both, range_limit=rng_lim, stream=st)
+        T16.copy_(T_init_cm)
+        binding.match_batch_device(ms, idx, ms, idx_src, T16, results, B, stream=st)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    kb, km = [], []
+    t0 = time.perf_counter()
+    n_steps = 5
+    for _ in range(n_steps):
+        step()
+        torch.cuda.synchronize()                       # (serial: the events of the library bracket each kernel alone)
+        kb.append(ms.last_kernel_ms(0)); km.append(ms.last_kernel_ms(1))
+    elapsed = time.perf_counter() - t0
+    r = results.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
+    T_out = T16.cpu().numpy().reshape(B, 4, 4).transpose(0, 2, 1)
+    cells = float(r["n_target"].astype(np.int64).sum() + r["n_source"].astype(np.int64).sum())
+    build_ms, match_ms = float(np.median(kb)), float(np.median(km))
+    build_bytes = 2 * B * 12.0 * NP + 80.0 * cells
+    gflop = (130.0 * float(r["pair_terms_g"].sum()) + 610.0 * float(r["pair_terms_h"].sum())) / 1e9
+    if build_ms >= match_ms:
+        roof = {"kernel": "ndt_build_kernel", "bound": "hbm", "achieved": build_bytes / build_ms / 1e6, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": build_bytes / build_ms / 1e6 / HBM_PEAK_GBS, "traffic": None}
+    else:
+        roof = {"kernel": "ndt_match_kernel", "bound": "fp64_valu", "achieved": gflop / match_ms, "peak": 78.6, "unit": "TFLOP/s",
+                "frac": gflop / match_ms / 78.6, "traffic": None}
+    out = {"value": B * n_steps / elapsed, "unit": "registrations/s", "pairs": B, "steps": n_steps,
+           "ms_per_step_serial": 1e3 * elapsed / n_steps,
+           "workload": "%d pairs x %d pts, %.2f m cells, synth scene 'dense' (the hall of the headline scene + 3000 posts of 2-4 cm), "
+                       "fuser preset, one build launch + one matcher launch per step, one stream (no pipeline)" % (B, NP, res),
+           "mean_cells_per_map": cells / (2 * B), "kernel_ms": {"ndt_build_kernel": build_ms, "ndt_match_kernel": match_ms},
+           "build_hbm_frac": build_bytes / build_ms / 1e6 / HBM_PEAK_GBS, "match_fp64_frac": gflop / match_ms / 78.6,
+           "pair_terms_per_registration": float((r["pair_terms_g"].sum() + r["pair_terms_h"].sum()) / B),
+           "mean_iterations": float(r["iterations"].mean()), "converged_frac": float(r["converged"].mean()), "roofline": roof}
+    if with_cpu:
+        S = min(args.dense_cpu_sample, B)
+        one, omp, To = cpu_baseline_c(pr["fixed"][:S].cpu().numpy(), pr["moving"][:S].cpu().numpy(), pr["T_init"][:S].cpu().numpy(),
+                                      res, size_m, rng_lim, 1e-6, 2, 30, reps=3, tag="dense")
+        max_dt = max_dr = 0.0
+        for b in range(S):
+            max_dt = max(max_dt, float(np.linalg.norm(T_out[b][:3, 3] - To[b][:3, 3])))
+            max_dr = max(max_dr, float(2 * np.arcsin(min(1.0, np.linalg.norm(T_out[b][:3, :3] - To[b][:3, :3]) / (2 * np.sqrt(2))))))
+        out["cpu_baseline"] = {"value": one["registrations_per_s"], "unit": "registrations/s", "cores": 1, "kind": "port",
+                               "sample": "first %d pairs of the dense batch, oracle/cpu_baseline.c pinned to one core, median of %d passes "
+                                         "(%.2f s per pass)" % (S, one["reps"], one["median_pass_s"]),
+                               "all_cores": {"value": omp["registrations_per_s"], "threads": omp["threads"]}}
+        out["parity"] = {"pairs_checked": S, "max_dt_m": max_dt, "max_drot_rad": max_dr, "tolerance": "1e-4 m / 1e-4 rad",
+                         "ok": bool(max_dt <= 1e-4 and max_dr <= 1e-4)}
+        out["speedup_vs_cpu_1thread"] = out["value"] / one["registrations_per_s"]
+    return out
+
+
 def _masked_stream(torch, dev, first_cu, n_cus, n_cu_dev):
     """A HIP stream whose kernels only run on CUs [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask)."""
     import ctypes as C
@@ -487,6 +559,8 @@ def main():
     ap.add_argument("--scans-per-node", type=int, default=10, help="--config 4: scans fused into every node map")
     ap.add_argument("--node-points", type=int, default=20000, help="--config 4: points per scan")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dense-pairs", type=int, default=384, help="pairs of the dense-scene leg (0 = skip it)")
+    ap.add_argument("--dense-cpu-sample", type=int, default=16, help="pairs of the dense-scene leg timed on the CPU")
     ap.add_argument("--buffers", type=int, default=3, help="pipeline depth (mapset pairs / streams)")
     ap.add_argument("--cu-split", type=int, default=0, help="CUs given to the build streams (hipExtStreamCreateWithCUMask), the "
                     "matcher streams get the rest; 0: every stream sees the whole chip")
@@ -799,9 +873,47 @@ def main():
             hs.build(both, range_limit=rng_lim)                                  # H2D of the raw scans + build (synchronous)
             N.match_batch(hs, np.arange(Bp), hs, np.arange(Bp) + Bp, Tp)         # H2D of poses, match, D2H of results
             best = min(best, time.perf_counter() - c0)
-        out["pcie_inclusive"] = {"value": Bp / best, "unit": "registrations/s", "pairs": Bp,
-                                 "note": "host (pageable) clouds in, host poses out through ndtgpu_mapset_build_host + "
-                                         "ndtgpu_match_batch: %.1f MB H2D per registration; never the headline value" % (2 * NP * 12 / 1e6)}
+        # the asynchronous form: batch after batch of host clouds on one stream -- ndtgpu_mapset_build_host_async returns when
+        # the host memory has been read, the registrations of batch k run on the device under the copies of batch k + 1;
+        # poses and results come back with one copy per batch at the end
+        hs2 = N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * Bp, max_cells=4096)
+        sets, n_batches = [hs, hs2], 6
+        pst = torch.cuda.Stream(device=dev)
+        idx_p = torch.arange(Bp, dtype=torch.int32, device=dev)
+        idx_ps = idx_p + Bp
+        Tp_cm = torch.as_tensor(np.ascontiguousarray(Tp.transpose(0, 2, 1)).reshape(Bp, 16), device=dev)
+        T_b = [Tp_cm.clone() for _ in range(n_batches)]
+        R_b = [torch.zeros((Bp, 64), dtype=torch.uint8, device=dev) for _ in range(n_batches)]
+        asy = {}
+        for mode in ("ring", "direct"):
+            os.environ["NDTGPU_HOST_PIPE"] = "1" if mode == "ring" else "0"
+            t_best = 1e9
+            for _ in range(2):
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                with torch.cuda.stream(pst):
+                    for k in range(n_batches):
+                        ms_k = sets[k % 2]
+                        ms_k.build(both, range_limit=rng_lim, stream=pst)        # host clouds, asynchronous form
+                        T_b[k].copy_(Tp_cm)
+                        binding.match_batch_device(ms_k, idx_p, ms_k, idx_ps, T_b[k], R_b[k], Bp, stream=pst)
+                    T_host = [t.cpu() for t in T_b]
+                pst.synchronize()
+                t_best = min(t_best, time.perf_counter() - c0)
+            asy[mode] = n_batches * Bp / t_best
+        os.environ.pop("NDTGPU_HOST_PIPE", None)
+        dT = float(np.abs(T_host[-1].numpy().reshape(Bp, 4, 4).transpose(0, 2, 1)[:, :3, 3] - T_out[:Bp, :3, 3]).max())
+        out["pcie_inclusive"] = {"value": max(asy.values()), "unit": "registrations/s", "pairs": Bp,
+                                 "synchronous_calls": Bp / best, "async_pinned_ring": asy["ring"], "async_one_copy": asy["direct"],
+                                 "max_dt_vs_device_path_m": dT,
+                                 "note": "host (pageable) clouds in, host poses out, %.1f MB H2D per registration; never the headline value. "
+                                         "value = %d batches of %d pairs through ndtgpu_mapset_build_host_async + "
+                                         "ndtgpu_match_batch_device on one stream (the copies of batch k + 1 run under the registrations "
+                                         "of batch k; async_pinned_ring: chunks through the library's pinned ring, async_one_copy: one "
+                                         "pageable copy per batch); synchronous_calls = one batch through the host-synchronous entries "
+                                         "ndtgpu_mapset_build_host + ndtgpu_match_batch, the reference's call shape" % (
+                                             2 * NP * 12 / 1e6, n_batches, Bp)}
+        del hs2
         del hs
     # ---- single-pair latency of the other single-GPU configs (outside the timed region; rank 0, N=1): oracle side ---
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -824,6 +936,13 @@ def main():
                       "cells": [int(r["n_target"]), int(r["n_source"])], "iterations": int(r["iterations"]), "dt_m": dt, "drot_rad": dr})
             lat[name] = g
         out["single_pair_latency"] = lat
+    # ---- the same configuration on a scene with ~2 k cells per map (SURVEY.md 8a/8d's size of a 2D map), labelled extra ----
+    if rank == 0 and world == 1 and args.dense_pairs > 0 and B == 1024 and NP == 100000:
+        for b in bufs:
+            b.maps.close()
+        del both, fixed, moving
+        torch.cuda.empty_cache()
+        out["dense_scene"] = dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, not args.no_cpu)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -134,6 +134,14 @@ ndtgpu_status ndtgpu_mapset_build_host(ndtgpu_mapset *set, size_t first, size_t 
                                        size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
                                        double range_limit, const double *range_origins,
                                        const ndtgpu_cell_params *cell);
+/* The same with an explicit stream: returns as soon as the caller's memory has been read (it may be reused); the maps are
+ * complete when `stream` is.  Both forms cut batches of >= 24 MB into chunks of clouds that travel through a ring of
+ * pinned slots filled by host threads: the copy of chunk k + 1 runs under the build of chunk k, and nothing waits for the
+ * whole device (the synchronous form waits for a stream of its own). */
+ndtgpu_status ndtgpu_mapset_build_host_async(ndtgpu_mapset *set, size_t first, size_t count, const void *xyz_host,
+                                             size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                             double range_limit, const double *range_origins,
+                                             const ndtgpu_cell_params *cell, ndtgpu_stream stream);
 
 /* NDTMap::numberOfActiveCells / getAllCells (fuser_hmt.cpp:234; ndtgraph_conversion.h:34-43):
  * Gaussian cells in slot order (x-major, y, z).  Synchronises the build stream.
@@ -183,6 +191,11 @@ ndtgpu_status ndtgpu_mapset_add_cloud(ndtgpu_mapset *set, size_t first, size_t c
 ndtgpu_status ndtgpu_mapset_add_cloud_host(ndtgpu_mapset *set, size_t first, size_t count, const void *xyz_host,
                                            size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
                                            const double *origins, const ndtgpu_fuse_params *prm);
+/* (asynchronous form of the host entry, like ndtgpu_mapset_build_host_async) */
+ndtgpu_status ndtgpu_mapset_add_cloud_host_async(ndtgpu_mapset *set, size_t first, size_t count, const void *xyz_host,
+                                                 size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                                 const double *origins, const ndtgpu_fuse_params *prm,
+                                                 ndtgpu_stream stream);
 /* a fresh NDTMap in slots [first, first+count): no Gaussians, occupancy 0 (a new graph node, graph.cpp:87-101) */
 ndtgpu_status ndtgpu_mapset_clear(ndtgpu_mapset *set, size_t first, size_t count);
 /* NDTCell::getOccupancy of every cell of one map, slot order (x-major, y, z): cells_per_axis[0]*[1]*[2] floats */

@@ -119,7 +119,8 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_add_cloud_host", "ndtgpu_mapset_clear", "ndtgpu_mapset_export_occupancy",
            "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch", "ndtgpu_mapset_discard_cells", "ndtgpu_mapset_import_occupancy",
            "ndtgpu_match_fusion_feat_batch", "ndtgpu_match_aborted", "ndtgpu_mapset_pack_bytes",
-           "ndtgpu_mapset_pack_cells_device", "ndtgpu_mapset_unpack_cells_device"]
+           "ndtgpu_mapset_pack_cells_device", "ndtgpu_mapset_unpack_cells_device", "ndtgpu_mapset_build_host_async",
+           "ndtgpu_mapset_add_cloud_host_async"]
 
 _lib = None
 
@@ -155,6 +156,8 @@ def lib():
                                       dp, C.POINTER(CellParams), vp]
     L.ndtgpu_mapset_build_host.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t,
                                            C.c_double, dp, C.POINTER(CellParams)]
+    L.ndtgpu_mapset_build_host_async.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                 C.c_double, dp, C.POINTER(CellParams), vp]
     L.ndtgpu_mapset_num_cells.argtypes = [vp, C.c_size_t, u32p]
     L.ndtgpu_mapset_export_cells.argtypes = [vp, C.c_size_t, dp, dp, i32p, u32p]
     L.ndtgpu_mapset_set_cells.argtypes = [vp, C.c_size_t, dp, dp, C.c_size_t]
@@ -173,6 +176,8 @@ def lib():
                                           C.POINTER(FuseParams), vp]
     L.ndtgpu_mapset_add_cloud_host.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, dp,
                                                C.POINTER(FuseParams)]
+    L.ndtgpu_mapset_add_cloud_host_async.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_size_t, dp,
+                                                     C.POINTER(FuseParams), vp]
     L.ndtgpu_mapset_clear.argtypes = [vp, C.c_size_t, C.c_size_t]
     L.ndtgpu_mapset_export_occupancy.argtypes = [vp, C.c_size_t, C.POINTER(C.c_float)]
     L.ndtgpu_overlap_score_batch.argtypes = [vp, u32p, vp, u32p, dp, C.c_size_t, dp, C.POINTER(C.c_int64), vp]
@@ -283,8 +288,12 @@ class MapSet:
                                              float(range_limit), rop, C.byref(cp), _stream_ptr(stream)))
         else:
             a = np.ascontiguousarray(xyz, dtype=np.float32)
-            _check(lib().ndtgpu_mapset_build_host(self.h, int(first), B, C.c_void_p(a.ctypes.data), N, 4 * W,
-                                                  4 * W * N, float(range_limit), rop, C.byref(cp)))
+            if stream is not None:      # asynchronous host form: returns when `a` has been read, the maps are ready when `stream` is
+                _check(lib().ndtgpu_mapset_build_host_async(self.h, int(first), B, C.c_void_p(a.ctypes.data), N, 4 * W,
+                                                            4 * W * N, float(range_limit), rop, C.byref(cp), _stream_ptr(stream)))
+            else:
+                _check(lib().ndtgpu_mapset_build_host(self.h, int(first), B, C.c_void_p(a.ctypes.data), N, 4 * W,
+                                                      4 * W * N, float(range_limit), rop, C.byref(cp)))
 
     def enable_occupancy(self):
         """NDTMap::initialize: every cell exists and carries an occupancy; needed by add_cloud / overlap_score."""

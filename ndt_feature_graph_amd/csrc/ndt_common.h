@@ -52,6 +52,8 @@ struct NdtGrid {               // geometry shared by all maps of a set
     int size[3];               // cells per axis
     int slots;                 // size[0]*size[1]*size[2]
     uint32_t max_cells;
+    double half[3];            // size / 2.0 per axis, the addend of LazyGrid's index formula: made on the host so that
+                               // kernels find it in scalar registers (kernel arguments), not behind an int -> fp64 conversion
 };
 
 #define NDT_RANK_SEGS 32       // at most this many workgroups rank one map (ndt_build_kernel MODE 3)

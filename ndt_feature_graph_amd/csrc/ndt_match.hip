@@ -54,7 +54,17 @@ struct MapView {
     int n_cells;
     int sx, sy, sz;
     double cx, cy, cz, res;
+    double hx, hy, hz;          // size / 2.0 per axis (the addend of LazyGrid's index formula)
 };
+
+// lazygrid_index with size / 2.0 handed in (a value the large-map kernels keep in scalar registers)
+NDT_D int lazygrid_index_h(double p, double centre, double res, double half)
+{
+#pragma clang fp contract(off)
+    double v = floor((p - centre) / res + 0.5) + half;
+    if (!(v > -2.0e9 && v < 2.0e9)) return -1;
+    return (int)v;
+}
 
 NDT_D MapView map_view(const NdtSetView &s, unsigned map)
 {
@@ -65,6 +75,27 @@ NDT_D MapView map_view(const NdtSetView &s, unsigned map)
     v.sx = s.grid.size[0]; v.sy = s.grid.size[1]; v.sz = s.grid.size[2];
     v.cx = s.centres[map * 3]; v.cy = s.centres[map * 3 + 1]; v.cz = s.centres[map * 3 + 2];
     v.res = s.grid.res;
+    v.hx = s.grid.half[0]; v.hy = s.grid.half[1]; v.hz = s.grid.half[2];
+    return v;
+}
+
+// The same for a wave-uniform map index (the large-map kernels: one registration per workgroup / task): the grid
+// geometry moves to SCALAR registers.  The centres arrive through vector loads, and as vector registers they were what
+// the <2> variants of those kernels spilled (14 / 26 registers, profiles/r03_kernel_resources.txt).
+NDT_D double uniform_d(double v)
+{
+    // (v_readfirstlane in an asm statement, not the builtin: the optimiser folds the builtin away when it can prove its
+    //  operand uniform -- and then keeps the value in the vector register it was computed in)
+    int lo, hi;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"(__double2loint(v)));
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"(__double2hiint(v)));
+    return __hiloint2double(hi, lo);
+}
+NDT_D MapView map_view_uniform(const NdtSetView &s, unsigned map)
+{
+    MapView v = map_view(s, (unsigned)__builtin_amdgcn_readfirstlane((int)map));
+    v.n_cells = __builtin_amdgcn_readfirstlane(v.n_cells);
+    v.cx = uniform_d(v.cx); v.cy = uniform_d(v.cy); v.cz = uniform_d(v.cz);
     return v;
 }
 
@@ -391,9 +422,9 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
         w.mysrc[0 * 64 + lane] = m.x; w.mysrc[1 * 64 + lane] = m.y; w.mysrc[2 * 64 + lane] = m.z;
         w.mysrc[3 * 64 + lane] = C.xx; w.mysrc[4 * 64 + lane] = C.xy; w.mysrc[5 * 64 + lane] = C.xz;
         w.mysrc[6 * 64 + lane] = C.yy; w.mysrc[7 * 64 + lane] = C.yz; w.mysrc[8 * 64 + lane] = C.zz;
-        ix = lazygrid_index(m.x, tg.cx, tg.res, tg.sx);   // getCellsForPoint(mean, n_neighbours)
-        iy = lazygrid_index(m.y, tg.cy, tg.res, tg.sy);
-        iz = lazygrid_index(m.z, tg.cz, tg.res, tg.sz);
+        ix = lazygrid_index_h(m.x, tg.cx, tg.res, tg.hx);   // getCellsForPoint(mean, n_neighbours)
+        iy = lazygrid_index_h(m.y, tg.cy, tg.res, tg.hy);
+        iz = lazygrid_index_h(m.z, tg.cz, tg.res, tg.hz);
     }
     NDT_PROF_T(0)
     const HitCache hc = *w.cache;
@@ -1555,8 +1586,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         }
         return;
     }
-    const MapView tg = map_view(tset, ti);
-    const MapView sv = map_view(sset, si);
+    const MapView tg = map_view_uniform(tset, ti);
+    const MapView sv = map_view_uniform(sset, si);
     // The source cells are cut into NC CHUNKS of (about) cells_per_group cells -- a property of the map alone -- and every
     // chunk has its own row of partial sums; the rows are added in chunk order.  The G workgroups that the grid has for
     // this registration deal the chunks among themselves (workgroup g: chunks g, g + G, ...): one chunk each when a
@@ -1953,8 +1984,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
             const unsigned pair = s_task[0], task = s_task[1];
             const bool with_h = s_task[2] != 0u;
             double *rows = rows_of(pair);
-            const MapView tg = map_view(tset, tidx[pair]);
-            const MapView sv = map_view(sset, sidx[pair]);
+            const MapView tg = map_view_uniform(tset, tidx[pair]);
+            const MapView sv = map_view_uniform(sset, sidx[pair]);
             const unsigned NC = s_task[6], CH = s_task[7];
             const int per = (int)s_task[8];
             const rigid Te = s_T;

@@ -11,7 +11,10 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <atomic>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -135,9 +138,38 @@ struct ndtgpu_mapset {
         pin_bytes = bytes;
         return NDTGPU_OK;
     }
+    // Host clouds (the reference's call sites hand over pcl::PointCloud on the host): a ring of pinned slots that host
+    // threads fill from the caller's pageable memory while earlier slots travel to the device and earlier chunks of
+    // maps are being built (stage_host_clouds below).  The copies run on a stream of their own.
+    static constexpr int HOST_SLOTS = 6;
+    static constexpr size_t HOST_SLOT_BYTES = 16u << 20;
+    void *host_ring[HOST_SLOTS] = {};
+    hipEvent_t host_ev[HOST_SLOTS] = {};
+    bool host_ev_used[HOST_SLOTS] = {};
+    hipStream_t host_copy_stream = nullptr;
+    hipStream_t host_build_stream = nullptr;  // the synchronous host-cloud entries build on a stream of their own (no device-wide wait)
+    ndtgpu_status ensure_host_build_stream()
+    {
+        if (!host_build_stream) HIP_TRY(hipStreamCreateWithFlags(&host_build_stream, hipStreamNonBlocking));
+        return NDTGPU_OK;
+    }
+    hipEvent_t stage_free_ev = nullptr;      // recorded after the last kernel that reads the staged clouds
+    bool stage_free_valid = false;
+    ndtgpu_status ensure_host_ring()
+    {
+        if (host_copy_stream) return NDTGPU_OK;
+        for (int k = 0; k < HOST_SLOTS; k++) {
+            HIP_TRY(hipHostMalloc(&host_ring[k], HOST_SLOT_BYTES, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&host_ev[k], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&stage_free_ev, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&host_copy_stream, hipStreamNonBlocking));
+        return NDTGPU_OK;
+    }
     ndtgpu_status ensure_stage(size_t bytes)
     {
         if (bytes <= stage_bytes) return NDTGPU_OK;
+        if (stage_free_valid) { HIP_TRY(hipEventSynchronize(stage_free_ev)); stage_free_valid = false; }
         if (stage) (void)hipFree(stage);
         stage = nullptr;
         stage_bytes = 0;
@@ -208,6 +240,7 @@ ndtgpu_status ndtgpu_mapset_create(const ndtgpu_grid_params *grid, size_t n_maps
     }
     if (slots > (1ll << 30)) { delete s; return fail(NDTGPU_ERR_INVALID, "mapset_create: grid too large"); }
     g.slots = (int)slots;
+    for (int a = 0; a < 3; a++) g.half[a] = g.size[a] / 2.0;
     uint32_t cap = grid->max_cells ? grid->max_cells : (uint32_t)std::min<long long>(slots, 16384);
     if (cap > (1u << 24) - 1) cap = (1u << 24) - 1;
     g.max_cells = cap;
@@ -252,6 +285,13 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (!s) return NDTGPU_OK;
     (void)hipDeviceSynchronize();
     if (s->pin) (void)hipHostFree(s->pin);
+    for (int k = 0; k < ndtgpu_mapset::HOST_SLOTS; k++) {
+        if (s->host_ring[k]) (void)hipHostFree(s->host_ring[k]);
+        if (s->host_ev[k]) (void)hipEventDestroy(s->host_ev[k]);
+    }
+    if (s->stage_free_ev) (void)hipEventDestroy(s->stage_free_ev);
+    if (s->host_copy_stream) (void)hipStreamDestroy(s->host_copy_stream);
+    if (s->host_build_stream) (void)hipStreamDestroy(s->host_build_stream);
     if (s->v.rankmap) (void)hipFree(s->v.rankmap);
     if (s->v.wtable) (void)hipFree(s->v.wtable);
     if (s->v.bitmap) (void)hipFree(s->v.bitmap);
@@ -345,20 +385,117 @@ ndtgpu_status ndtgpu_last_kernel_ms(ndtgpu_mapset *s, int which, float *ms)
     return NDTGPU_OK;
 }
 
+// Host clouds -> device staging area -> per-chunk kernel launches.  `count` clouds of n_points records, map_stride bytes
+// apart, are cut into chunks of whole clouds that fit a pinned slot (16 MB); worker threads copy chunk after chunk from the
+// caller's (pageable) memory into the ring of pinned slots, the calling thread sends every filled slot to the device on the
+// copy stream and launches `launch(first_cloud, n_clouds, device pointer)` on `st` behind that copy: the copy of chunk
+// k + 1 runs under the kernels of chunk k, nothing waits for the whole device.  Returns when the caller's memory has been
+// read completely (the kernels may still be running on `st`).  Small inputs (< 24 MB) skip the ring: one ordinary copy.
+static ndtgpu_status stage_host_clouds(ndtgpu_mapset *s, const void *xyz_host, size_t count, size_t n_points, size_t stride_bytes,
+                                       size_t map_stride_bytes, hipStream_t st,
+                                       const std::function<ndtgpu_status(size_t, size_t, const void *)> &launch)
+{
+    if (count == 0) return NDTGPU_OK;
+    const size_t cloud_bytes = n_points * stride_bytes;
+    size_t bytes = (count - 1) * map_stride_bytes + cloud_bytes;
+    if (bytes == 0) bytes = 16;
+    ndtgpu_status rc = s->ensure_stage(bytes);
+    if (rc != NDTGPU_OK) return rc;
+    // the staging area may still be read by the kernels of the previous call (another stream): order behind them
+    if (s->stage_free_valid) HIP_TRY(hipStreamWaitEvent(st, s->stage_free_ev, 0));
+    const size_t slot = ndtgpu_mapset::HOST_SLOT_BYTES;
+    const char *force = getenv("NDTGPU_HOST_PIPE");            // 0: never the ring, 1: always (tests)
+    const bool ring = n_points && map_stride_bytes <= slot && cloud_bytes <= slot &&
+                      (force ? atoi(force) != 0 : bytes >= (24u << 20));
+    if (!ring) {
+        if (n_points) HIP_TRY(hipMemcpyAsync(s->stage, xyz_host, bytes, hipMemcpyHostToDevice, st));   // (pageable: returns when read)
+        rc = launch(0, count, s->stage);
+    } else {
+        rc = s->ensure_host_ring();
+        if (rc != NDTGPU_OK) return rc;
+        if (s->stage_free_valid) HIP_TRY(hipStreamWaitEvent(s->host_copy_stream, s->stage_free_ev, 0));
+        const size_t per = std::max<size_t>(1, std::min(count, slot / map_stride_bytes));      // clouds per chunk
+        const size_t n_chunks = (count + per - 1) / per;
+        constexpr int R = ndtgpu_mapset::HOST_SLOTS;
+        const int n_workers = (int)std::min<size_t>(4, n_chunks);
+        std::vector<std::atomic<int>> staged(n_chunks);
+        for (auto &a : staged) a.store(0, std::memory_order_relaxed);
+        std::atomic<long> allowed((long)std::min<size_t>(n_chunks, R));     // chunks < allowed may be written into their slots
+        std::atomic<int> stop(0);
+        auto chunk_bytes = [&](size_t c) {
+            const size_t c0 = c * per, cnt = std::min(per, count - c0);
+            return (cnt - 1) * map_stride_bytes + cloud_bytes;
+        };
+        // a slot that an earlier CALL sent off may still be in flight
+        for (int k = 0; k < R; k++)
+            if (s->host_ev_used[k]) { HIP_TRY(hipEventSynchronize(s->host_ev[k])); s->host_ev_used[k] = false; }
+        std::vector<std::thread> workers;
+        for (int w = 0; w < n_workers; w++)
+            workers.emplace_back([&, w]() {
+                for (size_t c = (size_t)w; c < n_chunks && !stop.load(std::memory_order_relaxed); c += (size_t)n_workers) {
+                    while ((long)c >= allowed.load(std::memory_order_acquire) && !stop.load(std::memory_order_relaxed)) std::this_thread::yield();
+                    if (stop.load(std::memory_order_relaxed)) break;
+                    memcpy(s->host_ring[c % R], (const char *)xyz_host + c * per * map_stride_bytes, chunk_bytes(c));
+                    staged[c].store(1, std::memory_order_release);
+                }
+            });
+        hipError_t herr = hipSuccess;
+        ndtgpu_status lrc = NDTGPU_OK;
+        for (size_t c = 0; c < n_chunks && herr == hipSuccess && lrc == NDTGPU_OK; c++) {
+            while (!staged[c].load(std::memory_order_acquire)) std::this_thread::yield();
+            const int k = (int)(c % R);
+            char *dst = (char *)s->stage + c * per * map_stride_bytes;
+            herr = hipMemcpyAsync(dst, s->host_ring[k], chunk_bytes(c), hipMemcpyHostToDevice, s->host_copy_stream);
+            if (herr == hipSuccess) herr = hipEventRecord(s->host_ev[k], s->host_copy_stream);
+            if (herr == hipSuccess) { s->host_ev_used[k] = true; herr = hipStreamWaitEvent(st, s->host_ev[k], 0); }
+            if (herr == hipSuccess) lrc = launch(c * per, std::min(per, count - c * per), dst);
+            // chunk c + R will reuse this slot: it may be written once this copy has left the host.  (The calling thread
+            // waits here while the workers fill the other slots and the device builds chunk c under the next copies.)
+            if (c + R < n_chunks && herr == hipSuccess) {
+                herr = hipEventSynchronize(s->host_ev[k]);
+                s->host_ev_used[k] = false;
+                allowed.store((long)(c + R) + 1, std::memory_order_release);
+            }
+        }
+        if (herr != hipSuccess || lrc != NDTGPU_OK) stop.store(1);
+        for (auto &t : workers) t.join();
+        if (herr != hipSuccess) return fail(NDTGPU_ERR_HIP, "host clouds: staging copy", herr);
+        rc = lrc;
+    }
+    if (rc != NDTGPU_OK) return rc;
+    if (!s->stage_free_ev) HIP_TRY(hipEventCreateWithFlags(&s->stage_free_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s->stage_free_ev, st));
+    s->stage_free_valid = true;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_build_host_async(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,
+                                             size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                             double range_limit, const double *range_origins, const ndtgpu_cell_params *cell,
+                                             ndtgpu_stream stream)
+{
+    if (!s || (!xyz_host && n_points) || count == 0 || first + count > s->n_maps)
+        return fail(NDTGPU_ERR_INVALID, "mapset_build_host: bad argument");
+    return stage_host_clouds(s, xyz_host, count, n_points, stride_bytes, map_stride_bytes, (hipStream_t)stream,
+                             [&](size_t c0, size_t cnt, const void *dev) {
+                                 return ndtgpu_mapset_build(s, first + c0, cnt, dev, n_points, stride_bytes, map_stride_bytes,
+                                                            range_limit, range_origins ? range_origins + 3 * c0 : nullptr, cell,
+                                                            stream);
+                             });
+}
+
 ndtgpu_status ndtgpu_mapset_build_host(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,
                                        size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
                                        double range_limit, const double *range_origins, const ndtgpu_cell_params *cell)
 {
-    if (!s || (!xyz_host && n_points) || count == 0) return fail(NDTGPU_ERR_INVALID, "mapset_build_host: bad argument");
-    size_t bytes = (count - 1) * map_stride_bytes + n_points * stride_bytes;
-    if (bytes == 0) bytes = 16;
-    ndtgpu_status rc = s->ensure_stage(bytes);
+    if (!s) return fail(NDTGPU_ERR_INVALID, "mapset_build_host: bad argument");
+    ndtgpu_status rc = s->ensure_host_build_stream();
     if (rc != NDTGPU_OK) return rc;
-    if (n_points) HIP_TRY(hipMemcpy(s->stage, xyz_host, bytes, hipMemcpyHostToDevice));
-    rc = ndtgpu_mapset_build(s, first, count, s->stage, n_points, stride_bytes, map_stride_bytes, range_limit,
-                             range_origins, cell, nullptr);
+    HIP_TRY(hipStreamSynchronize(s->last_stream));             // (earlier work on these maps, whatever stream it used)
+    rc = ndtgpu_mapset_build_host_async(s, first, count, xyz_host, n_points, stride_bytes, map_stride_bytes, range_limit,
+                                        range_origins, cell, (ndtgpu_stream)s->host_build_stream);
     if (rc != NDTGPU_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipStreamSynchronize(s->host_build_stream));       // the stream the maps were built on: no device-wide wait
     return NDTGPU_OK;
 }
 
@@ -591,19 +728,31 @@ ndtgpu_status ndtgpu_mapset_add_cloud(ndtgpu_mapset *s, size_t first, size_t cou
     return s->origins_used(st);
 }
 
+ndtgpu_status ndtgpu_mapset_add_cloud_host_async(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,
+                                                 size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                                 const double *origins, const ndtgpu_fuse_params *prm, ndtgpu_stream stream)
+{
+    if (!s || (!xyz_host && n_points) || count == 0 || first + count > s->n_maps || !origins)
+        return fail(NDTGPU_ERR_INVALID, "add_cloud_host: bad argument");
+    return stage_host_clouds(s, xyz_host, count, n_points, stride_bytes, map_stride_bytes, (hipStream_t)stream,
+                             [&](size_t c0, size_t cnt, const void *dev) {
+                                 return ndtgpu_mapset_add_cloud(s, first + c0, cnt, dev, n_points, stride_bytes, map_stride_bytes,
+                                                                origins + 3 * c0, prm, stream);
+                             });
+}
+
 ndtgpu_status ndtgpu_mapset_add_cloud_host(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,
                                            size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
                                            const double *origins, const ndtgpu_fuse_params *prm)
 {
-    if (!s || (!xyz_host && n_points) || count == 0) return fail(NDTGPU_ERR_INVALID, "add_cloud_host: bad argument");
-    size_t bytes = (count - 1) * map_stride_bytes + n_points * stride_bytes;
-    if (bytes == 0) bytes = 16;
-    ndtgpu_status rc = s->ensure_stage(bytes);
+    if (!s) return fail(NDTGPU_ERR_INVALID, "add_cloud_host: bad argument");
+    ndtgpu_status rc = s->ensure_host_build_stream();
     if (rc != NDTGPU_OK) return rc;
-    if (n_points) HIP_TRY(hipMemcpy(s->stage, xyz_host, bytes, hipMemcpyHostToDevice));
-    rc = ndtgpu_mapset_add_cloud(s, first, count, s->stage, n_points, stride_bytes, map_stride_bytes, origins, prm, nullptr);
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    rc = ndtgpu_mapset_add_cloud_host_async(s, first, count, xyz_host, n_points, stride_bytes, map_stride_bytes, origins, prm,
+                                            (ndtgpu_stream)s->host_build_stream);
     if (rc != NDTGPU_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipStreamSynchronize(s->host_build_stream));
     return NDTGPU_OK;
 }
 

@@ -58,21 +58,32 @@ def hash_normal(seed, stream, idx):
 # ----------------------------------------------------------------------------------------
 
 N_BOXES_2D = 6
+# The "dense" scene (SURVEY.md 8a/8d sizes a 2D map at M ~ 1-3 k Gaussian cells; the plain room above yields ~370): the
+# same hall with three thousand thin posts (rack legs, stanchions: 2-4 cm) -- thin enough that most of them stay visible from
+# the sensor, each one a cell or two of its own.
+N_BOXES_2D_DENSE = 3000
 
 
-def room_2d(seeds):
-    """Scene per seed: outer half extents [B,2] and boxes [B,K,4] = (cx, cy, hx, hy)."""
+def room_2d(seeds, scene="room"):
+    """Scene per seed: outer half extents [B,2] and boxes [B,K,4] = (cx, cy, hx, hy).  scene "room": 6 boxes of
+    1-5 m; "dense": 3000 posts of 2-4 cm in the same room."""
     seeds = torch.as_tensor(seeds, dtype=torch.int64)
     dev = seeds.device
     B = seeds.shape[0]
-    k = torch.arange(N_BOXES_2D, dtype=torch.int64, device=dev)[None, :].expand(B, -1)
+    dense = scene == "dense"
+    n_boxes = N_BOXES_2D_DENSE if dense else N_BOXES_2D
+    k = torch.arange(n_boxes, dtype=torch.int64, device=dev)[None, :].expand(B, -1)
     s = seeds[:, None]
     two = torch.arange(2, dtype=torch.int64, device=dev)[None, :]
     half = 12.0 + 12.0 * hash_uniform(s, 11, two)                              # [B,2] in [12,24)
     cx = (2.0 * hash_uniform(s, 21, k) - 1.0) * (half[:, 0:1] - 3.0)
     cy = (2.0 * hash_uniform(s, 22, k) - 1.0) * (half[:, 1:2] - 3.0)
-    hx = 0.5 + 2.0 * hash_uniform(s, 23, k)
-    hy = 0.5 + 2.0 * hash_uniform(s, 24, k)
+    if dense:
+        hx = 0.01 + 0.01 * hash_uniform(s, 23, k)
+        hy = 0.01 + 0.01 * hash_uniform(s, 24, k)
+    else:
+        hx = 0.5 + 2.0 * hash_uniform(s, 23, k)
+        hy = 0.5 + 2.0 * hash_uniform(s, 24, k)
     # keep a free area around the sensor poses (|x|,|y| < ~2): push close boxes outwards
     close = (cx.abs() < 4.5 + hx) & (cy.abs() < 4.5 + hy)
     cx = torch.where(close, torch.where(cx >= 0, cx + 7.0, cx - 7.0), cx)
@@ -80,7 +91,7 @@ def room_2d(seeds):
 
 
 def scan_2d(seeds, poses, n_points, noise_sigma=0.03, z_jitter=0.02, r_max=30.0, r_min=0.5,
-            noise_stream=0, chunk_bytes=256 << 20):
+            noise_stream=0, chunk_bytes=256 << 20, scene="room"):
     """Laser scans of room_2d(seed) from sensor poses (x, y, yaw) -> float32 [B, n_points, 3].
 
     Beams uniform over 2*pi in the sensor frame; range noise N(0, sigma^2)
@@ -92,9 +103,9 @@ def scan_2d(seeds, poses, n_points, noise_sigma=0.03, z_jitter=0.02, r_max=30.0,
     dev = seeds.device
     poses = torch.as_tensor(poses, dtype=torch.float64, device=dev)
     B = seeds.shape[0]
-    half, boxes = room_2d(seeds)
+    half, boxes = room_2d(seeds, scene)
     out = torch.empty((B, n_points, 3), dtype=torch.float32, device=dev)
-    nseg = 4 * (1 + N_BOXES_2D)
+    nseg = 4 * (1 + boxes.shape[1])
     per_scan = n_points * nseg * 8 * 6
     bchunk = max(1, int(chunk_bytes // max(per_scan, 1)))
     idx = torch.arange(n_points, dtype=torch.int64, device=dev)

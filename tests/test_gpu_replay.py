@@ -222,3 +222,51 @@ def test_pack_flags_a_map_that_does_not_fit(N):
     Ta, ra = N.match_batch(ms, [0], ms, [1], pr["T_init"].numpy()[:1])
     Tb, rb = N.match_batch(dst, [0], dst, [1], pr["T_init"].numpy()[:1])
     assert np.array_equal(Ta, Tb) and ra["iterations"][0] == rb["iterations"][0]
+
+
+def test_host_clouds_through_the_pinned_ring(N, monkeypatch):
+    """ndtgpu_mapset_build_host / _add_cloud_host on a batch large enough for the chunked path (pinned ring, worker
+    threads, the copy of chunk k + 1 under the build of chunk k; more chunks than ring slots): the same maps as the
+    one-copy path and as the device-pointer path (cell sets and point counts exact, moments to rounding: the chunks are
+    cut into other launch shapes), also through the asynchronous form on a caller's stream."""
+    import torch
+    from ndt_feature_graph_amd import synth
+    dev = torch.device("cuda", 0)
+    B, n_pts = 104, 100000                                 # 125 MB: 8 chunks of 13 clouds through 6 slots
+    pr = synth.pair_2d(torch.arange(1, B // 2 + 1, device=dev), n_pts, device=dev)
+    scans_d = torch.cat([pr["fixed"], pr["moving"]]).contiguous()
+    scans = scans_d.cpu().numpy()
+
+    def cells(ms):
+        return [ms.export_cells(k) for k in (0, 12, 13, 51, 103)]
+
+    ref = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=B, max_cells=4096)
+    ref.build(scans_d, range_limit=30.0)
+    want = cells(ref)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NDTGPU_HOST_PIPE", mode)
+        ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=B, max_cells=4096)
+        ms.build(scans, range_limit=30.0)                  # synchronous host form
+        ms.build(scans, range_limit=30.0)                  # again: the ring and the staging area are reused
+        st = torch.cuda.Stream(device=dev)
+        ms2 = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=B, max_cells=4096)
+        ms2.build(scans, range_limit=30.0, stream=st)      # asynchronous host form
+        st.synchronize()
+        for got in (cells(ms), cells(ms2)):
+            for a, b in zip(got, want):
+                assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+                assert np.max(np.abs(a[0] - b[0])) < 1e-12 and np.max(np.abs(a[1] - b[1])) < 1e-12
+        assert np.array_equal(ms.num_cells_all(), ref.num_cells_all())
+    # fused node maps from host clouds, chunked against one copy
+    org = np.zeros((B, 3))
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NDTGPU_HOST_PIPE", mode)
+        ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=B, max_cells=4096)
+        ms.enable_occupancy()
+        ms.add_cloud(scans, org, maxz=100.0, sensor_noise=0.1)
+        ms.add_cloud(scans, org)
+        outs.append((cells(ms), ms.occupancy(51)))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.max(np.abs(a[1] - b[1])) < 1e-12
+    assert np.array_equal(outs[0][1], outs[1][1])
