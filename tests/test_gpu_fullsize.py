@@ -275,3 +275,55 @@ def test_3dof_matcher_on_non_converging_pairs(N, O):
         stuck += pose_close(T[b], pr["T_gt"][b].numpy())[0] > 0.05
     assert stuck >= 1, "expected pairs on which the 3-DoF matcher does not reach the optimum (DESIGN.md section 7)"
     assert diverged <= B // 3
+
+
+def test_task_pool_32_pairs_of_full_size_3d_maps(N, O, monkeypatch):
+    """configs[4] as a BATCH: 32 pairs of 200 k-point sweeps (12 k cells per map, 0.25 m voxels, 400 x 400 x 40 slots)
+    through ndtgpu_match_batch_device -- more than 8 registrations of large maps, i.e. the task pool
+    (ndt_match_pool_kernel<2>: any workgroup serves any (registration, evaluation, chunk) task).  Five sampled pairs,
+    among them the one with the most evaluations, against the CPU oracle: identical cell sets and point counts, pose,
+    iterations; all 32 against the persistent kernel (one CU per registration); a second run gives the same bits."""
+    import torch
+    from ndt_feature_graph_amd import binding, synth
+    dev = torch.device("cuda", 0)
+    n = 32
+    pr = synth.pair_3d(torch.arange(1, n + 1, device=dev), device=dev)
+    sweeps = torch.cat([pr["fixed"], pr["moving"]]).contiguous()
+    res, size, rng = 0.25, [100.0, 100.0, 10.0], 70.0
+    ms = N.MapSet(res, [0, 0, 0], size, n_maps=2 * n, max_cells=120000)
+    ms.build(sweeps, range_limit=rng)
+    T0 = pr["T_init"].transpose(1, 2).contiguous().reshape(n, 16)
+    ti = torch.arange(n, dtype=torch.int32, device=dev)
+    si = ti + n
+    runs = {}
+    for tag, env in (("pool", {}), ("pool2", {}), ("persistent", {"NDTGPU_DEVICE_COOP": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        T16 = T0.clone()
+        out = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+        binding.match_batch_device(ms, ti, ms, si, T16, out, n, stream=torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        runs[tag] = (T16.cpu().numpy().reshape(n, 4, 4).transpose(0, 2, 1).copy(),
+                     out.cpu().numpy().view(binding.RESULT_DTYPE).reshape(n).copy())
+        for k in env:
+            monkeypatch.delenv(k)
+    T, r = runs["pool"]
+    assert np.all(r["exit_code"] >= 0) and r["converged"].mean() > 0.9
+    assert np.array_equal(T, runs["pool2"][0]) and all(np.array_equal(r[f], runs["pool2"][1][f]) for f in DET_FIELDS)
+    Tp, rp = runs["persistent"]
+    assert np.max(np.abs(T - Tp)) < 1e-7 and np.array_equal(r["iterations"], rp["iterations"])      # another summation order
+    longest = int(np.argmax(r["fevals"]))
+    sample = sorted({longest, 0, 7, 19, int(np.argmin(r["fevals"]))})
+    assert len(sample) >= 4
+    cells = ms.num_cells_all()
+    assert cells.min() > 8000
+    for k in sample:
+        fx, mv = sweeps[k].cpu().numpy(), sweeps[n + k].cpu().numpy()
+        a, b = oracle_map(O, fx, res, size, rng), oracle_map(O, mv, res, size, rng)
+        for m, om in ((k, a), (n + k, b)):
+            g, o = ms.export_cells(m), om.export_cells()
+            assert np.array_equal(g[2], o[2]) and np.array_equal(g[3], o[3]), (k, m)              # cell sets, point counts: exact
+        To, ro = O.match_d2d(a, b, pr["T_init"][k].cpu().numpy())
+        dt, dr = pose_close(T[k], To)
+        assert dt <= 1e-6 and dr <= 1e-6, (k, dt, dr)
+        assert r["iterations"][k] == ro["iterations"] and bool(r["converged"][k]) == ro["converged"], k
