@@ -31,6 +31,7 @@
 #include "ndt_math.h"
 #include "ndt_binning.h"
 #include "ndt_wave.h"
+#include <algorithm>
 
 #define NDT_FLAT_THREADS 256
 #define NDT_FLAT_WAVES (NDT_FLAT_THREADS / 64)
@@ -43,6 +44,12 @@
 #ifndef NDT_FLAT_SINGLE
 #define NDT_FLAT_SINGLE 1         // 1: a batch is loaded, awaited, worked on (the other waves of the SIMD cover the wait); 0: double buffer
 #endif
+#ifndef NDT_FLAT_LDSRED
+#define NDT_FLAT_LDSRED 0         // 1: a run's moments are summed over the wave through LDS (below: 14 additions instead of 57
+                                  // instructions, but three dependent LDS round trips -- measured 1.07 against 1.03 ms per 2048
+                                  // scans, the exact path is latency bound); 0: in registers (butterfly)
+#endif
+#define NDT_FLAT_RED_DOUBLES (9 * 64)   // LDS scratch of one wave's sum: nine moments x 64 lanes
 #define NDT_FLAT_LIST 16         // records in a wave's flush list
 #define NDT_FLAT_IDBITS 13       // hash entry = (slot + 1) << 13 | accumulator id
 
@@ -118,8 +125,11 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
     const uint32_t cap = g.max_cells;
     const unsigned bm_words = (unsigned)((g.slots + 31) >> 5);
     const unsigned hash_entries = 1u << hash_log2, hash_mask = hash_entries - 1u, hash_shift = 32u - hash_log2;
+    // region 0: the waves' reduction scratch during phase A (NDT_FLAT_LDSRED), the Gaussian-cell bitmap from phase B on
+    const unsigned region0_words = NDT_FLAT_LDSRED ? max(bm_words, (unsigned)(NDT_FLAT_WAVES * NDT_FLAT_RED_DOUBLES * 2)) : bm_words;
     unsigned *s_bits = s_dyn;                      // [bm_words]   Gaussian-cell bit per slot (phase B on)
-    unsigned *s_hash = s_bits + bm_words;          // [hash_entries] (slot + 1) << 13 | id; compacted per wave after phase A
+    double *s_red = reinterpret_cast<double *>(s_dyn);   // [waves][9][64] (phase A)
+    unsigned *s_hash = s_dyn + region0_words;      // [hash_entries] (slot + 1) << 13 | id; compacted per wave after phase A
 
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     NdtCell *cells = set.cells + (size_t)map * cap;
@@ -132,7 +142,7 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
     if (range_origins) { ox = range_origins[map_local * 3]; oy = range_origins[map_local * 3 + 1]; oz = range_origins[map_local * 3 + 2]; }
     const char *pts = xyz + (size_t)map_local * map_stride_bytes;
 
-    for (unsigned i = tid; i < bm_words + hash_entries; i += NDT_FLAT_THREADS) s_dyn[i] = 0u;
+    for (unsigned i = tid; i < hash_entries; i += NDT_FLAT_THREADS) s_hash[i] = 0u;
     if (tid == 0) { s_nalloc = 0u; s_binned = 0u; s_ovf = 0u; }
     __syncthreads();
 
@@ -152,7 +162,14 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
         const float lim_in = uniform_f(res32 * (0.5f - 4e-6f));   // |p - centre| below this on every axis: in the cell, exactly
         const float r2safe = uniform_f(range_limit > 0 ? (float)(range_limit * range_limit) * (1.0f - 2e-3f) : __builtin_inff());
         // which moment of a flushed run this lane hands to the list, and its scale to fixed point
+#if NDT_FLAT_LDSRED
+        // (lanes 0..8 end up with the totals of moments 0..8)
+        const int my_moment = lane < 9u ? (int)lane : -1;
+        double *red = s_red + wave * NDT_FLAT_RED_DOUBLES;
+        const unsigned red_v = lane / 7u, red_s = lane - red_v * 7u;          // stage 2: lane (v, s) sums 9 lanes' values of moment v
+#else
         const int my_moment = ndt_moment_of_lane(lane);
+#endif
         const double my_scale = my_moment < 3 ? ldexp(inv_res, s1_shift) : ldexp(inv_res * inv_res, s2_shift);
 
         long long *lval = s_lval + wave * (NDT_FLAT_LIST * 10);
@@ -190,12 +207,41 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
             NDT_FLAT_STAT(2);
 #if defined(NDT_FLAT_ABL) && NDT_FLAT_ABL == 1
             const double t = sd[0] + se[5];      // (ablation: no sum over the wave -- wrong results, timing only)
+#elif NDT_FLAT_LDSRED
+            // Sum over the 64 lanes through LDS, in a fixed order: every lane stores its nine values (moment-major: no
+            // bank conflict), 63 lanes add nine neighbours each (the last segment ten), nine lanes add the seven segment
+            // sums.  14 additions in the vector ALU instead of the 57 instructions of the register butterfly
+            // (csrc/ndt_wave.h), and three LDS round trips instead of its six dependent levels.
+#pragma unroll
+            for (int k = 0; k < 3; k++) red[k * 64 + lane] = sd[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) red[(3 + k) * 64 + lane] = se[k];
+            ndt_wave_sync();
+            double part = 0.0;
+            if (lane < 63u) {
+                const double *seg = red + red_v * 64u + red_s * 9u;
+                part = seg[0];
+#pragma unroll
+                for (int i = 1; i < 9; i++) part += seg[i];
+                if (red_s == 6u) part += seg[9];                       // (lane 63's value: the last segment has ten)
+            }
+            ndt_wave_sync();                                           // everybody has read: the area is reused
+            if (lane < 63u) red[lane] = part;
+            ndt_wave_sync();
+            double t = 0.0;
+            if (lane < 9u) {
+                const double *q = red + lane * 7u;
+                t = q[0];
+#pragma unroll
+                for (int i = 1; i < 7; i++) t += q[i];
+            }
+            ndt_wave_sync();
 #else
             const double t = wave_sum_moments(sd, se, lane);
 #endif
             if (nfl == NDT_FLAT_LIST) drain();
             if (my_moment >= 0) lval[nfl * 10u + 1u + (unsigned)my_moment] = ndt_fixed_from_double(t * my_scale);
-            if (lane == 1) { lval[nfl * 10u] = (long long)n; lslot[nfl] = slot; }
+            if (lane == 9) { lval[nfl * 10u] = (long long)n; lslot[nfl] = slot; }
             nfl++;
 #pragma unroll
             for (int k = 0; k < 3; k++) sd[k] = 0.0;
@@ -343,6 +389,7 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
 
     // ---------------- phase B: moments -> Gaussian ----------------------------------------------------------------------
     const long long t1 = __builtin_readcyclecounter();
+    for (unsigned i = tid; i < bm_words; i += NDT_FLAT_THREADS) s_bits[i] = 0u;      // (region 0 was the waves' scratch until here)
     // the hash IS the list of touched cells: every wave compacts its quarter of the entries in place (a wave reads 64
     // entries before it writes the survivors further down: the write index never passes the read index)
     const unsigned seg_len = hash_entries / NDT_FLAT_WAVES;
@@ -488,7 +535,8 @@ hipError_t ndt_launch_build_flat(const NdtSetView &set, size_t first, size_t cou
     // (entries >= cells the map may hold: at the usual few hundred to two thousand cells of a 4096-cell map the table is
     //  at most half full; a map that runs into max_cells probes long chains and is flagged as overflowing anyway)
     while ((1u << hash_log2) < g.max_cells) hash_log2++;
-    const size_t dyn = ((size_t)bm_words + ((size_t)1 << hash_log2)) * sizeof(unsigned);
+    const size_t region0 = NDT_FLAT_LDSRED ? std::max<size_t>(bm_words, (size_t)NDT_FLAT_WAVES * NDT_FLAT_RED_DOUBLES * 2) : bm_words;
+    const size_t dyn = (region0 + ((size_t)1 << hash_log2)) * sizeof(unsigned);
     // (static + dynamic LDS of the largest configuration exceed the 64 KB a workgroup gets by default)
     static bool attr_set[2][16] = {};
     int dev = 0;

@@ -249,6 +249,11 @@ def tcov_flips(reset=False):
     return int(L.oracle_debug_tcov_flips(int(bool(reset))))
 
 
+def set_sum_mode(mode):
+    """Order in which derivativesNDT adds the source cells' terms (test knob, see ndt_oracle.c): 0 = the reference's."""
+    lib().oracle_set_sum_mode(int(mode))
+
+
 def pose_to_T(p):
     p = _f64(p)
     T = np.zeros(16)

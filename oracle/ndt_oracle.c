@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 /* ------------------------------------------------------------------ */
 /* small dense algebra                                                  */
@@ -891,39 +892,101 @@ static void update_gradient_hessian_local(double g[6], double H[36], vec3 x, mat
 /* LazyGrid::getClosestNDTCells order: offsets 0,+1,-1,+2,-2 per axis, x outer, z inner */
 static int nb_offset(int k) { return (k % 2 == 0) ? k / 2 : -(k / 2); }
 
-static double derivatives_cells(const oracle_map *target, const ocell *src, size_t msrc, int n_neighbours,
-                                int with_hessian, double lfd1, double lfd2, double g[6], double H[36])
+/* the terms of ONE source cell added to score / g / H (the body of derivativesNDT's loop over the source cells) */
+static void derivatives_one_cell(const oracle_map *target, const ocell *sc, int n_neighbours, int with_hessian, double lfd1,
+                                 double lfd2, double *score, double g[6], double H[36])
+{
+    vec3 mm = {{sc->mean[0], sc->mean[1], sc->mean[2]}};
+    mat3 CM = sc->cov;
+    local_derivs L;
+    compute_derivatives_local(mm, CM, with_hessian, &L);
+    int ic[3];
+    index_for_point(target, sc->mean, ic);
+    for (int kx = 1; kx < 2 * n_neighbours + 2; kx++)
+        for (int ky = 1; ky < 2 * n_neighbours + 2; ky++)
+            for (int kz = 1; kz < 2 * n_neighbours + 2; kz++) {
+                int idx[3] = {ic[0] + nb_offset(kx), ic[1] + nb_offset(ky), ic[2] + nb_offset(kz)};
+                if (!idx_inside(target, idx)) continue;
+                int32_t c = target->cell_of_slot[slot_of(target, idx)];
+                if (c < 0 || !target->cells[c].has_gaussian) continue;
+                const ocell *tc = &target->cells[c];
+                vec3 x = {{mm.v[0] - tc->mean[0], mm.v[1] - tc->mean[1], mm.v[2] - tc->mean[2]}};
+                mat3 CS = m3_add(tc->cov, CM), B;
+                double det;
+                if (!m3_inverse_check(CS, &B, &det)) continue;
+                double l = v3_dot(x, m3_v(B, x));
+                if (l * 0 != 0) continue;
+                double sh = -lfd1 * exp(-lfd2 * l / 2.0);
+                update_gradient_hessian_local(g, H, x, B, sh, &L, with_hessian, lfd2);
+                *score += sh;
+            }
+}
+
+/* TEST KNOB (this file is test infrastructure): the ORDER in which the source cells' terms are added.  0 = the
+ * reference's order (source cells one after the other).  1 = the same cells in reverse; 2 = dealt to 8 shares (cell i ->
+ * share i mod 8), a partial sum per share, the partials added in share order -- the shape of the HIP matcher's sums;
+ * 3 = 8 shares, reversed inside a share; 4..15 = the reference order with every sum moved by <= 8 ulp afterwards; 16 and up = the reference's sums,
+ * the Newton increment of every iteration moved by <= cond(H) eps (in the Newton loop below).
+ * Modes 1-3 add exactly the same terms: what differs is rounding in the last
+ * bits of the 28 sums.  tests/test_gpu_fullsize.py uses it to MEASURE which registrations are chaotic (their control flow
+ * changes with the summation order alone) instead of asserting it. */
+static int g_sum_mode = 0;
+void oracle_set_sum_mode(int mode) { g_sum_mode = mode; }
+
+static double derivatives_cells_impl(const oracle_map *target, const ocell *src, size_t msrc, int n_neighbours,
+                                     int with_hessian, double lfd1, double lfd2, double g[6], double H[36])
 {
     double score = 0;
     memset(g, 0, 6 * sizeof(double));
     memset(H, 0, 36 * sizeof(double));
-    for (size_t i = 0; i < msrc; i++) {
-        vec3 mm = {{src[i].mean[0], src[i].mean[1], src[i].mean[2]}};
-        mat3 CM = src[i].cov;
-        local_derivs L;
-        compute_derivatives_local(mm, CM, with_hessian, &L);
-        int ic[3];
-        index_for_point(target, src[i].mean, ic);
-        for (int kx = 1; kx < 2 * n_neighbours + 2; kx++)
-            for (int ky = 1; ky < 2 * n_neighbours + 2; ky++)
-                for (int kz = 1; kz < 2 * n_neighbours + 2; kz++) {
-                    int idx[3] = {ic[0] + nb_offset(kx), ic[1] + nb_offset(ky), ic[2] + nb_offset(kz)};
-                    if (!idx_inside(target, idx)) continue;
-                    int32_t c = target->cell_of_slot[slot_of(target, idx)];
-                    if (c < 0 || !target->cells[c].has_gaussian) continue;
-                    const ocell *tc = &target->cells[c];
-                    vec3 x = {{mm.v[0] - tc->mean[0], mm.v[1] - tc->mean[1], mm.v[2] - tc->mean[2]}};
-                    mat3 CS = m3_add(tc->cov, CM), B;
-                    double det;
-                    if (!m3_inverse_check(CS, &B, &det)) continue;
-                    double l = v3_dot(x, m3_v(B, x));
-                    if (l * 0 != 0) continue;
-                    double sh = -lfd1 * exp(-lfd2 * l / 2.0);
-                    update_gradient_hessian_local(g, H, x, B, sh, &L, with_hessian, lfd2);
-                    score += sh;
-                }
+    if (g_sum_mode == 0) {
+        for (size_t i = 0; i < msrc; i++)
+            derivatives_one_cell(target, &src[i], n_neighbours, with_hessian, lfd1, lfd2, &score, g, H);
+        return score;
+    }
+    const int n_sh = (g_sum_mode == 2 || g_sum_mode == 3) ? 8 : 1, rev = (g_sum_mode == 1 || g_sum_mode == 3);
+    for (int sh = 0; sh < n_sh; sh++) {
+        double ps = 0, pg[6], pH[36];
+        memset(pg, 0, sizeof pg);
+        memset(pH, 0, sizeof pH);
+        for (size_t k = 0; k < msrc; k++) {
+            const size_t i = rev ? msrc - 1 - k : k;
+            if ((int)(i % (size_t)n_sh) != sh) continue;
+            derivatives_one_cell(target, &src[i], n_neighbours, with_hessian, lfd1, lfd2, &ps, pg, pH);
+        }
+        score += ps;
+        for (int a = 0; a < 6; a++) g[a] += pg[a];
+        for (int a = 0; a < 36; a++) H[a] += pH[a];
+    }
+    if (g_sum_mode >= 4 && g_sum_mode < 16) {
+        /* modes 4..15: reference order + every sum moved by at most 8 ulp (a deterministic hash of mode and position, the
+         * Hessian kept symmetric): the size of what ANY other arithmetic of the same formulas (another inverse, another exp,
+         * fused multiply-adds) does to the sums */
+        unsigned long long z = 0x9E3779B97F4A7C15ull * (unsigned long long)g_sum_mode;
+        double *v[1 + 6 + 21];
+        int n = 0;
+        v[n++] = &score;
+        for (int a = 0; a < 6; a++) v[n++] = &g[a];
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) v[n++] = &H[a * 6 + b];
+        for (int k = 0; k < n; k++) {
+            z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+            const int e = (int)(z % 17ull) - 8;                                 /* -8 .. 8 ulp */
+            *v[k] *= 1.0 + (double)e * 2.220446049250313e-16;
+        }
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < a; b++) H[a * 6 + b] = H[b * 6 + a];
     }
     return score;
+}
+/* (ORACLE_TRACE in the environment: one line per derivative evaluation on stderr -- debugging aid for parity work) */
+static double derivatives_cells(const oracle_map *target, const ocell *src, size_t msrc, int n_neighbours,
+                                int with_hessian, double lfd1, double lfd2, double g[6], double H[36])
+{
+    const double s = derivatives_cells_impl(target, src, msrc, n_neighbours, with_hessian, lfd1, lfd2, g, H);
+    if (getenv("ORACLE_TRACE"))
+        fprintf(stderr, "oracle eval with_h %d score %.17g g %.9e %.9e %.9e\n", with_hessian, s, g[0], g[1], g[5]);
+    return s;
 }
 
 /* NDTMatcherFeatureD2D::derivativesNDT (perception_oru ndt_registration, restated from memory): the D2D pair term of
@@ -1664,11 +1727,28 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
         /* [fusion.h]:966-997 */
         double dx[6], incr[6] = {0, 0, 0, 0, 0, 0};
         oracle_ldlt_solve(nd, H, g, dx);
+        if (g_sum_mode >= 16) {
+            /* modes 16..: the Newton increment moved by up to cond(H) eps per component -- the forward error of ANY
+             * backward-stable solve of H dx = g, i.e. what another implementation of the same solve (fused multiply-adds,
+             * a reciprocal square root in the Cholesky, another pivot order) does to it.  cond(H) from the eigenvalues the
+             * regulariser just computed (|lambda|max / |lambda|min of the matrix that is solved). */
+            double lo = fabs(ev[0]), hi = fabs(ev[0]);
+            for (int i = 1; i < nd; i++) { const double a = fabs(ev[i]); lo = a < lo ? a : lo; hi = a > hi ? a : hi; }
+            const double kappa = lo > 0 ? hi / lo : 1e16;
+            unsigned long long z = 0xD1B54A32D192ED03ull * (unsigned long long)(g_sum_mode + 31 * itr_ctr);
+            for (int i = 0; i < nd; i++) {
+                z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+                dx[i] *= 1.0 + ((double)((int)(z % 17ull) - 8) / 8.0) * kappa * 2.220446049250313e-16;
+            }
+        }
         double dginit = 0;
         for (int i = 0; i < nd; i++) {
             incr[dofs[i]] = -dx[i];
             dginit += -dx[i] * g[i];
         }
+        if (getenv("ORACLE_TRACE"))
+            fprintf(stderr, "oracle it %d score %.17g gnorm %.6e minC %.6e maxC %.6e dginit %.6e g %.6e %.6e %.6e\n", itr_ctr,
+                    score_here, gnorm, minC, maxC, dginit, g[0], g[1], nd > 2 ? g[2] : 0.0);
         if (dginit > 0) {
             if (score_here > score_best) memcpy(T, Tbest, sizeof Tbest);
             exit_code = 2;

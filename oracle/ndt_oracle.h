@@ -160,6 +160,10 @@ int oracle_ldlt_solve(int n, const double *A, const double *b, double *x);
 /* computeScore/Gradient/HessianMahalanobis (ndt_matcher_d2d_fusion.h:11-32) */
 double oracle_mahalanobis(const double x[6], const double Q[36], double g[6], double H[36]);
 
+/* test knob: order in which derivativesNDT adds the source cells' terms (0 reference order, 1 reversed, 2 eight shares
+ * i mod 8 added in share order, 3 eight shares reversed inside); same terms, other rounding */
+void oracle_set_sum_mode(int mode);
+
 #ifdef __cplusplus
 }
 #endif

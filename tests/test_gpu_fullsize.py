@@ -241,9 +241,11 @@ def test_3dof_matcher_on_non_converging_pairs(N, O):
     too long, the registration wanders and finally rolls back to its best pose, which is the initial one (DESIGN.md
     section 7).  The wandering is chaotic: a different summation order (HIP vs oracle, even HIP vs HIP on another
     execution shape) changes the number of iterations before the rollback -- measured, 4 of 24 pairs.  What is pinned:
-    the RESULT of every pair (pose within the contract's tolerance, score), bit-identical HIP re-runs, identical
-    control flow on the one-iteration paths, and that every control-flow difference is on a pair where both sides
-    rolled back to the initial pose."""
+    the RESULT of every pair (pose within the contract's tolerance, score), bit-identical HIP re-runs, and the control
+    flow of every pair on which the ORACLE ITSELF is stable: a control-flow difference is accepted only on a pair where the
+    oracle, adding the same pair terms in another order or with its sums moved by a few ulp (oracle_set_sum_mode), itself
+    takes another number of iterations or another exit; on every other pair the HIP path must take exactly the oracle's flow, and every control-flow difference must be on a chaotic pair
+    where both sides rolled back to the initial pose."""
     from ndt_feature_graph_amd import synth
     seeds = list(range(1, 25))
     pr = synth.pair_2d(seeds, 20000)
@@ -256,7 +258,7 @@ def test_3dof_matcher_on_non_converging_pairs(N, O):
     T, r = N.match_batch(tg, np.arange(B), sr, np.arange(B), T0, dof_mask=0x23)
     T2, r2 = N.match_batch(tg, np.arange(B), sr, np.arange(B), T0, dof_mask=0x23)
     assert np.array_equal(T, T2) and all(np.array_equal(r[f], r2[f]) for f in DET_FIELDS)
-    stuck = diverged = 0
+    stuck = diverged = chaotic_pairs = 0
     for b in range(B):
         ot = oracle_map(O, pr["fixed"][b].numpy(), 0.5, [100, 100, 1], 30.0)
         os_ = oracle_map(O, pr["moving"][b].numpy(), 0.5, [100, 100, 1], 30.0)
@@ -267,14 +269,33 @@ def test_3dof_matcher_on_non_converging_pairs(N, O):
         assert abs(T[b][2, 3]) < 1e-15 and abs(T[b][2, 2] - 1) < 1e-15             # z, roll, pitch untouched
         same_flow = (bool(r["converged"][b]) == ro["converged"] and r["iterations"][b] == ro["iterations"]
                      and r["exit_code"][b] == ro["exit_code"])
-        if ro["iterations"] <= 1:                # (even a 3-iteration path flips on a last-bit difference: measured)
-            assert same_flow, b
+        if not same_flow:
+            # "chaotic" as a measurement, not a statement: the ORACLE ALONE must change its control flow on this pair when
+            # the SAME pair terms are added in another order (reversed; eight shares i mod 8 added in share order -- the
+            # shape of the HIP sums; shares reversed inside), when its 28 sums are moved by a few ulp or its Newton increments by cond(H) eps (what any other
+            # arithmetic of the same formulas does; the regularised 3 x 3 system amplifies that by its condition number
+            # into the wild steps described above).  A difference on a pair whose oracle flow is stable under all of
+            # these would be a discrepancy of the HIP path, not chaos.
+            base = (ro["iterations"], ro["exit_code"], ro["converged"])
+            chaotic = False
+            for mode in list(range(16, 28)) + list(range(1, 16)):
+                O.set_sum_mode(mode)
+                try:
+                    Tq, rq = O.match_d2d(ot, os_, T0[b], dof_mask=0x23)
+                finally:
+                    O.set_sum_mode(0)
+                assert pose_close(Tq, To)[0] <= POSE_TOL_M            # (whatever the flow, the result is the same pose)
+                if (rq["iterations"], rq["exit_code"], rq["converged"]) != base:
+                    chaotic = True
+                    break
+            chaotic_pairs += chaotic
+            assert chaotic, (b, "the oracle's control flow is stable under other summation orders and ulp noise, the HIP path differs")
         if not same_flow:
             diverged += 1
             assert pose_close(T[b], T0[b])[0] < 1e-12 and pose_close(To, T0[b])[0] < 1e-12, b   # both rolled back
         stuck += pose_close(T[b], pr["T_gt"][b].numpy())[0] > 0.05
     assert stuck >= 1, "expected pairs on which the 3-DoF matcher does not reach the optimum (DESIGN.md section 7)"
-    assert diverged <= B // 3
+    assert diverged == chaotic_pairs and diverged <= B // 3, (diverged, chaotic_pairs)
 
 
 def test_task_pool_32_pairs_of_full_size_3d_maps(N, O, monkeypatch):

@@ -276,3 +276,31 @@ def test_order_free_ray_tracing_equals_the_sequential_walk_on_node_maps():
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), seed          # cell indices, N per cell
         assert np.max(np.abs(a[0] - b[0])) < 1e-12 and np.max(np.abs(a[1] - b[1])) < 1e-12, seed
         assert np.max(np.abs(maps[0].occupancy() - maps[1].occupancy())) < 1e-2, seed
+
+
+def test_summation_order_knob_adds_the_same_terms():
+    """oracle_set_sum_mode (the knob tests/test_gpu_fullsize.py measures chaos with): every mode adds the same pair terms
+    -- score, gradient and Hessian agree to rounding, and differ in their last bits for at least one mode."""
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_2d([3], 20000)
+    a = O.OracleMap(0.5, [0, 0, 0], [100, 100, 1]); a.load_points(pr["fixed"][0].numpy(), 30.0); a.compute_cells()
+    b = O.OracleMap(0.5, [0, 0, 0], [100, 100, 1]); b.load_points(pr["moving"][0].numpy(), 30.0); b.compute_cells()
+    T = pr["T_init"][0].numpy()
+    mean, cov, _, _ = b.export_cells()
+    m = mean @ T[:3, :3].T + T[:3, 3]
+    C = T[:3, :3] @ cov @ T[:3, :3].T
+    ref = O.derivatives(a, m, C)
+    differs = False
+    try:
+        for mode in (1, 2, 3):
+            O.set_sum_mode(mode)
+            got = O.derivatives(a, m, C)
+            for x, y in zip(got, ref):
+                x, y = np.asarray(x), np.asarray(y)
+                assert np.max(np.abs(x - y)) <= 1e-12 * max(1.0, np.max(np.abs(y)))
+                differs = differs or not np.array_equal(x, y)
+    finally:
+        O.set_sum_mode(0)
+    assert differs, "another summation order should move the last bits of some sum"
+    again = O.derivatives(a, m, C)
+    assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(again, ref))
