@@ -38,7 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r04_pmc_traffic.json"
 
 
 def cpu_info():
