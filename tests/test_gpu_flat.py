@@ -1,0 +1,149 @@
+"""The batch build kernel for flat grids (csrc/ndt_build_flat.hip: wave-uniform cell runs, LDS slot hash, dense rank-map
+write) against the CPU oracle and against the general kernel (NDTGPU_FLAT=0) on batches that take it by default
+(>= 256 maps).  -m gpu.
+
+Reference semantics: LazyGrid::getIndexForPoint / NDTMap::loadPointCloud(cloud, range) and
+computeNDTCells(SAMPLE_VARIANCE) (ndt_feature_fuser_hmt.cpp:195-227).  Bars as in test_gpu_parity.py: cell sets, point
+counts and dropped-point counts bit-exact; means 1e-9 m, covariances 1e-8 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    import ndt_feature_graph_amd as N
+    if N.device_count() < 1:
+        pytest.fail("no HIP device visible: the HIP path cannot run (there is no CPU fallback)")
+    return N
+
+
+@pytest.fixture(scope="module")
+def O():
+    import oracle
+    return oracle
+
+
+def assert_cells_equal(gpu, cpu, res=0.5):
+    gm, gc, gi, gn = gpu
+    cm, cc, ci, cn = cpu
+    assert len(gn) == len(cn), "number of Gaussian cells differs: %d vs %d" % (len(gn), len(cn))
+    assert np.array_equal(gi, ci), "cell index sets differ"
+    assert np.array_equal(gn.astype(np.int64), cn.astype(np.int64)), "per-cell point counts differ"
+    if len(gn):
+        assert np.max(np.abs(gm - cm)) < 1e-9 * max(1.0, res)
+        scale = np.max(np.abs(cc), axis=(1, 2), keepdims=True)
+        assert np.max(np.abs(gc - cc) / scale) < 1e-8
+
+
+def scans_with_trouble(n_maps, n_pts, seed0=700):
+    """n_maps scans of different rooms with what a real cloud brings along: NaN points (all coordinates, or one only),
+    an Inf, points outside the grid, a stretch of identical points, a scan that is all NaN, one with a single point."""
+    from ndt_feature_graph_amd import synth
+    poses = np.zeros((n_maps, 3))
+    poses[:, 0] = np.linspace(-1.0, 1.0, n_maps)
+    poses[:, 2] = np.linspace(0.0, 3.0, n_maps)
+    pts = synth.scan_2d(list(range(seed0, seed0 + n_maps)), poses, n_pts).numpy().copy()
+    g = np.random.default_rng(5)
+    for m in range(n_maps):
+        k = g.integers(0, n_pts, 12)
+        pts[m, k[0:3]] = np.nan                         # whole points
+        pts[m, k[3], 0] = np.nan                        # x only
+        pts[m, k[4], 1] = np.nan                        # y only
+        pts[m, k[5], 2] = np.nan                        # z only
+        pts[m, k[6], 0] = np.inf
+        pts[m, k[7]] = [300.0, -5.0, 0.01]              # outside the 100 m grid
+        pts[m, k[8]] = [3.0, 4.0, 2.0]                  # above the two z layers
+    pts[3, 100:400] = pts[3, 100]                       # 300 copies of one point: one cell, zero covariance -> no Gaussian
+    pts[5] = np.nan                                     # an empty scan
+    pts[7, 1:] = np.nan                                 # a single point
+    return pts
+
+
+@pytest.mark.parametrize("n_pts,rng,stride_dw", [(3001, 12.0, 3), (2048, 30.0, 4), (777, -1.0, 3)])
+def test_flat_batch_against_oracle_and_general_kernel(N, O, monkeypatch, n_pts, rng, stride_dw):
+    """260 scans per launch (the flat kernel's default territory), point counts that are no multiple of the 64-point
+    round, a range limit that cuts through the rooms (cells that are only partly inside the range sphere never take the
+    fast membership test), 12- and 16-byte records, NaN / Inf / out-of-grid points: sampled maps against the oracle, ALL
+    maps against the general kernel (cell sets, point counts, dropped points exact), and a second build gives the same bits."""
+    n_maps = 260
+    pts = scans_with_trouble(n_maps, n_pts)
+    if stride_dw == 4:
+        pts = np.concatenate([pts, np.full((n_maps, n_pts, 1), 7.0, np.float32)], axis=2)   # pcl::PointXYZ padding
+    sets = {}
+    for flat in ("1", "0"):
+        monkeypatch.setenv("NDTGPU_FLAT", flat)
+        ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=n_maps, max_cells=1024)
+        ms.build(pts, range_limit=rng)
+        sets[flat] = ms
+    monkeypatch.delenv("NDTGPU_FLAT")
+    f, g = sets["1"], sets["0"]
+    assert np.array_equal(f.num_cells_all(), g.num_cells_all())
+    for m in range(n_maps):
+        cf, cg = f.counters(m), g.counters(m)
+        assert cf["n_dropped"] == cg["n_dropped"] and cf["overflow"] == 0 and cg["overflow"] == 0, m
+    for m in list(range(0, n_maps, 13)) + [3, 5, 7, n_maps - 1]:
+        a, b = f.export_cells(m), g.export_cells(m)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), m
+        if len(a[3]):
+            assert np.max(np.abs(a[0] - b[0])) < 1e-12 and np.max(np.abs(a[1] - b[1])) < 1e-12, m
+        om = O.OracleMap(0.5, [0, 0, 0], [100, 100, 1])
+        om.load_points(pts[m][:, :3], rng)
+        om.compute_cells()
+        assert_cells_equal(a, om.export_cells())
+    assert f.num_cells(5) == 0 and f.num_cells(7) == 0 and f.counters(5)["n_dropped"] == n_pts
+    before = [f.export_cells(m) for m in (0, 100, 259)]
+    f.build(pts, range_limit=rng)
+    for m, was in zip((0, 100, 259), before):
+        for x, y in zip(f.export_cells(m), was):
+            assert np.array_equal(x, y)
+
+
+def test_flat_batch_range_origins_and_centres(N, O):
+    """Per-map range origins (loadPointCloudCentroid's sensor origin) and a grid centre that is not the origin (still
+    a grid whose cell centres are fp32 numbers): sampled maps against the oracle."""
+    from ndt_feature_graph_amd import synth
+    n_maps, n_pts = 256, 4000
+    poses = np.zeros((n_maps, 3))
+    poses[:, 1] = np.linspace(-2.0, 2.0, n_maps)
+    pts = synth.scan_2d(list(range(900, 900 + n_maps)), poses, n_pts).numpy()
+    origins = np.stack([np.linspace(-3, 3, n_maps), np.linspace(2, -2, n_maps), np.zeros(n_maps)], axis=1)
+    centre = [2.5, -1.5, 0.0]
+    ms = N.MapSet(0.5, centre, [100, 100, 1], n_maps=n_maps, max_cells=1024)
+    ms.build(pts, range_limit=15.0, range_origins=origins)
+    for m in range(0, n_maps, 17):
+        om = O.OracleMap(0.5, centre, [100, 100, 1])
+        om.load_points(pts[m], 15.0, range_origin=origins[m])
+        om.compute_cells()
+        assert_cells_equal(ms.export_cells(m), om.export_cells())
+
+
+def test_flat_batch_unordered_points_and_overflow(N, monkeypatch):
+    """Shuffled clouds (every round of 64 points meets dozens of cells: the exact path replaces runs over and over): the
+    same cells and point counts as the ordered cloud, moments to rounding.  A map with more touched cells than
+    max_cells overflows on both kernels and says so."""
+    from ndt_feature_graph_amd import synth
+    n_maps, n_pts = 256, 6000
+    pts = synth.scan_2d(list(range(300, 300 + n_maps)), np.zeros((n_maps, 3)), n_pts).numpy()
+    g = np.random.default_rng(1)
+    shuffled = np.stack([p[g.permutation(n_pts)] for p in pts])
+    a = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=n_maps, max_cells=1024)
+    b = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=n_maps, max_cells=1024)
+    a.build(pts, range_limit=30.0)
+    b.build(shuffled, range_limit=30.0)
+    assert np.array_equal(a.num_cells_all(), b.num_cells_all())
+    for m in range(0, n_maps, 19):
+        x, y = a.export_cells(m), b.export_cells(m)
+        assert np.array_equal(x[2], y[2]) and np.array_equal(x[3], y[3])
+        assert np.max(np.abs(x[0] - y[0])) < 1e-12
+        assert np.max(np.abs(x[1] - y[1]) / np.max(np.abs(x[1]), axis=(1, 2), keepdims=True)) < 1e-10
+    for flat in ("1", "0"):
+        monkeypatch.setenv("NDTGPU_FLAT", flat)
+        small = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=n_maps, max_cells=32)
+        small.build(pts, range_limit=30.0)
+        with pytest.raises(N.NdtGpuError) as e:
+            small.num_cells(10)
+        assert e.value.status == -4
+        small.build(np.full((n_maps, 64, 3), np.nan, np.float32))          # the set stays usable
+        assert small.num_cells(10) == 0
