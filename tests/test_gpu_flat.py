@@ -55,6 +55,8 @@ def scans_with_trouble(n_maps, n_pts, seed0=700):
         pts[m, k[6], 0] = np.inf
         pts[m, k[7]] = [300.0, -5.0, 0.01]              # outside the 100 m grid
         pts[m, k[8]] = [3.0, 4.0, 2.0]                  # above the two z layers
+    for m in range(0, n_maps, 3):                       # beams without a return, scattered: every round of 64 has some
+        pts[m, g.random(n_pts) < 0.2] = np.nan
     pts[3, 100:400] = pts[3, 100]                       # 300 copies of one point: one cell, zero covariance -> no Gaussian
     pts[5] = np.nan                                     # an empty scan
     pts[7, 1:] = np.nan                                 # a single point

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The flat-grid batch build kernel (csrc/ndt_build_flat.hip) against the general one (NDTGPU_FLAT=0) on the same scans:
 identical cell sets / point counts, moments within rounding, rank maps, counters; HIP-event timings of both and the
-flat kernel's phase clocks.  usage: python tools/flat_check.py [n_scans=2048] [points=100000]"""
+flat kernel's phase clocks.  usage: python tools/flat_check.py [n_scans=2048] [points=100000] [nan]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,6 +14,8 @@ dev = torch.device("cuda", 0)
 B = n // 2
 pr = synth.pair_2d(torch.arange(1, B + 1, device=dev), npts, device=dev, chunk_bytes=2 << 30)
 scans = torch.cat([pr["fixed"], pr["moving"]]).contiguous()
+if len(sys.argv) > 3 and sys.argv[3] == "nan":      # a fifth of the beams without a return, scattered
+    scans[torch.rand(scans.shape[:2], device=dev) < 0.2] = float("nan")
 st = torch.cuda.current_stream()
 
 
