@@ -207,9 +207,9 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         return ev, (Tg_, Rg_)
 
     E = Edges(edges)
-    steps = args.steps if args.steps != 20 else 3
+    steps = args.steps if args.steps != 100 else 3
     barrier()
-    for _ in range(1 if args.warmup == 3 else max(1, args.warmup)):
+    for _ in range(1 if args.warmup == 5 else max(1, args.warmup)):
         one_pass(E)
     barrier()
     t0 = time.perf_counter()
@@ -542,8 +542,8 @@ def config_fuse(args, torch, N, binding, synth, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=1024, help="scan pairs per GPU per step")
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--res", type=float, default=0.5)

@@ -36,7 +36,7 @@
 #define NDT_FLAT_THREADS 256
 #define NDT_FLAT_WAVES (NDT_FLAT_THREADS / 64)
 #ifndef NDT_FLAT_U
-#define NDT_FLAT_U 8             // rounds of 64 points a wave has in flight while it works on the previous ones
+#define NDT_FLAT_U 6             // rounds of 64 points a wave has in flight while it works on the previous ones
 #endif
 #ifndef NDT_FLAT_WPE
 #define NDT_FLAT_WPE 4            // waves per SIMD the register budget is cut for (four 256-thread workgroups per CU)
@@ -51,9 +51,10 @@
 #endif
 #define NDT_FLAT_RED_DOUBLES (9 * 64)   // LDS scratch of one wave's sum: nine moments x 64 lanes
 #ifndef NDT_FLAT_GONE
-#define NDT_FLAT_GONE 0           // 1: points that are certainly dropped (NaN, far out of range / grid) do not send a round to the
-                                  // exact path.  Measured on scans with a fifth of the beams NaN: 1.24 against 1.30 ms per 2048
-                                  // scans -- and 1.10 against 0.99 ms on clean scans (code size, registers): off
+#define NDT_FLAT_GONE 1           // points that are certainly dropped (NaN, far out of range / grid) do not send a round to the
+                                  // exact path.  Per 2048 scans, clean / a fifth of the beams NaN scattered: with it 1.00 / 1.13 ms,
+                                  // without 0.99 / 1.27 ms (U = 6).  The code must stay within the 64 KB instruction cache that two
+                                  // CUs share: with U = 8 the same switch costs 1.08 / 1.22 against 0.97 / 1.28
 #endif
 #define NDT_FLAT_LIST 16         // records in a wave's flush list
 #define NDT_FLAT_IDBITS 13       // hash entry = (slot + 1) << 13 | accumulator id
@@ -328,16 +329,23 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
                 const float c_cy = uniform_f(fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(gy), lead)), res32, c0y32));
                 const float c_cz = uniform_f(fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(gz), lead)), res32, c0z32));
                 const float c_lim = uniform_f(cell_lim(c_cx, c_cy, c_cz));
-                const bool to_b = a_slot >= 0 && (b_slot < 0 || !mru_b);       // an empty run first, else the older one
+                // the new cell replaces an empty run first, else the one used least recently.  The victim is always run A:
+                // when it would be B the two runs trade places first (scalars and the 36 registers, in place) -- ONE copy of
+                // the flush in the code instead of two, and the accumulators are only ever rewritten at this one point
+                const bool to_b = a_slot >= 0 && (b_slot < 0 || !mru_b);
                 if (to_b) {
-                    if (b_slot >= 0) flush(b_sd, b_se, b_slot, b_n);
-                    b_slot = c_slot; b_cx = c_cx; b_cy = c_cy; b_cz = c_cz; b_lim = c_lim; b_n = 0u;
-                    mru_b = true;
-                } else {
-                    if (a_slot >= 0) flush(a_sd, a_se, a_slot, a_n);
-                    a_slot = c_slot; a_cx = c_cx; a_cy = c_cy; a_cz = c_cz; a_lim = c_lim; a_n = 0u;
-                    mru_b = false;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { const double t = a_sd[k]; a_sd[k] = b_sd[k]; b_sd[k] = t; }
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { const double t = a_se[k]; a_se[k] = b_se[k]; b_se[k] = t; }
+                    { const int t = a_slot; a_slot = b_slot; b_slot = t; }
+                    { const unsigned t = a_n; a_n = b_n; b_n = t; }
+                    { float t = a_cx; a_cx = b_cx; b_cx = t; t = a_cy; a_cy = b_cy; b_cy = t; t = a_cz; a_cz = b_cz; b_cz = t;
+                      t = a_lim; a_lim = b_lim; b_lim = t; }
                 }
+                if (a_slot >= 0) flush(a_sd, a_se, a_slot, a_n);
+                a_slot = c_slot; a_cx = c_cx; a_cy = c_cy; a_cz = c_cz; a_lim = c_lim; a_n = 0u;
+                mru_b = false;
             }
         };
 
