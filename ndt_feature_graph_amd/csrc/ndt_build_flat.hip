@@ -7,27 +7,32 @@
 //   NDTMap::computeNDTCells(CELL_UPDATE_MODE_SAMPLE_VARIANCE) -> NDTCell::computeGaussian + rescaleCovariance
 //       ...fuser_hmt.cpp:227, ndt_odom_debug.cpp:179
 //
-// Design.  One 256-thread workgroup per map (three per CU); a wave owns a contiguous quarter of the scan and walks it in ROUNDS of 64
-// CONSECUTIVE points, lane l <-> point 64 r + l (one fully coalesced 12 / 16-byte load per lane, no staging through LDS).
+// Design.  One 256-thread workgroup per map, four per CU (128 VGPRs, 32 KB of LDS); a wave owns a contiguous quarter of the
+// scan and walks it in ROUNDS of 64 CONSECUTIVE points, lane l <-> point 64 r + l (one fully coalesced 12 / 16-byte load
+// per lane, six rounds issued together, no staging through LDS).
 //   * A planar sweep stays in a cell for hundreds of consecutive points, so the 64 points of a round lie in one cell, or in
 //     two when a wall hugs a cell face or the sweep crosses into the next cell.  The wave therefore tracks TWO cells
 //     ("runs" A and B) in SCALAR registers -- slot, centre, point count -- and every lane keeps its share of their nine
 //     moments (sum d, sum d d^T of d = p - cell centre) in fp64 registers.
-//   * Membership of a point in run A is max(|p - centreA|) < res (1/2 - guard): on a grid whose cell centres are fp32
-//     numbers the difference is exact, so this decides exactly what the reference's floor((p - c)/res + 0.5) decides for
-//     every point outside a 4e-6-cell band at the faces -- 5 instructions instead of a 33-instruction index.  A round
-//     whose 64 points all pass for A or B costs ~17 (one cell) to ~36 (two cells) vector instructions per point.
-//   * A round with a point that fails both tests (a new cell, a point in the guard band, NaN, out of range / grid) is
-//     binned with the reference-exact index arithmetic of csrc/ndt_binning.h; a new cell replaces the run used least
-//     recently, whose moments are summed over the wave (a value-halving butterfly: 57 instructions for the nine sums),
-//     converted to 64-bit fixed point and appended to the wave's flush list.  One record per cell VISIT of a wave.
+//   * Membership of a point in run A is |p - centreA| < res (1/2 - guard) on the three axes: on a grid whose cell centres
+//     are fp32 numbers the difference is exact, so this decides exactly what the reference's floor((p - c)/res + 0.5)
+//     decides for every point outside a 4e-6-cell band at the faces -- 6 instructions instead of a 40-instruction index.
+//     A round whose 64 points all pass for A or B costs 12 instructions of tests + 12 per run that received points.
+//     Points that are certainly dropped (NaN, far out of range / grid: beams without a return) count as passed.
+//   * A round with a point that fails everything (a new cell, a point in the guard band) is binned with the
+//     reference-exact index arithmetic of csrc/ndt_binning.h; a new cell replaces the run used least recently -- the runs
+//     trade places when that is B, so that the victim is always A and the flush exists once in the code --, whose moments
+//     are summed over the wave (a value-halving butterfly: 57 instructions for the nine sums), converted to 64-bit fixed
+//     point and appended to the wave's flush list.  One record per cell VISIT of a wave.  The rounds of a batch are
+//     processed in scan order by unrolled code with this path inline; the kernel's code (41 KB) has to stay within the
+//     64 KB instruction cache two CUs share (measured: +10 % time beyond it).
 //   * The list is drained 16 records at a time: slot -> accumulator id through a per-workgroup LDS hash (the map belongs
 //     to this workgroup: no global work table), then one 64-bit integer atomic per (record, moment) into the map's
 //     accumulators in L2 -- exact, hence order-independent and bit-reproducible, like the general kernel.
-//   * Finalise: moments -> Gaussian per cell (shared with the general kernel), Gaussian cells into an LDS bitmap, ranks by
-//     popcount prefix, the rank map written DENSELY (every word), cell records written in slot order.  No dense
-//     slot -> rank table, no global work table or bitmap: HBM traffic is the points, the accumulators (dense by id) and the
-//     outputs.
+//   * Finalise: the hash is the list of touched cells (compacted in place); moments -> Gaussian per cell (shared with the
+//     general kernel), Gaussian cells into an LDS bitmap, ranks by popcount prefix, the rank map written DENSELY (every
+//     word), cell records written in slot order.  No dense slot -> rank table, no global work table or bitmap: HBM traffic
+//     is the points, the accumulators (dense by id) and the outputs.
 #include "ndt_math.h"
 #include "ndt_binning.h"
 #include "ndt_wave.h"
