@@ -860,7 +860,9 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
     const unsigned n_tiles = (unsigned)((n_points + NDT_TILE - 1) / NDT_TILE);
     unsigned parts = 1;
     if (count < 256 && n_tiles > 8) {
-        parts = (unsigned)(1024 / count);
+        const char *pe = getenv("NDTGPU_BUILD_WGS");             // (experiments: workgroups of the accumulate launch, default 1024)
+        const unsigned wgs = pe && atoi(pe) > 0 ? (unsigned)atoi(pe) : 1024u;
+        parts = (unsigned)(wgs / count);
         if (parts > n_tiles / 4) parts = n_tiles / 4;
         if (parts < 1) parts = 1;
     }
