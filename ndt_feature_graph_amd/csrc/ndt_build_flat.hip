@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
         float a_lim = -1.0f, b_lim = -1.0f;                    // -1: no point passes the fast test (empty run, or a cell
                                                                // that is not entirely inside the range sphere)
         unsigned a_n = 0, b_n = 0;
-        bool mru_b = false;                                    // run B was used more recently than run A
+        bool seen_gone = false;                                // the exact path has dropped a point of this wave's share
         double a_sd[3] = {0, 0, 0}, a_se[6] = {0, 0, 0, 0, 0, 0}, b_sd[3] = {0, 0, 0}, b_se[6] = {0, 0, 0, 0, 0, 0};
 
         auto drain = [&]() {
@@ -268,17 +268,25 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
         };
 
         // One round through the fast tests.  Returns true when some point passes neither (nothing was added then).
-        // (single exit, accumulators updated in place under the lane masks: the register allocator then keeps ONE copy of
-        //  the 36 accumulator registers; a version with early returns was compiled with three)
+        // Run B is the cell the sweep entered last: a round that lies entirely in it -- the usual case -- is done after
+        // three compares.  (Single exit, accumulators updated in place under the lane masks at ONE site per run: the
+        // register allocator then keeps one copy of the 36 accumulator registers; a version with early returns was
+        // compiled with three.)
         auto fast_round = [&](float px, float py, float pz, unsigned long long m_gone) -> bool {
-            const float ax = px - a_cx, ay = py - a_cy, az = pz - a_cz;
             const float bx = px - b_cx, by = py - b_cy, bz = pz - b_cz;
             // (three compares, not a compare of the maximum: v_max3_f32 drops a NaN operand, and a point with one NaN
             //  coordinate must fail)
-            const bool in_a = (fabsf(ax) < a_lim) & (fabsf(ay) < a_lim) & (fabsf(az) < a_lim);
             const bool in_b = (fabsf(bx) < b_lim) & (fabsf(by) < b_lim) & (fabsf(bz) < b_lim);
-            const unsigned long long m_a = __ballot(in_a), m_b = __ballot(in_b);
-            const bool all = (m_a | m_b | m_gone) == ~0ull;            // m_gone: lanes whose point is certainly dropped
+            const unsigned long long m_b = ndt_ballot(in_b);
+            const float ax = px - a_cx, ay = py - a_cy, az = pz - a_cz;
+            bool in_a = false;
+            unsigned long long m_a = 0ull;
+            bool all = m_b == ~0ull;
+            if (!all) {
+                in_a = (fabsf(ax) < a_lim) & (fabsf(ay) < a_lim) & (fabsf(az) < a_lim);
+                m_a = ndt_ballot(in_a);
+                all = (m_a | m_b | m_gone) == ~0ull;               // m_gone: lanes whose point is certainly dropped
+            }
             if (all) {
                 if (m_a) {
                     if (in_a) flat_acc(a_sd, a_se, ax, ay, az);
@@ -288,7 +296,6 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
                 }
                 a_n += (unsigned)__popcll(m_a);
                 b_n += (unsigned)__popcll(m_b);
-                if (m_a | m_b) mru_b = m_b > m_a;                // the run of the round's last point that has one
             }
             return !all;
         };
@@ -303,19 +310,24 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
             const float dx = px - ox32, dy = py - oy32, dz = pz - oz32;
             const bool in_box = (px > glo_x) & (px < ghi_x) & (py > glo_y) & (py < ghi_y) & (pz > glo_z) & (pz < ghi_z);   // false for NaN
             const bool far = dx * dx + dy * dy + dz * dz > r2gone;
-            return __ballot(!in_box | far);
+            return ndt_ballot(!in_box | far);
         };
-        // The same round with the reference's index arithmetic; new cells replace the run used least recently.
+        // The same round with the reference's index arithmetic.  A new cell becomes run B; the cell that was B becomes A
+        // and what was A -- the run that was opened first -- leaves through the flush list: first in, first out.  (Least
+        // recently USED was the first policy: 7 vector instructions per round to keep track of it, and a victim that is
+        // A or B -- two copies of the flush, or 72 register moves per new cell to make it always A.  On a sweep the
+        // cell entered first is the one left behind: 410 flushes per scan of the bench's rooms with either policy.)
         auto slow_round = [&](float px, float py, float pz) {
             float gx, gy, gz;
             int slot;
             const bool near = bn.fast(px, py, pz, gx, gy, gz, slot);
-            if (__ballot(near)) {
+            if (ndt_ballot(near)) {
                 if (near) bn.exact(px, py, pz, gx, gy, gz, slot);
             }
-            for (;;) {
+            seen_gone = seen_gone || ndt_ballot(slot < 0) != 0ull;
+            {
                 const bool in_a = slot == a_slot, in_b = slot == b_slot;       // (empty runs: -2 / -3, dropped points: -1)
-                const unsigned long long m_a = __ballot(in_a), m_b = __ballot(in_b);
+                const unsigned long long m_a = ndt_ballot(in_a), m_b = ndt_ballot(in_b);
                 if (m_a) {
                     if (in_a) flat_acc(a_sd, a_se, px - a_cx, py - a_cy, pz - a_cz);
                     a_n += (unsigned)__popcll(m_a);
@@ -324,33 +336,35 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
                     if (in_b) flat_acc(b_sd, b_se, px - b_cx, py - b_cy, pz - b_cz);
                     b_n += (unsigned)__popcll(m_b);
                 }
-                if (m_a | m_b) mru_b = m_b > m_a;              // the run of the later point
                 slot = (in_a | in_b) ? -1 : slot;
-                const unsigned long long m_s = __ballot(slot >= 0);
-                if (!m_s) break;
+            }
+            // points of other cells: the first one's cell becomes run B, what was B becomes A, what was A is flushed.  (The
+            // loop starts with the flush and ends with the new run's first points: the runs' registers change hands
+            // once per new cell, at the bottom, on the way to the exit and to the next pass alike.)
+            unsigned long long m_s = ndt_ballot(slot >= 0);
+            while (m_s) {
                 const int lead = __ffsll((long long)m_s) - 1;
                 const int c_slot = __builtin_amdgcn_readlane(slot, lead);
                 const float c_cx = uniform_f(fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(gx), lead)), res32, c0x32));
                 const float c_cy = uniform_f(fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(gy), lead)), res32, c0y32));
                 const float c_cz = uniform_f(fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(gz), lead)), res32, c0z32));
                 const float c_lim = uniform_f(cell_lim(c_cx, c_cy, c_cz));
-                // the new cell replaces an empty run first, else the one used least recently.  The victim is always run A:
-                // when it would be B the two runs trade places first (scalars and the 36 registers, in place) -- ONE copy of
-                // the flush in the code instead of two, and the accumulators are only ever rewritten at this one point
-                const bool to_b = a_slot >= 0 && (b_slot < 0 || !mru_b);
-                if (to_b) {
-#pragma unroll
-                    for (int k = 0; k < 3; k++) { const double t = a_sd[k]; a_sd[k] = b_sd[k]; b_sd[k] = t; }
-#pragma unroll
-                    for (int k = 0; k < 6; k++) { const double t = a_se[k]; a_se[k] = b_se[k]; b_se[k] = t; }
-                    { const int t = a_slot; a_slot = b_slot; b_slot = t; }
-                    { const unsigned t = a_n; a_n = b_n; b_n = t; }
-                    { float t = a_cx; a_cx = b_cx; b_cx = t; t = a_cy; a_cy = b_cy; b_cy = t; t = a_cz; a_cz = b_cz; b_cz = t;
-                      t = a_lim; a_lim = b_lim; b_lim = t; }
-                }
                 if (a_slot >= 0) flush(a_sd, a_se, a_slot, a_n);
-                a_slot = c_slot; a_cx = c_cx; a_cy = c_cy; a_cz = c_cz; a_lim = c_lim; a_n = 0u;
-                mru_b = false;
+                const bool in_c = slot == c_slot;
+                const unsigned long long m_c = ndt_ballot(in_c);
+                // the new run's first points: d = p - centre where the lane's point is in the cell, 0 elsewhere
+                const float dx = in_c ? px - c_cx : 0.0f, dy = in_c ? py - c_cy : 0.0f, dz = in_c ? pz - c_cz : 0.0f;
+                const double x = (double)dx, y = (double)dy, z = (double)dz;
+#pragma unroll
+                for (int k = 0; k < 3; k++) a_sd[k] = b_sd[k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) a_se[k] = b_se[k];
+                b_sd[0] = x; b_sd[1] = y; b_sd[2] = z;
+                b_se[0] = x * x; b_se[1] = x * y; b_se[2] = x * z; b_se[3] = y * y; b_se[4] = y * z; b_se[5] = z * z;
+                a_slot = b_slot; a_cx = b_cx; a_cy = b_cy; a_cz = b_cz; a_lim = b_lim; a_n = b_n;
+                b_slot = c_slot; b_cx = c_cx; b_cy = c_cy; b_cz = c_cz; b_lim = c_lim; b_n = (unsigned)__popcll(m_c);
+                slot = in_c ? -1 : slot;
+                m_s = ndt_ballot(slot >= 0);
             }
         };
 
@@ -401,7 +415,7 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
                     if (r0 + (unsigned)u == last_round) px = lane < tail ? px : __builtin_nanf("");   // past the end: NaN points
                     bool todo = fast_round(px, qy[u], qz[u], 0ull);
 #if NDT_FLAT_GONE
-                    if (todo) {
+                    if (todo && seen_gone) {           // (a scan that has not dropped a point so far does not pay for the test)
                         const unsigned long long m_gone = gone_mask(px, qy[u], qz[u]);
                         if (m_gone) todo = fast_round(px, qy[u], qz[u], m_gone);
                     }
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
         unsigned out = 0;
         for (unsigned i = 0; i < seg_len; i += 64u) {
             const unsigned e = seg[i + lane];
-            const unsigned long long m = __ballot(e != 0u);
+            const unsigned long long m = ndt_ballot(e != 0u);
             const unsigned before = (unsigned)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64u - lane))));
             ndt_wave_sync();
             if (e != 0u) seg[out + before] = e;

@@ -3,6 +3,10 @@
 #pragma once
 #include "ndt_common.h"
 
+// ballot of a lane predicate as the compare's own lane mask (HIP's __ballot(int) first turns the predicate into 0 / 1 in a
+// vector register and compares that with zero: two vector instructions per ballot)
+NDT_D unsigned long long ndt_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // inclusive scan over the 64 lanes (DPP row shifts, then the two row broadcasts)
 NDT_D unsigned ndt_wave_incl_scan(unsigned v)
 {
