@@ -256,14 +256,14 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
         nfl = 0;
     };
     auto push_runs = [&](bool mine, int slot, double n, const double *sd3, const double *se6) {
-        unsigned long long m = __ballot(mine);
+        unsigned long long m = ndt_ballot(mine);
         while (m) {
             if (nfl == (unsigned)FLC) drain_list();
             const unsigned room = (unsigned)FLC - nfl;
             const unsigned rank = (unsigned)__popcll(m & lt_mask);
             const bool now = mine && ((m >> lane) & 1ull) && rank < room;
             if (now) write_flush_record(bc, fl_val + (nfl + rank) * 10u, fl_id + nfl + rank, slot, n, sd3, se6);
-            const unsigned long long done = __ballot(now);
+            const unsigned long long done = ndt_ballot(now);
             nfl += (unsigned)__popcll(done);
             m &= ~done;
         }
@@ -329,7 +329,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
         // table.  Nothing here touches LDS or memory on the common path.
         auto add_point = [&](float fx, float fy, float fz, float gx, float gy, float gz, int slot) {
             const bool newc = (slot >= 0) & (slot != cs0) & (slot != cs1);
-            if (__ballot(newc)) {
+            if (ndt_ballot(newc)) {
                 if (SCAT) {
                     // every lane with a replaced run appends one record to the wave's flush list (drained with wide
                     // atomics whenever it is full)
@@ -394,7 +394,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
                 se[0] = fma(x, x, se[0]); se[1] = fma(x, y, se[1]); se[2] = fma(x, z, se[2]);
                 se[3] = fma(y, y, se[3]); se[4] = fma(y, z, se[4]); se[5] = fma(z, z, se[5]);
             }
-            if (__ballot(in1)) {
+            if (ndt_ballot(in1)) {
                 if (in1) {
                     rn1 += 1u;
                     sd1[0] += x; sd1[1] += y; sd1[2] += z;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             int aslot, bslot;
             const bool na = bn.fast(ax, ay, az, agx, agy, agz, aslot);
             const bool nb = bn.fast(bx, by, bz, bgx, bgy, bgz, bslot);
-            if (__ballot(na | nb)) {
+            if (ndt_ballot(na | nb)) {
                 if (na) bn.exact(ax, ay, az, agx, agy, agz, aslot);
                 if (nb) bn.exact(bx, by, bz, bgx, bgy, bgz, bslot);
             }
@@ -480,7 +480,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             // face neighbouring lanes then agree on which cell is run 0 and which is run 1, so both form
             // long contiguous segments for the scans below instead of alternating lane by lane.
             const bool swap = cs1 >= 0 && cs1 < cs0;
-            if (__ballot(swap)) {
+            if (ndt_ballot(swap)) {
                 if (swap) {
                     double t;
                     { const unsigned tn = rn1; rn1 = rn; rn = tn; }
@@ -495,7 +495,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             for (int pass = 0; pass < 2; pass++) {
                 int cs = cs0;
                 if (pass == 1) {
-                    if (!__ballot(cs1 >= 0)) break;
+                    if (!ndt_ballot(cs1 >= 0)) break;
                     // second pass: the lanes' run 1
                     const bool has = cs1 >= 0;
                     cs = cs1;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
                 // segmented wavefront reduction over contiguous lanes that hold the same cell
                 int prev = __shfl_up(cs, 1, 64);
                 bool head = (lane == 0) || (prev != cs);
-                unsigned long long hm = __ballot(head);
+                unsigned long long hm = ndt_ballot(head);
                 // lanes remaining in my segment (me included): distance to the next head above me
                 unsigned long long above = (lane == 63) ? 0ull : (hm >> (lane + 1));
                 int rem = above ? (__ffsll((long long)above)) : (int)(64 - lane);
@@ -699,7 +699,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             unsigned bits[WPL];
 #pragma unroll
             for (unsigned k = 0; k < WPL; k++) bits[k] = (w0 + k < we) ? bc.bitmap[w0 + k] : 0u;
-            if (!__ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u)) continue;
+            if (!ndt_ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u)) continue;
             unsigned cnt = 0;
 #pragma unroll
             for (unsigned k = 0; k < WPL; k++) cnt += (unsigned)__popc(bits[k]);
@@ -734,7 +734,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
         unsigned bits[WPL], vmask[WPL];
 #pragma unroll
         for (unsigned k = 0; k < WPL; k++) bits[k] = (w0 + k < we) ? bc.bitmap[w0 + k] : 0u;
-        if (!__ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u)) continue;
+        if (!ndt_ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u)) continue;
         unsigned cnt = 0;
 #pragma unroll
         for (unsigned k = 0; k < WPL; k++) {

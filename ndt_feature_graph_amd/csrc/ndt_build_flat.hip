@@ -38,7 +38,9 @@
 #include "ndt_wave.h"
 #include <algorithm>
 
+#ifndef NDT_FLAT_THREADS
 #define NDT_FLAT_THREADS 256
+#endif
 #define NDT_FLAT_WAVES (NDT_FLAT_THREADS / 64)
 #ifndef NDT_FLAT_U
 #define NDT_FLAT_U 6             // rounds of 64 points a wave has in flight while it works on the previous ones
@@ -159,6 +161,9 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
 
     // ---------------- phase A: the scan, once ---------------------------------------------------------------------------
     const long long t0 = __builtin_readcyclecounter();
+#ifdef NDT_FLAT_TIMES
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+#endif
     {
         NdtBinner bn;
         bn.init(g, cx, cy, cz, ox, oy, oz, range_limit, __builtin_inff());
@@ -564,6 +569,14 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
 #ifdef NDT_FLAT_STATS
         for (int k = 0; k < 4; k++) ctr->cyc[k] = s_stat[k];
 #endif
+#ifdef NDT_FLAT_TIMES
+        // (timeline of the launch: start and end of this workgroup on the 100 MHz clock, its core clocks, where it ran)
+        ctr->cyc[0] = (uint32_t)rt0;
+        ctr->cyc[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        ctr->cyc[2] = (uint32_t)(t3 - t0);
+        ctr->cyc[3] = ((uint32_t)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |      // HW_ID: cu 11:8, sh 12, se 15:13
+                      ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);             // XCC_ID
+#endif
         if (set.cell_sel) set.cell_sel[map] = 0u;
     }
 }
@@ -583,7 +596,8 @@ hipError_t ndt_launch_build_flat(const NdtSetView &set, size_t first, size_t cou
 {
     const NdtGrid &g = set.grid;
     const unsigned bm_words = (unsigned)((g.slots + 31) / 32);
-    unsigned hash_log2 = 9;                      // (>= 64 entries per wave: the in-place compaction reads whole waves)
+    unsigned hash_log2 = 6;                      // (>= 64 entries per wave: the in-place compaction reads whole waves)
+    while ((1u << hash_log2) < 64u * NDT_FLAT_WAVES) hash_log2++;
     // (entries >= cells the map may hold: at the usual few hundred to two thousand cells of a 4096-cell map the table is
     //  at most half full; a map that runs into max_cells probes long chains and is flagged as overflowing anyway)
     while ((1u << hash_log2) < g.max_cells) hash_log2++;

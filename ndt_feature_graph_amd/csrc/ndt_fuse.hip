@@ -26,6 +26,7 @@
 // after beam, so a cell that loses its Gaussian half way through a cloud is treated as empty by the remaining beams,
 // and it accumulates in float.  Here every beam sees the cells as they were when the call started.
 #include "ndt_math.h"
+#include "ndt_wave.h"
 
 #define NDT_FUSE_THREADS 1024
 // the finalise kernel: 512 threads = 8 waves = 256 VGPRs each (at 1024 threads the 128-register budget spilled the
@@ -171,7 +172,7 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
     // 4 cm apart at 10 m).  64 atomics on ONE address in one instruction are served one after the other at the L2
     // (the launch ran at 11 G updates/s); the lanes of a wave therefore add up the updates of a cell -- integers, so
     // the sum is exact and the result the same -- and one lane adds the sum.
-    for (int k = 0; __ballot(k < N - 2); k++) {
+    for (int k = 0; ndt_ballot(k < N - 2); k++) {
         int slot = -1;
         long long val = 0;
         if (k < N - 2) {
@@ -182,7 +183,7 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
             int ix = (int)flx, iy = (int)fly, iz = (int)flz;
             const bool nx = !(fabsf((vx - flx) - 0.5f) <= frac_lim), ny = !(fabsf((vy - fly) - 0.5f) <= frac_lim),
                        nz = !(fabsf((vz - flz) - 0.5f) <= frac_lim);
-            if (__ballot(nx | ny | nz)) {                 // (rare; a sample far outside the grid is out of bounds on either path)
+            if (ndt_ballot(nx | ny | nz)) {                 // (rare; a sample far outside the grid is out of bounds on either path)
                 if (nx) ix = lazygrid_index((double)px, cx, g.res, g.size[0]);
                 if (ny) iy = lazygrid_index((double)py, cy, g.res, g.size[1]);
                 if (nz) iz = lazygrid_index((double)pz, cz, g.res, g.size[2]);
@@ -205,7 +206,7 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
                 }
             }
         }
-        unsigned long long todo = __ballot(slot >= 0);
+        unsigned long long todo = ndt_ballot(slot >= 0);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int s0 = __shfl(slot, leader, 64);
@@ -214,7 +215,7 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
             const long long mv = mine ? val : 0ll;
             const long long v = ((long long)wave_sum_i32((int)(mv >> 20)) << 20) + (long long)wave_sum_i32((int)(mv & 0xFFFFF));
             if ((int)lane == leader) atomicAdd(reinterpret_cast<unsigned long long *>(delta + s0), (unsigned long long)v);
-            todo &= ~__ballot(mine);
+            todo &= ~ndt_ballot(mine);
         }
     }
 }
@@ -428,7 +429,7 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
         const unsigned w = step + lane;
         const unsigned bits = (w < we) ? bitmap[w] : 0u;
         const uint2 old = (w < we) ? rankmap[w] : make_uint2(0u, 0u);   // the old cells of this word: bits and first rank
-        if (!__ballot((bits | old.x) != 0u)) continue;
+        if (!ndt_ballot((bits | old.x) != 0u)) continue;
         const unsigned vmask = (ovf && bits) ? valid_bits(w, bits) : bits;
         const unsigned cnt = (unsigned)__popc(vmask);
         const unsigned incl = fuse_wave_incl_scan(cnt);
@@ -560,7 +561,7 @@ extern "C" __global__ __launch_bounds__(NDT_FUSE_THREADS) void ndt_discard_kerne
             c = cells[r];
             keep = ((__hip_atomic_load(&rankmap[c.slot >> 5].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (c.slot & 31u)) & 1u) != 0u;
         }
-        const unsigned long long m = __ballot(keep);
+        const unsigned long long m = ndt_ballot(keep);
         const unsigned before = (unsigned)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64u - lane))));
         if (lane == 0) s_wave[wave] = (unsigned)__popcll(m);
         __syncthreads();

@@ -429,11 +429,11 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
     NDT_PROF_T(0)
     const HitCache hc = *w.cache;
     const bool moved = vi && (w.mycell[lane] != ix || w.mycell[64 + lane] != iy || w.mycell[128 + lane] != iz);
-    const bool reuse = cache_key != 0u && hc.key == cache_key && hc.base == base && !__ballot(moved);
+    const bool reuse = cache_key != 0u && hc.key == cache_key && hc.base == base && !ndt_ballot(moved);
     if (vi && !reuse) { w.mycell[lane] = ix; w.mycell[64 + lane] = iy; w.mycell[128 + lane] = iz; }
     // flat form only when every lane's z-neighbourhood is the whole column (a source cell that lies two or
     // more cells above / below a thin map sees only part of it, or nothing): wave-uniform
-    const bool flat = tg.sz <= NN + 1 && !__ballot(vi && !(iz - NN <= 0 && iz + NN >= tg.sz - 1));
+    const bool flat = tg.sz <= NN + 1 && !ndt_ballot(vi && !(iz - NN <= 0 && iz + NN >= tg.sz - 1));
     const int zlo = flat ? 0 : max(iz - NN, 0), zhi = flat ? tg.sz - 1 : min(iz + NN, tg.sz - 1);
     grank_ptr rmw = tg.rankmap;
     // The runs are fetched W at a time (flat map: the W runs of the W x-neighbours; otherwise, per x, the W runs of the
@@ -618,7 +618,7 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
         const unsigned incl = wave_incl_scan_u32(cnt);
         const unsigned total_all = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
         const unsigned off_all = incl - cnt;
-        const unsigned long long have = __ballot(vi);
+        const unsigned long long have = ndt_ballot(vi);
         const unsigned n_seg = have ? (63u - (unsigned)__builtin_clzll(have)) / seg_lanes + 1u : 0u;   // segments that hold cells
         // list offset at which segment x starts (x == n_seg: the end of the list)
         auto seg_off = [&](unsigned x) -> unsigned {
@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
                 NdtPoolPair *P = pair_at(q);
                 unsigned long long t = 0ull;
                 if (k < n_pairs) t = __hip_atomic_load(&P->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long open = __ballot(tk_seq(t) != 0u && tk_drawn(t) < tk_tasks(t));
+                unsigned long long open = ndt_ballot(tk_seq(t) != 0u && tk_drawn(t) < tk_tasks(t));
                 while (open != 0ull && code == POOL_NONE) {
                     const unsigned l = (unsigned)__builtin_ctzll(open);
                     open &= open - 1ull;
@@ -1945,7 +1945,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
                             s_task[0] = q; s_task[1] = tk_drawn(t); s_task[5] = tk_seq(t); s_task[9] = tk_tasks(t);
                         }
                     }
-                    if (__ballot(won)) code = POOL_TASK;
+                    if (ndt_ballot(won)) code = POOL_TASK;
                 }
             }
             if (code == POOL_TASK) {
