@@ -53,7 +53,7 @@ def build_library(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     # (spills never go to AGPRs: with AGPRs in use the matcher kernel would not keep 256 architectural VGPRs at two
     #  waves per SIMD)
-    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical",
               "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", *extra]
     jobs = []
     for name, src in zip(_SOURCES, srcs):

@@ -39,7 +39,7 @@ cyc = np.array([mf.counters(i)["cyc"][:3] for i in range(0, n, max(1, n // 64))]
 print("flat phase clocks (mean over sampled maps): A %.0f  B %.0f  C %.0f" % tuple(cyc.mean(0)))
 if "stats" in os.environ.get("NDTGPU_LIB", ""):
     c4 = np.array([mf.counters(i)["cyc"] for i in range(0, n, max(1, n // 64))], dtype=np.float64).mean(0)
-    print("flat stats per map: clocks per wave in the exact path %.0f, exact-path rounds %.0f, flushes %.0f, drains %.0f (of %d rounds)" % (c4[0], c4[1], c4[2], c4[3], (npts + 63) // 64))
+    print("flat stats per map: rounds with the index arithmetic %.0f, rounds that failed the fast tests %.0f, flushes %.0f, drains %.0f (of %d rounds)" % (c4[0], c4[1], c4[2], c4[3], (npts + 63) // 64))
 bad = 0
 worst = 0.0
 for i in list(range(0, n, max(1, n // 48))) + [n - 1]:
