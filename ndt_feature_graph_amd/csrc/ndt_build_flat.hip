@@ -20,12 +20,13 @@
 //     A round whose 64 points all pass for A or B costs 12 instructions of tests + 12 per run that received points.
 //     Points that are certainly dropped (NaN, far out of range / grid: beams without a return) count as passed.
 //   * A round with a point that fails everything (a new cell, a point in the guard band) is binned with the
-//     reference-exact index arithmetic of csrc/ndt_binning.h; a new cell replaces the run used least recently -- the runs
-//     trade places when that is B, so that the victim is always A and the flush exists once in the code --, whose moments
-//     are summed over the wave (a value-halving butterfly: 57 instructions for the nine sums), converted to 64-bit fixed
-//     point and appended to the wave's flush list.  One record per cell VISIT of a wave.  The rounds of a batch are
-//     processed in scan order by unrolled code with this path inline; the kernel's code (41 KB) has to stay within the
-//     64 KB instruction cache two CUs share (measured: +10 % time beyond it).
+//     reference-exact index arithmetic of csrc/ndt_binning.h; a new cell becomes run B, what was B becomes A, and what
+//     was A -- the run opened first -- leaves: its moments are summed over the wave (a value-halving butterfly: 57
+//     instructions for the nine sums), converted to 64-bit fixed point and appended to the wave's flush list.  One
+//     record per cell VISIT of a wave.  The rounds of a batch are processed in scan order by unrolled code with this
+//     path inline; the kernel's code (40 KB) has to stay within the 64 KB instruction cache two CUs share (measured:
+//     +10 % time beyond it).  The kernel issues vector instructions 80 % of the time its waves are resident: what
+//     counts is the number of instructions per round and per visit (DESIGN.md 4.1a has the census).
 //   * The list is drained 16 records at a time: slot -> accumulator id through a per-workgroup LDS hash (the map belongs
 //     to this workgroup: no global work table), then one 64-bit integer atomic per (record, moment) into the map's
 //     accumulators in L2 -- exact, hence order-independent and bit-reproducible, like the general kernel.
