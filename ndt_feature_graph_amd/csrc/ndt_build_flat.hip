@@ -442,8 +442,16 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
         if (a_slot >= 0) flush(a_sd, a_se, a_slot, a_n);
         if (b_slot >= 0) flush(b_sd, b_se, b_slot, b_n);
         if (nfl) drain();
+#ifdef NDT_FLAT_TIMES
+        if (lane == 0) s_wave_cnt[wave] = (unsigned)(__builtin_readcyclecounter() - t0);
+#endif
     }
     __syncthreads();
+#ifdef NDT_FLAT_TIMES
+    unsigned wclk_max = 0, wclk_sum = 0;
+    for (int k = 0; k < NDT_FLAT_WAVES; k++) { wclk_max = max(wclk_max, s_wave_cnt[k]); wclk_sum += s_wave_cnt[k]; }
+    __syncthreads();
+#endif
 
     // ---------------- phase B: moments -> Gaussian ----------------------------------------------------------------------
     const long long t1 = __builtin_readcyclecounter();
@@ -574,9 +582,8 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
         // (timeline of the launch: start and end of this workgroup on the 100 MHz clock, its core clocks, where it ran)
         ctr->cyc[0] = (uint32_t)rt0;
         ctr->cyc[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        ctr->cyc[2] = (uint32_t)(t3 - t0);
-        ctr->cyc[3] = ((uint32_t)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |      // HW_ID: cu 11:8, sh 12, se 15:13
-                      ((uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 16);             // XCC_ID
+        ctr->cyc[2] = wclk_max;            // phase A: the slowest wave's clocks ...
+        ctr->cyc[3] = wclk_sum / NDT_FLAT_WAVES;   // ... and the mean of the waves
 #endif
         if (set.cell_sel) set.cell_sel[map] = 0u;
     }

@@ -24,20 +24,11 @@ base = t0.min()
 s, e = (t0 - base) / 100.0, (t1 - base) / 100.0          # microseconds
 dur = e - s
 print("workgroups: first start 0, last start %.1f us, last end %.1f us" % (s.max(), e.max()))
-print("duration per workgroup: mean %.1f us  min %.1f  max %.1f;  core clocks mean %.0f  => %.2f GHz" %
-      (dur.mean(), dur.min(), dur.max(), clk.mean(), clk.mean() / dur.mean() / 1e3))
+print("duration per workgroup: mean %.1f us  min %.1f  max %.1f" % (dur.mean(), dur.min(), dur.max()))
+print("phase A, clocks of the slowest wave / mean of the four waves: %.0f / %.0f  (mean over maps: the waves wait %.1f %% of phase A for the slowest)" % (clk.mean(), where.mean(), 100.0 * (1.0 - where.mean() / clk.mean())))
 order = np.argsort(s)
 print("start times (us) of workgroups in start order, every 128th:", np.round(s[order][::128], 1))
 print("end times, every 128th:", np.round(np.sort(e)[::128], 1))
-xcc = where >> 16
-cu = (where >> 8) & 0xff
-print("workgroups per XCC:", np.bincount(xcc, minlength=8))
-busy = np.zeros(8)
-for x in range(8):
-    busy[x] = dur[xcc == x].sum()
-print("busy workgroup-us per XCC:", np.round(busy), " last end per XCC:", [round(float(e[xcc == x].max()), 1) for x in range(8) if (xcc == x).any()])
-blk = np.arange(n)
-print("XCC of blocks 0..15:", xcc[:16], " CU/SE ids:", cu[:16])
 # concurrency: how many workgroups are running at time t
 ts = np.linspace(0, e.max(), 21)
 print("running workgroups at t:", [(round(float(t)), int(((s <= t) & (e > t)).sum())) for t in ts])
