@@ -37,7 +37,9 @@ __device__ long long g_solver_prof[16];
 #include "ndt_solver.h"
 #include <float.h>
 
+#ifndef NDT_MATCH_THREADS
 #define NDT_MATCH_THREADS 512
+#endif
 #define NDT_MATCH_WAVES (NDT_MATCH_THREADS / 64)
 #define NDT_VW 8             // shares the source cells of an evaluation are dealt to (= waves of a wide workgroup)
 

@@ -959,7 +959,8 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
     // (a stream that owns only part of the chip -- hipExtStreamCreateWithCUMask, bench.py --cu-split -- wants one workgroup
     //  per CU it has, not per CU of the device)
     const char *grp_env = getenv("NDTGPU_MATCH_GROUPS");
-    if (grp_env && atoi(grp_env) > 0) n_groups = std::min<unsigned>(n_groups, (unsigned)atoi(grp_env));
+    // (more workgroups than CUs: narrow-workgroup builds of the kernel, -DNDT_MATCH_THREADS=256, of which two share a CU)
+    if (grp_env && atoi(grp_env) > 0) n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)atoi(grp_env));
     const char *dbl_env = getenv("NDTGPU_DOUBLE_THRESH");
     const unsigned double_thresh = dbl_env ? (unsigned)atoi(dbl_env) : n_groups;
     // The work area (ticket counters, parked solver states) belongs to the target set: a launch on another stream
