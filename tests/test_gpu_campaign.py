@@ -80,3 +80,35 @@ def test_parity_campaign_3d_8_pairs(N, O):
         dr = float(np.linalg.norm(T[k][:3, :3] - To[:3, :3]))
         assert dt <= 1e-6 and dr <= 1e-6, (seeds[k], dt, dr)
         assert r["iterations"][k] == ro["iterations"] and bool(r["converged"][k]) == ro["converged"], seeds[k]
+
+
+def test_3d_pair_that_runs_into_itr_max(N, O):
+    """Seed 371 of the 3D campaign does not converge: 32 iterations and exit "too many iterations" on both sides, and the
+    two poses are 3.7e-4 m apart.  What is asserted: the control flow is the oracle's (iterations, exit, convergence
+    flag), the maps are identical, and the HIP path's pose is the ORACLE's pose under one of its summation orders
+    (oracle_set_sum_mode 0..3: default, reversed, eight shares, shares reversed) to 1e-6 m -- a registration that does
+    not converge has no pose to agree on beyond the order in which its pair terms are added."""
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_3d([371], rings=32, azimuths=1500)
+    fixed, moving, T0 = pr["fixed"].numpy(), pr["moving"].numpy(), pr["T_init"].numpy()
+    res, size, rng = 0.25, [100.0, 100.0, 10.0], 70.0
+    ms = N.MapSet(res, [0, 0, 0], size, n_maps=2, max_cells=32768)
+    ms.build(np.concatenate([fixed, moving]), range_limit=rng)
+    T, r = N.match_batch(ms, [0], ms, [1], T0)
+    a = O.OracleMap(res, [0, 0, 0], size); a.load_points(fixed[0], rng); a.compute_cells()
+    b = O.OracleMap(res, [0, 0, 0], size); b.load_points(moving[0], rng); b.compute_cells()
+    for m, om in ((0, a), (1, b)):
+        g, o = ms.export_cells(m), om.export_cells()
+        assert np.array_equal(g[2], o[2]) and np.array_equal(g[3], o[3])
+    dts = []
+    try:
+        for mode in (0, 1, 2, 3):
+            O.set_sum_mode(mode)
+            To, ro = O.match_d2d(a, b, T0[0])
+            assert r["iterations"][0] == ro["iterations"] and bool(r["converged"][0]) == bool(ro["converged"])
+            dts.append(float(np.linalg.norm(T[0][:3, 3] - To[:3, 3])))
+    finally:
+        O.set_sum_mode(0)
+    print("3D pair 371: |dt| to the oracle under summation orders 0..3:", ["%.2e" % d for d in dts])
+    assert not r["converged"][0] and r["exit_code"][0] == 3
+    assert min(dts) <= 1e-6 and max(dts) <= 2e-3, dts
