@@ -1,12 +1,12 @@
 """Randomised parity campaign (not part of the test suite): n 2D scan pairs, HIP path against the oracle.
-usage (GPU box): python tools/parity_campaign.py 1500 [3dof]   (3dof: NDTMatcherD2D_2D, dof_mask 0x23)"""
+usage (GPU box): python tools/parity_campaign.py 1500 [6dof|3dof] [points=20000]   (3dof: NDTMatcherD2D_2D, dof_mask 0x23)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import ndt_feature_graph_amd as N
 from ndt_feature_graph_amd import synth
 from oracle import binding as O
-n, npts, res, size, rng = int(sys.argv[1]), 20000, 0.5, [100.0, 100.0, 1.0], 30.0
+n, npts, res, size, rng = int(sys.argv[1]), (int(sys.argv[3]) if len(sys.argv) > 3 else 20000), 0.5, [100.0, 100.0, 1.0], 30.0
 kw = dict(dof_mask=0x23) if len(sys.argv) > 2 and sys.argv[2] == "3dof" else {}
 seeds = list(range(5000, 5000 + n))
 pr = synth.pair_2d(seeds, npts)
