@@ -30,8 +30,11 @@ def library_path():
 # goes to the stack (the only private segment the matcher kernels would have).
 # ndt_build_flat.hip: the same pass merges the two symmetric "replace run A / run B" branches into one that works through a
 # POINTER to the run's scalar state, which then lives in scratch memory instead of scalar registers.
+# ndt_build.hip: the same for the two runs of a lane in the 3D (SCAT) point loop -- their second moments were 112 B of
+# scratch per lane and a memory round trip per point until round 4.
 _SOURCE_FLAGS = {"ndt_match.hip": ["-mllvm", "-simplifycfg-sink-common=false"],
-                 "ndt_build_flat.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
+                 "ndt_build_flat.hip": ["-mllvm", "-simplifycfg-sink-common=false"],
+                 "ndt_build.hip": ["-mllvm", "-simplifycfg-sink-common=false"]}
 
 
 def build_library(force=False, verbose=False):

@@ -92,8 +92,8 @@ NDT_D int get_or_assign(const BuildCtx &b, int slot)
     // them that way to run a map out of accumulators that would have fitted
     if (id == NDT_EMPTY) id = __hip_atomic_load(&b.wtable[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (id != NDT_EMPTY) { idc_put(ce, slot, id); return id; }
-    unsigned nid = __hip_atomic_fetch_add(&b.ctr->n_alloc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int expected = NDT_EMPTY;
+    unsigned nid = __hip_atomic_fetch_add(&b.ctr->n_alloc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (__hip_atomic_compare_exchange_strong(&b.wtable[slot], &expected, (int)nid, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT)) {
         __hip_atomic_fetch_or(&b.bitmap[slot >> 5], 1u << (slot & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -106,14 +106,74 @@ NDT_D int get_or_assign(const BuildCtx &b, int slot)
     return expected;   // somebody else assigned it first
 }
 
+// slot -> accumulator id for up to 64 records at once (lane = record): what a 3D sweep needs, whose waves meet ~640
+// distinct cells per super-tile.  One L2-served load for all the lanes, ONE addition to the map's allocation counter for
+// all the new cells of the wave (the lanes take consecutive ids), one compare-and-swap each: three dependent round trips per
+// 64 records, where a look-up per replaced run was up to four per POINT step of the wave.
+NDT_D int get_or_assign_wave(const BuildCtx &b, int slot, bool active, unsigned lane)
+{
+    unsigned long long *ce = b.idc + (slot & (NDT_IDC - 1));
+    int id = NDT_EMPTY;
+    bool hit = false;
+    if (active) {
+        const unsigned long long c = *ce;
+        if ((int)(c >> 32) == slot) { id = (int)(unsigned)c; hit = true; }
+    }
+    const bool miss = active && !hit;
+    // (a memory-side atomic drops the line from the L2 it passes; another XCD's L2 may still hold an EMPTY: the
+    // compare-and-swap below then fails and returns the id, at the price of the id drawn for nothing)
+    if (miss) id = __hip_atomic_load(&b.wtable[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool need = miss && id == NDT_EMPTY;
+    const unsigned long long nm = ndt_ballot(need);
+    if (nm) {
+        const int leader = __ffsll((long long)nm) - 1;
+        unsigned base = 0;
+        if ((int)lane == leader)
+            base = __hip_atomic_fetch_add(&b.ctr->n_alloc, (unsigned)__popcll(nm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = (unsigned)__shfl((int)base, leader, 64);
+        if (need) {
+            const unsigned long long below = lane ? (nm & (~0ull >> (64u - lane))) : 0ull;
+            const unsigned nid = base + (unsigned)__popcll(below);
+            int expected = NDT_EMPTY;
+            if (__hip_atomic_compare_exchange_strong(&b.wtable[slot], &expected, (int)nid, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_fetch_or(&b.bitmap[slot >> 5], 1u << (slot & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (nid < b.cap) b.acc_slot[nid] = (uint32_t)slot;
+                else __hip_atomic_store(&b.ctr->overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                id = (int)nid;
+            } else {
+                id = expected;   // somebody else assigned it first
+            }
+        }
+    }
+    if (miss) idc_put(ce, slot, id);
+    return id;
+}
+
+// one moment word of a cell's accumulator += v, at the memory side, where the L2s of all XCDs agree.  (Scopes below
+// "agent" compile to the same instruction on gfx950: where an atomic is performed is decided by the memory type, not by
+// the instruction -- a map dealt to one XCD gains nothing.)
+NDT_D void acc_add(const BuildCtx &b, unsigned long long *p, unsigned long long v)
+{
+#ifdef NDT_BUILD_PROF
+    if (b.dbg & 4) return;   // timing experiment: no accumulator traffic (1.31 -> 1.27 ms per 64 sweeps: not the limiter)
+#endif
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One partial run {n, sum d (m), sum d d^T (m^2)} becomes a 10-word record in the per-wave flush list: the sums are
 // scaled to cell units * 2^s and rounded to 64-bit integers (see NdtAcc), so that the integer atomic adds that consume
 // the list are exact, hence order-independent.
+template <bool DEFER = false>
 NDT_D void write_flush_record(const BuildCtx &b, long long *rec, int *rec_id, int slot, double n, const double *sd,
                               const double *sdd)
 {
-    int id = get_or_assign(b, slot);
-    *rec_id = (id >= 0 && (uint32_t)id < b.cap) ? id : -1;
+    if (DEFER) {
+        *rec_id = slot;                     // the ids of a whole list are looked up together when it is drained
+    } else {
+        int id = get_or_assign(b, slot);
+        *rec_id = (id >= 0 && (uint32_t)id < b.cap) ? id : -1;
+    }
     rec[0] = (long long)(unsigned long long)(unsigned)n;
 #pragma unroll
     for (int k = 0; k < 3; k++) rec[1 + k] = ndt_fixed_from_double(sd[k] * b.q1);
@@ -148,8 +208,9 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     constexpr int FLC = SCAT ? 64 : NDT_FLCAP;                       // records in a wave's flush list
     __shared__ int s_flid[NDT_BUILD_WAVES * FLC];
     __shared__ long long s_list[SCAT ? NDT_BUILD_WAVES * 64 * 10 : 1];
-    __shared__ double s_qval[NDT_BUILD_WAVES * 10 * NDT_QRUNS];
-    __shared__ int s_qslot[NDT_BUILD_WAVES * NDT_QRUNS];
+    // (the table of replaced runs is not used by SCAT: without it three of its workgroups fit a CU's LDS, not two)
+    __shared__ double s_qval[SCAT ? 1 : NDT_BUILD_WAVES * 10 * NDT_QRUNS];
+    __shared__ int s_qslot[SCAT ? 1 : NDT_BUILD_WAVES * NDT_QRUNS];
     __shared__ unsigned s_qcnt[NDT_BUILD_WAVES];
     __shared__ unsigned long long s_idc[NDT_BUILD_WAVES * NDT_IDC];
     __shared__ unsigned s_wave_cnt[NDT_FIN_THREADS / 64];
@@ -160,7 +221,11 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     // the wave index through readfirstlane: everything derived from it (tile ranges, staging bases) is scalar
     const unsigned lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned nthreads = (MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BUILD_THREADS, nwaves = nthreads / 64;
-    const unsigned map_local = (MODE == 0) ? blockIdx.x : blockIdx.y;
+    // MODE 1 with dbg bit 1: maps are dealt to XCDs (map m of the launch -> XCD m mod 8) and the workgroups of a map
+    // are those the dispatcher places there (workgroup b of the launch runs on XCD b mod 8)
+    const bool xcd_map = (MODE == 1) && (dbg & 2);
+    const unsigned lin_block = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned map_local = (MODE == 0) ? blockIdx.x : xcd_map ? (lin_block & 7u) + 8u * ((lin_block >> 3) / gridDim.x) : blockIdx.y;
     // MODE 2: gridDim.x workgroups share phases 0 and B of one map; the last one to finish runs phases C and D
     const unsigned fin_parts = (MODE == 2) ? gridDim.x : 1u, fin_part = (MODE == 2) ? blockIdx.x : 0u;
     const unsigned map = first + map_local;
@@ -184,7 +249,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     bc.cap = cap;
     bc.q1 = ldexp(inv_res, s1_shift);
     bc.q2 = ldexp(inv_res * inv_res, s2_shift);
-    bc.dbg = dbg;
+    bc.dbg = (MODE == 1) ? dbg : 0;
     bc.idc = s_idc + ((MODE == 2 || MODE == 3) ? 0u : wave) * NDT_IDC;
     if (MODE != 2 && MODE != 3) bc.idc[lane & (NDT_IDC - 1)] = ~0ull;
     double ox = 0, oy = 0, oz = 0;
@@ -211,8 +276,8 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     }
     if (tid == 0) { s_base = 0; s_dropped = 0; }
     if (MODE != 2 && MODE != 3) {
-        for (unsigned i = tid; i < NDT_BUILD_WAVES * NDT_QRUNS; i += nthreads) s_qslot[i] = -1;
-        for (unsigned i = tid; i < NDT_BUILD_WAVES * 10 * NDT_QRUNS; i += nthreads) s_qval[i] = 0.0;
+        for (unsigned i = tid; !SCAT && i < NDT_BUILD_WAVES * NDT_QRUNS; i += nthreads) s_qslot[i] = -1;
+        for (unsigned i = tid; !SCAT && i < NDT_BUILD_WAVES * 10 * NDT_QRUNS; i += nthreads) s_qval[i] = 0.0;
         if (tid < NDT_BUILD_WAVES) s_qcnt[tid] = 0u;
     }
     __syncthreads();
@@ -225,7 +290,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     // the flush run once per up to 2048 points while the LDS tile stays 6.4 KB.
     const unsigned n_tiles = (n_points + NDT_TILE - 1) / NDT_TILE;
     // MODE 1: this workgroup's share of the map's sub-tiles; otherwise all of them.  Waves split the share.
-    const unsigned n_parts = (MODE == 1) ? gridDim.x : 1u, part = (MODE == 1) ? blockIdx.x : 0u;
+    const unsigned n_parts = (MODE == 1) ? gridDim.x : 1u, part = (MODE == 1) ? (xcd_map ? (lin_block >> 3) % gridDim.x : blockIdx.x) : 0u;
     const unsigned tiles_per_part = (n_tiles + n_parts - 1) / n_parts;
     const unsigned part_begin = min(n_tiles, part * tiles_per_part), part_end = min(n_tiles, part_begin + tiles_per_part);
     const unsigned tiles_per_wave = (part_end - part_begin + NDT_BUILD_WAVES - 1) / NDT_BUILD_WAVES;
@@ -243,17 +308,32 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     int *fl_id = s_flid + awave * FLC;
     unsigned nfl = 0;   // wave-uniform
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
+#ifdef NDT_BUILD_PROF
+    long long pa_stage = 0, pa_points = 0, pa_drain = 0, pa_end = 0;
+#endif
     auto drain_list = [&]() {
+#ifdef NDT_BUILD_PROF
+        const long long td0 = __builtin_readcyclecounter();
+#endif
         ndt_wave_sync();                                  // the records were written by other lanes
+        if (SCAT) {                                       // (FLC == 64: one record per lane) slots -> ids, all at once
+            const bool act = lane < nfl;
+            const int id = get_or_assign_wave(bc, act ? fl_id[lane] : 0, act, lane);
+            if (act) fl_id[lane] = (id >= 0 && (uint32_t)id < bc.cap) ? id : -1;
+            ndt_wave_sync();
+        }
         const unsigned items = nfl * 10u;
         for (unsigned it = lane; it < items; it += 64u) {
             unsigned e = it / 10u, k = it % 10u;
             int id = fl_id[e];
             if (id >= 0)
-                atomicAdd(reinterpret_cast<unsigned long long *>(bc.acc + id) + k, (unsigned long long)fl_val[e * 10u + k]);
+                acc_add(bc, reinterpret_cast<unsigned long long *>(bc.acc + id) + k, (unsigned long long)fl_val[e * 10u + k]);
         }
         ndt_wave_sync();                                  // the list may be overwritten now
         nfl = 0;
+#ifdef NDT_BUILD_PROF
+        pa_drain += __builtin_readcyclecounter() - td0;
+#endif
     };
     auto push_runs = [&](bool mine, int slot, double n, const double *sd3, const double *se6) {
         unsigned long long m = ndt_ballot(mine);
@@ -262,7 +342,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             const unsigned room = (unsigned)FLC - nfl;
             const unsigned rank = (unsigned)__popcll(m & lt_mask);
             const bool now = mine && ((m >> lane) & 1ull) && rank < room;
-            if (now) write_flush_record(bc, fl_val + (nfl + rank) * 10u, fl_id + nfl + rank, slot, n, sd3, se6);
+            if (now) write_flush_record<SCAT>(bc, fl_val + (nfl + rank) * 10u, fl_id + nfl + rank, slot, n, sd3, se6);
             const unsigned long long done = ndt_ballot(now);
             nfl += (unsigned)__popcll(done);
             m &= ~done;
@@ -270,8 +350,8 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     };
     // evicted runs are queued in LDS and added to their cells at the end of the tile by all lanes in
     // parallel: nothing in the point loop waits for global memory
-    double *q_val = s_qval + awave * (10 * NDT_QRUNS);
-    int *q_slot = s_qslot + awave * NDT_QRUNS;
+    double *q_val = s_qval + (SCAT ? 0u : awave * (10 * NDT_QRUNS));
+    int *q_slot = s_qslot + (SCAT ? 0u : awave * NDT_QRUNS);
     for (unsigned tile = tile_begin; tile < tile_end;) {
         const unsigned R = min((unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
         const unsigned p0 = tile * NDT_TILE;                              // its first point
@@ -320,7 +400,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
                 write_flush_record(bc, rec, &rid, victim, vn, v3, v6);
                 if (rid >= 0)
                     for (int k = 0; k < 10; k++)
-                        atomicAdd(reinterpret_cast<unsigned long long *>(bc.acc + rid) + k, (unsigned long long)rec[k]);
+                        acc_add(bc, reinterpret_cast<unsigned long long *>(bc.acc + rid) + k, (unsigned long long)rec[k]);
             }
         };
         // A lane keeps the moments of TWO cells in registers (range noise on a wall that hugs a cell face makes its
@@ -335,11 +415,15 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
                     // atomics whenever it is full)
                     const bool to1 = cs0 >= 0 && (cs1 < 0 || mru1 == 0);
                     const int victim = to1 ? cs1 : cs0;
+                    // (the sums of run 0 pass through an empty asm: a select between two LOADS of the register arrays is
+                    // turned into one load through a selected POINTER, and an array that is indexed that way lives in
+                    // scratch memory -- both runs' second moments did, at a memory round trip per point: 112 B of scratch
+                    // and 8 k clocks per point step of a wave until round 4)
                     double vn = (double)(to1 ? rn1 : rn), v3[3], v6[6];
 #pragma unroll
-                    for (int k = 0; k < 3; k++) v3[k] = to1 ? sd1[k] : sd[k];
+                    for (int k = 0; k < 3; k++) { double a = sd[k]; asm volatile("" : "+v"(a)); v3[k] = to1 ? sd1[k] : a; }
 #pragma unroll
-                    for (int k = 0; k < 6; k++) v6[k] = to1 ? se1[k] : se[k];
+                    for (int k = 0; k < 6; k++) { double a = se[k]; asm volatile("" : "+v"(a)); v6[k] = to1 ? se1[k] : a; }
                     push_runs(newc && victim >= 0, victim, vn, v3, v6);
                     if (newc) {
                         if (to1) {
@@ -406,6 +490,9 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
         };
 #pragma unroll 1
         for (unsigned r = 0; r < R; r++) {
+#ifdef NDT_BUILD_PROF
+        const long long tr0 = __builtin_readcyclecounter();
+#endif
         if (STRIDE_DW) {
             // Round r of the super-tile: lane `owner` needs its points [8r, 8r+8) = dwords
             // (owner*R + r)*8*SD + e, e < 8*SD, of the super-tile.  Lane l fetches item d = l + 64k
@@ -455,6 +542,10 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             }
         }
         ndt_wave_sync();   // a lane's row of the tile was written by other lanes
+#ifdef NDT_BUILD_PROF
+        const long long tr1 = __builtin_readcyclecounter();
+        pa_stage += tr1 - tr0;
+#endif
         // Two points per trip: their index arithmetic is independent and interleaves (the loop is latency bound at the
         // 3 waves per SIMD the register state allows); the run bookkeeping then takes them in scan order.
 #pragma unroll 1
@@ -473,8 +564,14 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
             add_point(ax, ay, az, agx, agy, agz, aslot);
             add_point(bx, by, bz, bgx, bgy, bgz, bslot);
         }
+#ifdef NDT_BUILD_PROF
+        pa_points += __builtin_readcyclecounter() - tr1;
+#endif
         }   // rounds
         {
+#ifdef NDT_BUILD_PROF
+            const long long te0 = __builtin_readcyclecounter();
+#endif
             ndt_wave_sync();   // table / flag written by other lanes during the rounds
             // Canonical order of a lane's two runs (run 0 = smaller slot): along a wall that hugs a cell
             // face neighbouring lanes then agree on which cell is run 0 and which is run 1, so both form
@@ -525,7 +622,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
                 push_runs(head && cs >= 0, cs, (double)rn, sd, se);
             }
             ndt_wave_sync();
-            if (s_qcnt[wave]) {                  // records of the replaced runs; the table goes back to empty
+            if (!SCAT && s_qcnt[wave]) {         // records of the replaced runs; the table goes back to empty
                 const unsigned ql = lane & (NDT_QRUNS - 1u);
                 const int qs = q_slot[ql];
                 const bool has = lane < NDT_QRUNS && qs >= 0;
@@ -543,8 +640,17 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
                 push_runs(has, qs, vn, v3, v6);
             }
             drain_list();
+#ifdef NDT_BUILD_PROF
+            pa_end += __builtin_readcyclecounter() - te0;
+#endif
         }
     }
+#ifdef NDT_BUILD_PROF
+    if (MODE == 1 && wave == 0 && lane == 0) {
+        atomicAdd(&ctr->cyc[0], (unsigned)(pa_stage >> 4)); atomicAdd(&ctr->cyc[1], (unsigned)(pa_points >> 4));
+        atomicAdd(&ctr->cyc[2], (unsigned)(pa_drain >> 4)); atomicAdd(&ctr->cyc[3], (unsigned)(pa_end >> 4));
+    }
+#endif
     __syncthreads();
     if (MODE == 1) return;   // the finalise launch does the rest
     // atomics bypass the vector L1: drop lines that phase A cached before they were updated
@@ -684,7 +790,38 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
         running += s_segbase;
         total_cells += s_segbase;      // (cells up to the end of this segment)
     }
-    if (!ovf) {
+#ifdef NDT_BUILD_PROF
+    const long long tp1 = __builtin_readcyclecounter();
+#endif
+    if (!ovf && MODE == 3) {
+        // Big grids (round 4): the ranking launch only writes the RANK MAP -- per bitmap word its Gaussian bits and the rank
+        // of its first cell -- and clears the bitmap; every cell record is then put in its place by the placement launch
+        // (ndt_place_cells_kernel), one thread per accumulator id with ONE dependent load.  Until round 4 this pass also
+        // wrote every cell's slot into its final record (a 4-byte store into an 80-byte record per cell) and a third pass
+        // walked slot -> work table -> record -> cell array, three dependent round trips into a 1.6 GB working set:
+        // 0.34 ms of the 0.88 ms that 64 sweeps took.
+        for (unsigned step = wb; step < we; step += 64u * WPL) {
+            const unsigned w0 = step + lane * WPL;
+            unsigned bits[WPL];
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) bits[k] = (w0 + k < we) ? bc.bitmap[w0 + k] : 0u;
+            if (!ndt_ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u)) continue;
+            unsigned cnt = 0;
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) cnt += (unsigned)__popc(bits[k]);
+            const unsigned incl = ndt_wave_incl_scan(cnt);
+            unsigned before = running + incl - cnt;
+            running += __shfl(incl, 63, 64);
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) {
+                if (bits[k]) {
+                    rankmap[w0 + k] = make_uint2(bits[k], before);
+                    bc.bitmap[w0 + k] = 0u;
+                    before += (unsigned)__popc(bits[k]);
+                }
+            }
+        }
+    } else if (!ovf) {
         // Pass 2, usual case (the bitmap holds exactly the Gaussian cells): 32 words per wave and step, one half
         // word per lane.  The lanes list their slots in LDS in slot order (rank = list position), then the whole
         // wave walks the list: work table -> record -> cell array are dependent global accesses, 64 chains at a
@@ -763,6 +900,12 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     }
     if (tid == 0) s_base = total_cells;
     __syncthreads();
+#ifdef NDT_BUILD_PROF
+    if (MODE == 3 && tid == 0) {
+        const long long tp2 = __builtin_readcyclecounter();
+        atomicAdd(&ctr->cyc[0], (unsigned)((tp1 - t0) >> 4)); atomicAdd(&ctr->cyc[1], (unsigned)((tp2 - tp1) >> 4));
+    }
+#endif
     if (MODE == 3) {
         // the last segment knows the number of cells; the workgroup that finishes last cleans up for everybody
         __shared__ unsigned s_done;
@@ -780,19 +923,96 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
 
     // ---------------- phase D: leave the scratch zeroed, publish counters -----------------------------
     long long t3 = __builtin_readcyclecounter();
-    {
+    const bool placed_later = (MODE == 3) && !ovf;         // ndt_place_cells_kernel still needs the records and n_alloc
+    if (!placed_later) {
         unsigned long long *z = reinterpret_cast<unsigned long long *>(bc.acc);
         for (unsigned k = tid; k < n_alloc * 10u; k += nthreads) z[k] = 0ull;
     }
+#ifdef NDT_BUILD_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
     if (tid == 0) {
         if (MODE != 3) ctr->n_cells = s_base;
         if (set.cell_sel) set.cell_sel[map] = 0u;
-        ctr->n_alloc = 0;
+        if (!placed_later) ctr->n_alloc = 0;
         ctr->n_dropped = n_points - s_dropped;          // s_dropped holds the number of binned points here
+#ifdef NDT_BUILD_PROF
+        if (MODE == 3) atomicAdd(&ctr->cyc[2], (uint32_t)((__builtin_readcyclecounter() - t3) >> 4)); else
+#endif
+        {
         ctr->cyc[0] = (uint32_t)(t1 - t0);
         ctr->cyc[1] = (uint32_t)(t2 - t1);
         ctr->cyc[2] = (uint32_t)(t3 - t2);
+        }
         ctr->cyc[3] = 0u;                                  // reserved: ticket counter of the multi-workgroup finalise
+    }
+}
+
+// After the ranking launch of a big grid (MODE 3, no overflow): every Gaussian goes from its accumulator id to its rank.
+// One thread per id: the 80-byte record (coalesced), ONE dependent 8-byte load of the rank map, the record's final
+// place, the work table entry back to EMPTY, the accumulator back to zero.  gridDim.x workgroups per map; the one that
+// finishes last resets the map's allocation counter.
+extern "C" __global__ __launch_bounds__(NDT_FIN_THREADS) void ndt_place_cells_kernel(NdtSetView set, unsigned first)
+{
+    const NdtGrid g = set.grid;
+    const unsigned map = first + blockIdx.y, tid = threadIdx.x;
+    NdtMapCounters *ctr = set.counters + map;
+    if (ctr->overflow) return;                              // the ranking launch took the general path and did all of this
+    const uint32_t cap = g.max_cells;
+    unsigned n_alloc = ctr->n_alloc;
+    if (n_alloc > cap) n_alloc = cap;
+    const uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
+    NdtCell *cells = set.cells + (size_t)map * cap;
+    NdtAcc *acc = set.acc + (size_t)map * cap;
+    int32_t *wtable = set.wtable + (size_t)map * g.slots;
+    // A wave moves 64 records at a time.  Lane l looks at the tail of record l (n | slot, the last 8 bytes) and finds its
+    // rank; then the 64 x 80 bytes are read as 320 consecutive 16-byte pieces, five per lane, and every piece goes to its
+    // record's final place (five neighbouring lanes write one record) and is zeroed where it came from.
+    __shared__ int s_dst[NDT_FIN_THREADS];
+    const unsigned lane = tid & 63u, wave = tid >> 6;
+    int *dst_of = s_dst + wave * 64u;
+    for (unsigned base = (blockIdx.x * (NDT_FIN_THREADS / 64u) + wave) * 64u; base < n_alloc;
+         base += NDT_FIN_THREADS * gridDim.x) {
+        const unsigned nrec = min(64u, n_alloc - base), npieces = nrec * 5u;
+        int dst = -1;
+        if (lane < nrec) {
+            const uint2 tail = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(acc + base + lane) + 72);
+            if (tail.x > 0u) {                              // (n == 0: an id lost to an allocation race, or a cell without a Gaussian)
+                const uint2 rm = rankmap[tail.y >> 5];
+                dst = (int)(rm.y + (unsigned)__popc(rm.x & ((1u << (tail.y & 31u)) - 1u)));
+                wtable[tail.y] = NDT_EMPTY;                 // work table back to its clean state
+            }
+        }
+        dst_of[lane] = dst;
+        uint4 *src = reinterpret_cast<uint4 *>(acc + base);
+        uint4 v[5];
+#pragma unroll
+        for (unsigned j = 0; j < 5u; j++) {
+            const unsigned q = lane + 64u * j;
+            v[j] = q < npieces ? src[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        ndt_wave_sync();                                    // dst_of[] was written by other lanes
+#pragma unroll
+        for (unsigned j = 0; j < 5u; j++) {
+            const unsigned q = lane + 64u * j;
+            if (q < npieces) {
+                const unsigned r = q / 5u, piece = q - 5u * r;
+                const int d = dst_of[r];
+                if (d >= 0) reinterpret_cast<uint4 *>(cells + d)[piece] = v[j];
+                src[q] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        ndt_wave_sync();                                    // dst_of[] may be overwritten now
+    }
+    __shared__ unsigned s_last;
+    uint32_t *agg = set.rank_agg + (size_t)map * (NDT_RANK_SEGS + 2);
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&agg[NDT_RANK_SEGS + 1], 1u);
+    __syncthreads();
+    if (s_last == gridDim.x - 1u && tid == 0) {
+        agg[NDT_RANK_SEGS + 1] = 0u;                        // the ticket rests at zero between builds
+        ctr->n_alloc = 0;
     }
 }
 
@@ -861,7 +1081,9 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
     unsigned parts = 1;
     if (count < 256 && n_tiles > 8) {
         const char *pe = getenv("NDTGPU_BUILD_WGS");             // (experiments: workgroups of the accumulate launch, default 1024)
-        const unsigned wgs = pe && atoi(pe) > 0 ? (unsigned)atoi(pe) : 1024u;
+        // as many workgroups as are resident at once: four per CU of the flat-grid variants (34 KB of LDS), three of the
+        // 3D ones (49 KB); 64 sweeps on 512 / 768 / 1024 / 1536 / 2048 workgroups: 0.74 / 0.71 / 0.78 / 0.75 / 0.78 ms
+        const unsigned wgs = pe && atoi(pe) > 0 ? (unsigned)atoi(pe) : (set.grid.size[2] > 4 ? 768u : 1024u);
         parts = (unsigned)(wgs / count);
         if (parts > n_tiles / 4) parts = n_tiles / 4;
         if (parts < 1) parts = 1;
@@ -903,9 +1125,18 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
         hipError_t e = hipMemset2DAsync(&set.counters[first].overflow, sizeof(NdtMapCounters), 0, 2 * sizeof(uint32_t),
                                         count, stream);
         if (e != hipSuccess) return e;
-        NDT_LAUNCH_BUILD_SD(1, dim3(parts, (unsigned)count));
+        {
+            const char *xe = getenv("NDTGPU_BUILD_XCD");           // experiment: bit 1 deals the maps to XCDs (map m -> XCD m mod 8): 1.31 -> 1.28 ms per 64 sweeps
+            const int xm = xe ? atoi(xe) : 0;
+            const int dbg = (count % 8 == 0) ? xm : 0;
+            NDT_LAUNCH_BUILD_SD(1, dim3(parts, (unsigned)count));
+#ifdef NDT_BUILD_PROF
+            if (xm & 16) return hipGetLastError();                  // (section clocks of phase A stay in the counters)
+#endif
+        }
         // phases 0 and B (moments -> Gaussians, one per thread) on up to 32 workgroups per map
-        unsigned fin_parts = (unsigned)(512 / count);
+        const char *fe = getenv("NDTGPU_FIN_WGS");               // (experiments: workgroups of the finalise launches, default 512)
+        unsigned fin_parts = (unsigned)((fe && atoi(fe) > 0 ? (unsigned)atoi(fe) : 512u) / count);
         if (fin_parts > 32u) fin_parts = 32u;
         if (fin_parts < 1u) fin_parts = 1u;
         // big grids (a 400 x 400 x 40 grid has 200 k bitmap words): the ranking is a third launch on the same number of
@@ -921,6 +1152,9 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
                                stream, set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
                                map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, 0,
                                __builtin_inff());
+        if (split_rank)
+            hipLaunchKernelGGL(ndt_place_cells_kernel, dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
+                               (unsigned)first);
     }
 #undef NDT_LAUNCH_BUILD_SD
 #undef NDT_LAUNCH_BUILD
