@@ -443,8 +443,10 @@ def config5(args, torch, N, binding, synth, dev):
            "roofline": {"kernel": "ndt_build_kernel (MODE 1 accumulate + MODE 2/3 finalise, 64 sweeps)", "bound": "hbm",
                         "achieved": build_bytes / build_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": build_bytes / build_ms / 1e6 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "algorithmic bytes 12 N + 80 M per sweep / wall time of the build call (three launches); atomic-rate "
-                                "bound: ~1 flush record per 6 points on ring-ordered sweeps (DESIGN.md 7)"},
+                        "note": "algorithmic bytes 12 N + 80 M per sweep / wall time of the build call (four launches: accumulate, "
+                                "moments -> Gaussians, ranking, placement); instruction-issue bound: a ring crosses a cell "
+                                "every ~6 points, ~1 flush record per 6 points, 16 % of the lanes of a point step push one "
+                                "(DESIGN.md 4.1b, 7)"},
            "kernels": {"build_64_sweeps": {"ms": build_ms, "points_per_s": 2 * B * NP / (build_ms * 1e-3), "algorithmic_bytes": build_bytes},
                        "match_32_pairs": {"ms": match_ms, "fp64_gflop": gflop, "fp64_tflops": gflop / match_ms,
                                           "frac_of_fp64_peak": gflop / match_ms / 78.6, "mean_iterations": float(r["iterations"].mean()),

@@ -1184,7 +1184,7 @@ hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t cou
     const bool aligned4 = (((uintptr_t)xyz_dev | map_stride_bytes) & 3u) == 0;
     const int sdw = (stride_bytes == 12 && aligned4) ? 3 : (stride_bytes == 16 && aligned4) ? 4 : 0;
     const unsigned n_tiles = (unsigned)((n_points + NDT_TILE - 1) / NDT_TILE);
-    unsigned parts = (unsigned)(1024 / count);
+    unsigned parts = (unsigned)((set.grid.size[2] > 4 ? 768u : 1024u) / count);   // resident workgroups (see ndt_launch_build)
     if (parts > n_tiles / 4) parts = n_tiles / 4;
     if (parts < 1) parts = 1;
     hipError_t e = hipMemset2DAsync(&set.counters[first].overflow, sizeof(NdtMapCounters), 0, 2 * sizeof(uint32_t), count, stream);

@@ -59,7 +59,10 @@ print(json.dumps(out, indent=1)[:1500])
 # ---- the 3D (--config 5) and node-map (--config fuse) benches: kernel statistics + per-kernel counters -------------
 import re
 def short(name):
-    return re.sub(r"<.*", "", name.replace("void ", "")).split("(")[0].strip()
+    # the build kernel keeps its template arguments: <stride, MODE, nice, SCAT> are different kernels (accumulate /
+    # moments -> Gaussians / ranking), and the 3D build is judged launch by launch
+    n = name.replace("void ", "").split("(")[0].strip()
+    return n if n.startswith("ndt_build_kernel") else re.sub(r"<.*", "", n)
 for c in ("5", "fuse"):
     kt = os.path.join(go, "prof_kt_%s" % c, "bench_kernel_stats.csv")
     if not os.path.exists(kt):
