@@ -270,6 +270,34 @@ def test_capacity_overflow_is_reported(N):
     assert e.value.status == -4
 
 
+def test_big_grid_rebuilds_leave_a_clean_state(N, O):
+    """A grid big enough for the split finalise (rank-map launch + placement launch): the same set is built three times with
+    different sweeps -- the second one overflows max_cells and takes the general ranking path -- and the third build must
+    equal the oracle: work table, bitmap, accumulators and tickets are back in their clean state after either path."""
+    import torch
+    from ndt_feature_graph_amd import synth
+    pr = synth.pair_3d([3, 4], rings=16, azimuths=700)
+    a, b = pr["fixed"].numpy(), pr["moving"].numpy()                    # 2 + 2 sweeps of 11 200 points
+    dense = synth.pair_3d([5], rings=64, azimuths=3125)["fixed"].numpy()  # 200 000 points: more cells than the set holds
+    res, size, rng = 0.2, [80.0, 80.0, 10.0], 60.0
+    ms = N.MapSet(res, [0, 0, 0], size, n_maps=2, max_cells=8000)       # (accumulators: every TOUCHED cell needs one)
+    n0 = len(oracle_map(O, a[0], res, size, rng=rng).export_cells()[3])
+    assert 500 < n0 < 8000
+    ms.build(torch.from_numpy(a).cuda(), range_limit=rng)
+    torch.cuda.synchronize()
+    for m in range(2):
+        assert ms.counters(m)["overflow"] == 0 and ms.counters(m)["n_alloc"] == 0, ms.counters(m)
+        assert_cells_equal(ms.export_cells(m), oracle_map(O, a[m], res, size, rng=rng).export_cells(), res)
+    ms.build(torch.from_numpy(np.concatenate([dense, dense])).cuda(), range_limit=rng)
+    torch.cuda.synchronize()
+    assert ms.counters(0)["overflow"] != 0 and ms.counters(1)["overflow"] != 0, ms.counters(0)
+    ms.build(torch.from_numpy(b).cuda(), range_limit=rng)
+    torch.cuda.synchronize()
+    for m in range(2):
+        assert ms.counters(m)["overflow"] == 0 and ms.counters(m)["n_alloc"] == 0, ms.counters(m)
+        assert_cells_equal(ms.export_cells(m), oracle_map(O, b[m], res, size, rng=rng).export_cells(), res)
+
+
 # ---------------------------------------------------------------------------------------------
 def test_derivatives_golden_and_oracle(N, O, golden):
     res = float(golden["d2d_res"])
