@@ -666,15 +666,16 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     const double IS1 = ldexp(1.0, -s1_shift), IS2 = ldexp(1.0, -s2_shift);
     for (unsigned id = fin_part * nthreads + tid; MODE != 3 && id < n_alloc; id += nthreads * fin_parts) {
         NdtAcc a = bc.acc[id];
+        const unsigned slot_of_id = bc.acc_slot[id];    // (read beside the record, not after it: stale for an id without points)
         unsigned long long n = (unsigned long long)a.n;
         binned += (unsigned)n;               // points that reached a cell (the others were NaN, out of range / grid)
         if (set.occ && n > 0) {
             // NDTCell::computeGaussian on a fresh cell: occ = n log(0.6 / 0.4), clamped to the default limit 255
             // (the launcher zeroed the map's occupancies)
             const float o = (float)((double)n * NDT_LOGODD_OCC);
-            set.occ[(size_t)map * g.slots + bc.acc_slot[id]] = o > 255.0f ? 255.0f : o;
+            set.occ[(size_t)map * g.slots + slot_of_id] = o > 255.0f ? 255.0f : o;
         }
-        const unsigned slot = n ? bc.acc_slot[id] : 0u;
+        const unsigned slot = n ? slot_of_id : 0u;
         const int iz = slot % g.size[2], iy = (slot / g.size[2]) % g.size[1], ix = slot / (g.size[2] * g.size[1]);
         const double centre[3] = {cx + (ix - hx) * res, cy + (iy - hy) * res, cz + (iz - hz) * res};
         const NdtCell c = ndt_gaussian_from_moments(a, slot, centre, res, n_min, eval_factor, IS1, IS2);
@@ -682,7 +683,7 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
         // a touched cell without a Gaussian leaves the occupancy bitmap here, so that phase C finds exactly the
         // Gaussian cells in it (n == 0: an id wasted by an allocation race, it has no slot)
         if (n > 0 && c.n == 0) {
-            const unsigned sl = bc.acc_slot[id];
+            const unsigned sl = slot_of_id;
             __hip_atomic_fetch_and(&bc.bitmap[sl >> 5], ~(1u << (sl & 31u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bc.wtable[sl] = NDT_EMPTY;
         }
@@ -755,7 +756,28 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
     constexpr unsigned WPL = 4;
-    {
+    // The ranking launch of a big grid keeps its wave's share of the bitmap in REGISTERS when it fits (up to 8 steps of
+    // 64 lanes x 4 words; 200 k words on 8 workgroups of 16 waves: 7 steps): every load of the share is in flight at once,
+    // and the second pass does not read the bitmap again.  Step by step the two passes were 14 dependent round trips.
+    constexpr unsigned KI = (MODE == 3) ? 8u : 1u;
+    const bool cached = (MODE == 3) && !ovf && (we - wb) <= KI * 64u * WPL;
+    unsigned cb[KI][WPL];
+    if (cached) {
+#pragma unroll
+        for (unsigned it = 0; it < KI; it++)
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) {
+                const unsigned w = wb + (it * 64u + lane) * WPL + k;
+                cb[it][k] = w < we ? bc.bitmap[w] : 0u;
+            }
+        unsigned cnt = 0;
+#pragma unroll
+        for (unsigned it = 0; it < KI; it++)
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) cnt += (unsigned)__popc(cb[it][k]);
+        unsigned incl = ndt_wave_incl_scan(cnt);
+        if (lane == 63) s_wave_cnt[wave] = incl;
+    } else {
         unsigned cnt = 0;
         for (unsigned w0 = wb + lane * WPL; w0 < we; w0 += 64u * WPL) {
             unsigned bits[WPL];
@@ -793,7 +815,28 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
 #ifdef NDT_BUILD_PROF
     const long long tp1 = __builtin_readcyclecounter();
 #endif
-    if (!ovf && MODE == 3) {
+    if (!ovf && MODE == 3 && cached) {
+        // (the share of the bitmap is in registers: see pass 1)
+#pragma unroll
+        for (unsigned it = 0; it < KI; it++) {
+            const unsigned w0 = wb + (it * 64u + lane) * WPL;
+            unsigned cnt = 0;
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) cnt += (unsigned)__popc(cb[it][k]);
+            if (!ndt_ballot(cnt != 0u)) continue;
+            const unsigned incl = ndt_wave_incl_scan(cnt);
+            unsigned before = running + incl - cnt;
+            running += __shfl(incl, 63, 64);
+#pragma unroll
+            for (unsigned k = 0; k < WPL; k++) {
+                if (cb[it][k]) {
+                    rankmap[w0 + k] = make_uint2(cb[it][k], before);
+                    bc.bitmap[w0 + k] = 0u;
+                    before += (unsigned)__popc(cb[it][k]);
+                }
+            }
+        }
+    } else if (!ovf && MODE == 3) {
         // Big grids (round 4): the ranking launch only writes the RANK MAP -- per bitmap word its Gaussian bits and the rank
         // of its first cell -- and clears the bitmap; every cell record is then put in its place by the placement launch
         // (ndt_place_cells_kernel), one thread per accumulator id with ONE dependent load.  Until round 4 this pass also
@@ -975,6 +1018,13 @@ extern "C" __global__ __launch_bounds__(NDT_FIN_THREADS) void ndt_place_cells_ke
     for (unsigned base = (blockIdx.x * (NDT_FIN_THREADS / 64u) + wave) * 64u; base < n_alloc;
          base += NDT_FIN_THREADS * gridDim.x) {
         const unsigned nrec = min(64u, n_alloc - base), npieces = nrec * 5u;
+        uint4 *src = reinterpret_cast<uint4 *>(acc + base);
+        uint4 v[5];                                         // (in flight beside the tail -> rank map chain below)
+#pragma unroll
+        for (unsigned j = 0; j < 5u; j++) {
+            const unsigned q = lane + 64u * j;
+            v[j] = q < npieces ? src[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
         int dst = -1;
         if (lane < nrec) {
             const uint2 tail = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(acc + base + lane) + 72);
@@ -985,13 +1035,6 @@ extern "C" __global__ __launch_bounds__(NDT_FIN_THREADS) void ndt_place_cells_ke
             }
         }
         dst_of[lane] = dst;
-        uint4 *src = reinterpret_cast<uint4 *>(acc + base);
-        uint4 v[5];
-#pragma unroll
-        for (unsigned j = 0; j < 5u; j++) {
-            const unsigned q = lane + 64u * j;
-            v[j] = q < npieces ? src[q] : make_uint4(0u, 0u, 0u, 0u);
-        }
         ndt_wave_sync();                                    // dst_of[] was written by other lanes
 #pragma unroll
         for (unsigned j = 0; j < 5u; j++) {
