@@ -174,6 +174,17 @@ NDT_D void write_flush_record(const BuildCtx &b, long long *rec, int *rec_id, in
         int id = get_or_assign(b, slot);
         *rec_id = (id >= 0 && (uint32_t)id < b.cap) ? id : -1;
     }
+    if (DEFER) {
+        // ... and so are the fixed-point words: the list holds the RAW sums (as doubles) and the drain converts them, 64
+        // (record, word) items per instruction at full width -- here the nine conversions ran for the one lane in six
+        // that replaces a run in a point step (90 of the ~500 instructions of a 3D point step)
+        rec[0] = __builtin_bit_cast(long long, n);
+#pragma unroll
+        for (int k = 0; k < 3; k++) rec[1 + k] = __builtin_bit_cast(long long, sd[k]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) rec[4 + k] = __builtin_bit_cast(long long, sdd[k]);
+        return;
+    }
     rec[0] = (long long)(unsigned long long)(unsigned)n;
 #pragma unroll
     for (int k = 0; k < 3; k++) rec[1 + k] = ndt_fixed_from_double(sd[k] * b.q1);
@@ -326,8 +337,13 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
         for (unsigned it = lane; it < items; it += 64u) {
             unsigned e = it / 10u, k = it % 10u;
             int id = fl_id[e];
-            if (id >= 0)
-                acc_add(bc, reinterpret_cast<unsigned long long *>(bc.acc + id) + k, (unsigned long long)fl_val[e * 10u + k]);
+            long long word = fl_val[e * 10u + k];
+            if (SCAT) {                                   // raw sums: word 0 the count, 1..3 sum d, 4..9 sum d d^T
+                const double raw = __builtin_bit_cast(double, word);
+                const long long fx = ndt_fixed_from_double(raw * (k < 4u ? bc.q1 : bc.q2));
+                word = k == 0u ? (long long)(unsigned long long)(unsigned)raw : fx;
+            }
+            if (id >= 0) acc_add(bc, reinterpret_cast<unsigned long long *>(bc.acc + id) + k, (unsigned long long)word);
         }
         ndt_wave_sync();                                  // the list may be overwritten now
         nfl = 0;

@@ -10,13 +10,13 @@ dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream()
 p3 = synth.pair_3d(torch.arange(1, 33, device=dev), device=dev)
 sw = torch.cat([p3["fixed"], p3["moving"]]).contiguous()
-os.environ["NDTGPU_BUILD_XCD"] = "16"
-for wgs in (1024, 2048):
+for wgs, xcd in ((768, 16), (768, 16), (768, 20), (512, 16), (1536, 16)):       # (the first one warms the process up; 20: no accumulator atomics)
+    os.environ["NDTGPU_BUILD_XCD"] = str(xcd)
     os.environ["NDTGPU_BUILD_WGS"] = str(wgs)
     m3 = N.MapSet(0.25, [0, 0, 0], [100, 100, 10], n_maps=64, max_cells=120000)
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(st); m3.build(sw, range_limit=70.0, stream=st); e1.record(st); torch.cuda.synchronize()
     c = np.array([m3.counters(i)["cyc"] for i in range(64)], dtype=np.float64).sum(0) * 16 / wgs
-    print("wgs %d: launch %.3f ms; per wave (clocks): staging %.0f, point loop %.0f (of which drains %.0f), end of super-tile %.0f (drains in both: %.0f)"
-          % (wgs, e0.elapsed_time(e1), c[0], c[1], 0, c[3], c[2]), "alloc", m3.counters(0)["n_alloc"])
+    print("wgs %d xcd %d: launch %.3f ms; per wave (clocks): staging %.0f, point loop %.0f (of which drains %.0f), end of super-tile %.0f (drains in both: %.0f)"
+          % (wgs, xcd, e0.elapsed_time(e1), c[0], c[1], 0, c[3], c[2]), "alloc", m3.counters(0)["n_alloc"])
     del m3
