@@ -156,7 +156,12 @@ NDT_D int get_or_assign_wave(const BuildCtx &b, int slot, bool active, unsigned 
 NDT_D void acc_add(const BuildCtx &b, unsigned long long *p, unsigned long long v)
 {
 #ifdef NDT_BUILD_PROF
-    if (b.dbg & 4) return;   // timing experiment: no accumulator traffic (1.31 -> 1.27 ms per 64 sweeps: not the limiter)
+    if (b.dbg & 4) return;   // timing experiment: no accumulator traffic
+    if (b.dbg & 8) {         // timing experiment: records on a 128-byte stride (one line each; the sums land in the wrong places):
+                             // 0.42 ms against 0.38 -- the atomics are not priced per line
+        const size_t off = (size_t)(reinterpret_cast<char *>(p) - reinterpret_cast<char *>(b.acc));
+        p = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(b.acc) + (off / 80u) * 128u + off % 80u);
+    }
 #endif
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

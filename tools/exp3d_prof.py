@@ -10,7 +10,7 @@ dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream()
 p3 = synth.pair_3d(torch.arange(1, 33, device=dev), device=dev)
 sw = torch.cat([p3["fixed"], p3["moving"]]).contiguous()
-for wgs, xcd in ((768, 16), (768, 16), (768, 20), (512, 16), (1536, 16)):       # (the first one warms the process up; 20: no accumulator atomics)
+for wgs, xcd in ((768, 16), (768, 16), (768, 20), (768, 24), (768, 16), (768, 24)):       # (the first one warms the process up; 20: no accumulator atomics)
     os.environ["NDTGPU_BUILD_XCD"] = str(xcd)
     os.environ["NDTGPU_BUILD_WGS"] = str(wgs)
     m3 = N.MapSet(0.25, [0, 0, 0], [100, 100, 10], n_maps=64, max_cells=120000)
