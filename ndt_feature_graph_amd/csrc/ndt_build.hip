@@ -374,7 +374,9 @@ __global__ __launch_bounds__((MODE == 2 || MODE == 3) ? NDT_FIN_THREADS : NDT_BU
     double *q_val = s_qval + (SCAT ? 0u : awave * (10 * NDT_QRUNS));
     int *q_slot = s_qslot + (SCAT ? 0u : awave * NDT_QRUNS);
     for (unsigned tile = tile_begin; tile < tile_end;) {
-        const unsigned R = min((unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
+        // (3D sweeps: up to 12 rounds, so that the 9 sub-tiles a wave gets of a 200 k-point sweep on 768 workgroups are ONE
+        //  super-tile -- a second one of a single round paid a whole wavefront merge and flush for an eighth of the points)
+        const unsigned R = min(SCAT ? 12u : (unsigned)NDT_ROUNDS, tile_end - tile);   // rounds of this super-tile
         const unsigned p0 = tile * NDT_TILE;                              // its first point
         tile += R;
         int cs0 = -2, cs1 = -3;                // empty (negative, and never equal to the "no cell" slot -1)
