@@ -1146,10 +1146,12 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
     const unsigned n_tiles = (unsigned)((n_points + NDT_TILE - 1) / NDT_TILE);
     unsigned parts = 1;
     if (count < 256 && n_tiles > 8) {
-        const char *pe = getenv("NDTGPU_BUILD_WGS");             // (experiments: workgroups of the accumulate launch, default 1024)
-        // as many workgroups as are resident at once: four per CU of the flat-grid variants (34 KB of LDS), three of the
-        // 3D ones (49 KB); 64 sweeps on 512 / 768 / 1024 / 1536 / 2048 workgroups: 0.74 / 0.71 / 0.78 / 0.75 / 0.78 ms
-        const unsigned wgs = pe && atoi(pe) > 0 ? (unsigned)atoi(pe) : (set.grid.size[2] > 4 ? 768u : 1024u);
+        const char *pe = getenv("NDTGPU_BUILD_WGS");             // (experiments: workgroups of the accumulate launch)
+        // as many workgroups as are resident at once: three per CU (149 - 161 registers: three waves per SIMD; the LDS of the
+        // flat-grid variants would hold four).  64 3D sweeps on 512 / 768 / 1024 / 1536 / 2048 workgroups: 0.68 / 0.64 /
+        // 0.78 / 0.68 / 0.70 ms per build; 32 / 64 / 128 planar scans on 768 against 1024: 0.105 / 0.132 / 0.181 against
+        // 0.117 / 0.149 / 0.190 ms
+        const unsigned wgs = pe && atoi(pe) > 0 ? (unsigned)atoi(pe) : 768u;
         parts = (unsigned)(wgs / count);
         if (parts > n_tiles / 4) parts = n_tiles / 4;
         if (parts < 1) parts = 1;
@@ -1250,7 +1252,7 @@ hipError_t ndt_launch_accumulate(const NdtSetView &set, size_t first, size_t cou
     const bool aligned4 = (((uintptr_t)xyz_dev | map_stride_bytes) & 3u) == 0;
     const int sdw = (stride_bytes == 12 && aligned4) ? 3 : (stride_bytes == 16 && aligned4) ? 4 : 0;
     const unsigned n_tiles = (unsigned)((n_points + NDT_TILE - 1) / NDT_TILE);
-    unsigned parts = (unsigned)((set.grid.size[2] > 4 ? 768u : 1024u) / count);   // resident workgroups (see ndt_launch_build)
+    unsigned parts = (unsigned)(768u / count);   // resident workgroups (see ndt_launch_build)
     if (parts > n_tiles / 4) parts = n_tiles / 4;
     if (parts < 1) parts = 1;
     hipError_t e = hipMemset2DAsync(&set.counters[first].overflow, sizeof(NdtMapCounters), 0, 2 * sizeof(uint32_t), count, stream);
