@@ -1203,25 +1203,38 @@ hipError_t ndt_launch_build(const NdtSetView &set, size_t first, size_t count, c
 #endif
         }
         // phases 0 and B (moments -> Gaussians, one per thread) on up to 32 workgroups per map
-        const char *fe = getenv("NDTGPU_FIN_WGS");               // (experiments: workgroups of the finalise launches, default 512)
-        unsigned fin_parts = (unsigned)((fe && atoi(fe) > 0 ? (unsigned)atoi(fe) : 512u) / count);
-        if (fin_parts > 32u) fin_parts = 32u;
-        if (fin_parts < 1u) fin_parts = 1u;
         // big grids (a 400 x 400 x 40 grid has 200 k bitmap words): the ranking is a third launch on the same number of
         // workgroups per map instead of the last workgroup of the second one walking the whole bitmap alone
         const unsigned bm_words = (unsigned)((set.grid.slots + 31) / 32);
+        // Workgroups of the finalise launches (1024 threads, 118 registers: ONE is resident per CU).  Measured, end of round
+        // 4: big grids, 64 sweeps on 128 / 256 / 512 / 1024 workgroups per launch: 0.72 / 0.60 / 0.64 / 0.69 ms per build
+        // (more segments lengthen the look-back of the ranking launch: 2048 of them 0.77 ms); small grids, where the last
+        // workgroup of a map ranks it alone, 8 / 32 / 64 / 128 planar scans on 64 against 512: 0.059 / 0.073 / 0.092 / 0.138 against
+        // 0.066 / 0.108 / 0.137 / 0.180 ms.
+        const char *fe = getenv("NDTGPU_FIN_WGS");               // (experiments)
+        unsigned fin_parts = (unsigned)((fe && atoi(fe) > 0 ? (unsigned)atoi(fe) : (bm_words >= 16384u ? 256u : 64u)) / count);
+        if (fin_parts > 32u) fin_parts = 32u;
+        if (fin_parts < 1u) fin_parts = 1u;
         const int split_rank = (fin_parts > 1u && bm_words >= 16384u) ? 1 : 0;
         hipLaunchKernelGGL((ndt_build_kernel<0, 2, false, false>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream,
                            set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
                            map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, split_rank,
                            __builtin_inff());
+        // (the ranking and the placement launch may take other workgroup counts than the Gaussians: experiments)
+        auto parts_of = [&](const char *name, unsigned dflt, unsigned cap) {
+            const char *e = getenv(name);
+            unsigned p = (e && atoi(e) > 0 ? (unsigned)atoi(e) : dflt) / (unsigned)count;
+            return p > cap ? cap : (p < 1u ? 1u : p);
+        };
+        const unsigned rank_parts = split_rank ? parts_of("NDTGPU_RANK_WGS", fin_parts * (unsigned)count, (unsigned)NDT_RANK_SEGS) : 1u;
+        const unsigned place_parts = split_rank ? parts_of("NDTGPU_PLACE_WGS", fin_parts * (unsigned)count, 64u) : 1u;
         if (split_rank)
-            hipLaunchKernelGGL((ndt_build_kernel<0, 3, false, false>), dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0,
+            hipLaunchKernelGGL((ndt_build_kernel<0, 3, false, false>), dim3(rank_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0,
                                stream, set, (unsigned)first, (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes,
                                map_stride_bytes, range_limit, range_origins_dev, n_min, eval_factor, s1_shift, s2_shift, 0,
                                __builtin_inff());
         if (split_rank)
-            hipLaunchKernelGGL(ndt_place_cells_kernel, dim3(fin_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
+            hipLaunchKernelGGL(ndt_place_cells_kernel, dim3(place_parts, (unsigned)count), dim3(NDT_FIN_THREADS), 0, stream, set,
                                (unsigned)first);
     }
 #undef NDT_LAUNCH_BUILD_SD

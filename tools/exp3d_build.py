@@ -22,7 +22,7 @@ def digest():
             h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()[:16], int(m3.num_cells_all().sum())
 
-KNOBS = ("NDTGPU_BUILD_XCD", "NDTGPU_BUILD_WGS", "NDTGPU_FIN_WGS")
+KNOBS = ("NDTGPU_BUILD_XCD", "NDTGPU_BUILD_WGS", "NDTGPU_FIN_WGS", "NDTGPU_RANK_WGS", "NDTGPU_PLACE_WGS")
 def run(tag, **env):
     for k in KNOBS:
         os.environ.pop(k, None)
@@ -38,10 +38,23 @@ def run(tag, **env):
     print("%-28s total %.3f ms (min %.3f) kernels %s digest %s cells %d" % (tag, float(np.median(v[1:])), min(v), ["%.3f" % x for x in ks], d[0], d[1]), flush=True)
     return d
 
-KNOBS = ("NDTGPU_BUILD_XCD", "NDTGPU_BUILD_WGS", "NDTGPU_FIN_WGS")
+KNOBS = ("NDTGPU_BUILD_XCD", "NDTGPU_BUILD_WGS", "NDTGPU_FIN_WGS", "NDTGPU_RANK_WGS", "NDTGPU_PLACE_WGS")
 ref = run("default")
 print("digest of the round-3 kernel on these sweeps: 476fd03cb5939def")
 if len(sys.argv) > 1 and sys.argv[1] == "one":
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "fin":
+    for fin in (256, 512, 1024):
+        run("gaussians on %d" % fin, NDTGPU_FIN_WGS=fin, NDTGPU_RANK_WGS=512, NDTGPU_PLACE_WGS=512)
+    for r in (256, 1024, 2048):
+        run("rank map on %d" % r, NDTGPU_RANK_WGS=r)
+    for r in (256, 1024, 2048, 4096):
+        run("placement on %d" % r, NDTGPU_PLACE_WGS=r)
+    for a in (64, 128, 256):
+        run("all three on %d" % a, NDTGPU_FIN_WGS=a, NDTGPU_RANK_WGS=a, NDTGPU_PLACE_WGS=a)
+    for r in (64, 128):
+        run("rank map on %d, others 256" % r, NDTGPU_FIN_WGS=256, NDTGPU_RANK_WGS=r, NDTGPU_PLACE_WGS=256)
+    run("default again")
     sys.exit(0)
 for fin in (1024,):
     run("fin %d" % fin, NDTGPU_FIN_WGS=fin)
