@@ -30,8 +30,11 @@
 
 #define NDT_FUSE_THREADS 1024
 // the finalise kernel: 512 threads = 8 waves = 256 VGPRs each (at 1024 threads the 128-register budget spilled the
-// Gaussian update of a cell -- 110 registers, 292 bytes of scratch per lane)
+// Gaussian update of a cell -- 110 registers, 292 bytes of scratch per lane; 256 threads, three workgroups per CU instead of
+// one: add_cloud of 256 maps 3.55 against 3.44 ms, the node builds of --config 4 135.7 against 134.8 ms -- measured, round 4)
+#ifndef NDT_FIN2_THREADS
 #define NDT_FIN2_THREADS 512
+#endif
 #define NDT_EMPTY (-1)
 #define NDT_DROPPED (-2)   // work-table marker inside ndt_fuse_finalize_kernel: an old Gaussian that this update dropped
 
