@@ -615,8 +615,14 @@ hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, co
 {
     if (count == 0) return hipSuccess;
     if (n_points) {
-        const unsigned blocks = (unsigned)((n_points + 255) / 256);
-        hipLaunchKernelGGL(ndt_raytrace_kernel, dim3(blocks, (unsigned)count), dim3(256), 0, stream, set, (unsigned)first,
+        // One wave per workgroup: the waves of a launch are independent (no LDS, no barrier), rays differ a lot in length,
+        // and a 256-thread workgroup held its four wave slots until its longest ray was done.  Measured, round 4: 256 / 128 /
+        // 64 threads: add_cloud of 256 x 100 k points 3.45 / 3.43 / 3.37 ms, the 5000 node builds of `bench.py --config 4`
+        // 135.3 / 132.7 / 127.1 ms (294 -> 310 k gated edge registrations/s).  The same rays in the same waves: the same bits.
+        const char *te = getenv("NDTGPU_RAY_THREADS");           // (experiments: 64 / 128 / 256 threads per workgroup)
+        const unsigned rt = te && (atoi(te) == 128 || atoi(te) == 256) ? (unsigned)atoi(te) : 64u;
+        const unsigned blocks = (unsigned)((n_points + rt - 1) / rt);
+        hipLaunchKernelGGL(ndt_raytrace_kernel, dim3(blocks, (unsigned)count), dim3(rt), 0, stream, set, (unsigned)first,
                            (const char *)xyz_dev, (unsigned)n_points, (unsigned)stride_bytes, map_stride_bytes, origins_dev,
                            prm.maxz, prm.sensor_noise);
         hipError_t e = hipGetLastError();
