@@ -38,7 +38,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-PMC_FILE = "r04_pmc_traffic.json"
+ROUND_TAG = "r05"
+PMC_FILE = ROUND_TAG + "_pmc_traffic.json"
 
 
 def cpu_info():
@@ -159,7 +160,7 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
     build_local()
     cap_local = int(local_set.num_cells_all()[:n_local].max()) if n_local else 0
     capt = torch.tensor([cap_local], dtype=torch.int64, device=dev)
-    if world > 1:
+    if args.use_dist:
         dist.all_reduce(capt, op=dist.ReduceOp.MAX)
     cells_cap = min(4096, (int(capt.item()) * 5 // 4 + 63) // 64 * 64)
     stride = local_set.pack_bytes(cells_cap, True)
@@ -177,7 +178,7 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
             self.results = torch.zeros((len(self.mine), 64), dtype=torch.uint8, device=dev)
 
     def barrier():
-        if world > 1:
+        if args.use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -219,7 +220,7 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         evs.append(ev)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if args.use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -264,6 +265,12 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
                              "that share no cell ends at its first evaluation -- this rate is not comparable with `value`"}
         del EA
     what = "all-pairs" if timed_all_pairs else "gated"
+    # (the exchange and the final gather as they came back, against what this rank put in: its own records / rows)
+    coll = {"process_group": "nccl (RCCL)" if args.use_dist else None, "world": world,
+            "forced_on_one_rank": bool(args.use_dist and world == 1),
+            "collectives_per_step": {"exchange_all_gather": 1, "edge_result_all_gathers": 2} if args.use_dist else {},
+            "gathered_rows_equal_local": (bool(torch.equal(gathered[0][torch.as_tensor(E.mine, device=dev)], E.T16))
+                                          if args.use_dist else None)}
     model = D.phase_model(build_ms * world, match_ms * world, n_nodes, stride, n_edges) if world == 1 else None
     out = {"metric": "NDT graph-edge registrations/sec on fused node maps (%d scans x %d pts per node, %.2f m cells), %s candidate edges"
                      % (S, NPn, res, what),
@@ -294,9 +301,10 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
            "note": "value counts registrations of the %s candidate edges on fused node maps (the unit the graph layer consumes, "
                    "graph.cpp:273) per second of whole steps (node builds + exchange + registrations + gather); a node map is built "
                    "once per node per step, not per edge" % what}
+    out["collectives"] = coll
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if args.use_dist:
         dist.destroy_process_group()
 
 
@@ -346,10 +354,35 @@ def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_c
     else:
         roof = {"kernel": "ndt_match_kernel", "bound": "fp64_valu", "achieved": gflop / match_ms, "peak": 78.6, "unit": "TFLOP/s",
                 "frac": gflop / match_ms / 78.6, "traffic": None}
-    out = {"value": B * n_steps / elapsed, "unit": "registrations/s", "pairs": B, "steps": n_steps,
-           "ms_per_step_serial": 1e3 * elapsed / n_steps,
+    # the same steps through the registrar (ONE ndtgpu_register_batch_device call per step, three internal map sets / streams):
+    # the builds and the first registrations of step k + 1 fill the CUs that the long registrations of step k have left
+    ms.profiling(False)
+    reg = N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=B, depth=3, max_cells=4096)
+    outs = [(T_init_cm.clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev), [0]) for _ in range(3)]
+    n_pipe = 12
+
+    def pstep(k):
+        T_k, r_k, tk = outs[k % 3]
+        if tk[0]:
+            reg.wait_stream(st, ticket=tk[0])
+        T_k.copy_(T_init_cm)
+        tk[0] = reg.submit(both[:B], both[B:], T_k, r_k, range_limit=rng_lim, stream=st)
+    for k in range(3):
+        pstep(k)
+    reg.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n_pipe):
+        pstep(k)
+    reg.sync(); torch.cuda.synchronize()
+    elapsed_pipe = time.perf_counter() - t0
+    same = bool(torch.equal(outs[(n_pipe - 1) % 3][0], T16) and torch.equal(outs[(n_pipe - 1) % 3][1][:, :32], results[:, :32]))
+    reg.close()
+    out = {"value": B * n_pipe / elapsed_pipe, "unit": "registrations/s", "pairs": B, "steps": n_pipe,
+           "ms_per_step": 1e3 * elapsed_pipe / n_pipe, "value_serial": B * n_steps / elapsed,
+           "ms_per_step_serial": 1e3 * elapsed / n_steps, "pipelined_equals_serial_bits": same,
            "workload": "%d pairs x %d pts, %.2f m cells, synth scene 'dense' (the hall of the headline scene + 3000 posts of 2-4 cm), "
-                       "fuser preset, one build launch + one matcher launch per step, one stream (no pipeline)" % (B, NP, res),
+                       "fuser preset; value: ONE ndtgpu_register_batch_device call per step (one build launch + one matcher launch, three "
+                       "internal map sets / streams); *_serial and kernel_ms: the two launches alone on one stream" % (B, NP, res),
            "mean_cells_per_map": cells / (2 * B), "kernel_ms": {"ndt_build_kernel": build_ms, "ndt_match_kernel": match_ms},
            "build_hbm_frac": build_bytes / build_ms / 1e6 / HBM_PEAK_GBS, "match_fp64_frac": gflop / match_ms / 78.6,
            "pair_terms_per_registration": float((r["pair_terms_g"].sum() + r["pair_terms_h"].sum()) / B),
@@ -566,6 +599,9 @@ def main():
     ap.add_argument("--buffers", type=int, default=3, help="pipeline depth (mapset pairs / streams)")
     ap.add_argument("--cu-split", type=int, default=0, help="CUs given to the build streams (hipExtStreamCreateWithCUMask), the "
                     "matcher streams get the rest; 0: every stream sees the whole chip")
+    ap.add_argument("--legacy-pipeline", action="store_true",
+                    help="the round-4 form: bench.py itself drives mapset pairs, streams and events (ndtgpu_mapset_build + "
+                         "ndtgpu_match_batch_device per step) instead of ONE ndtgpu_register_batch_device call per step")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one stream, one mapset pair: every step waits for the previous one (default: --buffers mapset pairs, the "
                          "grid builds of step k+1 run on the CUs the matcher of step k has already left)")
@@ -583,7 +619,11 @@ def main():
         raise RuntimeError("bench.py needs a HIP device: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    from ndt_feature_graph_amd import distributed as _D
+    use_dist = world > 1 or _D.collectives_forced()     # NDTGPU_FORCE_COLLECTIVES=1: the RCCL path on ONE rank (tests/test_gpu_rccl.py)
+    args.use_dist = use_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -609,27 +649,30 @@ def main():
     idx = torch.arange(B, dtype=torch.int32, device=dev)
     idx_src = idx + B
 
-    # Two buffers (mapset pair + outputs + stream).  Steps alternate between them; the builds of step k+1 are
-    # released when the matcher of step k starts: its workgroups leave their CUs as soon as no registration is
-    # left to start (csrc/ndt_match.hip), so the next step's builds fill the CUs that the few long registrations
-    # of this step do not occupy.  Every step still does all of its work; results are identical to the serial run.
+    # The timed step is ONE C-ABI call: ndtgpu_register_batch_device (scans in HBM -> poses).  The registrar owns `n_buf`
+    # internal map sets and streams; the builds of step k+1 are released when the builds of step k are done, i.e. while the
+    # matcher of step k runs: its workgroups leave their CUs as soon as no registration is left to start
+    # (csrc/ndt_match.hip), so the next step's builds fill the CUs that the few long registrations of this step do not
+    # occupy.  Every step still does all of its work; results are identical to the serial run.  (Until round 4 this
+    # choreography lived here, in Python: --legacy-pipeline keeps it for A/B.)
     n_buf = 1 if args.no_pipeline else args.buffers
     n_cu_dev = torch.cuda.get_device_properties(dev).multi_processor_count
+    legacy = args.legacy_pipeline or args.cu_split > 0
     if args.cu_split > 0 and n_buf > 1:
         os.environ["NDTGPU_MATCH_GROUPS"] = str(n_cu_dev - args.cu_split)
 
     class Buf:
         pass
     bufs = []
-    for _ in range(n_buf):
+    reg = None if legacy else N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=B, depth=n_buf, max_cells=4096)
+    main_stream = torch.cuda.current_stream()
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    for k in range(n_buf):
         b = Buf()
-        b.maps = N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * B, max_cells=4096)
+        b.maps = N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * B, max_cells=4096) if legacy else reg.mapset(k)
         b.T16 = T_init_cm.clone()
         b.results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
         b.stream = torch.cuda.Stream(device=dev)
-        # (measured and not kept: the matcher on a second stream of HIGHER priority than the builds, so that its 256
-        #  one-per-CU workgroups do not queue behind the 2048 small build workgroups of the next step: 366 k against 403 k
-        #  registrations/s, gpurun_out/r03A.log -- the builds then only get the CUs the matcher has left)
         b.mstream = b.stream
         if args.cu_split > 0 and n_buf > 1:
             # builds on the first `cu_split` CUs, matchers on the rest: the matcher's one-per-CU workgroups never wait for a CU
@@ -637,14 +680,33 @@ def main():
             b.stream = _masked_stream(torch, dev, 0, args.cu_split, n_cu_dev)
             b.mstream = _masked_stream(torch, dev, args.cu_split, n_cu_dev - args.cu_split, n_cu_dev)
         b.match_done = None
+        b.ticket = 0
         b.gathered = None
-        if world > 1:
+        b.gathered_ev = None
+        if use_dist:
             b.gathered = [torch.empty((world * B, 16), dtype=torch.float64, device=dev),
                           torch.empty((world * B, 64), dtype=torch.uint8, device=dev)]
         bufs.append(b)
     state = {"k": 0, "match_started": None}
 
-    def step(ev=None):
+    def step_registrar(ev=None):
+        b = bufs[state["k"] % n_buf]
+        state["k"] += 1
+        if b.ticket:                                   # the matcher of step k - n_buf wrote b.T16 / b.results
+            reg.wait_stream(main_stream, ticket=b.ticket)
+        if b.gathered_ev is not None:
+            main_stream.wait_event(b.gathered_ev)      # ... and its all-gather read them
+        b.T16.copy_(T_init_cm)
+        b.ticket = reg.submit(both[:B], both[B:], b.T16, b.results, range_limit=rng_lim, stream=main_stream)
+        if use_dist:   # final gather of the edge transforms (the only collective on the path)
+            reg.wait_stream(comm_stream, ticket=b.ticket)
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(b.gathered[0], b.T16)
+                dist.all_gather_into_tensor(b.gathered[1], b.results)
+                b.gathered_ev = torch.cuda.Event()
+                b.gathered_ev.record(comm_stream)
+
+    def step_legacy(ev=None):
         b = bufs[state["k"] % n_buf]
         state["k"] += 1
         st, mst = b.stream, b.mstream
@@ -671,48 +733,67 @@ def main():
             if marks:
                 marks[3].record(mst)
                 ev.append(marks)
-            if world > 1:   # final gather of the edge transforms (the only collective on the path)
+            if use_dist:   # final gather of the edge transforms (the only collective on the path)
                 dist.all_gather_into_tensor(b.gathered[0], b.T16)
                 dist.all_gather_into_tensor(b.gathered[1], b.results)
             if mst is not st:
                 b.match_done = torch.cuda.Event()
                 b.match_done.record(mst)
 
+    step = step_legacy if legacy else step_registrar
+
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     barrier()
-    # isolated kernel durations (one serial step, events inside the library), outside the timed region
-    for b in bufs[:1]:
-        b.maps.profiling(True)
+    # isolated kernel durations (a serial step on a plain map set: build launch, then matcher launch, alone on the chip;
+    # events inside the library), outside the timed region
+    iso = bufs[0].maps
+    iso.profiling(True)
+    iso_T16 = T_init_cm.clone()
+    for _ in range(2):
+        iso.build(both, range_limit=rng_lim, stream=main_stream)
+        iso_T16.copy_(T_init_cm)
+        binding.match_batch_device(iso, idx, iso, idx_src, iso_T16, bufs[0].results, B, stream=main_stream)
+        barrier()
+    iso_build_ms = iso.last_kernel_ms(0)       # one launch: 2B scans
+    iso_match_ms = iso.last_kernel_ms(1)
+    iso.profiling(False)
     for _ in range(n_buf):     # one serial step per buffer: code objects loaded, every buffer's pages touched
-        step(); barrier()
+        step()
+        if reg is not None:
+            reg.sync()
+        barrier()
         state["match_started"] = None
     state["k"] = 0
-    step(); barrier()          # isolated kernel durations: a warm serial step on buffer 0
-    iso_build_ms = bufs[0].maps.last_kernel_ms(0)       # one launch: 2B scans
-    iso_match_ms = bufs[0].maps.last_kernel_ms(1)
-    for b in bufs[:1]:
-        b.maps.profiling(False)
-    state["k"] = 0
-    state["match_started"] = None
 
     for _ in range(args.warmup):
         step()
+    if reg is not None:
+        reg.sync()
+        reg.profiling(True)    # HIP events on the registrar's internal streams bracket every launch of the timed region
     barrier()
     marks = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(marks)          # HIP events on the launch stream bracket every kernel of the timed region
+        step(marks)          # (legacy pipeline: HIP events on the launch stream bracket every kernel of the timed region)
+    if reg is not None:
+        reg.sync()           # the host waits for the registrar's streams (the caller's stream was never made to wait)
     barrier()
     elapsed = time.perf_counter() - t0
-    k_build = [m[0].elapsed_time(m[1]) for m in marks]
-    k_match = [m[4].elapsed_time(m[3]) for m in marks]
+    if reg is not None:
+        build_ms_ev, match_ms_ev, n_prof = reg.kernel_ms()
+        assert n_prof == args.steps
+        k_build, k_match = [build_ms_ev], [match_ms_ev]
+        reg.profiling(False)
+    else:
+        k_build = [m[0].elapsed_time(m[1]) for m in marks]
+        k_match = [m[4].elapsed_time(m[3]) for m in marks]
     last = bufs[(state["k"] - 1) % n_buf]
     T16, results = last.T16, last.results
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -769,24 +850,24 @@ def main():
                                 "profiles/%s" % PMC_FILE)
     except Exception:
         traffic = None
-    note = ("achieved = algorithmic work per launch / HIP-event kernel duration over the timed region (events on the "
-            "launch stream; with the pipeline a kernel shares the chip with the other steps' kernels, *_isolated is the "
-            "kernel alone); " + traffic_note)
+    note = ("achieved / frac = algorithmic work per launch / HIP-event duration of the launch ALONE on the chip (events on the "
+            "launch stream, a warm serial step of this run before the timed region; agrees with profiles/%s_bench_kernel_stats_serial.csv); "
+            "*_timed_region = the same work / the HIP-event duration of the launch inside the timed region, where it shares the chip "
+            "with the neighbouring steps' kernels (events on the registrar's internal streams); " % ROUND_TAG + traffic_note)
     if dominant == "ndt_build_kernel":       # streaming pass over the points: HBM roof
-        roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": dk["GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                    "achieved_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6,
-                    "frac_isolated": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6 / HBM_PEAK_GBS, "note": note}
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": dk["algorithmic_bytes"] / dk["ms_isolated"] / 1e6 / HBM_PEAK_GBS, "traffic": traffic,
+                    "achieved_timed_region": dk["GBps"], "frac_timed_region": dk["GBps"] / HBM_PEAK_GBS, "note": note}
     else:
         # the matcher re-reads two cell maps that live in L2 ~1000 times: its roof is fp64 arithmetic,
         # 78.6 TFLOP/s on MI355X for matrix and vector fp64 alike.  Flops = the kernel's own pair-term counters x
         # 130 (gradient term) / 610 (Hessian term), DESIGN.md 4.2.  kernels.ndt_match_kernel.GBps is the HBM view.
-        roofline = {"kernel": dominant, "bound": "fp64_valu", "achieved": mk["fp64_tflops"], "peak": 78.6, "unit": "TFLOP/s",
-                    "frac": mk["fp64_tflops"] / 78.6, "traffic": traffic,
-                    "achieved_isolated": mk["fp64_gflop_per_launch"] / mk["ms_isolated"],
-                    "frac_isolated": mk["fp64_gflop_per_launch"] / mk["ms_isolated"] / 78.6,
-                    "note": note + "; fp64 vector work (no MFMA instruction is issued: every pair term has its own 3x3 "
-                                   "inverse), counted against the fp64 peak"}
+        roofline = {"kernel": dominant, "bound": "fp64_valu", "achieved": mk["fp64_gflop_per_launch"] / mk["ms_isolated"], "peak": 78.6,
+                    "unit": "TFLOP/s", "frac": mk["fp64_gflop_per_launch"] / mk["ms_isolated"] / 78.6, "traffic": traffic,
+                    "achieved_timed_region": mk["fp64_tflops"], "frac_timed_region": mk["fp64_tflops"] / 78.6,
+                    "frac_step": mk["fp64_gflop_per_launch"] / ms_per_step / 78.6,
+                    "note": note + "; frac_step = the same flops / ms_per_step (what the pipelined step sustains); fp64 vector work (no "
+                                   "MFMA instruction is issued: every pair term has its own 3x3 inverse), counted against the fp64 peak"}
 
     out = {
         "metric": "NDT scan-pair registrations/sec (100k pts, 0.5 m cells)",
@@ -797,9 +878,11 @@ def main():
                                "map 100x100x1 m, range 30 m, n_neighbours 2, ITR_MAX 30, DELTA_SCORE 1e-6, 6-DoF, "
                                "grid build of both scans + D2D match per registration" % (B, NP, res),
                    "pairs_per_gpu": B, "points_per_scan": NP, "cell_m": res,
+                   "entry": ("ndtgpu_mapset_build + ndtgpu_match_batch_device per step, streams and events driven by bench.py" if legacy
+                             else "ONE ndtgpu_register_batch_device call per step (scans in HBM -> poses); reg.sync() ends the timed region"),
                    "pipeline": ("serial: one stream" if n_buf == 1 else
-                                "%d buffers / streams: builds of step k+1 start when the matcher of step k starts and run "
-                                "on the CUs its finished workgroups have left" % n_buf),
+                                "%d internal map sets / streams: builds of step k+1 start when the builds of step k are done and run "
+                                "on the CUs the matcher's finished workgroups have left" % n_buf),
                    "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2)},
         "roofline": roofline, "kernels": kern,
         # SURVEY.md 8d (config 4): node maps and edges are separate units when node maps are reused across edges
@@ -808,6 +891,13 @@ def main():
         "hbm_fraction": {k: {"timed_region": kern[k]["GBps"] / HBM_PEAK_GBS,
                              "kernel_alone": kern[k]["algorithmic_bytes"] / kern[k]["ms_isolated"] / 1e6 / HBM_PEAK_GBS}
                          for k in kern},
+        "collectives": {"process_group": "nccl (RCCL)" if use_dist else None, "world": world,
+                        "forced_on_one_rank": bool(use_dist and world == 1),
+                        "all_gather_into_tensor_calls": 2 * (args.steps + args.warmup + n_buf) if use_dist else 0,
+                        # this rank's rows of the last step's gathered poses / results are the rows it computed
+                        "gathered_rows_equal_local": (bool(torch.equal(last.gathered[0][rank * B:(rank + 1) * B], last.T16) and
+                                                           torch.equal(last.gathered[1][rank * B:(rank + 1) * B], last.results))
+                                                      if use_dist else None)},
         "nodes_per_s_build_only": world * 2 * B / (iso_build_ms * 1e-3),
         "edges_per_s_match_only_prebuilt_maps": world * B / (iso_match_ms * 1e-3),
     }
@@ -942,12 +1032,14 @@ def main():
     if rank == 0 and world == 1 and args.dense_pairs > 0 and B == 1024 and NP == 100000:
         for b in bufs:
             b.maps.close()
+        if reg is not None:
+            reg.close()
         del both, fixed, moving
         torch.cuda.empty_cache()
         out["dense_scene"] = dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, not args.no_cpu)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -340,6 +340,53 @@ ndtgpu_status ndtgpu_mapset_pack_cells_device(ndtgpu_mapset *set, size_t first, 
 ndtgpu_status ndtgpu_mapset_unpack_cells_device(ndtgpu_mapset *set, size_t first, size_t count, const void *buf_dev,
                                                 size_t record_stride_bytes, int with_occupancy, ndtgpu_stream stream);
 
+/* ---- scans in, poses out: the whole path as ONE call ------------------------------------------------------------------
+ * The reference reaches the path through calls that do everything for their inputs at once:
+ * NDTFeatureGraph::updateLinksUsingNDTRegistration (ndt_feature_graph.cpp:347-353: every link of the list) and the fuser's
+ * loadPointCloud + computeNDTCells + match of ndt_feature_fuser_hmt.cpp:195-227, 353-357 (raw scan -> NDT map -> pose).
+ * A registrar is that call shape for batches of scan pairs: it owns `depth` internal map sets (2 x pairs_per_batch maps of
+ * one grid geometry each), one stream per map set and the index arrays, and every submitted batch travels
+ *     grid build of all target and source scans of a sub-batch (ONE launch)  ->  D2D matcher (ONE launch)
+ * on the next internal stream, released when the previous sub-batch's builds are done: the builds of sub-batch k + 1 run on
+ * the CUs that the long registrations of sub-batch k do not occupy (the pipeline that bench.py drove by hand until round 4).
+ * Results are bit for bit those of ndtgpu_mapset_build + ndtgpu_match_batch_device on the same scans. */
+typedef struct ndtgpu_registrar ndtgpu_registrar;
+/* grid: as ndtgpu_mapset_create (grid->max_cells applies per scan).  pairs_per_batch: registrations per internal sub-batch
+ * (1024 fills an MI355X: two registrations per CU in flight); depth: internal map sets / streams, >= 1 (3 hides the
+ * matcher's tail; memory per map set: see ndtgpu_mapset_create x 2 x pairs_per_batch maps). */
+ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pairs_per_batch, int depth,
+                                      ndtgpu_registrar **out);
+ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *reg);
+/* n_pairs registrations: pair k builds the target map from cloud k of targets_dev and the source map from cloud k of
+ * sources_dev (DEVICE pointers; n_points records each, stride_bytes apart, clouds map_stride_bytes apart; range filter as
+ * ndtgpu_mapset_build with the sensor at the frame origin) and runs NDTMatcherD2D::match(target, source, T, prm).
+ * T16_dev: DEVICE, n_pairs x 16 doubles column-major, in: initial guess, out: registered pose; results_dev: DEVICE.
+ * ASYNCHRONOUS: the inputs must be complete in `stream` order at the time of the call (the library records an event there);
+ * the work itself runs on the registrar's own streams, n_pairs > pairs_per_batch in sub-batches on successive streams.
+ * The call neither waits for the device nor makes `stream` wait: successive calls overlap (whatever streams they name).
+ * *ticket (may be NULL) names the call: its outputs are complete -- and its input and output buffers may be reused -- once
+ * ndtgpu_registrar_wait_stream(reg, ticket, s) has made a stream wait for it, or ndtgpu_registrar_sync has returned.  A pair
+ * whose map overflowed grid->max_cells reports exit_code -3 like ndtgpu_match_batch_device. */
+ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *reg, const void *targets_dev, const void *sources_dev,
+                                           size_t n_points, size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                           const ndtgpu_cell_params *cell, double *T16_dev, size_t n_pairs,
+                                           const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
+                                           ndtgpu_stream stream, uint64_t *ticket);
+/* `stream` waits (on the device, the host does not) for the call `ticket` names and every call before it; ticket 0: for
+ * every call submitted so far */
+ndtgpu_status ndtgpu_registrar_wait_stream(ndtgpu_registrar *reg, uint64_t ticket, ndtgpu_stream stream);
+/* the host waits for every batch submitted so far; NDTGPU_ERR_HIP if a matcher launch gave up (ndtgpu_match_aborted) */
+ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *reg);
+/* Profiling: when enabled every sub-batch's build and matcher launch is bracketed by HIP events on the internal stream it
+ * runs on.  ndtgpu_registrar_kernel_ms waits for the recorded sub-batches, returns their number and the mean durations
+ * (mean_ms[0] build launch, mean_ms[1] matcher launch; under a pipeline these include the time a launch shares the chip with
+ * its neighbours), and forgets them. */
+ndtgpu_status ndtgpu_registrar_profiling(ndtgpu_registrar *reg, int on);
+ndtgpu_status ndtgpu_registrar_kernel_ms(ndtgpu_registrar *reg, float mean_ms[2], int32_t *launches);
+/* the internal map set a sub-batch slot uses (tests: cell-by-cell parity of what the registrar built; slot < depth).  Owned by
+ * the registrar. */
+ndtgpu_status ndtgpu_registrar_mapset(ndtgpu_registrar *reg, int slot, ndtgpu_mapset **set);
+
 /* single pair convenience == graph.cpp:273 */
 ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *target_set, size_t target_map, ndtgpu_mapset *source_set,
                                size_t source_map, double T16[16], const ndtgpu_match_params *prm,

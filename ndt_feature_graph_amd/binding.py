@@ -123,7 +123,9 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch", "ndtgpu_mapset_discard_cells", "ndtgpu_mapset_import_occupancy",
            "ndtgpu_match_fusion_feat_batch", "ndtgpu_match_aborted", "ndtgpu_mapset_pack_bytes",
            "ndtgpu_mapset_pack_cells_device", "ndtgpu_mapset_unpack_cells_device", "ndtgpu_mapset_build_host_async",
-           "ndtgpu_mapset_add_cloud_host_async"]
+           "ndtgpu_mapset_add_cloud_host_async", "ndtgpu_registrar_create", "ndtgpu_registrar_destroy",
+           "ndtgpu_register_batch_device", "ndtgpu_registrar_wait_stream", "ndtgpu_registrar_sync",
+           "ndtgpu_registrar_profiling", "ndtgpu_registrar_kernel_ms", "ndtgpu_registrar_mapset"]
 
 _lib = None
 
@@ -192,6 +194,15 @@ def lib():
     L.ndtgpu_mapset_pack_bytes.argtypes = [vp, C.c_uint32, C.c_int]
     L.ndtgpu_mapset_pack_cells_device.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_int, vp]
     L.ndtgpu_mapset_unpack_cells_device.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
+    L.ndtgpu_registrar_create.argtypes = [C.POINTER(GridParams), C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.ndtgpu_registrar_destroy.argtypes = [vp]
+    L.ndtgpu_register_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(CellParams),
+                                               vp, C.c_size_t, C.POINTER(MatchParams), vp, vp, C.POINTER(C.c_uint64)]
+    L.ndtgpu_registrar_wait_stream.argtypes = [vp, C.c_uint64, vp]
+    L.ndtgpu_registrar_sync.argtypes = [vp]
+    L.ndtgpu_registrar_profiling.argtypes = [vp, C.c_int]
+    L.ndtgpu_registrar_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), i32p]
+    L.ndtgpu_registrar_mapset.argtypes = [vp, C.c_int, C.POINTER(vp)]
     _lib = L
     return L
 
@@ -500,6 +511,80 @@ def match_batch_device(target_set, tidx_dev, source_set, sidx_dev, T16_dev, resu
     _check(lib().ndtgpu_match_batch_device(target_set.h, C.c_void_p(tidx_dev.data_ptr()), source_set.h,
                                            C.c_void_p(sidx_dev.data_ptr()), C.c_void_p(T16_dev.data_ptr()), int(n_pairs),
                                            C.byref(p), C.c_void_p(results_dev.data_ptr()), _stream_ptr(stream)))
+
+
+class _BorrowedMapSet(MapSet):
+    """A map set owned by somebody else (a registrar): same methods, never destroyed from here."""
+
+    def __init__(self, h, n_maps, res):
+        self.h, self.n_maps, self.res = h, int(n_maps), float(res)
+
+    def close(self):
+        self.h = None
+
+
+class Registrar:
+    """ndtgpu_registrar: scans in, poses out -- grid builds + D2D matcher of batches of scan pairs as ONE asynchronous call,
+    pipelined over the library's own streams (include/ndtgpu.h)."""
+
+    def __init__(self, res, centre, size_m, pairs_per_batch=1024, depth=3, max_cells=0):
+        gp = GridParams()
+        gp.res = float(res)
+        gp.centre[:] = [float(x) for x in centre]
+        gp.size[:] = [float(x) for x in size_m]
+        gp.max_cells = int(max_cells)
+        h = C.c_void_p()
+        _check(lib().ndtgpu_registrar_create(C.byref(gp), int(pairs_per_batch), int(depth), C.byref(h)))
+        self.h, self.depth, self.per, self.res = h, int(depth), int(pairs_per_batch), float(res)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ndtgpu_registrar_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, targets, sources, T16_dev, results_dev, range_limit=-1.0, n_min=3, eval_factor=1000.0, stream=None, **params):
+        """targets / sources: torch CUDA float32 tensors [n, N, 3 or 4] (contiguous in the last two dims); T16_dev float64
+        [n, 16] column-major (in: initial guess, out: pose); results_dev uint8 [n, 64].  Asynchronous; returns the call's
+        ticket (wait_stream / sync)."""
+        n, npts = int(targets.shape[0]), int(targets.shape[1])
+        assert tuple(sources.shape) == tuple(targets.shape) and targets.stride(1) == targets.shape[2] and targets.stride(2) == 1
+        assert sources.stride(0) == targets.stride(0) and sources.stride(1) == targets.stride(1) and sources.stride(2) == 1
+        cp = CellParams(int(n_min), float(eval_factor))
+        p = match_params(**params)
+        t = C.c_uint64()
+        _check(lib().ndtgpu_register_batch_device(self.h, C.c_void_p(targets.data_ptr()), C.c_void_p(sources.data_ptr()), npts,
+                                                  4 * int(targets.shape[2]), 4 * int(targets.stride(0)), float(range_limit),
+                                                  C.byref(cp), C.c_void_p(T16_dev.data_ptr()), n, C.byref(p),
+                                                  C.c_void_p(results_dev.data_ptr()), _stream_ptr(stream), C.byref(t)))
+        return int(t.value)
+
+    def wait_stream(self, stream=None, ticket=0):
+        """`stream` waits for the call `ticket` names (0: for everything submitted so far); the host does not wait."""
+        _check(lib().ndtgpu_registrar_wait_stream(self.h, int(ticket), _stream_ptr(stream)))
+
+    def sync(self):
+        _check(lib().ndtgpu_registrar_sync(self.h))
+
+    def profiling(self, on=True):
+        _check(lib().ndtgpu_registrar_profiling(self.h, 1 if on else 0))
+
+    def kernel_ms(self):
+        """-> (mean build ms, mean matcher ms, profiled sub-batches) since the last call; forgets them."""
+        ms = (C.c_float * 2)()
+        n = C.c_int32()
+        _check(lib().ndtgpu_registrar_kernel_ms(self.h, ms, C.byref(n)))
+        return float(ms[0]), float(ms[1]), int(n.value)
+
+    def mapset(self, slot):
+        h = C.c_void_p()
+        _check(lib().ndtgpu_registrar_mapset(self.h, int(slot), C.byref(h)))
+        return _BorrowedMapSet(h, 2 * self.per, self.res)
 
 
 def match_d2d(target_set, tmap, source_set, smap, T, **params):

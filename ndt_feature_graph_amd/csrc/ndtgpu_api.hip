@@ -182,7 +182,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.4.3 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.5.0 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1024,6 +1024,193 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
         }
     }
     return match_device_core(ts, tidx_dev, ss, sidx_dev, T16_dev, n_pairs, p, results_dev, nullptr, (hipStream_t)stream);
+}
+
+// ---- the registrar: scans in, poses out (include/ndtgpu.h) ---------------------------------------------------------------
+// `depth` map sets with a stream each.  A sub-batch = ONE build launch for its 2 p scans + ONE matcher launch on the next
+// stream in turn.  What orders the streams: (i) the inputs (an event recorded on the caller's stream at the call), (ii) the
+// builds among themselves -- sub-batch k + 1 builds once sub-batch k's build has finished, i.e. while matcher k runs: the
+// matcher's workgroups leave their CUs as soon as no registration is left to start (csrc/ndt_match.hip), so the next builds
+// fill the CUs that the few long registrations do not hold --, (iii) a map set against its own previous use (same stream).
+struct ndtgpu_registrar {
+    size_t per = 0;
+    int depth = 0;
+    std::vector<ndtgpu_mapset *> sets;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> built;
+    // completion events, one per sub-batch, in a ring of 4 x depth: sub-batch j records done[j % ring] -- an entry always
+    // belongs to stream j % depth, so whoever waits on an entry that a later sub-batch has re-recorded waits for a superset
+    std::vector<hipEvent_t> done;
+    hipEvent_t in_ev = nullptr;
+    int last_built = -1;
+    uint32_t *iota = nullptr;          // device: 0 .. 2 per - 1 (target indices: iota, source indices: iota + p)
+    size_t submitted = 0;              // sub-batches so far
+    bool profiling = false;
+    std::vector<hipEvent_t> marks;     // 4 per profiled sub-batch: build start / end, matcher start / end
+};
+
+ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
+{
+    if (!r) return NDTGPU_OK;
+    for (hipStream_t st : r->streams)
+        if (st) (void)hipStreamSynchronize(st);
+    for (hipEvent_t e : r->marks) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->built) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->done) if (e) (void)hipEventDestroy(e);
+    if (r->in_ev) (void)hipEventDestroy(r->in_ev);
+    for (ndtgpu_mapset *s : r->sets) (void)ndtgpu_mapset_destroy(s);
+    for (hipStream_t st : r->streams)
+        if (st) (void)hipStreamDestroy(st);
+    if (r->iota) (void)hipFree(r->iota);
+    delete r;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pairs_per_batch, int depth, ndtgpu_registrar **out)
+{
+    if (!grid || !out || pairs_per_batch == 0 || pairs_per_batch > (1u << 30) || depth < 1 || depth > 16)
+        return fail(NDTGPU_ERR_INVALID, "registrar_create: bad argument (pairs_per_batch >= 1, 1 <= depth <= 16)");
+    if (!have_device()) return fail(NDTGPU_ERR_NO_DEVICE, "registrar_create: no HIP device");
+    ndtgpu_registrar *r = new (std::nothrow) ndtgpu_registrar();
+    if (!r) return fail(NDTGPU_ERR_ALLOC, "registrar_create: host alloc");
+    r->per = pairs_per_batch;
+    r->depth = depth;
+    r->sets.assign(depth, nullptr);
+    r->streams.assign(depth, nullptr);
+    r->built.assign(depth, nullptr);
+    r->done.assign(4 * (size_t)depth, nullptr);
+    hipError_t e = hipSuccess;
+    ndtgpu_status rc = NDTGPU_OK;
+    for (int k = 0; k < depth && rc == NDTGPU_OK && e == hipSuccess; k++) {
+        rc = ndtgpu_mapset_create(grid, 2 * pairs_per_batch, &r->sets[k]);
+        if (rc != NDTGPU_OK) break;
+        e = hipStreamCreateWithFlags(&r->streams[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r->built[k], hipEventDisableTiming);
+    }
+    for (size_t k = 0; k < r->done.size() && rc == NDTGPU_OK && e == hipSuccess; k++)
+        e = hipEventCreateWithFlags(&r->done[k], hipEventDisableTiming);
+    if (rc == NDTGPU_OK && e == hipSuccess) e = hipEventCreateWithFlags(&r->in_ev, hipEventDisableTiming);
+    if (rc == NDTGPU_OK && e == hipSuccess) e = hipMalloc((void **)&r->iota, 2 * pairs_per_batch * sizeof(uint32_t));
+    if (rc == NDTGPU_OK && e == hipSuccess) {
+        std::vector<uint32_t> h(2 * pairs_per_batch);
+        for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)i;
+        e = hipMemcpy(r->iota, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    }
+    if (rc != NDTGPU_OK || e != hipSuccess) {
+        const std::string why = rc != NDTGPU_OK ? g_err : std::string("registrar_create: ") + hipGetErrorString(e);
+        ndtgpu_registrar_destroy(r);
+        return fail(rc != NDTGPU_OK ? rc : NDTGPU_ERR_HIP, why.c_str());
+    }
+    *out = r;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_registrar_mapset(ndtgpu_registrar *r, int slot, ndtgpu_mapset **set)
+{
+    if (!r || !set || slot < 0 || slot >= r->depth) return fail(NDTGPU_ERR_INVALID, "registrar_mapset: bad argument");
+    *set = r->sets[slot];
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_registrar_profiling(ndtgpu_registrar *r, int on)
+{
+    if (!r) return fail(NDTGPU_ERR_INVALID, "registrar_profiling: null");
+    r->profiling = on != 0;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_registrar_kernel_ms(ndtgpu_registrar *r, float mean_ms[2], int32_t *launches)
+{
+    if (!r || !mean_ms || !launches) return fail(NDTGPU_ERR_INVALID, "registrar_kernel_ms: bad argument");
+    const size_t n = r->marks.size() / 4;
+    double sum[2] = {0.0, 0.0};
+    for (size_t k = 0; k < n; k++) {
+        HIP_TRY(hipEventSynchronize(r->marks[4 * k + 3]));
+        for (int w = 0; w < 2; w++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, r->marks[4 * k + 2 * w], r->marks[4 * k + 2 * w + 1]));
+            sum[w] += ms;
+        }
+    }
+    for (hipEvent_t e : r->marks) (void)hipEventDestroy(e);
+    r->marks.clear();
+    *launches = (int32_t)n;
+    mean_ms[0] = n ? (float)(sum[0] / (double)n) : 0.f;
+    mean_ms[1] = n ? (float)(sum[1] / (double)n) : 0.f;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targets_dev, const void *sources_dev, size_t n_points,
+                                           size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                           const ndtgpu_cell_params *cell, double *T16_dev, size_t n_pairs,
+                                           const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev, ndtgpu_stream stream,
+                                           uint64_t *ticket)
+{
+    if (ticket) *ticket = r ? (uint64_t)r->submitted : 0;
+    if (!r || (n_pairs && (!T16_dev || !results_dev || (n_points && (!targets_dev || !sources_dev)))) || stride_bytes < 12 ||
+        (stride_bytes & 3) || n_points > 0xFFFFFFFFull)
+        return fail(NDTGPU_ERR_INVALID, "register_batch_device: bad argument");
+    if (n_pairs == 0) return NDTGPU_OK;
+    HIP_TRY(hipEventRecord(r->in_ev, (hipStream_t)stream));
+    for (size_t off = 0; off < n_pairs; off += r->per) {
+        const size_t p = std::min(r->per, n_pairs - off);
+        const int slot = (int)(r->submitted % (size_t)r->depth);
+        hipStream_t st = r->streams[slot];
+        ndtgpu_mapset *set = r->sets[slot];
+        HIP_TRY(hipStreamWaitEvent(st, r->in_ev, 0));
+        if (r->last_built >= 0 && r->last_built != slot) HIP_TRY(hipStreamWaitEvent(st, r->built[r->last_built], 0));
+        hipEvent_t *mk = nullptr;
+        if (r->profiling) {
+            const size_t at = r->marks.size();
+            r->marks.resize(at + 4, nullptr);
+            for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreate(&r->marks[at + k]));
+            mk = &r->marks[at];
+            HIP_TRY(hipEventRecord(mk[0], st));
+        }
+        const char *tg = (const char *)targets_dev + off * map_stride_bytes, *sc = (const char *)sources_dev + off * map_stride_bytes;
+        ndtgpu_status rc;
+        if (sc == tg + p * map_stride_bytes) {
+            rc = ndtgpu_mapset_build(set, 0, 2 * p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+        } else {
+            rc = ndtgpu_mapset_build(set, 0, p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+            if (rc == NDTGPU_OK)
+                rc = ndtgpu_mapset_build(set, p, p, sc, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+        }
+        if (rc != NDTGPU_OK) return rc;
+        if (mk) { HIP_TRY(hipEventRecord(mk[1], st)); HIP_TRY(hipEventRecord(mk[2], st)); }
+        HIP_TRY(hipEventRecord(r->built[slot], st));
+        r->last_built = slot;
+        rc = ndtgpu_match_batch_device(set, r->iota, set, r->iota + p, T16_dev + off * 16, p, prm, results_dev + off, st);
+        if (rc != NDTGPU_OK) return rc;
+        if (mk) HIP_TRY(hipEventRecord(mk[3], st));
+        HIP_TRY(hipEventRecord(r->done[r->submitted % r->done.size()], st));
+        r->submitted++;
+        if (ticket) *ticket = (uint64_t)r->submitted;      // "every sub-batch before this count"
+    }
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_registrar_wait_stream(ndtgpu_registrar *r, uint64_t ticket, ndtgpu_stream stream)
+{
+    if (!r || ticket > (uint64_t)r->submitted) return fail(NDTGPU_ERR_INVALID, "registrar_wait_stream: bad argument");
+    // the newest sub-batch before `end` on every internal stream (earlier ones precede it in stream order)
+    const size_t end = ticket ? (size_t)ticket : r->submitted;
+    for (size_t j = end > (size_t)r->depth ? end - (size_t)r->depth : 0; j < end; j++)
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, r->done[j % r->done.size()], 0));
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
+{
+    if (!r) return fail(NDTGPU_ERR_INVALID, "registrar_sync: null");
+    for (int k = 0; k < r->depth; k++) HIP_TRY(hipStreamSynchronize(r->streams[k]));
+    for (int k = 0; k < r->depth && (size_t)k < r->submitted; k++) {
+        int aborted = 0;
+        ndtgpu_status rc = ndtgpu_match_aborted(r->sets[k], &aborted);
+        if (rc != NDTGPU_OK) return rc;
+        if (aborted) return fail(NDTGPU_ERR_HIP, "registrar: a matcher launch gave up (a wave found no work for ~1 s)");
+    }
+    return NDTGPU_OK;
 }
 
 // host arrays -> staging -> persistent matcher -> host arrays; synchronous

@@ -14,7 +14,26 @@ state), so there is NO data-path collective.  One process per GPU:
   * the only collective is the FINAL all-gather of the edge results {T 16 f64, result 64 B}
     (RCCL over xGMI on GPUs, gloo in the CPU tests): ~192 B/edge.
 """
+import os
+
 import numpy as np
+
+
+def collectives_forced():
+    """NDTGPU_FORCE_COLLECTIVES=1: a ONE-rank run still creates the process group and goes through every collective of the
+    path (both all-gathers of the edge results, the exchange of the packed node maps) instead of taking the world == 1
+    short cuts -- the RCCL calls, their streams and their buffer layouts are executed on whatever single GPU is there
+    (tests/test_gpu_rccl.py), before an 8-GPU node ever runs them."""
+    return os.environ.get("NDTGPU_FORCE_COLLECTIVES", "0") not in ("", "0")
+
+
+def _collective(world):
+    if world > 1:
+        return True
+    if not collectives_forced():
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_edges(n_edges, rank, world, chunk=256):
@@ -37,7 +56,7 @@ def gather_edge_results(T_local, res_local, n_edges, rank, world, chunk=256, gro
     on every rank."""
     import torch
     import torch.distributed as dist
-    if world <= 1:
+    if not _collective(world):
         return T_local, res_local
     sizes = shard_sizes(n_edges, world, chunk)
     kmax = max(sizes)
@@ -93,7 +112,7 @@ def exchange_node_maps(packed_local, n_nodes, rank, world, group=None):
     one call."""
     import torch
     import torch.distributed as dist
-    if world <= 1:
+    if not _collective(world):
         return packed_local[:n_nodes]
     n_max = (n_nodes + world - 1) // world
     stride = packed_local.shape[1]

@@ -1,0 +1,162 @@
+"""ndtgpu_register_batch_device: scans in, poses out as ONE asynchronous C-ABI call (-m gpu).
+
+The call shape of NDTFeatureGraph::updateLinksUsingNDTRegistration (ndt_feature_graph.cpp:347-353) and of the fuser's
+loadPointCloud + computeNDTCells + match (ndt_feature_fuser_hmt.cpp:195-227, 353-357).  The registrar pipelines sub-batches over
+its own streams; what it returns must be, bit for bit, what ndtgpu_mapset_build + ndtgpu_match_batch_device give for the same
+scans, whatever the sub-batch size, the depth, the number of calls in flight and the streams the caller names -- and the oracle's
+poses within the contract's tolerance."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DET_FIELDS = ["converged", "iterations", "fevals", "exit_code", "score", "n_source", "n_target", "pair_terms_g", "pair_terms_h"]
+RES, SIZE, RNG = 0.5, [100.0, 100.0, 1.0], 30.0
+
+
+@pytest.fixture(scope="module")
+def N():
+    import ndt_feature_graph_amd as N
+    if N.device_count() < 1:
+        pytest.fail("no HIP device visible: the HIP path cannot run (there is no CPU fallback)")
+    return N
+
+
+@pytest.fixture(scope="module")
+def O():
+    import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def scene(N):
+    """96 scan pairs of 20 k points in HBM + the two-call reference result (build, then ndtgpu_match_batch_device)."""
+    import torch
+    from ndt_feature_graph_amd import binding, synth
+    dev = torch.device("cuda", 0)
+    B, NP = 96, 20000
+    pr = synth.pair_2d(torch.arange(7001, 7001 + B, dtype=torch.int64, device=dev), NP, device=dev)
+    both = torch.cat([pr["fixed"], pr["moving"]]).contiguous()
+    T0 = pr["T_init"].transpose(1, 2).contiguous().reshape(B, 16)
+    ms = N.MapSet(RES, [0, 0, 0], SIZE, n_maps=2 * B, max_cells=4096)
+    st = torch.cuda.current_stream()
+    ms.build(both, range_limit=RNG, stream=st)
+    idx = torch.arange(B, dtype=torch.int32, device=dev)
+    T16 = T0.clone()
+    res = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    binding.match_batch_device(ms, idx, ms, idx + B, T16, res, B, stream=st)
+    torch.cuda.synchronize()
+    return {"B": B, "NP": NP, "both": both, "T0": T0, "T_ref": T16.cpu().numpy(), "T_init": pr["T_init"].cpu().numpy(),
+            "r_ref": res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B), "dev": dev, "maps": ms}
+
+
+def same_bits(binding, T16, res, T_ref, r_ref):
+    assert np.array_equal(T16.cpu().numpy(), T_ref)
+    r = res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(-1)
+    for f in DET_FIELDS:
+        assert np.array_equal(r[f], r_ref[f]), f
+    return r
+
+
+@pytest.mark.parametrize("per,depth", [(96, 1), (32, 3), (40, 2)])
+def test_registrar_same_bits_as_build_plus_match(N, scene, per, depth):
+    """one call; sub-batches of 96 / 32 / 40 (ragged last one) pairs over 1 / 3 / 2 internal map sets"""
+    import torch
+    from ndt_feature_graph_amd import binding
+    B, both, dev = scene["B"], scene["both"], scene["dev"]
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=per, depth=depth, max_cells=4096)
+    T16 = scene["T0"].clone()
+    res = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    reg.submit(both[:B], both[B:], T16, res, range_limit=RNG, stream=torch.cuda.current_stream())
+    reg.sync()
+    r = same_bits(binding, T16, res, scene["T_ref"], scene["r_ref"])
+    assert r["converged"].mean() > 0.8
+    # the maps the registrar built are the maps of the plain build (slot 0 holds the first sub-batch: targets, then sources)
+    p0 = min(per, B)
+    first_slot = reg.mapset(0)
+    if depth == 1 and per >= B:
+        for k in (0, B - 1, B, 2 * B - 1):
+            a, b = first_slot.export_cells(k), scene["maps"].export_cells(k)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+    assert p0 >= 1
+    reg.close()
+
+
+def test_registrar_calls_in_flight_and_streams(N, scene):
+    """four calls submitted back to back from two caller streams (inputs made on those streams just before), separate
+    target / source buffers that are not adjacent, then wait_stream + a copy on a third stream"""
+    import torch
+    from ndt_feature_graph_amd import binding
+    B, both, dev = scene["B"], scene["both"], scene["dev"]
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=48, depth=3, max_cells=4096)
+    sa, sb, sc = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    outs, tickets = [], []
+    for k, st in enumerate((sa, sb, sa, sb)):
+        with torch.cuda.stream(st):
+            tg = both[:B].clone()                         # the inputs are produced on the caller's stream ...
+            pad = torch.empty(1 + k, dtype=torch.float32, device=dev)
+            src = both[B:].clone()                        # ... and sources do not follow targets in memory
+            T16 = scene["T0"].clone()
+            res = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+            tickets.append(reg.submit(tg, src, T16, res, range_limit=RNG, stream=st))
+            outs.append((tg, src, pad, T16, res))
+    assert tickets == [2, 4, 6, 8]                        # two sub-batches of 48 pairs per call
+    # a ticket covers its call and the calls before it: the first two calls' outputs on a stream that waited for ticket 2
+    reg.wait_stream(sc, ticket=tickets[1])
+    with torch.cuda.stream(sc):
+        copies = [(o[3].clone(), o[4].clone()) for o in outs[:2]]
+    reg.wait_stream(sc)                                   # ... and everything submitted so far
+    with torch.cuda.stream(sc):
+        copies += [(o[3].clone(), o[4].clone()) for o in outs[2:]]
+    sc.synchronize()
+    with pytest.raises(N.NdtGpuError):
+        reg.wait_stream(sc, ticket=99)                    # a ticket nobody was given
+    for T16, res in copies:
+        same_bits(binding, T16, res, scene["T_ref"], scene["r_ref"])
+    reg.sync()
+    reg.close()
+
+
+def test_registrar_against_the_oracle(N, O, scene):
+    """8 of the pairs against the CPU oracle: cells of both maps exact, pose within 1e-4 m / 1e-4 rad, same iterations"""
+    import torch
+    from ndt_feature_graph_amd import binding
+    B, both, dev = scene["B"], scene["both"], scene["dev"]
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=B, depth=1, max_cells=4096)
+    T16 = scene["T0"].clone()
+    res = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    reg.submit(both[:B], both[B:], T16, res, range_limit=RNG)
+    reg.sync()
+    T = T16.cpu().numpy().reshape(B, 4, 4).transpose(0, 2, 1)
+    r = res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
+    ms = reg.mapset(0)
+    for b in np.linspace(0, B - 1, 8).astype(int):
+        f, m = both[b].cpu().numpy(), both[B + b].cpu().numpy()
+        ot = O.OracleMap(RES, [0, 0, 0], SIZE); ot.load_points(f, RNG); ot.compute_cells()
+        os_ = O.OracleMap(RES, [0, 0, 0], SIZE); os_.load_points(m, RNG); os_.compute_cells()
+        gi, ci = ms.export_cells(int(b))[2], ot.export_cells()[2]
+        assert np.array_equal(gi, ci)
+        assert np.array_equal(ms.export_cells(int(B + b))[2], os_.export_cells()[2])
+        To, ro = O.match_d2d(ot, os_, scene["T_init"][b])
+        dt = np.linalg.norm(T[b][:3, 3] - To[:3, 3])
+        dr = 2.0 * np.arcsin(min(1.0, np.linalg.norm(T[b][:3, :3] - To[:3, :3]) / (2.0 * np.sqrt(2.0))))
+        assert dt <= 1e-4 and dr <= 1e-4, (b, dt, dr)           # the tolerance BASELINE.json's north_star states
+        assert r["iterations"][b] == ro["iterations"] and bool(r["converged"][b]) == ro["converged"]
+    reg.close()
+
+
+def test_registrar_rejects_bad_arguments(N, scene):
+    import torch
+    B, both, dev = scene["B"], scene["both"], scene["dev"]
+    with pytest.raises(N.NdtGpuError):
+        N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=0, depth=3)
+    with pytest.raises(N.NdtGpuError):
+        N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=0)
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=1, max_cells=4096)
+    reg.sync()                                                   # nothing submitted: returns at once
+    assert reg.kernel_ms() == (0.0, 0.0, 0)
+    reg.close()
