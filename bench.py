@@ -666,13 +666,16 @@ def main():
     bufs = []
     reg = None if legacy else N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=B, depth=n_buf, max_cells=4096)
     main_stream = torch.cuda.current_stream()
+    if os.environ.get("BENCH_MAIN_SIDE"):      # (experiment: the caller's stream is not the null stream)
+        main_stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(main_stream)
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     for k in range(n_buf):
         b = Buf()
         b.maps = N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * B, max_cells=4096) if legacy else reg.mapset(k)
         b.T16 = T_init_cm.clone()
         b.results = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
-        b.stream = torch.cuda.Stream(device=dev)
+        b.stream = torch.cuda.Stream(device=dev) if legacy else None      # (the registrar brings its own streams)
         b.mstream = b.stream
         if args.cu_split > 0 and n_buf > 1:
             # builds on the first `cu_split` CUs, matchers on the rest: the matcher's one-per-CU workgroups never wait for a CU

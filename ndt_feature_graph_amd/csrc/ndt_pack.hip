@@ -58,8 +58,13 @@ extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_unpack_kernel
     const char *rec = buf + (size_t)blockIdx.x * stride;
     const NdtPackedHeader h = *reinterpret_cast<const NdtPackedHeader *>(rec);
     unsigned n = h.n_cells;
-    const bool too_many = n > g.max_cells;
-    if (too_many) n = g.max_cells;
+    // the header is data from elsewhere: never read past the record -- n_cells <= cells_cap, both inside `stride`
+    const size_t room = stride > sizeof(NdtPackedHeader) ? (stride - sizeof(NdtPackedHeader)) / sizeof(NdtCell) : 0;
+    const unsigned cap_rec = (unsigned)(h.cells_cap < room ? h.cells_cap : room);
+    const bool too_many = n > g.max_cells || n > cap_rec;
+    if (n > cap_rec) n = cap_rec;
+    if (n > g.max_cells) n = g.max_cells;
+    const bool occ_fits = sizeof(NdtPackedHeader) + (size_t)h.cells_cap * sizeof(NdtCell) + (size_t)g.slots * sizeof(float) <= stride;
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     const unsigned bm_words = (unsigned)((g.slots + 31) >> 5);
     NdtCell *cells = set.cells + (size_t)map * g.max_cells;          // an installed map lives in the first cell array
@@ -79,7 +84,7 @@ extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_unpack_kernel
         atomicOr(&rankmap[slot >> 5].x, 1u << (slot & 31u));
         if (i == 0 || (src[i - 1].slot >> 5) != (slot >> 5)) rankmap[slot >> 5].y = i;
     }
-    if (with_occ && set.occ && (h.flags & NDT_PACK_F_OCC)) {
+    if (with_occ && set.occ && (h.flags & NDT_PACK_F_OCC) && occ_fits) {
         const float *o = reinterpret_cast<const float *>(rec + sizeof(NdtPackedHeader) + (size_t)h.cells_cap * sizeof(NdtCell));
         float *od = set.occ + (size_t)map * g.slots;
         for (unsigned i = tid; i < (unsigned)g.slots; i += NDT_PACK_THREADS) od[i] = o[i];
@@ -88,7 +93,9 @@ extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_unpack_kernel
         NdtMapCounters c = set.counters[map];
         c.n_cells = n;
         c.n_alloc = 0;
-        c.overflow = ((h.flags & NDT_PACK_F_OVERFLOW) || too_many) ? 1u : 0u;
+        // (a record that had to be clamped, or whose occupancy block does not fit its stride, is flagged like an overflow:
+        //  the matcher refuses the map)
+        c.overflow = ((h.flags & NDT_PACK_F_OVERFLOW) || too_many || (with_occ && (h.flags & NDT_PACK_F_OCC) && !occ_fits)) ? 1u : 0u;
         c.n_dropped = h.n_dropped;
         set.counters[map] = c;
         if (set.cell_sel) set.cell_sel[map] = 0u;

@@ -55,8 +55,32 @@ struct ndtgpu_mapset {
             if (!nice_host[m]) return 0;
         return 1;
     }
-    hipStream_t last_stream = nullptr;
-    hipStream_t last_match_stream = nullptr;   // stream of the last persistent matcher launch with this set as target
+    // Streams that may still hold work on this set (writers: builds, unpack, add_cloud; readers: matcher launches): one event
+    // per recently used stream, recorded AFTER the launch.  The host-synchronous entries wait for these events -- not for
+    // stream handles, which the caller may have destroyed since, and not only for the last writer (a matcher that still reads
+    // the maps on another stream is waited for as well).
+    struct StreamMark { hipStream_t st; hipEvent_t ev; };
+    std::vector<StreamMark> marks;
+    ndtgpu_status touch(hipStream_t st)
+    {
+        for (StreamMark &m : marks)
+            if (m.st == st) { HIP_TRY(hipEventRecord(m.ev, st)); return NDTGPU_OK; }
+        if (marks.size() >= 8) {                 // many streams over time: retire the oldest entry once its work is done
+            HIP_TRY(hipEventSynchronize(marks.front().ev));
+            (void)hipEventDestroy(marks.front().ev);
+            marks.erase(marks.begin());
+        }
+        StreamMark m{st, nullptr};
+        HIP_TRY(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(m.ev, st));
+        marks.push_back(m);
+        return NDTGPU_OK;
+    }
+    ndtgpu_status wait_all()
+    {
+        for (StreamMark &m : marks) HIP_TRY(hipEventSynchronize(m.ev));
+        return NDTGPU_OK;
+    }
     // staging buffers reused across calls
     void *stage = nullptr;
     size_t stage_bytes = 0;
@@ -285,6 +309,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (!s) return NDTGPU_OK;
     (void)hipDeviceSynchronize();
     if (s->pin) (void)hipHostFree(s->pin);
+    for (auto &m : s->marks) (void)hipEventDestroy(m.ev);
     for (int k = 0; k < ndtgpu_mapset::HOST_SLOTS; k++) {
         if (s->host_ring[k]) (void)hipHostFree(s->host_ring[k]);
         if (s->host_ev[k]) (void)hipEventDestroy(s->host_ev[k]);
@@ -354,7 +379,6 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
         HIP_TRY(hipMemcpyAsync(s->origins_dev, range_origins, count * 3 * sizeof(double), hipMemcpyHostToDevice, st));
         orig_dev = s->origins_dev;
     }
-    s->last_stream = st;
     if (s->v.occ && count)   // a rebuilt map starts from cells without readings
         HIP_TRY(hipMemsetAsync(s->v.occ + first * (size_t)s->v.grid.slots, 0, count * (size_t)s->v.grid.slots * sizeof(float), st));
     if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
@@ -362,6 +386,7 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
                          orig_dev, cp.n_min, cp.eval_factor, s->nice_range(first, count), st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: launch", e);
     if (s->profiling) { HIP_TRY(hipEventRecord(s->ev[1], st)); s->ev_valid[0] = true; }
+    { ndtgpu_status trc = s->touch(st); if (trc != NDTGPU_OK) return trc; }
     if (orig_dev) return s->origins_used(st);
     return NDTGPU_OK;
 }
@@ -405,7 +430,9 @@ static ndtgpu_status stage_host_clouds(ndtgpu_mapset *s, const void *xyz_host, s
     if (s->stage_free_valid) HIP_TRY(hipStreamWaitEvent(st, s->stage_free_ev, 0));
     const size_t slot = ndtgpu_mapset::HOST_SLOT_BYTES;
     const char *force = getenv("NDTGPU_HOST_PIPE");            // 0: never the ring, 1: always (tests)
-    const bool ring = n_points && map_stride_bytes <= slot && cloud_bytes <= slot &&
+    // (the ring cuts the input into chunks of WHOLE clouds that lie one after the other: clouds that overlap in memory --
+    //  map_stride_bytes < cloud_bytes, e.g. sliding windows over one point stream, or stride 0 -- take the single copy)
+    const bool ring = n_points && map_stride_bytes >= cloud_bytes && map_stride_bytes <= slot && cloud_bytes <= slot &&
                       (force ? atoi(force) != 0 : bytes >= (24u << 20));
     if (!ring) {
         if (n_points) HIP_TRY(hipMemcpyAsync(s->stage, xyz_host, bytes, hipMemcpyHostToDevice, st));   // (pageable: returns when read)
@@ -414,7 +441,8 @@ static ndtgpu_status stage_host_clouds(ndtgpu_mapset *s, const void *xyz_host, s
         rc = s->ensure_host_ring();
         if (rc != NDTGPU_OK) return rc;
         if (s->stage_free_valid) HIP_TRY(hipStreamWaitEvent(s->host_copy_stream, s->stage_free_ev, 0));
-        const size_t per = std::max<size_t>(1, std::min(count, slot / map_stride_bytes));      // clouds per chunk
+        // clouds per chunk: a chunk of `per` clouds occupies (per - 1) * map_stride_bytes + cloud_bytes of its slot
+        const size_t per = std::max<size_t>(1, std::min(count, 1 + (slot - cloud_bytes) / map_stride_bytes));
         const size_t n_chunks = (count + per - 1) / per;
         constexpr int R = ndtgpu_mapset::HOST_SLOTS;
         const int n_workers = (int)std::min<size_t>(4, n_chunks);
@@ -459,14 +487,13 @@ static ndtgpu_status stage_host_clouds(ndtgpu_mapset *s, const void *xyz_host, s
         }
         if (herr != hipSuccess || lrc != NDTGPU_OK) stop.store(1);
         for (auto &t : workers) t.join();
-        if (herr != hipSuccess) return fail(NDTGPU_ERR_HIP, "host clouds: staging copy", herr);
-        rc = lrc;
+        rc = herr != hipSuccess ? fail(NDTGPU_ERR_HIP, "host clouds: staging copy", herr) : lrc;
     }
-    if (rc != NDTGPU_OK) return rc;
-    if (!s->stage_free_ev) HIP_TRY(hipEventCreateWithFlags(&s->stage_free_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(s->stage_free_ev, st));
-    s->stage_free_valid = true;
-    return NDTGPU_OK;
+    // (also after a failure: chunks that were launched before it may still be reading the staging area)
+    if (!s->stage_free_ev && hipEventCreateWithFlags(&s->stage_free_ev, hipEventDisableTiming) != hipSuccess) s->stage_free_ev = nullptr;
+    if (s->stage_free_ev && hipEventRecord(s->stage_free_ev, st) == hipSuccess) s->stage_free_valid = true;
+    else if (rc == NDTGPU_OK) return fail(NDTGPU_ERR_HIP, "host clouds: event");
+    return rc;
 }
 
 ndtgpu_status ndtgpu_mapset_build_host_async(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,
@@ -491,7 +518,7 @@ ndtgpu_status ndtgpu_mapset_build_host(ndtgpu_mapset *s, size_t first, size_t co
     if (!s) return fail(NDTGPU_ERR_INVALID, "mapset_build_host: bad argument");
     ndtgpu_status rc = s->ensure_host_build_stream();
     if (rc != NDTGPU_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(s->last_stream));             // (earlier work on these maps, whatever stream it used)
+    { ndtgpu_status wrc_ = s->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }             // (earlier work on these maps, whatever stream it used)
     rc = ndtgpu_mapset_build_host_async(s, first, count, xyz_host, n_points, stride_bytes, map_stride_bytes, range_limit,
                                         range_origins, cell, (ndtgpu_stream)s->host_build_stream);
     if (rc != NDTGPU_OK) return rc;
@@ -501,7 +528,7 @@ ndtgpu_status ndtgpu_mapset_build_host(ndtgpu_mapset *s, size_t first, size_t co
 
 static ndtgpu_status read_counters(ndtgpu_mapset *s, size_t map, NdtMapCounters *c)
 {
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    { ndtgpu_status wrc_ = s->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     HIP_TRY(hipMemcpy(c, s->v.counters + map, sizeof *c, hipMemcpyDeviceToHost));
     return NDTGPU_OK;
 }
@@ -609,7 +636,6 @@ ndtgpu_status ndtgpu_mapset_set_cells(ndtgpu_mapset *s, size_t map, const double
     ndtgpu_status rc = s->ensure_stage(std::max<size_t>(uniq.size() * sizeof(NdtCell), 16));
     if (rc != NDTGPU_OK) return rc;
     if (!uniq.empty()) HIP_TRY(hipMemcpy(s->stage, uniq.data(), uniq.size() * sizeof(NdtCell), hipMemcpyHostToDevice));
-    s->last_stream = nullptr;
     hipError_t e = ndt_launch_install_cells(s->v, map, (const NdtCell *)s->stage, uniq.size(), nullptr);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "set_cells: launch", e);
     HIP_TRY(hipStreamSynchronize(nullptr));
@@ -630,7 +656,7 @@ ndtgpu_status ndtgpu_derivatives(ndtgpu_mapset *t, size_t tmap, const double *sr
     if (rc != NDTGPU_OK) return rc;
     double *out_dev = (double *)t->stage;
     NdtCell *src_dev = (NdtCell *)((char *)t->stage + 32 * sizeof(double));
-    HIP_TRY(hipStreamSynchronize(t->last_stream));
+    { ndtgpu_status wrc_ = t->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     if (!cells.empty()) HIP_TRY(hipMemcpy(src_dev, cells.data(), cells.size() * sizeof(NdtCell), hipMemcpyHostToDevice));
     hipError_t e = ndt_launch_derivatives(t->v, tmap, src_dev, cells.size(), n_neighbours, compute_hessian, lfd1, lfd2,
                                           out_dev, nullptr);
@@ -653,7 +679,7 @@ ndtgpu_status ndtgpu_mapset_discard_cells(ndtgpu_mapset *s, size_t map, const fl
     if (n_points == 0) return NDTGPU_OK;
     ndtgpu_status rc = s->ensure_stage(n_points * 3 * sizeof(float));
     if (rc != NDTGPU_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    { ndtgpu_status wrc_ = s->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     HIP_TRY(hipMemcpy(s->stage, xyz, n_points * 3 * sizeof(float), hipMemcpyHostToDevice));
     hipError_t e = ndt_launch_discard(s->v, map, (const float *)s->stage, n_points, nullptr);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "discard_cells: launch", e);
@@ -666,7 +692,7 @@ ndtgpu_status ndtgpu_mapset_enable_occupancy(ndtgpu_mapset *s)
     if (!s) return fail(NDTGPU_ERR_INVALID, "enable_occupancy: null");
     if (s->v.occ) return NDTGPU_OK;
     const size_t slots = (size_t)s->v.grid.slots, cap = s->v.grid.max_cells, n = s->n_maps;
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    { ndtgpu_status wrc_ = s->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     float *occ = nullptr;
     long long *delta = nullptr;
     NdtCell *alt = nullptr;
@@ -718,13 +744,13 @@ ndtgpu_status ndtgpu_mapset_add_cloud(ndtgpu_mapset *s, size_t first, size_t cou
         if (orc != NDTGPU_OK) return orc;
     }
     HIP_TRY(hipMemcpyAsync(s->origins_dev, origins, count * 3 * sizeof(double), hipMemcpyHostToDevice, st));
-    s->last_stream = st;
     NdtFuseParams p;
     p.maxz = fp.maxz; p.sensor_noise = fp.sensor_noise; p.maxnumpoints = fp.maxnumpoints;
     p.occupancy_limit = fp.occupancy_limit; p.eval_factor = fp.eval_factor; p.n_min = fp.n_min;
     hipError_t e = ndt_launch_fuse(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, s->origins_dev, p,
                                    s->nice_range(first, count), st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "add_cloud: launch", e);
+    { ndtgpu_status trc = s->touch(st); if (trc != NDTGPU_OK) return trc; }
     return s->origins_used(st);
 }
 
@@ -748,7 +774,7 @@ ndtgpu_status ndtgpu_mapset_add_cloud_host(ndtgpu_mapset *s, size_t first, size_
     if (!s) return fail(NDTGPU_ERR_INVALID, "add_cloud_host: bad argument");
     ndtgpu_status rc = s->ensure_host_build_stream();
     if (rc != NDTGPU_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    { ndtgpu_status wrc_ = s->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     rc = ndtgpu_mapset_add_cloud_host_async(s, first, count, xyz_host, n_points, stride_bytes, map_stride_bytes, origins, prm,
                                             (ndtgpu_stream)s->host_build_stream);
     if (rc != NDTGPU_OK) return rc;
@@ -760,7 +786,7 @@ ndtgpu_status ndtgpu_mapset_clear(ndtgpu_mapset *s, size_t first, size_t count)
 {
     if (!s || first + count > s->n_maps) return fail(NDTGPU_ERR_INVALID, "mapset_clear: bad argument");
     if (count == 0) return NDTGPU_OK;
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    { ndtgpu_status wrc_ = s->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     const NdtGrid &g = s->v.grid;
     const size_t slots = (size_t)g.slots;
     HIP_TRY(hipMemset(s->v.rankmap + first * ndt_rm_stride(g), 0, count * ndt_rm_stride(g) * sizeof(uint2)));
@@ -776,7 +802,7 @@ ndtgpu_status ndtgpu_mapset_export_occupancy(ndtgpu_mapset *s, size_t map, float
 {
     if (!s || map >= s->n_maps || !occ_out) return fail(NDTGPU_ERR_INVALID, "export_occupancy: bad argument");
     if (!s->v.occ) return fail(NDTGPU_ERR_INVALID, "export_occupancy: occupancy not enabled on this set");
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    { ndtgpu_status wrc_ = s->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     HIP_TRY(hipMemcpy(occ_out, s->v.occ + map * (size_t)s->v.grid.slots, (size_t)s->v.grid.slots * sizeof(float), hipMemcpyDeviceToHost));
     return NDTGPU_OK;
 }
@@ -785,7 +811,7 @@ ndtgpu_status ndtgpu_mapset_import_occupancy(ndtgpu_mapset *s, size_t map, const
 {
     if (!s || map >= s->n_maps || !occ) return fail(NDTGPU_ERR_INVALID, "import_occupancy: bad argument");
     if (!s->v.occ) return fail(NDTGPU_ERR_INVALID, "import_occupancy: occupancy not enabled on this set");
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    { ndtgpu_status wrc_ = s->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     HIP_TRY(hipMemcpy(s->v.occ + map * (size_t)s->v.grid.slots, occ, (size_t)s->v.grid.slots * sizeof(float), hipMemcpyHostToDevice));
     return NDTGPU_OK;
 }
@@ -801,8 +827,8 @@ ndtgpu_status ndtgpu_overlap_score_batch(ndtgpu_mapset *rs, const uint32_t *ridx
     for (size_t k = 0; k < n_links; k++)
         if (ridx[k] >= rs->n_maps || midx[k] >= ms->n_maps) return fail(NDTGPU_ERR_INVALID, "overlap_score: map index");
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipStreamSynchronize(rs->last_stream));
-    HIP_TRY(hipStreamSynchronize(ms->last_stream));
+    { ndtgpu_status wrc_ = rs->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
+    { ndtgpu_status wrc_ = ms->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     const size_t bT = n_links * 16 * sizeof(double), bI = n_links * sizeof(uint32_t), bS = n_links * sizeof(double);
     const size_t off_r = (bT + 255) & ~(size_t)255, off_m = (off_r + bI + 255) & ~(size_t)255,
                  off_s = (off_m + bI + 255) & ~(size_t)255, off_n = (off_s + bS + 255) & ~(size_t)255;
@@ -932,6 +958,8 @@ static ndtgpu_status coop_enqueue(ndtgpu_mapset *ts, ndtgpu_mapset *ss, const ui
         HIP_TRY(hipEventRecord(g_coop_ev, st));
         g_coop_ev_valid = true;
     }
+    { ndtgpu_status trc = ts->touch(st); if (trc != NDTGPU_OK) return trc; }
+    if (ss != ts) { ndtgpu_status trc = ss->touch(st); if (trc != NDTGPU_OK) return trc; }
     return NDTGPU_OK;
 }
 
@@ -942,7 +970,6 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
                                        const unsigned *feat_off_dev = nullptr, const double *feat_cells_dev = nullptr)
 {
     if (n_pairs == 0) return NDTGPU_OK;
-    ts->last_match_stream = st;
     // persistent workgroups, one per CU (8 waves x 256 VGPRs), each with `slots` registrations in flight whose evaluation
     // shares its waves take in turn (csrc/ndt_match.hip); pairs are pulled from a ticket counter.
     // NDTGPU_PARK_ITERS: iterations after which a long registration yields to a fresh pair.  NDTGPU_SLOTS=1: one
@@ -980,6 +1007,9 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
     HIP_TRY(hipEventRecord(ts->work_ev, st));
     ts->work_ev_valid = true;
     ts->work_stream = st;
+    // the launch reads both sets' maps: host-synchronous rebuilds of either wait for it
+    { ndtgpu_status trc = ts->touch(st); if (trc != NDTGPU_OK) return trc; }
+    if (ss != ts) { ndtgpu_status trc = ss->touch(st); if (trc != NDTGPU_OK) return trc; }
     return NDTGPU_OK;
 }
 
@@ -1090,7 +1120,7 @@ ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pai
     for (size_t k = 0; k < r->done.size() && rc == NDTGPU_OK && e == hipSuccess; k++)
         e = hipEventCreateWithFlags(&r->done[k], hipEventDisableTiming);
     if (rc == NDTGPU_OK && e == hipSuccess) e = hipEventCreateWithFlags(&r->in_ev, hipEventDisableTiming);
-    if (rc == NDTGPU_OK && e == hipSuccess) e = hipMalloc((void **)&r->iota, 2 * pairs_per_batch * sizeof(uint32_t));
+    if (rc == NDTGPU_OK && e == hipSuccess) e = hipMalloc((void **)&r->iota, (2 * pairs_per_batch + 4) * sizeof(uint32_t));
     if (rc == NDTGPU_OK && e == hipSuccess) {
         std::vector<uint32_t> h(2 * pairs_per_batch);
         for (size_t i = 0; i < h.size(); i++) h[i] = (uint32_t)i;
@@ -1180,6 +1210,16 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
         if (mk) { HIP_TRY(hipEventRecord(mk[1], st)); HIP_TRY(hipEventRecord(mk[2], st)); }
         HIP_TRY(hipEventRecord(r->built[slot], st));
         r->last_built = slot;
+        // `built` releases the next sub-batch's build AND, on this stream, this sub-batch's matcher.  The matcher's persistent
+        // workgroups (one per CU, all registers and LDS of it) must not be placed first: the build would then only get the CUs
+        // the matcher leaves, its end -- which releases the build after it -- moves out, and the pipeline loses a tenth of its
+        // rate (measured: 430 k against 470 k registrations/s).  Two 4-byte fills keep this stream busy for the few
+        // microseconds the next build's dispatch needs to get ahead (NDTGPU_REG_GAP: their number).
+        if (r->depth > 1) {
+            const char *gap = getenv("NDTGPU_REG_GAP");
+            const int n_gap = gap ? atoi(gap) : 2;
+            for (int g = 0; g < n_gap; g++) HIP_TRY(hipMemsetAsync(r->iota + 2 * r->per, 0, 4, st));
+        }
         rc = ndtgpu_match_batch_device(set, r->iota, set, r->iota + p, T16_dev + off * 16, p, prm, results_dev + off, st);
         if (rc != NDTGPU_OK) return rc;
         if (mk) HIP_TRY(hipEventRecord(mk[3], st));
@@ -1280,10 +1320,9 @@ ndtgpu_status ndtgpu_mapset_unpack_cells_device(ndtgpu_mapset *s, size_t first, 
         stride < sizeof(ndtgpu_packed_header))
         return fail(NDTGPU_ERR_INVALID, "unpack_cells: bad argument");
     if (with_occupancy && !s->v.occ) return fail(NDTGPU_ERR_INVALID, "unpack_cells: call ndtgpu_mapset_enable_occupancy first");
-    s->last_stream = (hipStream_t)stream;
     hipError_t e = ndt_launch_unpack(s->v, first, count, buf_dev, stride, with_occupancy ? 1 : 0, (hipStream_t)stream);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "unpack_cells: launch", e);
-    return NDTGPU_OK;
+    return s->touch((hipStream_t)stream);
 }
 
 ndtgpu_status ndtgpu_match_aborted(ndtgpu_mapset *ts, int *aborted)
@@ -1291,7 +1330,7 @@ ndtgpu_status ndtgpu_match_aborted(ndtgpu_mapset *ts, int *aborted)
     if (!ts || !aborted) return fail(NDTGPU_ERR_INVALID, "match_aborted: bad argument");
     *aborted = 0;
     if (!ts->work) return NDTGPU_OK;                     // no persistent launch has used this set as a target
-    HIP_TRY(hipStreamSynchronize(ts->last_match_stream));
+    { ndtgpu_status wrc_ = ts->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     unsigned w = 0;
     HIP_TRY(hipMemcpy(&w, (char *)ts->work + ndt_match_abort_offset(), sizeof w, hipMemcpyDeviceToHost));
     *aborted = w != 0u;
@@ -1539,8 +1578,8 @@ ndtgpu_status ndtgpu_match_fusion_feat_batch(ndtgpu_mapset *ts, const uint32_t *
         for (int a = 0; a < 6; a++) { c[3 + a] = feat->src_cov[6 * i + a]; c[12 + a] = feat->tgt_cov[6 * i + a]; }
     }
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipStreamSynchronize(ts->last_stream));
-    HIP_TRY(hipStreamSynchronize(ss->last_stream));
+    { ndtgpu_status wrc_ = ts->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
+    { ndtgpu_status wrc_ = ss->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     NdtMatchParamsDev p = to_dev(prm);
     p.fusion_flags = flags;          // bit 2 (step_control_fusion) selects lineSearchMTFusion when bit 0 is clear (fusion.h:1004)
     if (p.n_neighbours < 0 || p.n_neighbours > 3 || (p.dof_mask & 0x3f) == 0)
@@ -1561,8 +1600,8 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
         if (tidx[k] >= ts->n_maps || sidx[k] >= ss->n_maps) return fail(NDTGPU_ERR_INVALID, "match_batch: map index");
     hipStream_t st = (hipStream_t)stream;
     // builds on other streams must have finished before the maps are read
-    HIP_TRY(hipStreamSynchronize(ts->last_stream));
-    HIP_TRY(hipStreamSynchronize(ss->last_stream));
+    { ndtgpu_status wrc_ = ts->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
+    { ndtgpu_status wrc_ = ss->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     {
         NdtMatchParamsDev p = to_dev(prm);
         p.fusion_flags = fusion_flags;
@@ -1593,8 +1632,8 @@ ndtgpu_status ndtgpu_covariance_batch(ndtgpu_mapset *ts, const uint32_t *tidx, n
     NdtMatchParamsDev p = to_dev(prm);
     if (p.n_neighbours < 0 || p.n_neighbours > 3) return fail(NDTGPU_ERR_INVALID, "covariance: n_neighbours must be 0..3");
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipStreamSynchronize(ts->last_stream));
-    HIP_TRY(hipStreamSynchronize(ss->last_stream));
+    { ndtgpu_status wrc_ = ts->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
+    { ndtgpu_status wrc_ = ss->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     const size_t bT = n_links * 16 * sizeof(double), bI = n_links * sizeof(uint32_t), bC = n_links * 36 * sizeof(double);
     const size_t off_t = (bT + 255) & ~(size_t)255, off_s = (off_t + bI + 255) & ~(size_t)255,
                  off_c = (off_s + bI + 255) & ~(size_t)255, off_f = (off_c + bC + 255) & ~(size_t)255;

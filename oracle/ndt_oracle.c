@@ -1735,10 +1735,14 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
             double lo = fabs(ev[0]), hi = fabs(ev[0]);
             for (int i = 1; i < nd; i++) { const double a = fabs(ev[i]); lo = a < lo ? a : lo; hi = a > hi ? a : hi; }
             const double kappa = lo > 0 ? hi / lo : 1e16;
+            /* bounded: a (near-)singular H must not turn this into an O(1) change of the step, behind which a real
+             * discrepancy of the implementation under test could hide -- at most 1e-9 relative */
+            double amp = kappa * 2.220446049250313e-16;
+            if (!(amp < 1e-9)) amp = 1e-9;
             unsigned long long z = 0xD1B54A32D192ED03ull * (unsigned long long)(g_sum_mode + 31 * itr_ctr);
             for (int i = 0; i < nd; i++) {
                 z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
-                dx[i] *= 1.0 + ((double)((int)(z % 17ull) - 8) / 8.0) * kappa * 2.220446049250313e-16;
+                dx[i] *= 1.0 + ((double)((int)(z % 17ull) - 8) / 8.0) * amp;
             }
         }
         double dginit = 0;

@@ -269,6 +269,8 @@ def test_3dof_matcher_on_non_converging_pairs(N, O):
         assert abs(T[b][2, 3]) < 1e-15 and abs(T[b][2, 2] - 1) < 1e-15             # z, roll, pitch untouched
         same_flow = (bool(r["converged"][b]) == ro["converged"] and r["iterations"][b] == ro["iterations"]
                      and r["exit_code"][b] == ro["exit_code"])
+        # a registration that ends at its first iteration has no wandering to be chaotic about: the oracle's flow, always
+        assert same_flow or ro["iterations"] > 1, (b, r["iterations"][b], ro["iterations"])
         if not same_flow:
             # "chaotic" as a measurement, not a statement: the ORACLE ALONE must change its control flow on this pair when
             # the SAME pair terms are added in another order (reversed; eight shares i mod 8 added in share order -- the

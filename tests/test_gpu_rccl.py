@@ -24,9 +24,15 @@ def run(args, port, timeout=900):
     return p.stdout
 
 
+def bench_line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert lines, "no bench line in: " + out[-3000:]
+    return json.loads(lines[-1])
+
+
 def test_bench_headline_path_through_rccl_on_one_rank():
     out = run(["bench.py", "--steps", "4", "--warmup", "1", "--pairs", "96", "--points", "20000", "--no-cpu", "--dense-pairs", "0"], 29611)
-    line = json.loads(out.strip().splitlines()[-1])
+    line = bench_line(out)
     c = line["collectives"]
     assert c["process_group"] == "nccl (RCCL)" and c["forced_on_one_rank"] and c["all_gather_into_tensor_calls"] >= 8
     assert c["gathered_rows_equal_local"] is True
@@ -36,7 +42,7 @@ def test_bench_headline_path_through_rccl_on_one_rank():
 def test_bench_config4_exchange_and_gather_through_rccl_on_one_rank():
     out = run(["bench.py", "--config", "4", "--nodes", "150", "--scans-per-node", "2", "--node-points", "5000", "--no-all-pairs",
                "--steps", "2", "--warmup", "1"], 29612)
-    line = json.loads(out.strip().splitlines()[-1])
+    line = bench_line(out)
     c = line["collectives"]
     assert c["process_group"] == "nccl (RCCL)" and c["forced_on_one_rank"] and c["gathered_rows_equal_local"] is True
     assert line["value"] > 0
