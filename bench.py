@@ -241,7 +241,19 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         sub = gi[:200000]
         tcov = _timed(torch, lambda: binding.covariance(pool, edges[sub, 0], pool, edges[sub, 1], Tg[sub]), reps=1, warm=1)
         tovl = _timed(torch, lambda: binding.overlap_score(pool, edges[sub, 0], pool, edges[sub, 1], Tg[sub]), reps=1, warm=1)
+        # what the reference does with the registered links next: getValidLinks (ndt_feature_graph.cpp:527-556) with the
+        # defaults of ndt_feature_graph_opt.cpp:49-52 -- score <= 0.1, >= 2 indices apart, the moving node's pose predicted
+        # through the link within 1.0 m / 0.2 rad of its odometry pose
+        sc_sub, _ = binding.overlap_score(pool, edges[sub, 0], pool, edges[sub, 1], Tg[sub])
+        kept = D.valid_links(edges[sub], Tg[sub], odo_T, scores=sc_sub)
+        kept_geo = D.valid_links(edges[sub], Tg[sub], odo_T)
         extra = {"gated_edges": int(len(gi)), "gated_same_room_frac": float(same_room.mean()),
+                 "reference_getValidLinks": {"max_score": 0.1, "max_dist_m": 1.0, "max_angular_dist_rad": 0.2, "min_idx_dist": 2,
+                                             "links_in": int(len(sub)), "links_kept": int(len(kept)),
+                                             "links_kept_without_the_score_test": int(len(kept_geo)),
+                                             "note": "the reference's 1.0 m / 0.2 rad / 2 are a filter on REGISTERED links "
+                                                     "(ndt_feature_graph_opt.cpp:155), not a candidate gate; candidates come "
+                                                     "from FLIRT matching (not built), for which --gate-dist stands in"},
                  "gated_converged_frac": float(r["converged"][gi].mean()), "gated_mean_iterations": float(r["iterations"][gi].mean()),
                  "gated_median_translation_error_m": float(np.median(err)), "gated_err_below_5cm_frac": float((err < 0.05).mean()),
                  "covariance_us_per_edge": 1e3 * tcov / len(sub), "overlap_us_per_edge": 1e3 * tovl / len(sub),

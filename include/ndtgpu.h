@@ -297,7 +297,13 @@ typedef struct ndtgpu_feat_pairs {
  * clear the reference runs the JOINT line search lineSearchMTFusion (fusion.h:1004-1006, 390-793) instead: one search
  * on f_ndt(trial) + f_feat -- where, as written upstream, the feature maps are evaluated on the UN-stepped cells in every
  * trial (fusion.h:619), so their score and gradient at the current pose enter as constants.  Restated as written.
- * `fevals` counts derivative evaluations of the NDT maps.  feat == NULL: ndtgpu_match_fusion_batch. */
+ * `fevals` counts derivative evaluations of the NDT maps.  feat == NULL: ndtgpu_match_fusion_batch.
+ * A registration WITHOUT correspondences (offsets[k + 1] == offsets[k]) inside such a batch is run with useFeat = false, i.e.
+ * by the rules of ndtgpu_match_fusion_batch: the reference's only call site passes useFeat = true together with at least
+ * one correspondence (FLIRT matches that passed the consistency check, or the 40 odometry cells:
+ * ndt_feature_fuser_hmt.cpp:296-320, 341-347).  What upstream's feature line search would do on EMPTY maps -- a zero
+ * directional derivative, hence the in-place negation of the increment and the recovery step -- is deliberately not
+ * restated, neither here nor in oracle/ndt_oracle.c (match_common: use_feat = n_feat > 0). */
 ndtgpu_status ndtgpu_match_fusion_feat_batch(ndtgpu_mapset *target_set, const uint32_t *target_idx,
                                              ndtgpu_mapset *source_set, const uint32_t *source_idx, double *T16,
                                              const double *Tcov36, const ndtgpu_feat_pairs *feat, size_t n_pairs,

@@ -194,6 +194,26 @@ def all_pairs(n_nodes):
     return np.stack([i, j], axis=1).astype(np.int64)
 
 
+def valid_links(edges, T_links, node_T, scores=None, max_score=0.1, max_dist=1.0, max_angle=0.2, min_idx_dist=2):
+    """NDTFeatureGraph::getValidLinks (ndt_feature_graph.cpp:527-556) with the defaults of ndt_feature_graph_opt.cpp:49-52,
+    the filter the reference applies to the REGISTERED links before it optimises: a link (ref, mov, T) stays when its
+    score <= max_score (skipped when `scores` is None), its nodes are at least min_idx_dist indices apart and the pose it
+    predicts for the moving node, node_T[ref] * T, lies within max_dist / max_angle of the node's own pose
+    (distanceBetweenAffine3d: translation norm, rotation angle).  Returns the indices of the links that stay."""
+    edges = np.asarray(edges)
+    T_links = np.asarray(T_links, dtype=np.float64).reshape(-1, 4, 4)
+    node_T = np.asarray(node_T, dtype=np.float64)
+    pred = np.einsum("eij,ejk->eik", node_T[edges[:, 0]], T_links)
+    own = node_T[edges[:, 1]]
+    dist = np.linalg.norm(pred[:, :3, 3] - own[:, :3, 3], axis=1)
+    rel = np.einsum("eji,ejk->eik", own[:, :3, :3], pred[:, :3, :3])
+    ang = np.arccos(np.clip((np.trace(rel, axis1=1, axis2=2) - 1.0) / 2.0, -1.0, 1.0))
+    keep = (np.abs(edges[:, 1].astype(np.int64) - edges[:, 0].astype(np.int64)) >= min_idx_dist) & (dist < max_dist) & (ang < max_angle)
+    if scores is not None:
+        keep &= np.asarray(scores) <= max_score
+    return np.nonzero(keep)[0].astype(np.int64)
+
+
 def gate_links(edges, node_T, max_dist=1.0, max_angle=0.2, min_idx_dist=2):
     """The reference's candidate gates (NDTFeatureGraph::getValidLinks, ndt_feature_graph.cpp:527-556,
     defaults ndt_feature_graph_opt.cpp:49-52) applied to the odometry-predicted relative poses:

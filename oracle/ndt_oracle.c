@@ -1620,6 +1620,9 @@ static int match_common(const oracle_map *target, const oracle_map *source, doub
 {
     const int soft = Q && (flags & 1), tikhonov = Q && (flags & 2);
     const size_t nf = feat ? feat->n : 0;
+    /* a registration without correspondences runs with useFeat = false: the reference's call site never passes useFeat = true
+     * with empty feature maps (ndt_feature_fuser_hmt.cpp:296-320, 341-347); what the feature line search would do on empty
+     * maps (dginit = 0: negated increment, recovery step) is not restated -- include/ndtgpu.h says the same of the HIP path */
     const int use_feat = nf > 0;
     const int joint_ls = (flags & 4) && !soft;      /* useNDT && useFeat && step_control_fusion && !useSoftConstraints */
     double Tinit[16], x0[6] = {0, 0, 0, 0, 0, 0};

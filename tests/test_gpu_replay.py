@@ -270,3 +270,124 @@ def test_host_clouds_through_the_pinned_ring(N, monkeypatch):
     for a, b in zip(outs[0][0], outs[1][0]):
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.max(np.abs(a[1] - b[1])) < 1e-12
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_config4_full_size(N, O):
+    """configs[3] at FULL size: 5000 fused node maps (10 ray-traced scans of 20 k points each, bench.py --config 4's node),
+    built data-parallel as on 8 ranks, exchanged as packed records, the 44 k gated candidate edges registered in the
+    block-cyclic shards of 8 ranks.  Properties over all of them (results independent of the shard they were registered in,
+    counters against the maps, convergence, the true relative pose recovered, the reference's getValidLinks keeps them);
+    300 sampled edges against the CPU oracle (pose, iterations, convergence)."""
+    import torch
+    from ndt_feature_graph_amd import binding, distributed as D, synth
+    dev = torch.device("cuda", 0)
+    n_nodes, S, n_pts, res, size, world = 5000, 10, 20000, 0.5, [100.0, 100.0, 1.0], 8
+    room, local, world_pose = replay_layout(n_nodes)
+    node_T = synth.pose2d_to_T(torch.as_tensor(world_pose)).numpy()
+    g = np.random.default_rng(11)
+    odo_T = node_T.copy()
+    odo_T[:, 0, 3] += g.normal(scale=0.03, size=n_nodes)
+    odo_T[:, 1, 3] += g.normal(scale=0.03, size=n_nodes)
+    fuse_kw = [dict(maxz=100.0, sensor_noise=0.1)] + [dict(maxz=25.0, sensor_noise=0.06)] * (S - 1)
+    anchors = np.concatenate([np.arange(20, 40), np.arange(2510, 2530), np.arange(4960, 4980)])
+    seeds = torch.as_tensor(4000 + room, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream()
+
+    # phase A as on 8 ranks: node k in the set of rank k % 8; the scans of one step at a time (1.2 GB each)
+    locs, mines = [], []
+    for rank in range(world):
+        mine = D.shard_nodes(n_nodes, rank, world)
+        loc = N.MapSet(res, [0, 0, 0], size, n_maps=len(mine), max_cells=4096)
+        loc.enable_occupancy()
+        locs.append(loc); mines.append(mine)
+    scans_anchor = []
+    for k in range(S):
+        dx = 0.9 * k / S
+        pk = local.copy()
+        pk[:, 0] += dx * np.cos(local[:, 2]); pk[:, 1] += dx * np.sin(local[:, 2])
+        sc = synth.scan_2d(seeds, torch.as_tensor(pk, device=dev), n_pts, noise_stream=k, chunk_bytes=2 << 30).contiguous()
+        sc[:, :, 0] += dx
+        org = np.tile(np.array([[dx, 0.0, 0.0]]), (n_nodes, 1))
+        for loc, mine in zip(locs, mines):
+            loc.add_cloud(sc[torch.as_tensor(mine, device=dev)].contiguous(), org[mine], stream=st, **fuse_kw[k])
+        scans_anchor.append((sc[torch.as_tensor(anchors, device=dev)].cpu().numpy(), org[anchors]))
+        torch.cuda.synchronize()
+        del sc
+    cells_local = [loc.num_cells_all() for loc in locs]
+    cap_max = max(int(c.max()) for c in cells_local)
+    assert cap_max < 4096 and min(int(c.min()) for c in cells_local) > 5
+    # phase B: packed records, rank-major -> node order, ONE unpack
+    cells_cap = min(4096, (cap_max * 5 // 4 + 63) // 64 * 64)
+    n_max = (n_nodes + world - 1) // world
+    stride = locs[0].pack_bytes(cells_cap, True)
+    gathered = torch.zeros((world, n_max, stride), dtype=torch.uint8, device=dev)
+    for rank, (loc, mine) in enumerate(zip(locs, mines)):
+        loc.pack_cells(gathered[rank], 0, len(mine), cells_cap=cells_cap, with_occupancy=True, stream=st)
+    allrec = D.records_to_node_order(gathered.view(world * n_max, stride), n_nodes, world)
+    pool = N.MapSet(res, [0, 0, 0], size, n_maps=n_nodes, max_cells=4096)
+    pool.enable_occupancy()
+    pool.unpack_cells(allrec, 0, n_nodes, with_occupancy=True, stream=st)
+    torch.cuda.synchronize()
+    cells_per_map = pool.num_cells_all()
+    for rank in range(world):
+        assert np.array_equal(cells_per_map[mines[rank]], cells_local[rank])
+    for k in (0, 2517, 4999):
+        for x, y in zip(pool.export_cells(k), locs[k % world].export_cells(k // world)):
+            assert np.array_equal(x, y)
+        assert np.array_equal(pool.occupancy(k), locs[k % world].occupancy(k // world))
+    del gathered, allrec
+
+    # phase C: the gated candidate edges (bench.py's gate: odometry poses within 6 m, >= 2 indices apart), in 8 shards
+    edges_all = D.all_pairs(n_nodes)
+    assert len(edges_all) == 12497500
+    d_odo = np.linalg.norm(odo_T[edges_all[:, 0], :2, 3] - odo_T[edges_all[:, 1], :2, 3], axis=1)
+    gi_all = np.nonzero((d_odo <= 6.0) & ((edges_all[:, 1] - edges_all[:, 0]) >= 2))[0]
+    edges = edges_all[gi_all]
+    del edges_all, d_odo
+    assert 40000 < len(edges) < 50000
+    T0 = np.einsum("eij,ejk->eik", np.linalg.inv(odo_T)[edges[:, 0]], odo_T[edges[:, 1]])
+    T_all = np.zeros((len(edges), 4, 4))
+    r_all = None
+    for rank in range(world):
+        mine = D.shard_edges(len(edges), rank, world, 256)
+        Tm, rm = N.match_batch(pool, edges[mine, 0], pool, edges[mine, 1], T0[mine], delta_score=1e-3)     # the "edge" preset
+        if r_all is None:
+            r_all = np.zeros(len(edges), dtype=rm.dtype)
+        T_all[mine], r_all[mine] = Tm, rm
+    # ... and in ONE call: an edge's result does not depend on its shard or its place in the batch
+    Tg, rg = N.match_batch(pool, edges[:, 0], pool, edges[:, 1], T0, delta_score=1e-3)
+    assert np.array_equal(Tg, T_all)
+    for f in DET_FIELDS:
+        assert np.array_equal(rg[f], r_all[f]), f
+    assert np.array_equal(r_all["n_target"], cells_per_map[edges[:, 0]]) and np.array_equal(r_all["n_source"], cells_per_map[edges[:, 1]])
+    assert np.all(r_all["exit_code"] >= 0) and np.all(np.isfinite(T_all)) and np.all(r_all["iterations"] <= 32)
+    assert r_all["converged"].mean() > 0.98
+    same_room = room[edges[:, 0]] == room[edges[:, 1]]
+    assert same_room.all()                                   # (rooms are 80 m apart: the gate never joins two of them)
+    gt = np.einsum("eij,ejk->eik", np.linalg.inv(node_T)[edges[:, 0]], node_T[edges[:, 1]])
+    err = np.linalg.norm(T_all[:, :2, 3] - gt[:, :2, 3], axis=1)
+    assert np.median(err) < 0.02 and (err < 0.05).mean() > 0.9
+    # the reference's filter on registered links (getValidLinks, ndt_feature_graph.cpp:527-556; defaults
+    # ndt_feature_graph_opt.cpp:49-52: 1.0 m / 0.2 rad / 2 indices) keeps what was registered onto the truth
+    kept = D.valid_links(edges, T_all, odo_T)
+    assert len(kept) > 0.95 * len(edges)
+
+    # 300 sampled edges against the oracle, between the 60 anchor nodes (their fused maps built by the CPU ray tracer)
+    in_a = np.isin(edges[:, 0], anchors) & np.isin(edges[:, 1], anchors)
+    cand = np.nonzero(in_a)[0]
+    assert len(cand) >= 300
+    sample = g.choice(cand, 300, replace=False)
+    omaps = {}
+    for a, k in enumerate(anchors):
+        om = O.OracleMap(res, [0, 0, 0], size)
+        for (sc, org), kw in zip(scans_anchor, fuse_kw):
+            om.add_point_cloud(org[a], sc[a], maxz=kw["maxz"], sensor_noise=kw["sensor_noise"], order_free=True)
+            om.compute_cells_full()
+        assert om.num_cells() == cells_per_map[k], (k, om.num_cells(), cells_per_map[k])
+        omaps[int(k)] = om
+    for e in sample:
+        i, j = (int(v) for v in edges[e])
+        To, ro = O.match_d2d(omaps[i], omaps[j], T0[e], delta_score=1e-3)
+        dt, dr = pose_close(T_all[e], To)
+        assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (e, dt, dr)
+        assert r_all["iterations"][e] == ro["iterations"] and bool(r_all["converged"][e]) == ro["converged"], e
