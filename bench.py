@@ -765,7 +765,8 @@ def main():
     barrier()
     # isolated kernel durations (a serial step on a plain map set: build launch, then matcher launch, alone on the chip;
     # events inside the library), outside the timed region
-    iso = bufs[0].maps
+    # (a map set of its own: the registrar's sets keep their matcher launches on part of the chip)
+    iso = bufs[0].maps if legacy else N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * B, max_cells=4096)
     iso.profiling(True)
     iso_T16 = T_init_cm.clone()
     for _ in range(2):
@@ -776,6 +777,8 @@ def main():
     iso_build_ms = iso.last_kernel_ms(0)       # one launch: 2B scans
     iso_match_ms = iso.last_kernel_ms(1)
     iso.profiling(False)
+    if not legacy:
+        iso.close()
     for _ in range(n_buf):     # one serial step per buffer: code objects loaded, every buffer's pages touched
         step()
         if reg is not None:

@@ -57,6 +57,8 @@ struct MapView {
     int sx, sy, sz;
     double cx, cy, cz, res;
     double hx, hy, hz;          // size / 2.0 per axis (the addend of LazyGrid's index formula)
+    double inv_res;             // 1 / res when res is a power of two (the quotient of the index formula is then a product, bit for
+                                // bit: 3 instructions instead of the 42 of three IEEE divisions per source cell and evaluation), else 0
 };
 
 // lazygrid_index with size / 2.0 handed in (a value the large-map kernels keep in scalar registers)
@@ -66,6 +68,21 @@ NDT_D int lazygrid_index_h(double p, double centre, double res, double half)
     double v = floor((p - centre) / res + 0.5) + half;
     if (!(v > -2.0e9 && v < 2.0e9)) return -1;
     return (int)v;
+}
+// the same for a cell size that is a power of two: x / 2^k == x * 2^-k in every case (both are the correctly rounded value of
+// the same real number; no fused multiply-add: the product is rounded before 0.5 is added, like the quotient)
+NDT_D int lazygrid_index_p2(double p, double centre, double inv_res, double half)
+{
+#pragma clang fp contract(off)
+    double q = (p - centre) * inv_res;
+    double v = floor(q + 0.5) + half;
+    if (!(v > -2.0e9 && v < 2.0e9)) return -1;
+    return (int)v;
+}
+NDT_D double pow2_reciprocal(double res)
+{
+    int e;
+    return (res > 0.0 && frexp(res, &e) == 0.5 && e > -1000 && e < 1000) ? 1.0 / res : 0.0;
 }
 
 NDT_D MapView map_view(const NdtSetView &s, unsigned map)
@@ -77,6 +94,7 @@ NDT_D MapView map_view(const NdtSetView &s, unsigned map)
     v.sx = s.grid.size[0]; v.sy = s.grid.size[1]; v.sz = s.grid.size[2];
     v.cx = s.centres[map * 3]; v.cy = s.centres[map * 3 + 1]; v.cz = s.centres[map * 3 + 2];
     v.res = s.grid.res;
+    v.inv_res = pow2_reciprocal(s.grid.res);
     v.hx = s.grid.half[0]; v.hy = s.grid.half[1]; v.hz = s.grid.half[2];
     return v;
 }
@@ -415,6 +433,9 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
     const bool vi = i < end;
     int ix = 0, iy = 0, iz = 0;
     NDT_PROF_T(4)
+    // (wave-uniform: a branch, not a select.  Only in the persistent matcher of the 2D batches, whose map views live in LDS: the
+    //  large-map kernels -- KEEP_RUNS -- hold theirs in scalar registers and have none to spare for the reciprocal)
+    const bool res_pow2 = !KEEP_RUNS && __builtin_amdgcn_readfirstlane(tg.inv_res != 0.0 ? 1 : 0) != 0;
     if (vi) {
         gcell_ptr sc = src + i;
         d3 m0 = {sc->mean[0], sc->mean[1], sc->mean[2]};
@@ -424,9 +445,15 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
         w.mysrc[0 * 64 + lane] = m.x; w.mysrc[1 * 64 + lane] = m.y; w.mysrc[2 * 64 + lane] = m.z;
         w.mysrc[3 * 64 + lane] = C.xx; w.mysrc[4 * 64 + lane] = C.xy; w.mysrc[5 * 64 + lane] = C.xz;
         w.mysrc[6 * 64 + lane] = C.yy; w.mysrc[7 * 64 + lane] = C.yz; w.mysrc[8 * 64 + lane] = C.zz;
-        ix = lazygrid_index_h(m.x, tg.cx, tg.res, tg.hx);   // getCellsForPoint(mean, n_neighbours)
-        iy = lazygrid_index_h(m.y, tg.cy, tg.res, tg.hy);
-        iz = lazygrid_index_h(m.z, tg.cz, tg.res, tg.hz);
+        if (res_pow2) {                                     // getCellsForPoint(mean, n_neighbours)
+            ix = lazygrid_index_p2(m.x, tg.cx, tg.inv_res, tg.hx);
+            iy = lazygrid_index_p2(m.y, tg.cy, tg.inv_res, tg.hy);
+            iz = lazygrid_index_p2(m.z, tg.cz, tg.inv_res, tg.hz);
+        } else {
+            ix = lazygrid_index_h(m.x, tg.cx, tg.res, tg.hx);
+            iy = lazygrid_index_h(m.y, tg.cy, tg.res, tg.hy);
+            iz = lazygrid_index_h(m.z, tg.cz, tg.res, tg.hz);
+        }
     }
     NDT_PROF_T(0)
     const HitCache hc = *w.cache;

@@ -111,6 +111,9 @@ struct ndtgpu_mapset {
         origins_ev_valid = true;
         return NDTGPU_OK;
     }
+    // workgroups the persistent matcher launches with this set as target get at most (0: one per CU).  The registrar keeps its
+    // matcher launches on part of the chip: the rest stays free for the next sub-batch's builds while a launch runs
+    unsigned match_groups = 0;
     // matcher work area: ticket counters, parked list, parked solver states
     void *work = nullptr;
     size_t work_bytes = 0;
@@ -985,6 +988,7 @@ static ndtgpu_status match_device_core(ndtgpu_mapset *ts, const uint32_t *tidx_d
     unsigned n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)n_cu);
     // (a stream that owns only part of the chip -- hipExtStreamCreateWithCUMask, bench.py --cu-split -- wants one workgroup
     //  per CU it has, not per CU of the device)
+    if (ts->match_groups) n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)ts->match_groups);
     const char *grp_env = getenv("NDTGPU_MATCH_GROUPS");
     // (more workgroups than CUs: narrow-workgroup builds of the kernel, -DNDT_MATCH_THREADS=256, of which two share a CU)
     if (grp_env && atoi(grp_env) > 0) n_groups = (unsigned)std::min<size_t>(n_pairs, (size_t)atoi(grp_env));
@@ -1114,6 +1118,17 @@ ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pai
     for (int k = 0; k < depth && rc == NDTGPU_OK && e == hipSuccess; k++) {
         rc = ndtgpu_mapset_create(grid, 2 * pairs_per_batch, &r->sets[k]);
         if (rc != NDTGPU_OK) break;
+        // Pipelined (depth > 1), a matcher launch keeps to half of the CUs: its persistent workgroups hold a CU each, whole, until
+        // their registrations are done, and with all CUs taken the next sub-batch's builds would wait for the launch's first
+        // exits (measured, 1024 pairs per sub-batch: 470 k registrations/s with 256 workgroups, 488 k with 128..160;
+        // NDTGPU_REG_GROUPS overrides)
+        if (depth > 1) {
+            int dev = 0, n_cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+            const char *ge = getenv("NDTGPU_REG_GROUPS");
+            r->sets[k]->match_groups = ge && atoi(ge) > 0 ? (unsigned)atoi(ge) : (unsigned)(n_cu / 2);
+        }
         e = hipStreamCreateWithFlags(&r->streams[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&r->built[k], hipEventDisableTiming);
     }

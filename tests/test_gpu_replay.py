@@ -289,7 +289,7 @@ def test_config4_full_size(N, O):
     odo_T[:, 0, 3] += g.normal(scale=0.03, size=n_nodes)
     odo_T[:, 1, 3] += g.normal(scale=0.03, size=n_nodes)
     fuse_kw = [dict(maxz=100.0, sensor_noise=0.1)] + [dict(maxz=25.0, sensor_noise=0.06)] * (S - 1)
-    anchors = np.concatenate([np.arange(20, 40), np.arange(2510, 2530), np.arange(4960, 4980)])
+    anchors = np.concatenate([np.arange(10, 40), np.arange(1230, 1260), np.arange(2510, 2540), np.arange(4950, 4980)])
     seeds = torch.as_tensor(4000 + room, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream()
 
@@ -372,7 +372,7 @@ def test_config4_full_size(N, O):
     kept = D.valid_links(edges, T_all, odo_T)
     assert len(kept) > 0.95 * len(edges)
 
-    # 300 sampled edges against the oracle, between the 60 anchor nodes (their fused maps built by the CPU ray tracer)
+    # 300 sampled edges against the oracle, between the 120 anchor nodes (their fused maps built by the CPU ray tracer)
     in_a = np.isin(edges[:, 0], anchors) & np.isin(edges[:, 1], anchors)
     cand = np.nonzero(in_a)[0]
     assert len(cand) >= 300
