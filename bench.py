@@ -769,13 +769,15 @@ def main():
     iso = bufs[0].maps if legacy else N.MapSet(res, [0, 0, 0], size_m, n_maps=2 * B, max_cells=4096)
     iso.profiling(True)
     iso_T16 = T_init_cm.clone()
-    for _ in range(2):
+    iso_b, iso_m = [], []
+    for _ in range(6):
         iso.build(both, range_limit=rng_lim, stream=main_stream)
         iso_T16.copy_(T_init_cm)
         binding.match_batch_device(iso, idx, iso, idx_src, iso_T16, bufs[0].results, B, stream=main_stream)
         barrier()
-    iso_build_ms = iso.last_kernel_ms(0)       # one launch: 2B scans
-    iso_match_ms = iso.last_kernel_ms(1)
+        iso_b.append(iso.last_kernel_ms(0)); iso_m.append(iso.last_kernel_ms(1))
+    iso_build_ms = float(np.median(iso_b[1:]))     # one launch: 2B scans (median of five warm serial steps)
+    iso_match_ms = float(np.median(iso_m[1:]))
     iso.profiling(False)
     if not legacy:
         iso.close()
@@ -869,7 +871,7 @@ def main():
     except Exception:
         traffic = None
     note = ("achieved / frac = algorithmic work per launch / HIP-event duration of the launch ALONE on the chip (events on the "
-            "launch stream, a warm serial step of this run before the timed region; agrees with profiles/%s_bench_kernel_stats_serial.csv); "
+            "launch stream, the median of five warm serial steps of this run before the timed region; agrees with profiles/%s_bench_kernel_stats_serial.csv); "
             "*_timed_region = the same work / the HIP-event duration of the launch inside the timed region, where it shares the chip "
             "with the neighbouring steps' kernels (events on the registrar's internal streams); " % ROUND_TAG + traffic_note)
     if dominant == "ndt_build_kernel":       # streaming pass over the points: HBM roof

@@ -378,6 +378,14 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *reg, const void *ta
                                            const ndtgpu_cell_params *cell, double *T16_dev, size_t n_pairs,
                                            const ndtgpu_match_params *prm, ndtgpu_match_result *results_dev,
                                            ndtgpu_stream stream, uint64_t *ticket);
+/* The same with the scans, the poses and the results in HOST memory -- what the reference's call sites hold (pcl::PointCloud,
+ * Eigen::Affine3d).  Sub-batch after sub-batch the clouds are copied to the device under the builds and registrations of the
+ * sub-batch before; clouds must not overlap (map_stride_bytes >= n_points * stride_bytes).  Synchronous: returns with T16
+ * and results filled in (and everything submitted earlier through the device entry complete). */
+ndtgpu_status ndtgpu_register_batch_host(ndtgpu_registrar *reg, const void *targets_host, const void *sources_host,
+                                         size_t n_points, size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                         const ndtgpu_cell_params *cell, double *T16, size_t n_pairs,
+                                         const ndtgpu_match_params *prm, ndtgpu_match_result *results);
 /* `stream` waits (on the device, the host does not) for the call `ticket` names and every call before it; ticket 0: for
  * every call submitted so far */
 ndtgpu_status ndtgpu_registrar_wait_stream(ndtgpu_registrar *reg, uint64_t ticket, ndtgpu_stream stream);

@@ -125,7 +125,7 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_pack_cells_device", "ndtgpu_mapset_unpack_cells_device", "ndtgpu_mapset_build_host_async",
            "ndtgpu_mapset_add_cloud_host_async", "ndtgpu_registrar_create", "ndtgpu_registrar_destroy",
            "ndtgpu_register_batch_device", "ndtgpu_registrar_wait_stream", "ndtgpu_registrar_sync",
-           "ndtgpu_registrar_profiling", "ndtgpu_registrar_kernel_ms", "ndtgpu_registrar_mapset"]
+           "ndtgpu_registrar_profiling", "ndtgpu_registrar_kernel_ms", "ndtgpu_registrar_mapset", "ndtgpu_register_batch_host"]
 
 _lib = None
 
@@ -198,6 +198,8 @@ def lib():
     L.ndtgpu_registrar_destroy.argtypes = [vp]
     L.ndtgpu_register_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(CellParams),
                                                vp, C.c_size_t, C.POINTER(MatchParams), vp, vp, C.POINTER(C.c_uint64)]
+    L.ndtgpu_register_batch_host.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(CellParams),
+                                             dp, C.c_size_t, C.POINTER(MatchParams), vp]
     L.ndtgpu_registrar_wait_stream.argtypes = [vp, C.c_uint64, vp]
     L.ndtgpu_registrar_sync.argtypes = [vp]
     L.ndtgpu_registrar_profiling.argtypes = [vp, C.c_int]
@@ -563,6 +565,20 @@ class Registrar:
                                                   C.byref(cp), C.c_void_p(T16_dev.data_ptr()), n, C.byref(p),
                                                   C.c_void_p(results_dev.data_ptr()), _stream_ptr(stream), C.byref(t)))
         return int(t.value)
+
+    def register_host(self, targets, sources, T, range_limit=-1.0, n_min=3, eval_factor=1000.0, **params):
+        """Host form: targets / sources NumPy float32 [n, N, 3 or 4], T [n, 4, 4] initial guesses -> (T [n, 4, 4], results)."""
+        tg = np.ascontiguousarray(targets, dtype=np.float32)
+        sc = np.ascontiguousarray(sources, dtype=np.float32)
+        n, npts, w = tg.shape
+        assert sc.shape == tg.shape and w in (3, 4)
+        Tc = np.ascontiguousarray(np.transpose(np.asarray(T, dtype=np.float64).reshape(n, 4, 4), (0, 2, 1))).copy()
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        cp = CellParams(int(n_min), float(eval_factor))
+        p = match_params(**params)
+        _check(lib().ndtgpu_register_batch_host(self.h, C.c_void_p(tg.ctypes.data), C.c_void_p(sc.ctypes.data), npts, 4 * w, 4 * w * npts,
+                                                float(range_limit), C.byref(cp), _dp(Tc), n, C.byref(p), C.c_void_p(res.ctypes.data)))
+        return np.transpose(Tc.reshape(n, 4, 4), (0, 2, 1)).copy(), res
 
     def wait_stream(self, stream=None, ticket=0):
         """`stream` waits for the call `ticket` names (0: for everything submitted so far); the host does not wait."""

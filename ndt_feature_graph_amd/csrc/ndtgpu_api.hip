@@ -61,8 +61,11 @@ struct ndtgpu_mapset {
     // the maps on another stream is waited for as well).
     struct StreamMark { hipStream_t st; hipEvent_t ev; };
     std::vector<StreamMark> marks;
+    bool null_stream_used = false;       // the null stream needs no event: its handle is always valid (and an event record
+                                         // costs the reference's one-pair-at-a-time call shape ~10 us of its 0.37 ms)
     ndtgpu_status touch(hipStream_t st)
     {
+        if (st == nullptr) { null_stream_used = true; return NDTGPU_OK; }
         for (StreamMark &m : marks)
             if (m.st == st) { HIP_TRY(hipEventRecord(m.ev, st)); return NDTGPU_OK; }
         if (marks.size() >= 8) {                 // many streams over time: retire the oldest entry once its work is done
@@ -78,6 +81,7 @@ struct ndtgpu_mapset {
     }
     ndtgpu_status wait_all()
     {
+        if (null_stream_used) { HIP_TRY(hipStreamSynchronize(nullptr)); null_stream_used = false; }
         for (StreamMark &m : marks) HIP_TRY(hipEventSynchronize(m.ev));
         return NDTGPU_OK;
     }
@@ -1079,6 +1083,13 @@ struct ndtgpu_registrar {
     int last_built = -1;
     uint32_t *iota = nullptr;          // device: 0 .. 2 per - 1 (target indices: iota, source indices: iota + p)
     size_t submitted = 0;              // sub-batches so far
+    // host clouds (ndtgpu_register_batch_host): per slot a device staging area for the scans of a sub-batch, one for the
+    // poses / results of a call, a copy stream
+    std::vector<void *> hstage;
+    std::vector<size_t> hstage_bytes;
+    void *hio = nullptr;
+    size_t hio_bytes = 0;
+    hipStream_t hcopy = nullptr;
     bool profiling = false;
     std::vector<hipEvent_t> marks;     // 4 per profiled sub-batch: build start / end, matcher start / end
 };
@@ -1092,6 +1103,9 @@ ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
     for (hipEvent_t e : r->built) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->done) if (e) (void)hipEventDestroy(e);
     if (r->in_ev) (void)hipEventDestroy(r->in_ev);
+    if (r->hcopy) { (void)hipStreamSynchronize(r->hcopy); (void)hipStreamDestroy(r->hcopy); }
+    for (void *q : r->hstage) if (q) (void)hipFree(q);
+    if (r->hio) (void)hipFree(r->hio);
     for (ndtgpu_mapset *s : r->sets) (void)ndtgpu_mapset_destroy(s);
     for (hipStream_t st : r->streams)
         if (st) (void)hipStreamDestroy(st);
@@ -1265,6 +1279,63 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
         if (rc != NDTGPU_OK) return rc;
         if (aborted) return fail(NDTGPU_ERR_HIP, "registrar: a matcher launch gave up (a wave found no work for ~1 s)");
     }
+    return NDTGPU_OK;
+}
+
+// Host clouds in, host poses out: the reference's call sites hold pcl::PointCloud objects in host memory.  Sub-batch after
+// sub-batch the scans travel to a device staging area of the slot they will be built in (one copy stream; the copies of
+// sub-batch j + 1 run under the builds and registrations of sub-batch j), then the device entry takes over; poses and results
+// come back with one copy each when everything is done.  Synchronous.
+ndtgpu_status ndtgpu_register_batch_host(ndtgpu_registrar *r, const void *targets_host, const void *sources_host, size_t n_points,
+                                         size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                         const ndtgpu_cell_params *cell, double *T16, size_t n_pairs, const ndtgpu_match_params *prm,
+                                         ndtgpu_match_result *results)
+{
+    if (!r || (n_pairs && (!T16 || !results || (n_points && (!targets_host || !sources_host)))) || stride_bytes < 12 ||
+        (stride_bytes & 3) || n_points > 0xFFFFFFFFull || (n_pairs > 1 && map_stride_bytes < n_points * stride_bytes))
+        return fail(NDTGPU_ERR_INVALID, "register_batch_host: bad argument (clouds must not overlap: map_stride_bytes >= n_points * stride_bytes)");
+    if (n_pairs == 0) return NDTGPU_OK;
+    if (!r->hcopy) HIP_TRY(hipStreamCreateWithFlags(&r->hcopy, hipStreamNonBlocking));
+    if (r->hstage.empty()) { r->hstage.assign(r->depth, nullptr); r->hstage_bytes.assign(r->depth, 0); }
+    const size_t bT = n_pairs * 16 * sizeof(double), bR = n_pairs * sizeof(ndtgpu_match_result), offR = (bT + 255) & ~(size_t)255;
+    if (r->hio_bytes < offR + bR) {
+        HIP_TRY(hipStreamSynchronize(r->hcopy));
+        if (r->hio) (void)hipFree(r->hio);
+        r->hio = nullptr; r->hio_bytes = 0;
+        HIP_TRY(hipMalloc(&r->hio, offR + bR));
+        r->hio_bytes = offR + bR;
+    }
+    double *T_dev = (double *)r->hio;
+    ndtgpu_match_result *R_dev = (ndtgpu_match_result *)((char *)r->hio + offR);
+    HIP_TRY(hipMemcpyAsync(T_dev, T16, bT, hipMemcpyHostToDevice, r->hcopy));
+    const size_t cloud_bytes = n_points * stride_bytes;
+    for (size_t off = 0; off < n_pairs; off += r->per) {
+        const size_t p = std::min(r->per, n_pairs - off);
+        const int slot = (int)(r->submitted % (size_t)r->depth);
+        const size_t half = (p - 1) * map_stride_bytes + cloud_bytes, half_al = p * map_stride_bytes;   // targets, then sources
+        const size_t need = half_al + half;
+        // the staging area of this slot is read by the build of the sub-batch that used it last: wait for that build
+        if (r->submitted >= (size_t)r->depth) HIP_TRY(hipEventSynchronize(r->built[slot]));
+        if (r->hstage_bytes[slot] < need) {
+            if (r->hstage[slot]) (void)hipFree(r->hstage[slot]);
+            r->hstage[slot] = nullptr; r->hstage_bytes[slot] = 0;
+            HIP_TRY(hipMalloc(&r->hstage[slot], need));
+            r->hstage_bytes[slot] = need;
+        }
+        char *tg = (char *)r->hstage[slot], *sc = tg + half_al;        // sources follow targets: ONE build launch per sub-batch
+        if (n_points) {
+            HIP_TRY(hipMemcpyAsync(tg, (const char *)targets_host + off * map_stride_bytes, half, hipMemcpyHostToDevice, r->hcopy));
+            HIP_TRY(hipMemcpyAsync(sc, (const char *)sources_host + off * map_stride_bytes, half, hipMemcpyHostToDevice, r->hcopy));
+        }
+        // (p <= pairs_per_batch: ONE sub-batch, in this slot, behind these copies)
+        ndtgpu_status rc = ndtgpu_register_batch_device(r, tg, sc, n_points, stride_bytes, map_stride_bytes, range_limit, cell,
+                                                        T_dev + off * 16, p, prm, R_dev + off, (ndtgpu_stream)r->hcopy, nullptr);
+        if (rc != NDTGPU_OK) return rc;
+    }
+    ndtgpu_status rc = ndtgpu_registrar_sync(r);
+    if (rc != NDTGPU_OK) return rc;
+    HIP_TRY(hipMemcpy(T16, T_dev, bT, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(results, R_dev, bR, hipMemcpyDeviceToHost));
     return NDTGPU_OK;
 }
 

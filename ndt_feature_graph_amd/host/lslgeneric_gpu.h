@@ -626,3 +626,74 @@ public:
 };
 
 }  // namespace lslgeneric
+
+namespace ndtgpu_host {
+
+// (added; no counterpart class upstream) Scans in, poses out for MANY pairs in ONE call: what the reference does pair after pair
+// -- a NDTMap per scan through loadPointCloud + computeNDTCells (fuser_hmt.cpp:195-227), then NDTMatcherD2D::match
+// (graph.cpp:273; the loop graph.cpp:347-353) -- as one ndtgpu_register_batch_host: the grid builds of all scans of a sub-batch are
+// one launch, their registrations one launch, sub-batches pipelined over the library's streams.  Pair k registers moving[k]
+// (source) against fixed[k] (target); T[k] holds the initial guess and receives the pose.  Clouds shorter than the longest
+// are padded with NaN points, which loadPointCloud drops.
+class ScanRegistrar {
+public:
+    ScanRegistrar(double res, const double centre[3], const double size_m[3], size_t pairs_per_batch = 1024, int depth = 3,
+                  uint32_t max_cells = 0)
+    {
+        ndtgpu_grid_params g;
+        g.res = res;
+        for (int a = 0; a < 3; a++) { g.centre[a] = centre[a]; g.size[a] = size_m[a]; }
+        g.max_cells = max_cells;
+        check(ndtgpu_registrar_create(&g, pairs_per_batch, depth, &reg_), "ndtgpu_registrar_create");
+    }
+    ~ScanRegistrar() { ndtgpu_registrar_destroy(reg_); }
+    ScanRegistrar(const ScanRegistrar &) = delete;
+    ScanRegistrar &operator=(const ScanRegistrar &) = delete;
+
+    // returns match()'s return value per pair; `results` (optional) receives what the device matcher reported
+    std::vector<bool> match(const lslgeneric::NDTMatcherD2D &matcher, const std::vector<pcl::PointCloud<pcl::PointXYZ>> &fixed,
+                            const std::vector<pcl::PointCloud<pcl::PointXYZ>> &moving, std::vector<Eigen::Affine3d> &T,
+                            double range_limit = -1., bool useInitialGuess = true, std::vector<ndtgpu_match_result> *results = nullptr,
+                            int dof_mask = 0x3f)
+    {
+        const size_t n = fixed.size();
+        if (moving.size() != n || T.size() != n) throw Error(NDTGPU_ERR_INVALID, "ScanRegistrar::match: one moving cloud and one pose per fixed cloud");
+        size_t np = 0;
+        for (size_t k = 0; k < n; k++) np = std::max(np, std::max(fixed[k].size(), moving[k].size()));
+        static_assert(sizeof(pcl::PointXYZ) == 16, "pcl::PointXYZ is four floats");
+        const float nan = std::nanf("");
+        pts_.assign(2 * n * np * 4, nan);
+        for (size_t k = 0; k < n; k++) {
+            for (size_t i = 0; i < fixed[k].size(); i++) {
+                const pcl::PointXYZ &q = fixed[k].points[i];
+                float *o = &pts_[(k * np + i) * 4];
+                o[0] = q.x; o[1] = q.y; o[2] = q.z;
+            }
+            for (size_t i = 0; i < moving[k].size(); i++) {
+                const pcl::PointXYZ &q = moving[k].points[i];
+                float *o = &pts_[((n + k) * np + i) * 4];
+                o[0] = q.x; o[1] = q.y; o[2] = q.z;
+            }
+        }
+        std::vector<double> T16(16 * n);
+        for (size_t k = 0; k < n; k++)
+            for (int e = 0; e < 16; e++) T16[16 * k + e] = T[k].data()[e];
+        std::vector<ndtgpu_match_result> res(n);
+        ndtgpu_match_params p = matcher.params(dof_mask, useInitialGuess);
+        check(ndtgpu_register_batch_host(reg_, pts_.data(), pts_.data() + n * np * 4, np, 16, np * 16, range_limit, nullptr, T16.data(), n, &p,
+                                         res.data()), "ndtgpu_register_batch_host");
+        std::vector<bool> ok(n);
+        for (size_t k = 0; k < n; k++) {
+            for (int e = 0; e < 16; e++) T[k].data()[e] = T16[16 * k + e];
+            ok[k] = res[k].converged != 0;
+        }
+        if (results) *results = res;
+        return ok;
+    }
+
+private:
+    ndtgpu_registrar *reg_ = nullptr;
+    std::vector<float> pts_;
+};
+
+}  // namespace ndtgpu_host

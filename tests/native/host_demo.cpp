@@ -527,6 +527,48 @@ int main()
         CHECK(worst < 1e-3, "occupancy round trip off by %g", worst);
         delete back;
     }
+    // ---- F. scans in, poses out for a batch of pairs in ONE call (ndtgpu_host::ScanRegistrar over ndtgpu_register_batch_host)
+    //         against the reference's pair-at-a-time sequence loadPointCloud + computeNDTCells + NDTMatcherD2D::match -----------
+    {
+        const int P = 10;
+        const double cen[3] = {0, 0, 0}, ext[3] = {60, 60, 1.0};
+        std::vector<pcl::PointCloud<pcl::PointXYZ>> fixed, moving;
+        std::vector<Eigen::Affine3d> T, T_one;
+        std::mt19937 r2(77);
+        std::normal_distribution<double> gt_t(0.0, 0.03), gt_r(0.0, 0.004);
+        for (int k = 0; k < P; k++) {
+            fixed.push_back(corridor_scan(gt[k], 300 + k, 5000 + 37 * k));           // (clouds of different lengths)
+            moving.push_back(corridor_scan(gt[k + 1], 400 + k, 5200 - 41 * k));
+            const Eigen::Affine3d inc = gt[k].inverse() * gt[k + 1];
+            T.push_back(ndtgpu_host::affine_from_pose(inc(0, 3) + gt_t(r2), inc(1, 3) + gt_t(r2), 0, 0, 0, std::atan2(inc(1, 0), inc(0, 0)) + gt_r(r2)));
+        }
+        T_one = T;
+        lslgeneric::NDTMatcherD2D md;
+        md.n_neighbours = 2; md.ITR_MAX = 30; md.DELTA_SCORE = 1e-6;
+        ndtgpu_host::ScanRegistrar reg(0.5, cen, ext, 4, 3);                           // sub-batches of 4 pairs: 4 + 4 + 2
+        std::vector<ndtgpu_match_result> rr;
+        std::vector<bool> ok = reg.match(md, fixed, moving, T, 30.0, true, &rr);
+        double worst = 0, worst_gt = 0;
+        int same_iters = 0;
+        for (int k = 0; k < P; k++) {
+            lslgeneric::NDTMap tg(new lslgeneric::LazyGrid(0.5)), sr(new lslgeneric::LazyGrid(0.5));
+            tg.guessSize(0, 0, 0, ext[0], ext[1], ext[2]); sr.guessSize(0, 0, 0, ext[0], ext[1], ext[2]);
+            tg.loadPointCloud(fixed[k], 30.0); tg.computeNDTCells();
+            sr.loadPointCloud(moving[k], 30.0); sr.computeNDTCells();
+            const bool c1 = md.match(tg, sr, T_one[k], true);
+            double d, a, dg, ag;
+            pose_error(T_one[k], T[k], d, a);
+            pose_error(gt[k].inverse() * gt[k + 1], T[k], dg, ag);
+            worst = std::fmax(worst, std::fmax(d, a)); worst_gt = std::fmax(worst_gt, dg);
+            same_iters += md.last_result.iterations == rr[k].iterations;
+            CHECK(c1 == ok[k] && rr[k].n_target == tg.numberOfActiveCells() && rr[k].n_source == sr.numberOfActiveCells(),
+                  "pair %d: converged %d / %d, cells %d / %d vs %d / %d", k, (int)c1, (int)ok[k], rr[k].n_target, rr[k].n_source,
+                  tg.numberOfActiveCells(), sr.numberOfActiveCells());
+        }
+        std::printf("F: %d scan pairs in one call: poses within %.2e of the pair-at-a-time sequence (%d of %d with its iteration count), "
+                    "within %.3f m of the true motion\n", P, worst, same_iters, P, worst_gt);
+        CHECK(worst < 1e-6 && same_iters >= P - 1 && worst_gt < 0.08, "the batch call disagrees with the pair-at-a-time sequence");
+    }
     std::printf("%d failures in total\n", g_fails);
     return g_fails ? 1 : 0;
 }

@@ -185,3 +185,33 @@ def test_registrar_rejects_bad_arguments(N, scene):
     reg.sync()                                                   # nothing submitted: returns at once
     assert reg.kernel_ms() == (0.0, 0.0, 0)
     reg.close()
+
+
+def test_registrar_host_form(N, scene):
+    """ndtgpu_register_batch_host: host clouds in, host poses out, sub-batches staged under the work of the one before -- the
+    bits of the device form (same launches: sub-batches of 40 pairs, sources behind targets in the staging area)"""
+    import torch
+    from ndt_feature_graph_amd import binding
+    B, both, dev = scene["B"], scene["both"], scene["dev"]
+    per = 40
+    # reference: the device form on buffers laid out like the host form's staging (ONE build launch per sub-batch)
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=per, depth=2, max_cells=4096)
+    T16 = scene["T0"].clone()
+    res = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for off in range(0, B, per):
+        p = min(per, B - off)
+        pack = torch.cat([both[off:off + p], both[B + off:B + off + p]]).contiguous()
+        reg.submit(pack[:p], pack[p:], T16[off:off + p], res[off:off + p], range_limit=RNG)
+        reg.sync()
+    T_ref = T16.cpu().numpy().reshape(B, 4, 4).transpose(0, 2, 1)
+    r_ref = res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
+    reg.close()
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=per, depth=2, max_cells=4096)
+    scans = both.cpu().numpy()
+    for _ in range(2):                                            # (again: the staging areas are reused)
+        T, r = reg.register_host(scans[:B], scans[B:], scene["T_init"], range_limit=RNG)
+        assert np.array_equal(T, T_ref)
+        for f in DET_FIELDS:
+            assert np.array_equal(r[f], r_ref[f]), f
+    reg.close()
