@@ -159,18 +159,23 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
     long long *delta = set.occ_delta + (size_t)map * g.slots;
     int iox = 0, ioy = 0, ioz = 0;                    // idxo = idyo = idzo = 0 like upstream
     const unsigned lane = threadIdx.x & 63u;
-    // cell index of a sample: fp32 fast path v = fma(p, 1/res, 0.5 + size/2 - c/res) with the error bound of
-    // csrc/ndt_build.hip (samples within it of a cell face, odd grid sizes and absurd centres take the reference's fp64
-    // formula): three fp32 operations per axis instead of an fp64 division
+    // Cell index of a sample.  The reference rounds the sample to float, p = (float)(origin + f s), and takes
+    // floor((p - c) / res + 0.5) + size / 2.  Fast path: w = f (s / res) + ((origin - c) / res + 0.5 + size / 2) -- ONE fp64
+    // fma per axis -- differs from the reference's argument by the float rounding of p, at most 2^-24 |p| / res with |p| no
+    // larger than the larger of |origin| and |end point| on that axis, plus fp64 rounding (1e-13): a sample whose fraction is
+    // within `guard` (twice that bound) of a cell face, odd grid sizes and absurd coordinates take the reference's formula.
     const double inv_res = 1.0 / g.res;
-    const float inv32 = (float)inv_res;
-    const float kx32 = (float)(0.5 + g.size[0] / 2.0 - cx * inv_res), ky32 = (float)(0.5 + g.size[1] / 2.0 - cy * inv_res),
-                kz32 = (float)(0.5 + g.size[2] / 2.0 - cz * inv_res);
+    const double ax = sx * inv_res, ay = sy * inv_res, az = sz * inv_res;
+    const double bx = (origin[0] - cx) * inv_res + (0.5 + g.size[0] / 2.0), by = (origin[1] - cy) * inv_res + (0.5 + g.size[1] / 2.0),
+                 bz = (origin[2] - cz) * inv_res + (0.5 + g.size[2] / 2.0);
     const bool force_exact = ((g.size[0] | g.size[1] | g.size[2]) & 1) != 0;
-    const float kmax = fmaxf(fmaxf(fabsf(kx32), fabsf(ky32)), fabsf(kz32));
-    const float smax = (float)max(max(g.size[0], g.size[1]), g.size[2]) + 1.0f;
-    const float face_guard = 2.4e-7f * (smax + kmax);
-    const float frac_lim = (force_exact || !(face_guard < 0.25f)) ? -1.0f : 0.5f - face_guard;
+    const double pmax = fmax(fmax(fmax(fabs(origin[0]), fabs(origin[1])), fabs(origin[2])),
+                             (double)fmaxf(fmaxf(fabsf(ex), fabsf(ey)), fabsf(ez)));
+    const double guard = pmax * inv_res * 1.1920928955078125e-7 + 1e-9;           // 2^-23 |p| / res
+    const double frac_lim = (force_exact || !(guard < 0.25)) ? -1.0 : 0.5 - guard;
+    // (every update of a cell without a Gaussian is the float -0.2f, in units of 2^-32: -13421773 * 2^6, exactly)
+    constexpr long long NDT_EMPTY_UPDATE = -858993472ll;
+    static_assert((long long)((double)-0.2f * 4294967296.0) == NDT_EMPTY_UPDATE, "the update of a cell seen empty");
     // Neighbouring beams walk through the same cells at the same step (100 k beams per turn: the 64 beams of a wave are
     // 4 cm apart at 10 m).  64 atomics on ONE address in one instruction are served one after the other at the L2
     // (the launch ran at 11 G updates/s); the lanes of a wave therefore add up the updates of a cell -- integers, so
@@ -180,36 +185,42 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
         long long val = 0;
         if (k < N - 2) {
             const double f = (double)(float)(k + 1);
-            const float px = (float)(origin[0] + f * sx), py = (float)(origin[1] + f * sy), pz = (float)(origin[2] + f * sz);
-            const float vx = fmaf(px, inv32, kx32), vy = fmaf(py, inv32, ky32), vz = fmaf(pz, inv32, kz32);
-            const float flx = floorf(vx), fly = floorf(vy), flz = floorf(vz);
+            const double wx = fma(f, ax, bx), wy = fma(f, ay, by), wz = fma(f, az, bz);
+            const double flx = floor(wx), fly = floor(wy), flz = floor(wz);
             int ix = (int)flx, iy = (int)fly, iz = (int)flz;
-            const bool nx = !(fabsf((vx - flx) - 0.5f) <= frac_lim), ny = !(fabsf((vy - fly) - 0.5f) <= frac_lim),
-                       nz = !(fabsf((vz - flz) - 0.5f) <= frac_lim);
+            const bool nx = !(fabs((wx - flx) - 0.5) <= frac_lim), ny = !(fabs((wy - fly) - 0.5) <= frac_lim),
+                       nz = !(fabs((wz - flz) - 0.5) <= frac_lim);
             if (ndt_ballot(nx | ny | nz)) {                 // (rare; a sample far outside the grid is out of bounds on either path)
-                if (nx) ix = lazygrid_index((double)px, cx, g.res, g.size[0]);
-                if (ny) iy = lazygrid_index((double)py, cy, g.res, g.size[1]);
-                if (nz) iz = lazygrid_index((double)pz, cz, g.res, g.size[2]);
+                if (nx) ix = lazygrid_index((double)(float)(origin[0] + f * sx), cx, g.res, g.size[0]);
+                if (ny) iy = lazygrid_index((double)(float)(origin[1] + f * sy), cy, g.res, g.size[1]);
+                if (nz) iz = lazygrid_index((double)(float)(origin[2] + f * sz), cz, g.res, g.size[2]);
             }
             if (!(ix == iox && iy == ioy && iz == ioz)) {
                 iox = ix; ioy = iy; ioz = iz;
                 if ((unsigned)ix < (unsigned)g.size[0] && (unsigned)iy < (unsigned)g.size[1] && (unsigned)iz < (unsigned)g.size[2]) {
                     const int sl = (ix * g.size[1] + iy) * g.size[2] + iz;
                     const int r = ndt_rank_of(rankmap, (unsigned)sl);
-                    float upd = -0.2f;                // seen empty, no Gaussian to argue with
-                    bool ok = true;
-                    if (r >= 0) {
-                        const NdtCell c = cells[r];
-                        ok = beam_evidence(c, origin, ex, ey, ez, sensor_noise, &upd);
-                    }
-                    if (ok) {
+                    if (r < 0) {                      // seen empty, no Gaussian to argue with: -0.2f
                         slot = sl;
-                        val = (long long)((double)upd * 4294967296.0);   // exact: a float below 1 in magnitude times 2^32 is an integer
+                        val = NDT_EMPTY_UPDATE;
+                    } else {
+                        float upd;
+                        const NdtCell c = cells[r];
+                        if (beam_evidence(c, origin, ex, ey, ez, sensor_noise, &upd)) {
+                            slot = sl;
+                            val = (long long)((double)upd * 4294967296.0);   // exact: a float below 1 in magnitude times 2^32 is an integer
+                        }
                     }
                 }
             }
         }
         unsigned long long todo = ndt_ballot(slot >= 0);
+        // (Measured and not kept, round 5 -- the launch is bound by the rate of the memory-side atomics, 8-12 G/s, AND by its
+        //  ~45 vector instructions per step, each about half of its time: (i) the rank map staged in LDS, 2048-8192 beams per
+        //  workgroup: the node builds of --config 4 130-133 ms against 127; (ii) a workgroup-level LDS table of evidence sums
+        //  keyed by cell, one global atomic per cell and workgroup: 162 ms -- the compare-and-swap of the leader lane sits in
+        //  this loop; (iii) runs of consecutive lanes in the same cell, value x length, ONE atomic instruction for all run heads
+        //  instead of this loop: 137 ms -- more atomics in flight at once; without any atomic the same code takes 95 ms.)
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int s0 = __builtin_amdgcn_readlane(slot, leader);        // (the leader is wave-uniform: a register read, no LDS round trip)
