@@ -369,17 +369,17 @@ def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_c
     # the same steps through the registrar (ONE ndtgpu_register_batch_device call per step, three internal map sets / streams):
     # the builds and the first registrations of step k + 1 fill the CUs that the long registrations of step k have left
     ms.profiling(False)
-    reg = N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=B, depth=3, max_cells=4096)
-    outs = [(T_init_cm.clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev), [0]) for _ in range(3)]
+    reg = N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=B, depth=4, max_cells=4096)
+    outs = [(T_init_cm.clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev), [0]) for _ in range(4)]
     n_pipe = 12
 
     def pstep(k):
-        T_k, r_k, tk = outs[k % 3]
+        T_k, r_k, tk = outs[k % 4]
         if tk[0]:
             reg.wait_stream(st, ticket=tk[0])
         T_k.copy_(T_init_cm)
         tk[0] = reg.submit(both[:B], both[B:], T_k, r_k, range_limit=rng_lim, stream=st)
-    for k in range(3):
+    for k in range(4):
         pstep(k)
     reg.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -387,7 +387,7 @@ def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_c
         pstep(k)
     reg.sync(); torch.cuda.synchronize()
     elapsed_pipe = time.perf_counter() - t0
-    same = bool(torch.equal(outs[(n_pipe - 1) % 3][0], T16) and torch.equal(outs[(n_pipe - 1) % 3][1][:, :32], results[:, :32]))
+    same = bool(torch.equal(outs[(n_pipe - 1) % 4][0], T16) and torch.equal(outs[(n_pipe - 1) % 4][1][:, :32], results[:, :32]))
     reg.close()
     out = {"value": B * n_pipe / elapsed_pipe, "unit": "registrations/s", "pairs": B, "steps": n_pipe,
            "ms_per_step": 1e3 * elapsed_pipe / n_pipe, "value_serial": B * n_steps / elapsed,
@@ -608,7 +608,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense-pairs", type=int, default=384, help="pairs of the dense-scene leg (0 = skip it)")
     ap.add_argument("--dense-cpu-sample", type=int, default=16, help="pairs of the dense-scene leg timed on the CPU")
-    ap.add_argument("--buffers", type=int, default=3, help="pipeline depth (mapset pairs / streams)")
+    ap.add_argument("--buffers", type=int, default=4, help="pipeline depth (the registrar's internal map sets)")
     ap.add_argument("--cu-split", type=int, default=0, help="CUs given to the build streams (hipExtStreamCreateWithCUMask), the "
                     "matcher streams get the rest; 0: every stream sees the whole chip")
     ap.add_argument("--legacy-pipeline", action="store_true",
@@ -806,7 +806,10 @@ def main():
     if reg is not None:
         build_ms_ev, match_ms_ev, n_prof = reg.kernel_ms()
         assert n_prof == args.steps
-        k_build, k_match = [build_ms_ev], [match_ms_ev]
+        stream_fed = match_ms_ev <= 0.05       # the stream-fed matcher: ONE instance serves batch after batch, there is no launch per step
+        if stream_fed:
+            match_ms_ev = ms_per_step_hint = None
+        k_build, k_match = [build_ms_ev], [match_ms_ev if match_ms_ev is not None else 1e3 * elapsed / args.steps]
         reg.profiling(False)
     else:
         k_build = [m[0].elapsed_time(m[1]) for m in marks]

@@ -194,6 +194,16 @@ hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, co
 hipError_t ndt_launch_covariance(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                                  const uint32_t *sidx_dev, const double *T16_dev, size_t n_links, int n_neighbours,
                                  double lfd1, double lfd2, int mode, double *cov36_dev, int *status_dev, hipStream_t stream);
+// the stream-fed matcher of the registrar (csrc/ndt_match.hip): a queue of published batches in device memory
+size_t ndt_stream_queue_bytes();
+size_t ndt_stream_abort_offset();
+unsigned ndt_stream_ring();
+hipError_t ndt_stream_publish(void *queue_dev, const NdtSetView &set, double *T16_dev, NdtMatchResultDev *res_dev,
+                              const NdtMatchParamsDev &prm, unsigned n_pairs, unsigned seq, hipStream_t stream);
+size_t ndt_stream_ring_offset();
+hipError_t ndt_stream_wait(void *queue_dev, unsigned ring, unsigned seq, hipStream_t stream);   // `stream` waits until batch `seq` is complete
+hipError_t ndt_stream_skip(void *queue_dev, unsigned seq, hipStream_t stream);
+hipError_t ndt_launch_match_stream(void *queue_dev, int n_neighbours, unsigned n_groups, hipStream_t stream);
 size_t ndt_match_pool_ctrl_bytes();
 size_t ndt_match_pool_head_bytes();
 size_t ndt_match_pool_pair_bytes(size_t n_chunks);

@@ -1346,6 +1346,354 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
     }
 }
 
+// ---- the stream-fed matcher (round 5) ----------------------------------------------------------------------------------
+// The registrar's pipelined form of the kernel above.  A launch of ndt_match_kernel ends when its longest registration does, and
+// every batch of 1024 pairs has ~50 of them (ITR_MAX): two thirds of a launch is a tail on a fifth of its CUs, which the
+// registrar could only hide behind the neighbouring batches' launches (three streams, 2.1 ms per batch where the chip's
+// work is 1.8).  Here ONE running instance serves batch after batch: batches are published into a queue in device memory (a
+// one-thread kernel behind the batch's grid builds, on the build stream), a slot that finds its batch out of tickets moves on
+// to the next published one, and long registrations simply keep their slots while their neighbours work through later
+// batches -- no parking, no tail per batch, one tail per run.  The instance holds G < all CUs (one workgroup each, as
+// above); the grid builds of the next batches run on the rest of the chip, concurrently, for as long as there is work.
+//   * An instance exits when every published batch is complete and nothing is left to draw; every publish is followed by an
+//     instance launch on the matcher stream (it starts when the running one has ended, or finds its batch taken and leaves).
+//   * Memory: the maps of a batch are written by build kernels that have ENDED (stream order) before the batch is published;
+//     a slot that moves to a new batch does a system-scope acquire (L1 / L2 invalidate: the map set of a ring entry is reused
+//     every `depth` batches, stale lines may be cached).  Poses and results are written back with a system-scope release before
+//     a registration is counted as done; queue words are system-scope atomics.
+//   * A registration's arithmetic is that of ndt_match_kernel -- same shares, same order of sums: the same bits.
+#define NDT_STREAM_RING 8
+struct NdtStreamBatch {
+    NdtSetView set;                  // targets in maps [0, n_pairs), sources in [n_pairs, 2 n_pairs)
+    double *T16;
+    NdtMatchResultDev *res;
+    NdtMatchParamsDev prm;
+    unsigned n_pairs, seq;
+    unsigned fresh, done;            // tickets drawn, registrations finished
+};
+struct NdtStreamQueue {
+    unsigned published;              // batches published so far (their descriptors are complete)
+    unsigned first_open;             // batches below this one have no tickets left
+    unsigned completed;              // batches whose registrations have all finished
+    unsigned abort;
+    unsigned ring;                   // entries in use (= the registrar's depth: entry e always describes map set e; set by the host)
+    unsigned linger;                 // 100 MHz ticks an instance that has worked stays when it runs dry (set by the host)
+    unsigned pad_[2];
+    unsigned done_seq[NDT_STREAM_RING];   // ring entry e: seq + 1 of the last batch that completed in it
+    NdtStreamBatch b[NDT_STREAM_RING];
+};
+size_t ndt_stream_queue_bytes() { return sizeof(NdtStreamQueue); }
+size_t ndt_stream_abort_offset() { return offsetof(NdtStreamQueue, abort); }
+size_t ndt_stream_ring_offset() { return offsetof(NdtStreamQueue, ring); }     // {ring, linger}: two words the host sets
+unsigned ndt_stream_ring() { return NDT_STREAM_RING; }
+
+namespace {
+NDT_D unsigned sys_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+NDT_D void sys_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+struct StreamSlotExt {               // what a slot of the stream-fed matcher knows about the batch its registration belongs to
+    NdtMatchParamsDev prm;
+    double *T16;
+    NdtMatchResultDev *res;
+    unsigned *done_ctr;
+    unsigned n_pairs, seq;
+    unsigned cur;                    // the batch this slot draws its next ticket from
+    unsigned seen;                   // seq + 1 of the batch this slot last did its acquire for (0: none)
+    unsigned worked;                 // this slot has run a registration
+    unsigned dry_since;              // 100 MHz clock (low word) when the slot first found everything complete (0: not dry)
+};
+}  // namespace
+
+__global__ void ndt_stream_publish_kernel(NdtStreamQueue *q, NdtStreamBatch desc)
+{
+    NdtStreamBatch *b = &q->b[desc.seq % q->ring];
+    *b = desc;
+    b->fresh = 0u; b->done = 0u;
+    __threadfence_system();
+    __hip_atomic_store(&q->published, desc.seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// blocks its stream until ring entry `entry` has completed batch seq >= value - 1.  Bounded by PROGRESS, not by time: it gives
+// up (and raises the abort word) only when no registration of the queue has finished for ~2 s -- a caller may wait for a
+// batch that hundreds of others are queued in front of.
+__global__ void ndt_stream_wait_kernel(NdtStreamQueue *q, unsigned entry, unsigned value)
+{
+    unsigned spins = 0u, seen = 0u;
+    while ((int)(sys_load(&q->done_seq[entry]) - value) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if ((++spins & 255u) == 0u) {
+            unsigned progress = sys_load(&q->completed);
+            for (unsigned e = 0; e < q->ring; e++) progress += sys_load(&q->b[e].done);
+            if (progress != seen) { seen = progress; spins = 0u; }
+            if (spins > (1u << 21)) { sys_store(&q->abort, 2u); break; }
+            if (sys_load(&q->abort)) break;
+        }
+    }
+}
+
+template <int NN>
+__global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ndt_match_stream_kernel(NdtStreamQueue *q)
+{
+    constexpr int R = 2, QL = 1024;
+    typedef MatchSlot<QL> Slot;
+    __shared__ Slot slots[R];
+    __shared__ StreamSlotExt ext[R];
+    __shared__ double w_src[NDT_MATCH_WAVES * 9 * 64];
+    __shared__ uint2 w_win[NDT_MATCH_WAVES * 7 * 64];
+    __shared__ unsigned s_session, s_closed;
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const unsigned ring = sys_load(&q->ring);
+    if (tid == 0) { s_session = 0u; s_closed = 0u; }
+    if (tid < (unsigned)R) {
+        Slot &S = slots[tid];
+        S.state = SLOT_FREE; S.next = NDT_VW; S.done = 0u; S.retry = clock_lo(); S.preset = -1; S.resumed = 0;
+        S.n_feat = 0u; S.feat = nullptr;
+        ext[tid].cur = 0u; ext[tid].seen = 0u; ext[tid].worked = 0u; ext[tid].dry_since = 0u;
+    }
+    const unsigned linger = sys_load(&q->linger);
+    if (tid < (unsigned)(R * NDT_VW)) slots[tid / NDT_VW].cache[tid % NDT_VW].key = 0u;
+    __syncthreads();
+    double *const wsrc = w_src + wave * (9 * 64);
+    uint2 *const wwin = w_win + wave * (7 * 64);
+
+    unsigned idle_spins = 0u;
+    for (;;) {
+        int task = TASK_NONE;
+        bool running = false;
+        if (lane == 0) {
+#pragma unroll 1
+            for (unsigned r = 0; r < (unsigned)R && task == TASK_NONE; r++) {
+                const unsigned s = (wave + r) % (unsigned)R;
+                Slot &S = slots[s];
+                if (lds_load(&S.state) == SLOT_RUN) {
+                    running = true;
+                    if (lds_load(&S.next) < (unsigned)NDT_VW) {
+                        const unsigned v = atomicAdd(&S.next, 1u);
+                        if (v < (unsigned)NDT_VW) task = (int)(s * 16u + v);
+                    }
+                }
+            }
+            if (task == TASK_NONE) {
+                const unsigned now = clock_lo();
+#pragma unroll 1
+                for (unsigned s = 0; s < (unsigned)R && task == TASK_NONE; s++) {
+                    Slot &S = slots[s];
+                    if (lds_load(&S.state) == SLOT_FREE && (int)(now - lds_load(&S.retry)) >= 0 &&
+                        atomicCAS(&S.state, (unsigned)SLOT_FREE, (unsigned)SLOT_BUSY) == (unsigned)SLOT_FREE)
+                        task = TASK_LOAD + (int)s;
+                }
+            }
+            if (task == TASK_NONE && lds_load(&s_closed) >= (unsigned)R) task = TASK_EXIT;
+        }
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task == TASK_EXIT) return;
+        if (task == TASK_NONE) {
+            if (__builtin_amdgcn_readfirstlane(running ? 1 : 0)) __builtin_amdgcn_s_sleep(2);
+            else __builtin_amdgcn_s_sleep(16);
+            idle_spins += 1u;
+            if ((idle_spins & 1023u) == 0u) {
+                if (idle_spins > (1u << 21)) sys_store(&q->abort, 1u);          // ~1 s without work
+                if (sys_load(&q->abort)) return;
+            }
+            continue;
+        }
+        idle_spins = 0u;
+
+        if (task >= TASK_LOAD) {
+            // ---- fill a slot: the next ticket of the slot's batch, else of the next published batch ------------------------
+            if (lane == 0) {
+                const unsigned s = (unsigned)(task - TASK_LOAD);
+                Slot &S = slots[s];
+                StreamSlotExt &E = ext[s];
+                unsigned new_state = SLOT_BUSY;
+                while (new_state == SLOT_BUSY) {
+                    unsigned c = E.cur;
+                    const unsigned fo = sys_load(&q->first_open);
+                    if ((int)(c - fo) < 0) c = fo;
+                    const unsigned pub = __hip_atomic_load(&q->published, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    E.cur = c;
+                    if ((int)(c - pub) >= 0) {
+                        // nothing to draw.  Everything published complete as well: this instance is done (a batch published
+                        // later brings its own launch); else the tails of others are running: look again soon
+                        // (an instance that has worked stays for `linger`: when the builds are the slower side a batch is
+                        //  complete before the next one is published, and CUs given up now are taken by that build's workgroups,
+                        //  behind which the next instance would have to queue)
+                        new_state = SLOT_FREE;
+                        if (sys_load(&q->completed) == pub) {
+                            const unsigned now = (unsigned)wall_clock64() | 1u;
+                            if (!E.worked || linger == 0u) new_state = SLOT_CLOSED;
+                            else if (E.dry_since == 0u) E.dry_since = now;
+                            else if (now - E.dry_since > linger) new_state = SLOT_CLOSED;
+                        } else {
+                            E.dry_since = 0u;
+                        }
+                        break;
+                    }
+                    NdtStreamBatch *B = &q->b[c % ring];
+                    if (E.seen != c + 1u) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (system scope: this CU's L1, this XCD's L2)
+                        E.seen = c + 1u;
+                    }
+                    // (what changes from batch to batch in a ring entry is read past the caches; B->set never changes)
+                    const volatile NdtStreamBatch *Bv = B;
+                    const unsigned n = Bv->n_pairs;
+                    const unsigned f = __hip_atomic_fetch_add(&B->fresh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (f >= n) {
+                        __hip_atomic_fetch_max(&q->first_open, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        E.cur = c + 1u;
+                        continue;
+                    }
+                    E.prm.n_neighbours = Bv->prm.n_neighbours; E.prm.itr_max = Bv->prm.itr_max; E.prm.step_control = Bv->prm.step_control;
+                    E.prm.dof_mask = Bv->prm.dof_mask; E.prm.use_initial_guess = Bv->prm.use_initial_guess;
+                    E.prm.fusion_flags = Bv->prm.fusion_flags; E.prm.delta_score = Bv->prm.delta_score;
+                    E.prm.lfd1 = Bv->prm.lfd1; E.prm.lfd2 = Bv->prm.lfd2;
+                    E.T16 = Bv->T16; E.res = Bv->res; E.done_ctr = &B->done; E.n_pairs = n; E.seq = c;
+                    const unsigned pair = f, ti = f, si = n + f;
+                    bool finished = false;
+                    if (B->set.counters[ti].overflow != 0u || B->set.counters[si].overflow != 0u) {
+                        NdtMatchResultDev *o = E.res + pair;            // (converged = 0; the pose is left untouched)
+                        o->converged = 0; o->iterations = 0; o->fevals = 0; o->exit_code = -3;
+                        o->score = 0.0; o->n_source = 0; o->n_target = 0;
+                        o->cycles_eval = 0; o->cycles_solver = 0; o->pair_terms_g = 0; o->pair_terms_h = 0;
+                        finished = true;
+                    } else {
+                        S.tg = map_view(B->set, ti);
+                        S.sv = map_view(B->set, si);
+                        S.pair = pair;
+                        match_state_init(S.st, E.T16 + (size_t)pair * 16, E.prm, nullptr);
+                        S.cnt[0] = S.cnt[1] = S.cnt[2] = S.cnt[3] = 0ull;
+                        if (S.st.done) { slot_result(S, E.T16, E.res); finished = true; }   // parameters the solver rejects
+                    }
+                    if (finished) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                        const unsigned d = __hip_atomic_fetch_add(E.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (d + 1u == n) {
+                            __hip_atomic_fetch_max(&q->first_open, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            sys_store(&q->done_seq[c % ring], c + 1u);
+                            __hip_atomic_fetch_add(&q->completed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        continue;
+                    }
+                    S.st.use_feat = 0; S.st.ls_joint = 0;
+                    E.worked = 1u; E.dry_since = 0u;
+                    S.session = atomicAdd(&s_session, 1u) + 1u;
+                    S.with_h = S.st.with_h;
+                    S.done = 0u;
+                    new_state = SLOT_RUN;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (new_state == SLOT_RUN) {
+                    lds_store(&S.state, SLOT_RUN);
+                    lds_store(&S.next, 0u);
+                } else {
+                    if (new_state == SLOT_FREE) lds_store(&S.retry, clock_lo() + 4096u);
+                    else atomicAdd(&s_closed, 1u);
+                    lds_store(&S.state, new_state);
+                }
+            }
+            continue;
+        }
+
+        // ---- one share of an evaluation ---------------------------------------------------------------------------------
+        Slot &S = slots[task >> 4];
+        StreamSlotExt &E = ext[task >> 4];
+        {
+            const unsigned v = (unsigned)task & 15u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const long long c0 = __builtin_readcyclecounter();
+            const int with_h = S.with_h;
+            if (with_h) run_share<NN, true, QL>(S, v, wsrc, wwin, E.prm.lfd1, E.prm.lfd2);
+            else run_share<NN, false, QL>(S, v, wsrc, wwin, E.prm.lfd1, E.prm.lfd2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            unsigned d = 0;
+            if (lane == 0) {
+                atomicAdd(&S.cnt[0], (unsigned long long)((long long)__builtin_readcyclecounter() - c0));
+                d = atomicAdd(&S.done, 1u);
+            }
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)d) != (unsigned)NDT_VW - 1u) continue;
+        }
+        // ---- last share delivered: rows in share order, solver step ---------------------------------------------------------
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < 29u) {
+            double a = 0;
+#pragma unroll
+            for (int k = 0; k < NDT_VW; k++) a += S.part[k * 32 + lane];
+            S.sums[lane] = a;
+        }
+        ndt_wave_sync();
+        const long long c1 = __builtin_readcyclecounter();
+        slot_step(S, E.prm);
+        ndt_wave_sync();
+        if (lane == 0) {
+            S.cnt[S.with_h ? 3 : 2] += (unsigned long long)S.sums[28];
+            S.cnt[1] += (unsigned long long)((long long)__builtin_readcyclecounter() - c1);
+            lds_store(&S.done, 0u);
+            if (S.st.done) {
+                slot_result(S, E.T16, E.res);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");              // (system scope: pose and result reach memory)
+                const unsigned d = __hip_atomic_fetch_add(E.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (d + 1u == E.n_pairs) {
+                    // (a complete batch has no tickets left: nobody looks at its ring entry again, it may be re-published)
+                    __hip_atomic_fetch_max(&q->first_open, E.seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    sys_store(&q->done_seq[E.seq % ring], E.seq + 1u);
+                    __hip_atomic_fetch_add(&q->completed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                lds_store(&S.retry, clock_lo());
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lds_store(&S.state, SLOT_FREE);
+            } else {
+                S.with_h = S.st.with_h;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lds_store(&S.next, 0u);
+            }
+        }
+    }
+}
+
+// a batch that was registered outside the queue (the registrar's calibration batch): the queue counts it as published and done
+__global__ void ndt_stream_skip_kernel(NdtStreamQueue *q, unsigned seq)
+{
+    sys_store(&q->first_open, seq + 1u);
+    sys_store(&q->completed, seq + 1u);
+    sys_store(&q->done_seq[seq % q->ring], seq + 1u);
+    __threadfence_system();
+    __hip_atomic_store(&q->published, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t ndt_stream_skip(void *queue_dev, unsigned seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ndt_stream_skip_kernel, dim3(1), dim3(1), 0, stream, (NdtStreamQueue *)queue_dev, seq);
+    return hipGetLastError();
+}
+
+hipError_t ndt_stream_publish(void *queue_dev, const NdtSetView &set, double *T16_dev, NdtMatchResultDev *res_dev,
+                              const NdtMatchParamsDev &prm, unsigned n_pairs, unsigned seq, hipStream_t stream)
+{
+    NdtStreamBatch d;
+    d.set = set; d.T16 = T16_dev; d.res = res_dev; d.prm = prm; d.n_pairs = n_pairs; d.seq = seq; d.fresh = 0u; d.done = 0u;
+    hipLaunchKernelGGL(ndt_stream_publish_kernel, dim3(1), dim3(1), 0, stream, (NdtStreamQueue *)queue_dev, d);
+    return hipGetLastError();
+}
+
+hipError_t ndt_stream_wait(void *queue_dev, unsigned ring, unsigned seq, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ndt_stream_wait_kernel, dim3(1), dim3(1), 0, stream, (NdtStreamQueue *)queue_dev, seq % ring, seq + 1u);
+    return hipGetLastError();
+}
+
+hipError_t ndt_launch_match_stream(void *queue_dev, int n_neighbours, unsigned n_groups, hipStream_t stream)
+{
+    NdtStreamQueue *q = (NdtStreamQueue *)queue_dev;
+    switch (n_neighbours) {
+    case 0: hipLaunchKernelGGL(ndt_match_stream_kernel<0>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); break;
+    case 1: hipLaunchKernelGGL(ndt_match_stream_kernel<1>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); break;
+    case 2: hipLaunchKernelGGL(ndt_match_stream_kernel<2>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); break;
+    case 3: hipLaunchKernelGGL(ndt_match_stream_kernel<3>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // NDTMatcherD2D::derivativesNDT as a stand-alone entry (host-driven matchFusion loop, FD tests).
 template <int NN>
 __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_derivatives_kernel(

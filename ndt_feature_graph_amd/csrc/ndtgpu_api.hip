@@ -1083,6 +1083,13 @@ struct ndtgpu_registrar {
     int last_built = -1;
     uint32_t *iota = nullptr;          // device: 0 .. 2 per - 1 (target indices: iota, source indices: iota + p)
     size_t submitted = 0;              // sub-batches so far
+    // stream-fed form (csrc/ndt_match.hip, ndt_match_stream_kernel): ONE build stream, ONE matcher stream on which an instance of
+    // the matcher serves batch after batch from a queue in device memory
+    void *queue = nullptr;
+    hipStream_t bst = nullptr, bst2 = nullptr, pst = nullptr, mst = nullptr;   // builds (two, in turn), publishes (in order), matcher
+    std::vector<hipEvent_t> pub_ev;
+    unsigned stream_groups = 0;        // workgroups (= CUs) of a matcher instance; 0: not calibrated yet
+    int stream_nn = -1;
     // host clouds (ndtgpu_register_batch_host): per slot a device staging area for the scans of a sub-batch, one for the
     // poses / results of a call, a copy stream
     std::vector<void *> hstage;
@@ -1104,6 +1111,14 @@ ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
     for (hipEvent_t e : r->done) if (e) (void)hipEventDestroy(e);
     if (r->in_ev) (void)hipEventDestroy(r->in_ev);
     if (r->hcopy) { (void)hipStreamSynchronize(r->hcopy); (void)hipStreamDestroy(r->hcopy); }
+    if (r->bst) (void)hipStreamSynchronize(r->bst);
+    if (r->bst2) (void)hipStreamSynchronize(r->bst2);
+    if (r->pst) { (void)hipStreamSynchronize(r->pst); (void)hipStreamDestroy(r->pst); }
+    if (r->mst) { (void)hipStreamSynchronize(r->mst); (void)hipStreamDestroy(r->mst); }
+    if (r->bst) (void)hipStreamDestroy(r->bst);
+    if (r->bst2) (void)hipStreamDestroy(r->bst2);
+    for (hipEvent_t e : r->pub_ev) if (e) (void)hipEventDestroy(e);
+    if (r->queue) (void)hipFree(r->queue);
     for (void *q : r->hstage) if (q) (void)hipFree(q);
     if (r->hio) (void)hipFree(r->hio);
     for (ndtgpu_mapset *s : r->sets) (void)ndtgpu_mapset_destroy(s);
@@ -1148,6 +1163,39 @@ ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pai
     }
     for (size_t k = 0; k < r->done.size() && rc == NDTGPU_OK && e == hipSuccess; k++)
         e = hipEventCreateWithFlags(&r->done[k], hipEventDisableTiming);
+    // The stream-fed matcher (NDTGPU_REG_STREAM=0 keeps one matcher launch per sub-batch): pipelined registrars of small maps
+    {
+        const char *se = getenv("NDTGPU_REG_STREAM");
+        const bool want = se ? atoi(se) != 0 : true;
+        if (rc == NDTGPU_OK && e == hipSuccess && want && depth > 1 && (unsigned)depth <= ndt_stream_ring() &&
+            r->sets[0]->v.grid.max_cells < 16384u) {
+            int dev = 0, n_cu = 0, lo = 0, hi = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+            const char *ge = getenv("NDTGPU_REG_GROUPS");
+            r->stream_groups = ge && atoi(ge) > 0 ? (unsigned)atoi(ge) : 0u;        // 0: measured on the first sub-batch
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            e = hipMalloc(&r->queue, ndt_stream_queue_bytes());
+            if (e == hipSuccess) e = hipMemset(r->queue, 0, ndt_stream_queue_bytes());
+            const char *le = getenv("NDTGPU_REG_LINGER_US");
+            const unsigned ring_linger[2] = {(unsigned)depth, (unsigned)(100 * (le ? std::max(0, atoi(le)) : 300))};   // 100 MHz ticks
+            if (e == hipSuccess) e = hipMemcpy((char *)r->queue + ndt_stream_ring_offset(), ring_linger, sizeof ring_linger, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->bst, hipStreamNonBlocking);
+            // Two build streams that take the sub-batches in turn (NDTGPU_REG_BUILD_STREAMS=1: one): a build launch is one
+            // workgroup per map and every map costs about the same, so on F free CUs it takes ceil(maps / 4 F) whole rounds
+            // (measured: 1.47 ms beside a matcher instance on 128 CUs, 1.85 ms beside one on 129); with the next launch's
+            // workgroups filling the last, nearly empty round the build side runs at its average rate whatever F is.
+            // Publishes stay in order on a stream of their own.
+            const char *bse = getenv("NDTGPU_REG_BUILD_STREAMS");
+            if (e == hipSuccess && !(bse && atoi(bse) == 1) && depth >= 3) e = hipStreamCreateWithFlags(&r->bst2, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->pst, hipStreamNonBlocking, lo);
+            // (a priority of its own: the runtime then never maps the two streams onto one hardware queue, where the build of
+            //  batch k + 1 would sit behind the running matcher instance)
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->mst, hipStreamNonBlocking, hi);
+            r->pub_ev.assign(depth, nullptr);
+            for (int k = 0; k < depth && e == hipSuccess; k++) e = hipEventCreateWithFlags(&r->pub_ev[k], hipEventDisableTiming);
+        }
+    }
     if (rc == NDTGPU_OK && e == hipSuccess) e = hipEventCreateWithFlags(&r->in_ev, hipEventDisableTiming);
     if (rc == NDTGPU_OK && e == hipSuccess) e = hipMalloc((void **)&r->iota, (2 * pairs_per_batch + 4) * sizeof(uint32_t));
     if (rc == NDTGPU_OK && e == hipSuccess) {
@@ -1210,7 +1258,114 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
         (stride_bytes & 3) || n_points > 0xFFFFFFFFull)
         return fail(NDTGPU_ERR_INVALID, "register_batch_device: bad argument");
     if (n_pairs == 0) return NDTGPU_OK;
+    NdtMatchParamsDev pdev = to_dev(prm);
+    pdev.fusion_flags = 0;
+    if (pdev.n_neighbours < 0 || pdev.n_neighbours > 3 || (pdev.dof_mask & 0x3f) == 0)
+        return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
     HIP_TRY(hipEventRecord(r->in_ev, (hipStream_t)stream));
+    if (r->queue) {
+        // ---- stream-fed form: builds on one stream, batches published to the running matcher instance -------------------
+        if (r->stream_nn != pdev.n_neighbours) {                 // (an instance is compiled for one neighbourhood size)
+            if (r->stream_nn >= 0) {
+                HIP_TRY(hipStreamSynchronize(r->bst));
+                if (r->bst2) HIP_TRY(hipStreamSynchronize(r->bst2));
+                HIP_TRY(hipStreamSynchronize(r->pst));
+                HIP_TRY(hipStreamSynchronize(r->mst));
+            }
+            r->stream_nn = pdev.n_neighbours;
+        }
+        for (size_t off = 0; off < n_pairs; off += r->per) {
+            const size_t p = std::min(r->per, n_pairs - off);
+            const size_t j = r->submitted;
+            const int slot = (int)(j % (size_t)r->depth);
+            ndtgpu_mapset *set = r->sets[slot];
+            hipStream_t st = (r->bst2 && (j & 1u)) ? r->bst2 : r->bst;
+            HIP_TRY(hipStreamWaitEvent(st, r->in_ev, 0));
+            if (r->stream_groups == 0u) {
+                // ---- the first sub-batch of a registrar's life measures the split of the chip: its maps are built and its
+                // pairs registered with nothing else on the device (the whole chip each; the same bits), the host reads the
+                // kernels' own clocks -- CU-time of the builds B and of the registrations M -- and a matcher instance gets
+                // n_cu M / (M + B) CUs from then on: 144 of 256 on the bench's halls, 220 on a cluttered scene whose maps
+                // hold five times the cells.  Costs one synchronisation, once.
+                const char *tg0 = (const char *)targets_dev + off * map_stride_bytes, *sc0 = (const char *)sources_dev + off * map_stride_bytes;
+                ndtgpu_status rc0;
+                if (sc0 == tg0 + p * map_stride_bytes) {
+                    rc0 = ndtgpu_mapset_build(set, 0, 2 * p, tg0, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+                } else {
+                    rc0 = ndtgpu_mapset_build(set, 0, p, tg0, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+                    if (rc0 == NDTGPU_OK)
+                        rc0 = ndtgpu_mapset_build(set, p, p, sc0, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+                }
+                if (rc0 != NDTGPU_OK) return rc0;
+                const unsigned saved_groups = set->match_groups;
+                set->match_groups = 0;                            // (the whole chip)
+                rc0 = ndtgpu_match_batch_device(set, r->iota, set, r->iota + p, T16_dev + off * 16, p, prm, results_dev + off, st);
+                set->match_groups = saved_groups;
+                if (rc0 != NDTGPU_OK) return rc0;
+                hipError_t se = ndt_stream_skip(r->queue, (unsigned)j, st);
+                if (se != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: calibration", se);
+                HIP_TRY(hipEventRecord(r->built[slot], st));
+                HIP_TRY(hipStreamSynchronize(st));
+                std::vector<NdtMapCounters> ctr(2 * p);
+                std::vector<ndtgpu_match_result> res(p);
+                HIP_TRY(hipMemcpy(ctr.data(), set->v.counters, 2 * p * sizeof(NdtMapCounters), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(res.data(), results_dev + off, p * sizeof(ndtgpu_match_result), hipMemcpyDeviceToHost));
+                double B = 0, M = 0;
+                for (const NdtMapCounters &c : ctr) B += (double)c.cyc[0] + (double)c.cyc[1] + (double)c.cyc[2] + (double)c.cyc[3];
+                B /= 4.0;                                         // a build workgroup shares its CU with three others
+                for (const ndtgpu_match_result &q : res) M += (double)q.cycles_eval + (double)q.cycles_solver / 8.0;
+                M *= 1.125;                                       // (measured optimum on the bench scene: 144 of 256 CUs where the raw clocks say 138)
+                int dev = 0, n_cu = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                    n_cu = 256;
+                double share = (M + B) > 0 ? M / (M + B) : 0.5;
+                share = std::min(0.9, std::max(0.25, share));
+                r->stream_groups = std::max(8u, ((unsigned)(share * n_cu + 4.0) / 8u) * 8u);
+                if (getenv("NDTGPU_REG_VERBOSE")) fprintf(stderr, "ndtgpu registrar: build %.3g, registrations %.3g CU-clocks per sub-batch -> matcher instances of %u workgroups\n", B, M, r->stream_groups);
+                r->submitted++;
+                if (ticket) *ticket = (uint64_t)r->submitted;
+                continue;
+            }
+            // this map set was last used by sub-batch j - depth: its registrations must be complete before it is rebuilt
+            if (j >= (size_t)r->depth) {
+                hipError_t we = ndt_stream_wait(r->queue, (unsigned)r->depth, (unsigned)(j - (size_t)r->depth), st);
+                if (we != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: wait launch", we);
+            }
+            hipEvent_t *mk = nullptr;
+            if (r->profiling) {
+                const size_t at = r->marks.size();
+                r->marks.resize(at + 4, nullptr);
+                for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreate(&r->marks[at + k]));
+                mk = &r->marks[at];
+                HIP_TRY(hipEventRecord(mk[0], st));
+            }
+            const char *tg = (const char *)targets_dev + off * map_stride_bytes, *sc = (const char *)sources_dev + off * map_stride_bytes;
+            ndtgpu_status rc;
+            if (sc == tg + p * map_stride_bytes) {
+                rc = ndtgpu_mapset_build(set, 0, 2 * p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+            } else {
+                rc = ndtgpu_mapset_build(set, 0, p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+                if (rc == NDTGPU_OK)
+                    rc = ndtgpu_mapset_build(set, p, p, sc, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+            }
+            if (rc != NDTGPU_OK) return rc;
+            if (mk) { HIP_TRY(hipEventRecord(mk[1], st)); HIP_TRY(hipEventRecord(mk[2], st)); HIP_TRY(hipEventRecord(mk[3], st)); }
+            HIP_TRY(hipEventRecord(r->built[slot], st));
+            HIP_TRY(hipStreamWaitEvent(r->pst, r->built[slot], 0));
+            hipError_t pe = ndt_stream_publish(r->queue, set->v, T16_dev + off * 16, reinterpret_cast<NdtMatchResultDev *>(results_dev + off),
+                                               pdev, (unsigned)p, (unsigned)j, r->pst);
+            if (pe != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: publish", pe);
+            HIP_TRY(hipEventRecord(r->pub_ev[slot], r->pst));
+            // every published batch is followed by an instance launch: it starts when the running instance has ended (and
+            // then serves this batch and whatever is published while it runs), or finds the batch taken and leaves
+            HIP_TRY(hipStreamWaitEvent(r->mst, r->pub_ev[slot], 0));
+            pe = ndt_launch_match_stream(r->queue, pdev.n_neighbours, r->stream_groups, r->mst);
+            if (pe != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: matcher launch", pe);
+            r->submitted++;
+            if (ticket) *ticket = (uint64_t)r->submitted;
+        }
+        return NDTGPU_OK;
+    }
     for (size_t off = 0; off < n_pairs; off += r->per) {
         const size_t p = std::min(r->per, n_pairs - off);
         const int slot = (int)(r->submitted % (size_t)r->depth);
@@ -1262,8 +1417,16 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
 ndtgpu_status ndtgpu_registrar_wait_stream(ndtgpu_registrar *r, uint64_t ticket, ndtgpu_stream stream)
 {
     if (!r || ticket > (uint64_t)r->submitted) return fail(NDTGPU_ERR_INVALID, "registrar_wait_stream: bad argument");
-    // the newest sub-batch before `end` on every internal stream (earlier ones precede it in stream order)
     const size_t end = ticket ? (size_t)ticket : r->submitted;
+    if (r->queue) {
+        // the last `depth` sub-batches before `end` (a sub-batch is only published once the one `depth` before it is complete)
+        for (size_t j = end > (size_t)r->depth ? end - (size_t)r->depth : 0; j < end; j++) {
+            hipError_t we = ndt_stream_wait(r->queue, (unsigned)r->depth, (unsigned)j, (hipStream_t)stream);
+            if (we != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: wait launch", we);
+        }
+        return NDTGPU_OK;
+    }
+    // the newest sub-batch before `end` on every internal stream (earlier ones precede it in stream order)
     for (size_t j = end > (size_t)r->depth ? end - (size_t)r->depth : 0; j < end; j++)
         HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, r->done[j % r->done.size()], 0));
     return NDTGPU_OK;
@@ -1272,6 +1435,16 @@ ndtgpu_status ndtgpu_registrar_wait_stream(ndtgpu_registrar *r, uint64_t ticket,
 ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
 {
     if (!r) return fail(NDTGPU_ERR_INVALID, "registrar_sync: null");
+    if (r->queue) {
+        HIP_TRY(hipStreamSynchronize(r->bst));
+        if (r->bst2) HIP_TRY(hipStreamSynchronize(r->bst2));
+        HIP_TRY(hipStreamSynchronize(r->pst));
+        HIP_TRY(hipStreamSynchronize(r->mst));
+        unsigned aborted = 0;
+        HIP_TRY(hipMemcpy(&aborted, (char *)r->queue + ndt_stream_abort_offset(), sizeof aborted, hipMemcpyDeviceToHost));
+        if (aborted) return fail(NDTGPU_ERR_HIP, "registrar: the stream-fed matcher gave up (no work for ~2 s, or a wait that never ended)");
+        return NDTGPU_OK;
+    }
     for (int k = 0; k < r->depth; k++) HIP_TRY(hipStreamSynchronize(r->streams[k]));
     for (int k = 0; k < r->depth && (size_t)k < r->submitted; k++) {
         int aborted = 0;
