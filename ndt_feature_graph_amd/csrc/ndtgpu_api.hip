@@ -1087,6 +1087,8 @@ struct ndtgpu_registrar {
     // the matcher serves batch after batch from a queue in device memory
     void *queue = nullptr;
     hipStream_t bst = nullptr, bst2 = nullptr, pst = nullptr, mst = nullptr;   // builds (two, in turn), publishes (in order), matcher
+    hipStream_t hst = nullptr;         // the drain helper of ndtgpu_registrar_sync
+    size_t helped = 0;                 // sub-batches submitted when the last helper was launched
     std::vector<hipEvent_t> pub_ev;
     unsigned stream_groups = 0;        // workgroups (= CUs) of a matcher instance; 0: not calibrated yet
     int stream_nn = -1;
@@ -1114,6 +1116,7 @@ ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
     if (r->bst) (void)hipStreamSynchronize(r->bst);
     if (r->bst2) (void)hipStreamSynchronize(r->bst2);
     if (r->pst) { (void)hipStreamSynchronize(r->pst); (void)hipStreamDestroy(r->pst); }
+    if (r->hst) { (void)hipStreamSynchronize(r->hst); (void)hipStreamDestroy(r->hst); }
     if (r->mst) { (void)hipStreamSynchronize(r->mst); (void)hipStreamDestroy(r->mst); }
     if (r->bst) (void)hipStreamDestroy(r->bst);
     if (r->bst2) (void)hipStreamDestroy(r->bst2);
@@ -1178,7 +1181,7 @@ ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pai
             e = hipMalloc(&r->queue, ndt_stream_queue_bytes());
             if (e == hipSuccess) e = hipMemset(r->queue, 0, ndt_stream_queue_bytes());
             const char *le = getenv("NDTGPU_REG_LINGER_US");
-            const unsigned ring_linger[2] = {(unsigned)depth, (unsigned)(100 * (le ? std::max(0, atoi(le)) : 300))};   // 100 MHz ticks
+            const unsigned ring_linger[2] = {(unsigned)depth, (unsigned)(100 * (le ? std::max(0, atoi(le)) : 0))};   // 100 MHz ticks (measured: no gain from 300 / 1000 us; default 0)
             if (e == hipSuccess) e = hipMemcpy((char *)r->queue + ndt_stream_ring_offset(), ring_linger, sizeof ring_linger, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->bst, hipStreamNonBlocking);
             // Two build streams that take the sub-batches in turn (NDTGPU_REG_BUILD_STREAMS=1: one): a build launch is one
@@ -1436,10 +1439,25 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
 {
     if (!r) return fail(NDTGPU_ERR_INVALID, "registrar_sync: null");
     if (r->queue) {
+        // Nothing more is coming before this call returns: once the last sub-batch has been published the CUs that were kept
+        // for the builds are free, and a second instance on those takes its share of what is left to register.
+        if (r->submitted > r->helped && r->stream_groups && r->stream_nn >= 0 && !getenv("NDTGPU_REG_NO_HELPER")) {
+            int dev = 0, n_cu = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+                n_cu = 256;
+            if ((unsigned)n_cu > r->stream_groups + 8u) {
+                if (!r->hst) HIP_TRY(hipStreamCreateWithFlags(&r->hst, hipStreamNonBlocking));
+                HIP_TRY(hipStreamWaitEvent(r->hst, r->pub_ev[(r->submitted - 1) % (size_t)r->depth], 0));
+                hipError_t he = ndt_launch_match_stream(r->queue, r->stream_nn, (unsigned)n_cu - r->stream_groups, r->hst);
+                if (he != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: helper launch", he);
+            }
+            r->helped = r->submitted;
+        }
         HIP_TRY(hipStreamSynchronize(r->bst));
         if (r->bst2) HIP_TRY(hipStreamSynchronize(r->bst2));
         HIP_TRY(hipStreamSynchronize(r->pst));
         HIP_TRY(hipStreamSynchronize(r->mst));
+        if (r->hst) HIP_TRY(hipStreamSynchronize(r->hst));
         unsigned aborted = 0;
         HIP_TRY(hipMemcpy(&aborted, (char *)r->queue + ndt_stream_abort_offset(), sizeof aborted, hipMemcpyDeviceToHost));
         if (aborted) return fail(NDTGPU_ERR_HIP, "registrar: the stream-fed matcher gave up (no work for ~2 s, or a wait that never ended)");
