@@ -215,3 +215,39 @@ def test_registrar_host_form(N, scene):
         for f in DET_FIELDS:
             assert np.array_equal(r[f], r_ref[f]), f
     reg.close()
+
+
+@pytest.mark.parametrize("mode,groups", [("stream", None), ("stream", "8"), ("launch_per_batch", None)])
+def test_registrar_long_run_both_matcher_forms(N, scene, monkeypatch, mode, groups):
+    """Twelve calls (36 sub-batches: many turns of the ring of four map sets) without a host wait, four output buffers in
+    rotation guarded by tickets -- through the stream-fed matcher (one running instance serves batch after batch; its CU share
+    measured on the first sub-batch, or forced to 8 workgroups) and through the form with one matcher launch per sub-batch
+    (NDTGPU_REG_STREAM=0): every call returns the bits of ndtgpu_mapset_build + ndtgpu_match_batch_device."""
+    import torch
+    from ndt_feature_graph_amd import binding
+    monkeypatch.setenv("NDTGPU_REG_STREAM", "1" if mode == "stream" else "0")
+    if groups:
+        monkeypatch.setenv("NDTGPU_REG_GROUPS", groups)
+    B, both, dev = scene["B"], scene["both"], scene["dev"]
+    T_ref, r_ref = two_call_reference(N, scene, 32)
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=32, depth=4, max_cells=4096)
+    st = torch.cuda.Stream(device=dev)
+    outs = [(scene["T0"].clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev)) for _ in range(4)]
+    tickets = [0] * 4
+    kept = []
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        for k in range(12):
+            T16, res = outs[k % 4]
+            if tickets[k % 4]:
+                reg.wait_stream(st, ticket=tickets[k % 4])       # the call that wrote this buffer last is complete ...
+                kept.append((T16.clone(), res.clone()))           # ... its results are read on the stream that waited
+            T16.copy_(scene["T0"])
+            tickets[k % 4] = reg.submit(both[:B], both[B:], T16, res, range_limit=RNG, stream=st)
+    reg.sync()
+    kept += [(T16.clone(), res.clone()) for T16, res in outs]
+    torch.cuda.synchronize()
+    assert len(kept) == 12
+    for T16, res in kept:
+        same_bits(binding, T16, res, T_ref, r_ref)
+    reg.close()
