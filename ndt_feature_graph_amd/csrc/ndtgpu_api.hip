@@ -126,6 +126,7 @@ struct ndtgpu_mapset {
     hipStream_t work_stream = nullptr;
     // profiling hooks: [0,1] bracket the build kernel, [2,3] the match kernel
     bool profiling = false;
+    bool profile_span = false;         // a chunked host build is ONE bracket: the chunks' launches do not re-record the events
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid[2] = {false, false};
 
@@ -388,11 +389,11 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
     }
     if (s->v.occ && count)   // a rebuilt map starts from cells without readings
         HIP_TRY(hipMemsetAsync(s->v.occ + first * (size_t)s->v.grid.slots, 0, count * (size_t)s->v.grid.slots * sizeof(float), st));
-    if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
+    if (s->profiling && !s->profile_span) HIP_TRY(hipEventRecord(s->ev[0], st));
     hipError_t e = ndt_launch_build(s->v, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit,
                          orig_dev, cp.n_min, cp.eval_factor, s->nice_range(first, count), st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: launch", e);
-    if (s->profiling) { HIP_TRY(hipEventRecord(s->ev[1], st)); s->ev_valid[0] = true; }
+    if (s->profiling && !s->profile_span) { HIP_TRY(hipEventRecord(s->ev[1], st)); s->ev_valid[0] = true; }
     { ndtgpu_status trc = s->touch(st); if (trc != NDTGPU_OK) return trc; }
     if (orig_dev) return s->origins_used(st);
     return NDTGPU_OK;
@@ -476,6 +477,10 @@ static ndtgpu_status stage_host_clouds(ndtgpu_mapset *s, const void *xyz_host, s
             });
         hipError_t herr = hipSuccess;
         ndtgpu_status lrc = NDTGPU_OK;
+        // (profiling: one bracket around all chunks' launches -- ndtgpu_last_kernel_ms then reports the whole build, copies
+        //  that the chunks wait for included -- instead of the last chunk's alone)
+        const bool span = s->profiling && s->ev[0] && s->ev[1];
+        if (span) { herr = hipEventRecord(s->ev[0], st); s->profile_span = true; }
         for (size_t c = 0; c < n_chunks && herr == hipSuccess && lrc == NDTGPU_OK; c++) {
             while (!staged[c].load(std::memory_order_acquire)) std::this_thread::yield();
             const int k = (int)(c % R);
@@ -491,6 +496,10 @@ static ndtgpu_status stage_host_clouds(ndtgpu_mapset *s, const void *xyz_host, s
                 s->host_ev_used[k] = false;
                 allowed.store((long)(c + R) + 1, std::memory_order_release);
             }
+        }
+        if (span) {
+            s->profile_span = false;
+            if (herr == hipSuccess && lrc == NDTGPU_OK && hipEventRecord(s->ev[1], st) == hipSuccess) s->ev_valid[0] = true;
         }
         if (herr != hipSuccess || lrc != NDTGPU_OK) stop.store(1);
         for (auto &t : workers) t.join();

@@ -251,3 +251,54 @@ def test_registrar_long_run_both_matcher_forms(N, scene, monkeypatch, mode, grou
     for T16, res in kept:
         same_bits(binding, T16, res, T_ref, r_ref)
     reg.close()
+
+
+def test_registrar_stream_form_edges(N, scene):
+    """The stream-fed form at its edges: maps that overflowed max_cells are refused in the loader (exit code -3, pose untouched:
+    a batch whose registrations ALL end there still completes), single-pair calls, a ticket of the measuring first sub-batch, two
+    registrars alive at once, destruction with work in flight."""
+    import torch
+    from ndt_feature_graph_amd import binding
+    B, both, dev = scene["B"], scene["both"], scene["dev"]
+    T_ref, r_ref = two_call_reference(N, scene, 32)
+    st = torch.cuda.current_stream()
+    # (a) every map overflows
+    small = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=32, depth=4, max_cells=128)
+    T16 = scene["T0"].clone()
+    res = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        small.submit(both[:B], both[B:], T16, res, range_limit=RNG, stream=st)
+    small.sync()
+    r = res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
+    assert np.all(r["exit_code"] == -3) and not r["converged"].any() and torch.equal(T16, scene["T0"])
+    # (b) two registrars at once; single-pair calls; the first ticket
+    ra = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=32, depth=4, max_cells=4096)
+    rb = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=32, depth=2, max_cells=4096)
+    Ta, Tb = scene["T0"].clone(), scene["T0"].clone()
+    resa = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    resb = torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    t0 = ra.submit(both[:32], both[B:B + 32], Ta[:32], resa[:32], range_limit=RNG, stream=st)      # the measuring sub-batch
+    ra.wait_stream(st, ticket=t0)
+    first = Ta[:32].clone()
+    rb.submit(both[:B], both[B:], Tb, resb, range_limit=RNG, stream=st)
+    ra.submit(both[32:B], both[B + 32:], Ta[32:], resa[32:], range_limit=RNG, stream=st)
+    ra.sync(); rb.sync()
+    assert np.array_equal(first.cpu().numpy(), T_ref[:32]), "first"
+    same_bits(binding, Ta, resa, T_ref, r_ref)
+    same_bits(binding, Tb, resb, T_ref, r_ref)
+    one_T, one_r = scene["T0"][5:6].clone(), torch.zeros((1, 64), dtype=torch.uint8, device=dev)
+    ra.submit(both[5:6], both[B + 5:B + 6], one_T, one_r, range_limit=RNG, stream=st)
+    ra.sync()
+    assert pose_dist(one_T.cpu().numpy()[0], T_ref[5]) < 1e-6        # (a map built alone: another launch shape, the same pose)
+    # (c) destroyed with work in flight: destruction waits
+    Tb.copy_(scene["T0"])
+    rb.submit(both[:B], both[B:], Tb, resb, range_limit=RNG, stream=st)
+    rb.close(); ra.close(); small.close()
+    torch.cuda.synchronize()
+    same_bits(binding, Tb, resb, T_ref, r_ref)
+
+
+def pose_dist(a16, b16):
+    return float(np.max(np.abs(np.asarray(a16) - np.asarray(b16))))
