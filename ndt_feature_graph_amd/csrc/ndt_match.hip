@@ -1399,7 +1399,6 @@ struct StreamSlotExt {               // what a slot of the stream-fed matcher kn
     unsigned *done_ctr;
     unsigned n_pairs, seq;
     unsigned cur;                    // the batch this slot draws its next ticket from
-    unsigned seen;                   // seq + 1 of the batch this slot last did its acquire for (0: none)
     unsigned worked;                 // this slot has run a registration
     unsigned dry_since;              // 100 MHz clock (low word) when the slot first found everything complete (0: not dry)
 };
@@ -1441,17 +1440,17 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
     __shared__ StreamSlotExt ext[R];
     __shared__ double w_src[NDT_MATCH_WAVES * 9 * 64];
     __shared__ uint2 w_win[NDT_MATCH_WAVES * 7 * 64];
-    __shared__ unsigned s_session, s_closed;
+    __shared__ unsigned s_session, s_closed, s_seen;
 
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned ring = sys_load(&q->ring);
-    if (tid == 0) { s_session = 0u; s_closed = 0u; }
+    if (tid == 0) { s_session = 0u; s_closed = 0u; s_seen = 0u; }
     if (tid < (unsigned)R) {
         Slot &S = slots[tid];
         S.state = SLOT_FREE; S.next = NDT_VW; S.done = 0u; S.retry = clock_lo(); S.preset = -1; S.resumed = 0;
         S.n_feat = 0u; S.feat = nullptr;
-        ext[tid].cur = 0u; ext[tid].seen = 0u; ext[tid].worked = 0u; ext[tid].dry_since = 0u;
+        ext[tid].cur = 0u; ext[tid].worked = 0u; ext[tid].dry_since = 0u;
     }
     const unsigned linger = sys_load(&q->linger);
     if (tid < (unsigned)(R * NDT_VW)) slots[tid / NDT_VW].cache[tid % NDT_VW].key = 0u;
@@ -1533,9 +1532,11 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                         break;
                     }
                     NdtStreamBatch *B = &q->b[c % ring];
-                    if (E.seen != c + 1u) {
+                    // ONE acquire per workgroup and batch (batches are taken in order: whoever of the workgroup's slots reaches
+                    // batch c first does it -- the invalidate also drops the maps its XCD's other registrations are reading)
+                    if ((int)(lds_load(&s_seen) - (c + 1u)) < 0) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (system scope: this CU's L1, this XCD's L2)
-                        E.seen = c + 1u;
+                        lds_store(&s_seen, c + 1u);
                     }
                     // (what changes from batch to batch in a ring entry is read past the caches; B->set never changes)
                     const volatile NdtStreamBatch *Bv = B;
