@@ -10,6 +10,7 @@
 
 struct NdtBinner {
     double cx, cy, cz, res, ox, oy, oz, range_limit;
+    double hx, hy, hz;          // size / 2.0 (NdtGrid::half: scalar registers)
     int sx, sy, sz;
     float inv32, kx32, ky32, kz32, ox32, oy32, oz32, r2, r2eff, r2band, frac_lim, z_max32;
 
@@ -21,7 +22,7 @@ struct NdtBinner {
         sx = g.size[0]; sy = g.size[1]; sz = g.size[2];
         z_max32 = z_max32_;
         const double inv_res = 1.0 / g.res;
-        const double hx = g.size[0] / 2.0, hy = g.size[1] / 2.0, hz = g.size[2] / 2.0;
+        hx = g.half[0]; hy = g.half[1]; hz = g.half[2];
         inv32 = (float)inv_res;
         // fast-path constants: idx = floor(p*inv + k), k = 0.5 + size/2 - c*inv.  Only for EVEN sizes (size/2
         // integral); with an odd size the reference's double->int truncation makes the index formula
@@ -91,9 +92,9 @@ struct NdtBinner {
             ok = !(sqrt(ex * ex + ey * ey + ez * ez) > range_limit) && okz;
         }
         const float vx = fmaf(fx, inv32, kx32), vy = fmaf(fy, inv32, ky32), vz = fmaf(fz, inv32, kz32);
-        if (!(fabsf((vx - floorf(vx)) - 0.5f) <= frac_lim)) ix = lazygrid_index((double)fx, cx, res, sx);
-        if (!(fabsf((vy - floorf(vy)) - 0.5f) <= frac_lim)) iy = lazygrid_index((double)fy, cy, res, sy);
-        if (!(fabsf((vz - floorf(vz)) - 0.5f) <= frac_lim)) iz = lazygrid_index((double)fz, cz, res, sz);
+        if (!(fabsf((vx - floorf(vx)) - 0.5f) <= frac_lim)) ix = lazygrid_index_half((double)fx, cx, res, hx);
+        if (!(fabsf((vy - floorf(vy)) - 0.5f) <= frac_lim)) iy = lazygrid_index_half((double)fy, cy, res, hy);
+        if (!(fabsf((vz - floorf(vz)) - 0.5f) <= frac_lim)) iz = lazygrid_index_half((double)fz, cz, res, hz);
         slot = (ok && (unsigned)ix < (unsigned)sx && (unsigned)iy < (unsigned)sy && (unsigned)iz < (unsigned)sz)
                    ? (int)(((unsigned)ix * (unsigned)sy + (unsigned)iy) * (unsigned)sz + (unsigned)iz) : -1;
         gx = (float)ix; gy = (float)iy; gz = (float)iz;           // (only cells of the grid matter: exact below 2^24)

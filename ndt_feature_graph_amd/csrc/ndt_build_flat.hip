@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
     NdtMapCounters *ctr = set.counters + map;
     const double cx = set.centres[map * 3 + 0], cy = set.centres[map * 3 + 1], cz = set.centres[map * 3 + 2];
     const double res = g.res, inv_res = 1.0 / g.res;
-    const double hx = g.size[0] / 2.0, hy = g.size[1] / 2.0, hz = g.size[2] / 2.0;
+    const double hx = g.half[0], hy = g.half[1], hz = g.half[2];      // (kernel arguments: scalar registers)
     double ox = 0, oy = 0, oz = 0;
     if (range_origins) { ox = range_origins[map_local * 3]; oy = range_origins[map_local * 3 + 1]; oz = range_origins[map_local * 3 + 2]; }
     const char *pts = xyz + (size_t)map_local * map_stride_bytes;

@@ -1414,7 +1414,8 @@ __global__ void ndt_stream_publish_kernel(NdtStreamQueue *q, NdtStreamBatch desc
 }
 
 // blocks its stream until ring entry `entry` has completed batch seq >= value - 1.  Bounded by PROGRESS, not by time: it gives
-// up (and raises the abort word) only when no registration of the queue has finished for ~2 s -- a caller may wait for a
+// up (and raises the abort word) only when no registration of the queue has finished for ~30 s (a cold box pages code objects
+// in for seconds: the first profiled run of round 5 lost a batch to a 2 s bound) -- a caller may wait for a
 // batch that hundreds of others are queued in front of.
 __global__ void ndt_stream_wait_kernel(NdtStreamQueue *q, unsigned entry, unsigned value)
 {
@@ -1425,7 +1426,7 @@ __global__ void ndt_stream_wait_kernel(NdtStreamQueue *q, unsigned entry, unsign
             unsigned progress = sys_load(&q->completed);
             for (unsigned e = 0; e < q->ring; e++) progress += sys_load(&q->b[e].done);
             if (progress != seen) { seen = progress; spins = 0u; }
-            if (spins > (1u << 21)) { sys_store(&q->abort, 2u); break; }
+            if (spins > (1u << 25)) { sys_store(&q->abort, 2u); break; }      // ~30 s without any progress
             if (sys_load(&q->abort)) break;
         }
     }
@@ -1494,7 +1495,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
             else __builtin_amdgcn_s_sleep(16);
             idle_spins += 1u;
             if ((idle_spins & 1023u) == 0u) {
-                if (idle_spins > (1u << 21)) sys_store(&q->abort, 1u);          // ~1 s without work
+                if (idle_spins > (1u << 26)) sys_store(&q->abort, 1u);          // ~30 s without work
                 if (sys_load(&q->abort)) return;
             }
             continue;

@@ -603,6 +603,15 @@ NDT_HD void ldlt_solve_static6(const double (&A)[6][6], const double (&b)[6], do
 
 // LazyGrid::getIndexForPoint: idx = floor((p - centre)/res + 0.5) + size/2.0, double -> int.
 // Contraction is off so that the host oracle and the device agree bit-for-bit at cell faces.
+// (the same with size / 2.0 handed in: NdtGrid::half, a kernel argument, i.e. a scalar register -- computed in the kernel it is a
+//  wave-uniform value in a vector register, and the flat build kernel spilled three of them)
+NDT_HD int lazygrid_index_half(double p, double centre, double res, double half)
+{
+#pragma clang fp contract(off)
+    double v = floor((p - centre) / res + 0.5) + half;
+    if (!(v > -2.0e9 && v < 2.0e9)) return -1;
+    return (int)v;
+}
 NDT_HD int lazygrid_index(double p, double centre, double res, int size)
 {
 #pragma clang fp contract(off)

@@ -214,7 +214,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.5.0 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.5.1 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1203,6 +1203,8 @@ ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pai
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->pst, hipStreamNonBlocking, lo);
             // (a priority of its own: the runtime then never maps the two streams onto one hardware queue, where the build of
             //  batch k + 1 would sit behind the running matcher instance)
+            const char *pe_ = getenv("NDTGPU_REG_PRIO");                    // (experiment: 0 = every stream at the default priority)
+            if (pe_ && atoi(pe_) == 0) lo = hi = 0;
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->mst, hipStreamNonBlocking, hi);
             r->pub_ev.assign(depth, nullptr);
             for (int k = 0; k < depth && e == hipSuccess; k++) e = hipEventCreateWithFlags(&r->pub_ev[k], hipEventDisableTiming);
@@ -1472,7 +1474,7 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
         if (r->hst) HIP_TRY(hipStreamSynchronize(r->hst));
         unsigned aborted = 0;
         HIP_TRY(hipMemcpy(&aborted, (char *)r->queue + ndt_stream_abort_offset(), sizeof aborted, hipMemcpyDeviceToHost));
-        if (aborted) return fail(NDTGPU_ERR_HIP, "registrar: the stream-fed matcher gave up (no work for ~2 s, or a wait that never ended)");
+        if (aborted) return fail(NDTGPU_ERR_HIP, "registrar: the stream-fed matcher gave up (no work, or no progress behind a wait, for ~30 s)");
         return NDTGPU_OK;
     }
     for (int k = 0; k < r->depth; k++) HIP_TRY(hipStreamSynchronize(r->streams[k]));

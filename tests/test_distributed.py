@@ -95,6 +95,32 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
+def test_valid_links_restates_getValidLinks():
+    """NDTFeatureGraph::getValidLinks (ndt_feature_graph.cpp:527-556; defaults ndt_feature_graph_opt.cpp:49-52): score <= 0.1,
+    nodes >= 2 indices apart, the moving node's pose predicted through the link within 1.0 m / 0.2 rad of its own pose --
+    strict inequalities on distance and angle, like upstream."""
+    from ndt_feature_graph_amd import distributed as D
+
+    def pose(x, y, yaw):
+        T = np.eye(4)
+        T[:2, :2] = [[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]
+        T[0, 3], T[1, 3] = x, y
+        return T
+    nodes = np.stack([pose(0, 0, 0), pose(2, 0, 0.1), pose(4, 0, 0.2), pose(6, 1, 0.3)])
+    exact = lambda i, j: np.linalg.inv(nodes[i]) @ nodes[j]
+    edges = np.array([[0, 1], [0, 2], [1, 3], [0, 3], [0, 2], [1, 3]])
+    T = np.stack([exact(0, 1),                                  # consecutive nodes: dropped by min_idx_dist
+                  exact(0, 2),                                  # the odometry itself: kept
+                  exact(1, 3) @ pose(0.5, 0.0, 0.0),            # 0.5 m off: kept
+                  exact(0, 3) @ pose(1.001, 0.0, 0.0),          # 1.001 m off: dropped
+                  exact(0, 2) @ pose(0.0, 0.0, 0.25),           # 0.25 rad off: dropped
+                  exact(1, 3) @ pose(0.0, 0.3, 0.19)])          # 0.3 m and 0.19 rad off: kept
+    assert D.valid_links(edges, T, nodes).tolist() == [1, 2, 5]
+    assert D.valid_links(edges, T, nodes, scores=[0, 0.05, 0.2, 0, 0, 0.1]).tolist() == [1, 5]      # score > 0.1 dropped
+    assert D.valid_links(edges, T, nodes, min_idx_dist=1).tolist() == [0, 1, 2, 5]
+    assert D.valid_links(edges[:0], T[:0], nodes).tolist() == []
+
+
 def test_two_rank_gloo_matches_single_process(tmp_path):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

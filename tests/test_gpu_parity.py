@@ -970,3 +970,42 @@ def test_config4_replay_small(N, O):
         assert pose_close(T_all[e], gt)[0] < 0.05
     keep = D.gate_links(edges, node_T, max_dist=1.0, max_angle=0.2, min_idx_dist=2)
     assert 0 < len(keep) < len(edges)
+
+
+def test_matcher_paths_on_a_grid_far_from_the_origin(N, O, monkeypatch):
+    """Grid centres whose doubles have a busy low word, (12.3, -7.65, 0.2) and per-map centres on top: the persistent kernel
+    keeps the map geometry in LDS, the grid-barrier kernel and the task pool move the centres into scalar registers
+    (v_readfirstlane on both halves of the double) -- all three against the oracle built around the same centres."""
+    from ndt_feature_graph_amd import synth
+    B, res, size = 10, 0.5, [100.0, 100.0, 1.0]
+    pr = synth.pair_2d(list(range(31, 31 + B)), 20000)
+    base = np.array([12.3, -7.65, 0.2])
+    shift = np.stack([base + np.array([0.37 * k, -0.11 * k, 0.0]) for k in range(B)])
+    f = pr["fixed"].numpy() + shift[:, None, :].astype(np.float32)
+    m = pr["moving"].numpy() + shift[:, None, :].astype(np.float32)
+    tg = N.MapSet(res, list(base), size, n_maps=B)
+    sr = N.MapSet(res, list(base), size, n_maps=B)
+    om = []
+    T0 = np.zeros((B, 4, 4))
+    for k in range(B):
+        tg.set_centre(k, shift[k]); sr.set_centre(k, shift[k])
+        S = np.eye(4); S[:3, 3] = shift[k]
+        T0[k] = S @ pr["T_init"].numpy()[k] @ np.linalg.inv(S)
+        a = O.OracleMap(res, shift[k], size); a.load_points(f[k], 30.0, range_origin=shift[k]); a.compute_cells()
+        b = O.OracleMap(res, shift[k], size); b.load_points(m[k], 30.0, range_origin=shift[k]); b.compute_cells()
+        om.append((a, b))
+    tg.build(f, range_limit=30.0, range_origins=shift)
+    sr.build(m, range_limit=30.0, range_origins=shift)
+    idx = np.arange(B)
+    out = {}
+    for name, coop, pool in (("persistent", "0", "0"), ("grid barrier", "1", "0"), ("task pool", "1", "1")):
+        monkeypatch.setenv("NDTGPU_COOP", coop); monkeypatch.setenv("NDTGPU_POOL", pool)
+        out[name] = N.match_batch(tg, idx, sr, idx, T0)
+    for k in range(B):
+        assert np.array_equal(tg.export_cells(k)[2], om[k][0].export_cells()[2])
+        To, ro = O.match_d2d(om[k][0], om[k][1], T0[k])
+        for name, (T, r) in out.items():
+            dt, dr = pose_close(T[k], To)
+            assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (name, k, dt, dr)
+            assert r["iterations"][k] == ro["iterations"] and bool(r["converged"][k]) == ro["converged"], (name, k)
+            assert dt < 1e-7, (name, k, dt)                  # (in fact: summation order only)

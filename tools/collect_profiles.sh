@@ -9,9 +9,11 @@ CMD="python bench.py --steps 10 --warmup 2 --no-cpu --dense-pairs 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o bench -- $CMD > gpurun_out/bench_kt.log 2>&1
 # the same workload without the pipeline: kernel durations with the chip to themselves
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_serial -o bench -- $CMD --no-pipeline > gpurun_out/bench_kt_serial.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_fetch -o bench -- $CMD > gpurun_out/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_write -o bench -- $CMD > gpurun_out/bench_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_sq -o bench -- $CMD > gpurun_out/bench_sq.log 2>&1
+# PMC passes on the SERIAL form: every dispatch is then one build launch of 2048 scans / one matcher launch of 1024 pairs (in the
+# default form one instance of the stream-fed matcher serves many batches: its counters are not "per launch" of anything)
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_fetch -o bench -- $CMD --no-pipeline > gpurun_out/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_write -o bench -- $CMD --no-pipeline > gpurun_out/bench_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_sq -o bench -- $CMD --no-pipeline > gpurun_out/bench_sq.log 2>&1
 for c in 5 fuse; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_$c -o bench -- python bench.py --config $c > gpurun_out/bench_kt_$c.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "ndt_" --output-format csv -d gpurun_out/prof_fetch_$c -o bench -- python bench.py --config $c > gpurun_out/bench_fetch_$c.log 2>&1

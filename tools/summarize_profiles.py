@@ -15,7 +15,10 @@ with open(os.path.join(pr, "%s_bench_kernel_stats.csv" % tag), "w", newline="") 
     w.writerow(list(rows[0].keys()))
     for r in rows[:20]:
         w.writerow([(v[:110] if isinstance(v, str) else v) for v in r.values()])
-ours = {r["Name"][:24]: r for r in rows if "ndt_" in r["Name"]}
+# (the stream-fed matcher's instances, its publish / wait kernels and the pack kernels are not "a launch per step": listed in
+#  the CSV, not in the per-launch summary)
+ours = {r["Name"][:24]: r for r in rows if ("ndt_build" in r["Name"] or "ndt_match_kernel" in r["Name"])}
+stream_rows = [r for r in rows if "ndt_match_stream" in r["Name"] or "ndt_stream_" in r["Name"]]
 serial = {}
 sp = os.path.join(go, "prof_kt_serial", "bench_kernel_stats.csv")
 if os.path.exists(sp):
@@ -30,14 +33,14 @@ if os.path.exists(sp):
 def pmc(dirname):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(os.path.join(go, dirname, "bench_counter_collection.csv"))):
-        k = "ndt_build_kernel" if "ndt_build" in r["Kernel_Name"] else "ndt_match_kernel" if "ndt_match" in r["Kernel_Name"] else r["Kernel_Name"][:30]
+        k = "ndt_build_kernel" if "ndt_build" in r["Kernel_Name"] else "ndt_match_kernel" if "ndt_match_kernel" in r["Kernel_Name"] else r["Kernel_Name"][:30]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
 fetch, write, sq = pmc("prof_fetch"), pmc("prof_write"), pmc("prof_sq")
 sys.path.insert(0, root)
 from ndt_feature_graph_amd import binding
 out = {"round": tag, "lib_version": binding.lib().ndtgpu_version().decode(),   # bench.py refuses a summary of another binary
-       "command": "python bench.py --steps 10 --warmup 2 --no-cpu (1024 pairs x 100k pts per step: one build launch of 2048 scans + one matcher launch, three-buffer pipeline; *_serial: same with --no-pipeline)",
+       "command": "python bench.py --steps 10 --warmup 2 --no-cpu --dense-pairs 0 --no-pipeline for the PMC passes and *_serial (1024 pairs x 100k pts per step: one build launch of 2048 scans + one matcher launch of 1024 pairs, alone on the chip); avg_ns / calls: the same command without --no-pipeline (the registrar's default form: builds beside ONE running instance of ndt_match_stream_kernel; its ndt_match_kernel launches are the bench's serial measuring steps)",
        "note": "FETCH_SIZE / WRITE_SIZE are in KB per dispatch (rocprofv3, separate --pmc passes, --kernel-include-regex ndt_). "
                "On gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM): "
                "hbm_read_bytes = 2 * FETCH_SIZE * 1024.  WRITE_SIZE is taken at face value (uncalibrated).",
@@ -52,6 +55,7 @@ for name, r in ours.items():
     out["kernels"][key]["avg_ns"] = float(r["AverageNs"]); out["kernels"][key]["calls"] = int(r["Calls"])
 for key, r in serial.items():
     out["kernels"][key]["avg_ns_serial"] = float(r["AverageNs"])
+out["stream_fed"] = [{"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"])} for r in stream_rows]
 json.dump(out, open(os.path.join(pr, "%s_pmc_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
 
