@@ -6,6 +6,7 @@ cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 ulimit -c 0
 CMD="python bench.py --steps 10 --warmup 2 --no-cpu --dense-pairs 0"
+$CMD > gpurun_out/bench_warm.log 2>&1      # (a fresh box pages the image in for a minute: not inside a trace)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o bench -- $CMD > gpurun_out/bench_kt.log 2>&1
 # the same workload without the pipeline: kernel durations with the chip to themselves
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt_serial -o bench -- $CMD --no-pipeline > gpurun_out/bench_kt_serial.log 2>&1
