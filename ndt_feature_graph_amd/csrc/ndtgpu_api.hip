@@ -1666,7 +1666,8 @@ static ndtgpu_status match_host_driven(ndtgpu_mapset *ts, const uint32_t *tidx, 
             }
             if (ms.with_h) terms_h += (long long)sums[28]; else terms_g += (long long)sums[28];
             if (getenv("NDTGPU_TRACE"))      // (debugging aid of the host-driven loop: one line per evaluation)
-                fprintf(stderr, "hip eval with_h %d score %.17g g %.9e %.9e %.9e\n", ms.with_h, sums[0], sums[1], sums[2], sums[6]);
+                fprintf(stderr, "hip eval with_h %d phase %d itr %d nfev %d score %.17g g %.9e %.9e %.9e\n", ms.with_h, ms.phase, ms.itr_ctr, ms.mt.nfev,
+                        sums[0], sums[1], sums[2], sums[6]);
             match_state_step(ms, sums, p, ws);
         }
         NdtMatchResultDev o;
