@@ -46,7 +46,12 @@ struct MatchState {
     // ... unless accepting that trial would END the registration (apply_step: |increment| < DELTA_SCORE after the first
     // iteration, or the iteration cap): nobody reads a Hessian then.  That was one wasted Hessian evaluation per converged
     // registration -- 2.5 of the 10.6 evaluations with a Hessian of a bench registration were never consumed.
-    int spec_itr_max, spec_pad;
+    int spec_itr_max;
+    // The line search ended on a trial that met the More-Thuente conditions (info 1): the pose apply_step moves to IS that trial's
+    // pose (the same products, the same rigid product), so when the registration ends there the score the reference evaluates
+    // once more at the returned pose (fusion.h:1085) is the score of the trial just summed -- bit for bit -- and the final
+    // evaluation is not run (it still counts in `fevals`).
+    int final_from_trial;
     double spec_delta;
     // matchFusion soft constraint (fusion.h:875-890): X = pose_local_v, Q = Tcov^-1 (row-major)
     int use_prior;
@@ -603,6 +608,7 @@ NDT_HDN int linesearch_step(MatchState &st, const double *sums, const NdtMatchPa
         // the registration)
         st.reuse_sums = (first_accepted && st.trial_has_h) ? 1 : 0;
         st.spec_ok = first_accepted ? 1 : 0;
+        st.final_from_trial = (info == 1) ? 1 : 0;
         st.mt = m;
         st.step_size = (info == 1) ? m.stp : recoverystep;
         return NEXT_APPLY_STEP;
@@ -671,7 +677,7 @@ NDT_HD void match_state_init(MatchState &st, const double *T16, const NdtMatchPa
     st.itr_ctr = 0; st.fevals = 0; st.ret = 1; st.exit_code = 0;
     st.phase = PH_NEWTON; st.with_h = 1; st.done = 0;
     st.spec_ok = 0; st.trial_has_h = 0; st.reuse_sums = 0;   // the first line search is rarely a full step
-    st.spec_itr_max = prm.itr_max; st.spec_pad = 0; st.spec_delta = prm.delta_score;
+    st.spec_itr_max = prm.itr_max; st.final_from_trial = 0; st.spec_delta = prm.delta_score;
     if ((prm.dof_mask & 0x3f) == 0 || prm.n_neighbours < 0 || prm.n_neighbours > 3) { st.done = 1; st.ret = 0; st.exit_code = -1; }
 }
 
@@ -685,6 +691,7 @@ NDT_HD void match_state_step(MatchState &st, const double *sums, const NdtMatchP
         NDT_STAGE(7, next = linesearch_step(st, sums, prm))
         if (next == NEXT_REQUEST_TRIAL) { NDT_STAGE(6, mt_request_trial(st)) return; }
         NDT_STAGE(5, apply_step(st, prm))
+        if (st.phase == PH_FINAL && st.final_from_trial && !st.use_feat) { match_state_final(st, sums); return; }
         // an accepted first trial that was evaluated with its Hessian: the evaluation apply_step just requested (the
         // next Newton iteration's, or the final one) is the one these sums come from (same cells, same pose)
         if (!st.reuse_sums) return;
