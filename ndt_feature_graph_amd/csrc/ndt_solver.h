@@ -230,11 +230,20 @@ NDT_HDN void mt_request_trial(MatchState &st)
     rigid ps;
     pose_to_rigid(pincr, ps);
     rigid_mul(ps, st.T, st.Teval);     // trial cells = ps * nextNDT (fusion.h:556-589)
-    int spec = (nfev == 0 && st.spec_ok) ? 1 : 0;
-    if (spec && !st.use_feat && stp == 1.0) {
-        // the first trial is the full step: accepted, apply_step sees exactly this norm (incr * 1.0) and these tests
+    // Which trials are evaluated WITH their Hessian: the first one while first trials keep being accepted (spec_ok), and every
+    // trial from the third on -- a search that gets that far ends there nine times in ten (tools/spec_stats.py, 128 bench pairs:
+    // trials per search 1 / 2 / 3 / 4+: 434 / 454 / 244 / 24; the second trial ends 63 % of the searches that reach it, the third
+    // 91 %), and an evaluation with the Hessian that is consumed saves a whole gradient-only one (9.3 k against 11.5 k wave
+    // instructions lost when it is not: worth it above 55 %).  NDT_SPEC_FROM: the trial from which on (experiments).
+#ifndef NDT_SPEC_FROM
+#define NDT_SPEC_FROM 2
+#endif
+    int spec = ((nfev == 0 && st.spec_ok) || (!st.use_feat && nfev >= NDT_SPEC_FROM)) ? 1 : 0;
+    if (spec && !st.use_feat) {
+        // accepted, apply_step takes the step stp * incr and ends the registration when that is shorter than DELTA_SCORE (after
+        // the first iteration) or the iteration cap is reached: nobody reads a Hessian then
         double n2 = 0;
-        for (int a = 0; a < 6; a++) n2 += st.incr[a] * st.incr[a];
+        for (int a = 0; a < 6; a++) { const double v = stp * st.incr[a]; n2 += v * v; }
         if (st.itr_ctr > st.spec_itr_max || (st.itr_ctr > 0 && sqrt(n2) < st.spec_delta)) spec = 0;
     }
     st.trial_has_h = spec;
@@ -606,7 +615,7 @@ NDT_HDN int linesearch_step(MatchState &st, const double *sums, const NdtMatchPa
 
         // sums hold the Hessian at the accepted pose: match_state_step consumes them once more (unless apply_step ends
         // the registration)
-        st.reuse_sums = (first_accepted && st.trial_has_h) ? 1 : 0;
+        st.reuse_sums = (info == 1 && st.trial_has_h) ? 1 : 0;
         st.spec_ok = first_accepted ? 1 : 0;
         st.final_from_trial = (info == 1) ? 1 : 0;
         st.mt = m;

@@ -60,6 +60,11 @@ print("%d pairs, %d line searches, first trial accepted in %.1f %%; after an acc
     len(seqs), n_ls, 100.0 * n_acc / max(1, n_ls),
     100.0 * sum(sum(1 for a, b in zip(s, s[1:]) if a == 1 and b == 1) for s in seqs) / max(1, sum(sum(1 for a in s[:-1] if a == 1) for s in seqs)),
     100.0 * sum(sum(1 for a, b in zip(s, s[1:]) if a != 1 and b == 1) for s in seqs) / max(1, sum(sum(1 for a in s[:-1] if a != 1) for s in seqs))))
+hist = collections.Counter(k for s_ in seqs for k in s_)
+print("trials per line search:", dict(sorted(hist.items())))
+for t in (2, 3, 4):
+    reached = sum(v for k, v in hist.items() if k >= t); acc = hist.get(t, 0)
+    print("  reached trial %d: %d, accepted there: %.1f %%" % (t, reached, 100.0 * acc / max(1, reached)))
 base = cost(lambda i, last: False)
 for name, pol in (("never", lambda i, last: False), ("last outcome (shipped)", lambda i, last: last), ("always", lambda i, last: True),
                   ("always after the first search", lambda i, last: i > 0), ("oracle", None)):
