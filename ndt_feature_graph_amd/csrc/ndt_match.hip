@@ -1909,6 +1909,28 @@ NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &epoch, unsigned G)
     return __hip_atomic_load(&c->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
 }
 
+// Thread (r, k) of 16 x 32 adds value k of rows r, r + 16, ... of `rows` (NC rows of 32 doubles written by other
+// workgroups: system-scope loads).  The loads of a thread are issued EIGHT at a time before the first is used: written as
+// `a += load` the compiler waits for every load before it issues the next (they are atomic accesses and stay in program
+// order), and a registration of 96 chunks paid six dependent round trips across the fabric per evaluation.  Same order
+// of additions as the plain loop.
+NDT_D double sum_rows_16x32(const double *rows, unsigned NC, unsigned r, unsigned k)
+{
+    auto ldd = [](const double *q) {
+        return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    };
+    double a = 0;
+#pragma unroll 1
+    for (unsigned w0 = r; w0 < NC; w0 += 128u) {
+        double v[8];
+#pragma unroll
+        for (unsigned j = 0; j < 8u; j++) v[j] = ldd(rows + (size_t)min(w0 + 16u * j, NC - 1u) * 32 + k);
+#pragma unroll
+        for (unsigned j = 0; j < 8u; j++) if (w0 + 16u * j < NC) a += v[j];
+    }
+    return a;
+}
+
 template <int NN>
 __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
@@ -1981,8 +2003,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     // fewer workgroups than chunks: a workgroup takes CH chunks at a time through ONE pass of up to 64 cells per wave
     // (eval_chunks; with 16 cells per wave TRANSFORM and PROBE would run at a quarter of their width)
     const unsigned seg_lanes = (unsigned)per / 8u;
+    // (as few chunks per pass as give every workgroup at most one pass: 4 registrations of 96 chunks on 64 workgroups each
+    //  take TWO chunks per pass on 48 workgroups -- four per pass kept 24 busy: 2.03 against 1.34 ms)
     const bool packed = gridDim.x < NC && seg_lanes >= 8u && seg_lanes <= 32u;
-    const unsigned CH = packed ? min(4u, 64u / seg_lanes) : 1u;
+    const unsigned CH = !packed ? 1u : min(64u / seg_lanes, NC <= 2u * gridDim.x ? 2u : 4u);
     const unsigned NQ = (NC + CH - 1u) / CH;                     // passes of CH chunks
     const unsigned G = min(gridDim.x, NQ);
     if (g >= G) return;
@@ -2012,11 +2036,18 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         long long b0 = __builtin_readcyclecounter();
         if (!coop_barrier(ctrl, target, G)) { gave_up(); return; }   // the request is published
         if (threadIdx.x == 0) s_cnt[2] += (long long)__builtin_readcyclecounter() - b0;
-        if (threadIdx.x == 0) {
-            for (int i = 0; i < 9; i++) s_T.r[i] = ldd(&ctrl->Teval.r[i]);
-            for (int i = 0; i < 3; i++) s_T.t[i] = ldd(&ctrl->Teval.t[i]);
-            const unsigned long long hd = ld64(&ctrl->with_h);
-            s_with_h = (int)(unsigned)hd; s_done = (int)(unsigned)(hd >> 32);
+        {
+            // the request, one word per lane: ONE round trip across the fabric (a single lane reading the thirteen words
+            // pays one per word -- system-scope loads are issued in program order and each is waited for before its value
+            // goes to LDS)
+            unsigned t = threadIdx.x;
+            asm volatile("" : "+v"(t));
+            if (t < 9) s_T.r[t] = ldd(&ctrl->Teval.r[t]);
+            else if (t < 12) s_T.t[t - 9] = ldd(&ctrl->Teval.t[t - 9]);
+            else if (t == 12) {
+                const unsigned long long hd = ld64(&ctrl->with_h);
+                s_with_h = (int)(unsigned)hd; s_done = (int)(unsigned)(hd >> 32);
+            }
         }
         __syncthreads();
         if (s_done) break;
@@ -2050,9 +2081,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
                 unsigned t = threadIdx.x;
                 asm volatile("" : "+v"(t));           // (recomputed here: hoisted out of the loop the shift is kept in a spilled register)
                 const unsigned k = t & 31u, r = t >> 5;
-                double a = 0;
-                for (unsigned w = r; w < NC; w += 16u) a += ldd(partials + w * 32 + k);
-                sh.src[r * 32 + k] = a;                    // the source tile buffer is free between evaluations
+                sh.src[r * 32 + k] = sum_rows_16x32(partials, NC, r, k);    // the source tile buffer is free between evaluations
             }
             __syncthreads();
             if (threadIdx.x < 29) {
@@ -2206,7 +2235,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
     __shared__ rigid s_T;
     __shared__ double s_rows[4 * NDT_VW * 32];      // eval_chunks: up to 4 chunks x 8 shares x 32 sums
     __shared__ double s_out[4 * 32];                // ... and their sums over the shares
-    __shared__ unsigned s_task[10];         // pair, task, with_h, code, last, evaluation, chunks, chunks per task, cells per chunk, tasks
+    __shared__ unsigned s_task[12];         // pair, task, with_h, code, last, evaluation, chunks, chunks per task, cells per chunk, tasks, next chunks per task
     __shared__ long long s_clk;
     enum { POOL_TASK = 0, POOL_NONE = 1, POOL_EXIT = 2 };
     const unsigned tid = threadIdx.x;
@@ -2220,8 +2249,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
     auto tk_drawn = [](unsigned long long t) { return (unsigned)t & 0xFFFFFu; };
     // chunks per task of the NEXT evaluation of a registration of NC chunks (seg_lanes lanes per chunk and share): four
     // through one pass while the registrations still running have more chunks than the launch has workgroups, one otherwise
-    auto chunks_per_task = [&](unsigned NC, unsigned seg_lanes) {
+    auto chunks_per_task = [&](unsigned NC, unsigned seg_lanes) -> unsigned {
         const unsigned active = n_pairs - min(n_pairs, aload(&ctl->finished));
+        // (two chunks per task in the tail as well -- half as many draws and deliveries per evaluation -- was measured: 32
+        //  pairs of 12 k-cell maps 4.90 against 4.75 ms, four: 5.00)
         const bool packed = (size_t)active * NC > gridDim.x && seg_lanes >= 8u && seg_lanes <= 32u;
         return packed ? min(4u, 64u / seg_lanes) : 1u;
     };
@@ -2308,6 +2339,10 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
             // registrations; one lane walking them paid one round trip EACH, and an idle workgroup took 20 us to notice the
             // evaluation that the last registration of 32 had just opened), the first lane with an open ticket draws.
             unsigned code = POOL_NONE;
+            // (the two words that end the launch travel with the tickets: read on their own when nothing is open they made
+            //  an idle workgroup's look-around three round trips long)
+            unsigned ctl_word = 0u;
+            if (tid < 2) ctl_word = aload(tid == 0 ? &ctl->finished : &ctl->abort);
             for (unsigned base = 0; base < n_pairs && code == POOL_NONE; base += 64u) {
                 const unsigned k = base + tid;
                 const unsigned q = (home + k) % n_pairs;
@@ -2318,32 +2353,58 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
                 while (open != 0ull && code == POOL_NONE) {
                     const unsigned l = (unsigned)__builtin_ctzll(open);
                     open &= open - 1ull;
+                    // Lane l draws; the sixteen lanes after it read the request of that registration AT THE SAME TIME (one
+                    // word each).  The ticket was seen open for evaluation S before these loads were issued, so they return
+                    // the request of S or of a later evaluation -- and if the draw wins a task of S, S is still open when
+                    // it does (this task is undelivered) and its request has not been overwritten.  A draw that wins a task of a
+                    // LATER evaluation (S ended in between) may have read a request in the middle of being rewritten: it reads
+                    // again, the slow way.
+                    NdtPoolPair *Pl = pair_at((home + base + l) % n_pairs);
+                    const unsigned j = (tid - l - 1u) & 63u;
+                    unsigned long long req64 = 0ull;
+                    unsigned req32 = 0u;
                     int won = 0;
                     if (tid == l) {
+                        const unsigned seen = tk_seq(t);
                         t = __hip_atomic_fetch_add(&P->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (tk_seq(t) != 0u && tk_drawn(t) < tk_tasks(t)) {
                             won = 1;
                             s_task[0] = q; s_task[1] = tk_drawn(t); s_task[5] = tk_seq(t); s_task[9] = tk_tasks(t);
+                            s_task[11] = tk_seq(t) != seen ? 1u : 0u;
                         }
+                    } else if (j < 9u) req64 = ld64(&Pl->Teval.r[j]);
+                    else if (j < 12u) req64 = ld64(&Pl->Teval.t[j - 9u]);
+                    else if (j == 12u) req32 = ld32(&Pl->with_h);
+                    else if (j == 13u) req32 = ld32(&Pl->n_chunks);
+                    else if (j == 14u) req32 = ld32(&Pl->chunks_per_task);
+                    else if (j == 15u) req32 = ld32(&Pl->per);
+                    if (ndt_ballot(won)) {
+                        code = POOL_TASK;
+                        if (j < 9u) s_T.r[j] = __builtin_bit_cast(double, req64);
+                        else if (j < 12u) s_T.t[j - 9u] = __builtin_bit_cast(double, req64);
+                        else if (j == 12u) s_task[2] = req32;
+                        else if (j == 13u) s_task[6] = req32;
+                        else if (j == 14u) s_task[7] = req32;
+                        else if (j == 15u) s_task[8] = req32;
                     }
-                    if (ndt_ballot(won)) code = POOL_TASK;
                 }
             }
             if (code == POOL_TASK) {
-                // the request of the registration that was drawn from: one word per lane
                 ndt_wave_sync();
-                const unsigned q = s_task[0];
-                NdtPoolPair *P = pair_at(q);
-                if (tid < 9) s_T.r[tid] = ldd(&P->Teval.r[tid]);
-                else if (tid < 12) s_T.t[tid - 9] = ldd(&P->Teval.t[tid - 9]);
-                else if (tid == 12) s_task[2] = ld32(&P->with_h);
-                else if (tid == 13) s_task[6] = ld32(&P->n_chunks);
-                else if (tid == 14) s_task[7] = ld32(&P->chunks_per_task);
-                else if (tid == 15) s_task[8] = ld32(&P->per);
-                home = q;                                                     // (look here first next time)
+                if (s_task[11] != 0u) {
+                    NdtPoolPair *P = pair_at(s_task[0]);
+                    if (tid < 9) s_T.r[tid] = ldd(&P->Teval.r[tid]);
+                    else if (tid < 12) s_T.t[tid - 9] = ldd(&P->Teval.t[tid - 9]);
+                    else if (tid == 12) s_task[2] = ld32(&P->with_h);
+                    else if (tid == 13) s_task[6] = ld32(&P->n_chunks);
+                    else if (tid == 14) s_task[7] = ld32(&P->chunks_per_task);
+                    else if (tid == 15) s_task[8] = ld32(&P->per);
+                }
+                home = s_task[0];                                             // (look here first next time)
                 idle = 0;
             } else {
-                if (aload(&ctl->finished) >= n_pairs || aload(&ctl->abort) != 0u) code = POOL_EXIT;
+                const unsigned long long ended = ndt_ballot((tid == 0 && ctl_word >= n_pairs) || (tid == 1 && ctl_word != 0u));
+                if (ended != 0ull) code = POOL_EXIT;
                 // nothing open: somebody is in a solver step (or everything left is being evaluated).  ~10 s of this
                 // means a bug, not a wait: raise the abort word instead of hanging the device
                 else if (++idle > (1u << 23)) {
@@ -2406,9 +2467,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
         {
             // 16 x 32 threads: thread (r, k) adds value k of chunks r, r + 16, ...; the 16 rows are then added in order
             const unsigned k = ft & 31u, r = ft >> 5;
-            double a = 0;
-            for (unsigned w = r; w < NC; w += 16u) a += ldd(rows + w * 32 + k);
-            sh.src[r * 32 + k] = a;                        // the source tile buffer is free between evaluations
+            sh.src[r * 32 + k] = sum_rows_16x32(rows, NC, r, k);       // the source tile buffer is free between evaluations
         }
         {
             const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&P->st);
@@ -2422,14 +2481,18 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
             sh.sums[ft] = a;
         }
         __syncthreads();
+        // (how the NEXT evaluation is cut depends on how many registrations are still running: that word is read by another
+        //  wave while thread 0 runs the solver step, and travels with the request)
+        if (ft == 64) s_task[10] = chunks_per_task(NC, s_task[8] / 8u);
         if (ft == 0) {
             // (the delivery counter goes back to zero now: nobody touches it before the next ticket, and the store is long
             //  complete when that is published after the solver step)
             __hip_atomic_store(&P->done_tasks, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long long d0 = __builtin_readcyclecounter();
-            st64(&P->cnt[with_h ? 3 : 2], ld64(&P->cnt[with_h ? 3 : 2]) + (unsigned long long)(long long)sh.sums[28]);
+            // (counters: atomics that return nothing -- read, add, store cost two round trips across the fabric per evaluation)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&P->cnt[with_h ? 3 : 2]), (unsigned long long)(long long)sh.sums[28]);
             match_state_step(st, sh.sums, s_prm, s_ws);
-            st64(&P->cnt[1], ld64(&P->cnt[1]) + (unsigned long long)((long long)__builtin_readcyclecounter() - d0));
+            atomicAdd(reinterpret_cast<unsigned long long *>(&P->cnt[1]), (unsigned long long)((long long)__builtin_readcyclecounter() - d0));
         }
         __syncthreads();
         if (st.done) {
@@ -2441,12 +2504,11 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
             if (ft < 9) std_(&P->Teval.r[ft], st.Teval.r[ft]);
             else if (ft < 12) std_(&P->Teval.t[ft - 9], st.Teval.t[ft - 9]);
             else if (ft == 12) st32(&P->with_h, (unsigned)st.with_h);
+            else if (ft == 13) st32(&P->chunks_per_task, s_task[10]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (ft == 0) {
-                const unsigned CHn = chunks_per_task(NC, s_task[8] / 8u);
-                st32(&P->chunks_per_task, CHn);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned CHn = s_task[10];
                 __hip_atomic_store(&P->ticket, tk_make(s_task[5] + 1u, (NC + CHn - 1u) / CHn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }

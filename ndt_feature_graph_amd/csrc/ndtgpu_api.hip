@@ -214,7 +214,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.5.4 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.5.5 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -923,9 +923,14 @@ static bool coop_plan(const ndtgpu_mapset *ss, size_t n_pairs, const NdtMatchPar
 {
     const unsigned capacity = ndt_match_coop_capacity(p.n_neighbours);
     if (capacity == 0 || n_pairs == 0 || n_pairs > capacity) return false;
-    // 128 source cells per chunk (16 per wave; fewer stop paying: barrier + solver latency dominate)
+    // Source cells per chunk -- a property of the source SET (its cell capacity), so that a registration's rows, and with
+    // them its bits, do not depend on the batch it is in.  Sets of small maps (planar scans): 128 (16 per wave; fewer stop
+    // paying: barrier + solver latency dominate).  Sets that hold large maps (3D sweeps, >= 16 k cells): 256 -- every chunk
+    // costs its own pass over the pair terms (batches of 64 that end half empty) and its own wave sum, and every row a
+    // hand-over: 12 k-cell maps, 4 / 8 / 16 / 32 pairs 1.41 / 2.33 / 3.57 / 4.75 ms with 128 against 1.34 / 2.20 / 3.29 /
+    // 4.34 ms with 256 (384: 32 pairs 4.63, 512: 4.56); one pair alone 1.11 against 1.33 ms -- half as many workgroups.
     const char *cpg = getenv("NDTGPU_COOP_CELLS");
-    pl.per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : 128u;
+    pl.per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : (ss->v.grid.max_cells >= 16384u ? 256u : 128u);
     const unsigned n_chunks = std::max(1u, (ss->v.grid.max_cells + pl.per_group - 1u) / pl.per_group);
     // Up to 8 registrations: the grid-barrier kernel (static teams, the solver state stays in one workgroup's LDS: 12 k-cell
     // 3D maps, 1 / 4 / 8 pairs 1.63 / 2.30 / 3.01 ms against 1.94 / 2.57 / 3.14 ms).  More: the task pool (any workgroup
