@@ -497,11 +497,11 @@ def config5(args, torch, N, binding, synth, dev):
                                           "frac_of_fp64_peak": gflop / match_ms / 78.6, "mean_iterations": float(r["iterations"].mean()),
                                           "converged_frac": float(r["converged"].mean()),
                                           "note": "task-pool matcher (a batch that cannot fill the chip with one workgroup per registration): one "
-                                                  "asynchronous launch, any workgroup takes any (registration, evaluation, four 128-cell chunks) task; "
+                                                  "asynchronous launch, any workgroup takes any (registration, evaluation, two 256-cell chunks) task; "
                                                   "NDTGPU_POOL=0: static teams at a grid barrier, 10.7 ms; NDTGPU_DEVICE_COOP=0: persistent kernel, one "
                                                   "CU per registration, 65 ms"}},
            "single_pair": {"ms_build_x2_plus_match": pair_ms, "note": "host-synchronous ndtgpu_mapset_build + ndtgpu_match_d2d (grid-barrier "
-                                                                         "kernel, a workgroup per 128-cell chunk)"}}
+                                                                         "kernel, a workgroup per 256-cell chunk)"}}
     print(json.dumps(out))
 
 
