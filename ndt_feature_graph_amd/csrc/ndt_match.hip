@@ -1030,6 +1030,10 @@ NDT_D void feat_linesearch_and_apply(MatchSlot<QL> &S, const NdtMatchParamsDev &
 
 // The solver step of a slot whose evaluation (S.sums) is complete.  Without feature maps: match_state_step on lane 0.
 // With them the wave walks the same stages itself, because the feature sums are evaluated by all of its lanes.
+// (Round 5 measured the trial / step poses on TWELVE LANES -- three lanes take the (sin, cos) pairs, twelve the entries of
+//  TR = Trans Rx Ry Rz and of TR * T, operands handed over through a table in LDS, bit for bit the serial result: a lone
+//  ITR_MAX registration took 2.05 instead of 1.93 ms.  What a solver stage waits for is not its arithmetic but its LDS round
+//  trips -- five hand-overs through LDS cost more than the ~150 dependent instructions they replaced.  tools/timeline_match.py.)
 template <int QL>
 NDT_D void slot_step(MatchSlot<QL> &S, const NdtMatchParamsDev &prm)
 {
@@ -1511,9 +1515,13 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                 unsigned new_state = SLOT_BUSY;
                 while (new_state == SLOT_BUSY) {
                     unsigned c = E.cur;
+                    // (the queue words in ONE round trip: system-scope loads are issued in program order and waited for where
+                    //  they are first used.  `published` is a plain load here: the acquire that goes with it is the fence below,
+                    //  once per workgroup and batch -- as an acquire LOAD it invalidated this CU's L1 for every registration)
                     const unsigned fo = sys_load(&q->first_open);
+                    const unsigned pub = sys_load(&q->published);
+                    const unsigned comp = sys_load(&q->completed);
                     if ((int)(c - fo) < 0) c = fo;
-                    const unsigned pub = __hip_atomic_load(&q->published, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                     E.cur = c;
                     if ((int)(c - pub) >= 0) {
                         // nothing to draw.  Everything published complete as well: this instance is done (a batch published
@@ -1522,7 +1530,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                         //  complete before the next one is published, and CUs given up now are taken by that build's workgroups,
                         //  behind which the next instance would have to queue)
                         new_state = SLOT_FREE;
-                        if (sys_load(&q->completed) == pub) {
+                        if (comp == pub) {
                             const unsigned now = (unsigned)wall_clock64() | 1u;
                             if (!E.worked || linger == 0u) new_state = SLOT_CLOSED;
                             else if (E.dry_since == 0u) E.dry_since = now;
@@ -1533,26 +1541,39 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                         break;
                     }
                     NdtStreamBatch *B = &q->b[c % ring];
+                    // (what changes from batch to batch in a ring entry is read past the caches; B->set never changes)
+                    // The ticket first, the descriptor after it: a ring entry is only re-published once its batch is complete,
+                    // so whoever holds a ticket below n_pairs reads the descriptor of the batch the ticket belongs to -- and
+                    // takes the batch's number from there (a workgroup that was held up between the queue words and the draw
+                    // for longer than a whole batch takes would otherwise file the registration under the old number).
+                    const volatile NdtStreamBatch *Bv = B;
+                    const unsigned f = __hip_atomic_fetch_add(&B->fresh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // (the whole descriptor in one round trip, before the first of its words is looked at)
+                    const unsigned n = Bv->n_pairs, bseq = Bv->seq;
+                    const int d_nn = Bv->prm.n_neighbours, d_itr = Bv->prm.itr_max, d_sc = Bv->prm.step_control, d_dof = Bv->prm.dof_mask;
+                    const int d_uig = Bv->prm.use_initial_guess, d_ff = Bv->prm.fusion_flags;
+                    const double d_ds = Bv->prm.delta_score, d_l1 = Bv->prm.lfd1, d_l2 = Bv->prm.lfd2;
+                    double *const d_T16 = Bv->T16;
+                    NdtMatchResultDev *const d_res = Bv->res;
+                    if (f >= n) {
+                        if (bseq == c) {
+                            __hip_atomic_fetch_max(&q->first_open, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            E.cur = c + 1u;
+                        }
+                        continue;
+                    }
+                    c = bseq; E.cur = c;
                     // ONE acquire per workgroup and batch (batches are taken in order: whoever of the workgroup's slots reaches
                     // batch c first does it -- the invalidate also drops the maps its XCD's other registrations are reading)
                     if ((int)(lds_load(&s_seen) - (c + 1u)) < 0) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (system scope: this CU's L1, this XCD's L2)
                         lds_store(&s_seen, c + 1u);
                     }
-                    // (what changes from batch to batch in a ring entry is read past the caches; B->set never changes)
-                    const volatile NdtStreamBatch *Bv = B;
-                    const unsigned n = Bv->n_pairs;
-                    const unsigned f = __hip_atomic_fetch_add(&B->fresh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (f >= n) {
-                        __hip_atomic_fetch_max(&q->first_open, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        E.cur = c + 1u;
-                        continue;
-                    }
-                    E.prm.n_neighbours = Bv->prm.n_neighbours; E.prm.itr_max = Bv->prm.itr_max; E.prm.step_control = Bv->prm.step_control;
-                    E.prm.dof_mask = Bv->prm.dof_mask; E.prm.use_initial_guess = Bv->prm.use_initial_guess;
-                    E.prm.fusion_flags = Bv->prm.fusion_flags; E.prm.delta_score = Bv->prm.delta_score;
-                    E.prm.lfd1 = Bv->prm.lfd1; E.prm.lfd2 = Bv->prm.lfd2;
-                    E.T16 = Bv->T16; E.res = Bv->res; E.done_ctr = &B->done; E.n_pairs = n; E.seq = c;
+                    E.prm.n_neighbours = d_nn; E.prm.itr_max = d_itr; E.prm.step_control = d_sc;
+                    E.prm.dof_mask = d_dof; E.prm.use_initial_guess = d_uig;
+                    E.prm.fusion_flags = d_ff; E.prm.delta_score = d_ds;
+                    E.prm.lfd1 = d_l1; E.prm.lfd2 = d_l2;
+                    E.T16 = d_T16; E.res = d_res; E.done_ctr = &B->done; E.n_pairs = n; E.seq = c;
                     const unsigned pair = f, ti = f, si = n + f;
                     bool finished = false;
                     if (B->set.counters[ti].overflow != 0u || B->set.counters[si].overflow != 0u) {

@@ -46,6 +46,7 @@ NDT_HD bool inverse_check(sym3 a, sym3 &inv)
 }
 
 struct rigid { double r[9]; double t[3]; };   // row-major rotation + translation
+static_assert(sizeof(rigid) == 12 * sizeof(double), "rigid is twelve consecutive doubles (compose_pose_wave writes entry e of them)");
 
 NDT_HD d3 apply(const rigid &T, d3 p)
 {
@@ -78,16 +79,17 @@ NDT_HD sym3 rotate_cov(const double *R, sym3 c)
 // pose.  Larger angles take the library functions.
 NDT_HD void sincos_pose(double x, double &sn, double &cs)
 {
+    // (one fixed sequence of operations wherever this is inlined: explicit fma, no other contraction)
+#pragma clang fp contract(off)
     if (fabs(x) <= 0.78539816339744830962) {
         const double z = x * x, w = z * z;
-        const double rs = 8.33333333332248946124e-03 +
-                          z * (-1.98412698298579493134e-04 +
-                               z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-        sn = x + (z * x) * (-1.66666666666666324348e-01 + z * rs);
-        const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
-                          (w * w) * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+        const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+        sn = fma(z * x, fma(z, rs, -1.66666666666666324348e-01), x);
+        const double rc = fma(w * w, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                              z * fma(z, fma(z, 2.48015872894767294178e-05, -1.38888888888741095749e-03), 4.16666666666666019037e-02));
         const double hz = 0.5 * z, c1 = 1.0 - hz;
-        cs = c1 + (((1.0 - c1) - hz) + z * rc);
+        cs = c1 + fma(z, rc, (1.0 - c1) - hz);
     } else {
         sn = sin(x);
         cs = cos(x);
@@ -95,16 +97,20 @@ NDT_HD void sincos_pose(double x, double &sn, double &cs)
 }
 
 // TR = Translation(p0,p1,p2) * Rx(p3) * Ry(p4) * Rz(p5)   (ndt_matcher_d2d_fusion.h:1036-1039)
+// Every entry is written as ONE fixed sequence of operations (explicit fma, no expression the compiler may contract one way
+// here and another way there): the persistent matchers compute the twelve entries on twelve lanes (compose_pose_wave in
+// ndt_match.hip, from the same operands through the same operations), everybody else on one, and the bits agree.
 NDT_HD void pose_to_rigid(const double *p, rigid &T)
 {
     double cx, sx, cy, sy, cz, sz;
     sincos_pose(p[3], sx, cx);
     sincos_pose(p[4], sy, cy);
     sincos_pose(p[5], sz, cz);
+    const double P = sx * sy, Q = cx * sy;
     // Rx*Ry*Rz
-    T.r[0] = cy * cz;                  T.r[1] = -cy * sz;                 T.r[2] = sy;
-    T.r[3] = cx * sz + sx * sy * cz;   T.r[4] = cx * cz - sx * sy * sz;   T.r[5] = -sx * cy;
-    T.r[6] = sx * sz - cx * sy * cz;   T.r[7] = sx * cz + cx * sy * sz;   T.r[8] = cx * cy;
+    T.r[0] = cy * cz;               T.r[1] = (-cy) * sz;             T.r[2] = sy;
+    T.r[3] = fma(P, cz, cx * sz);   T.r[4] = fma(-P, sz, cx * cz);   T.r[5] = (-sx) * cy;
+    T.r[6] = fma(-Q, cz, sx * sz);  T.r[7] = fma(Q, sz, sx * cz);    T.r[8] = cx * cy;
     T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];
 }
 
@@ -114,8 +120,8 @@ NDT_HD void rigid_mul(const rigid &A, const rigid &B, rigid &C)
     rigid o;
     for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++)
-            o.r[i * 3 + j] = A.r[i * 3] * B.r[j] + A.r[i * 3 + 1] * B.r[3 + j] + A.r[i * 3 + 2] * B.r[6 + j];
-        o.t[i] = A.r[i * 3] * B.t[0] + A.r[i * 3 + 1] * B.t[1] + A.r[i * 3 + 2] * B.t[2] + A.t[i];
+            o.r[i * 3 + j] = fma(A.r[i * 3 + 2], B.r[6 + j], fma(A.r[i * 3 + 1], B.r[3 + j], A.r[i * 3] * B.r[j]));
+        o.t[i] = fma(A.r[i * 3 + 2], B.t[2], fma(A.r[i * 3 + 1], B.t[1], A.r[i * 3] * B.t[0])) + A.t[i];
     }
     C = o;
 }

@@ -205,6 +205,10 @@ NDT_HD int mt_cstep(double &stx, double &fx, double &dx, double &sty, double &fy
 // head of the More-Thuente while(1) body (fusion.h:523-561): pick the trial step and request its evaluation.
 // A stage of its own (the More-Thuente block is handed over in st.mt): the trial pose costs three rigid transforms
 // in registers.
+// EVERY stage reads what it needs FIRST, into locals, and stores at its end: the state lives in LDS behind a generic pointer,
+// a value that is only loaded where the code needs it costs a full round trip (the flat loads of a stage are waited for
+// all together), and a stage that loaded field by field between its branches and stores spent most of its time in those
+// waits (mt_request_trial: 16 of them, 3.3 k clocks for ~150 executed instructions; round 5).
 NDT_HDN void mt_request_trial(MatchState &st)
 {
     const double stpmax = 4.0, stpmin = 0.001, xtol = 0.01;
@@ -212,6 +216,11 @@ NDT_HDN void mt_request_trial(MatchState &st)
     double stp = st.mt.stp, stmin, stmax;
     const double stx = st.mt.stx, sty = st.mt.sty;
     const int brackt = st.mt.brackt, nfev = st.mt.nfev, infoc = st.mt.infoc;
+    double incr[6];
+    for (int a = 0; a < 6; a++) incr[a] = st.incr[a];
+    const rigid T = st.T;
+    const int spec_ok = st.spec_ok, use_feat = st.use_feat, itr_ctr = st.itr_ctr, spec_itr_max = st.spec_itr_max;
+    const double spec_delta = st.spec_delta;
     if (brackt) {
         stmin = dmin(stx, sty);
         stmax = dmax(stx, sty);
@@ -224,12 +233,11 @@ NDT_HDN void mt_request_trial(MatchState &st)
     if ((brackt && ((stp <= stmin) || (stp >= stmax))) || (nfev >= maxfev - 1) ||
         (infoc == 0) || (brackt && (stmax - stmin <= xtol * stmax)))
         stp = stx;
-    st.mt.stp = stp; st.mt.stmin = stmin; st.mt.stmax = stmax;
     double pincr[6];
-    for (int a = 0; a < 6; a++) pincr[a] = stp * st.incr[a];
-    rigid ps;
+    for (int a = 0; a < 6; a++) pincr[a] = stp * incr[a];
+    rigid ps, Te;
     pose_to_rigid(pincr, ps);
-    rigid_mul(ps, st.T, st.Teval);     // trial cells = ps * nextNDT (fusion.h:556-589)
+    rigid_mul(ps, T, Te);              // trial cells = ps * nextNDT (fusion.h:556-589)
     // Which trials are evaluated WITH their Hessian: the first one while first trials keep being accepted (spec_ok), and every
     // trial from the third on -- a search that gets that far ends there nine times in ten (tools/spec_stats.py, 128 bench pairs:
     // trials per search 1 / 2 / 3 / 4+: 434 / 454 / 244 / 24; the second trial ends 63 % of the searches that reach it, the third
@@ -238,16 +246,18 @@ NDT_HDN void mt_request_trial(MatchState &st)
 #ifndef NDT_SPEC_FROM
 #define NDT_SPEC_FROM 2
 #endif
-    int spec = ((nfev == 0 && st.spec_ok) || (!st.use_feat && nfev >= NDT_SPEC_FROM)) ? 1 : 0;
-    if (spec && !st.use_feat) {
+    int spec = ((nfev == 0 && spec_ok) || (!use_feat && nfev >= NDT_SPEC_FROM)) ? 1 : 0;
+    if (spec && !use_feat) {
         // accepted, apply_step takes the step stp * incr and ends the registration when that is shorter than DELTA_SCORE (after
         // the first iteration) or the iteration cap is reached: nobody reads a Hessian then
         double n2 = 0;
-        for (int a = 0; a < 6; a++) { const double v = stp * st.incr[a]; n2 += v * v; }
-        if (st.itr_ctr > st.spec_itr_max || (st.itr_ctr > 0 && sqrt(n2) < st.spec_delta)) spec = 0;
+        for (int a = 0; a < 6; a++) n2 += pincr[a] * pincr[a];
+        if (itr_ctr > spec_itr_max || (itr_ctr > 0 && sqrt(n2) < spec_delta)) spec = 0;
     }
+    st.mt.stp = stp; st.mt.stmin = stmin; st.mt.stmax = stmax;
+    st.Teval = Te;
     st.trial_has_h = spec;
-    st.with_h = st.trial_has_h;
+    st.with_h = spec;
     st.phase = PH_LS_TRIAL;
 }
 
@@ -255,27 +265,32 @@ NDT_HDN void mt_request_trial(MatchState &st)
 NDT_HDN void apply_step(MatchState &st, const NdtMatchParamsDev &prm)
 {
     const double step_size = st.step_size;
+    double incr[6], pl[6];
+    for (int a = 0; a < 6; a++) { incr[a] = st.incr[a]; pl[a] = st.pose_local[a]; }
+    const rigid T = st.T;
+    const int itr_ctr = st.itr_ctr, itr_max = prm.itr_max;
+    const double delta_score = prm.delta_score;
     double inorm = 0;
     for (int a = 0; a < 6; a++) {
-        st.incr[a] *= step_size;
-        inorm += st.incr[a] * st.incr[a];
+        incr[a] *= step_size;
+        inorm += incr[a] * incr[a];
     }
     inorm = sqrt(inorm);
-    for (int a = 0; a < 6; a++) st.pose_local[a] += st.incr[a];   // fusion.h:1045
-    rigid TR;
-    pose_to_rigid(st.incr, TR);
-    rigid_mul(TR, st.T, st.T);          // T = TR*T
+    for (int a = 0; a < 6; a++) pl[a] += incr[a];   // fusion.h:1045
+    rigid TR, Tn;
+    pose_to_rigid(incr, TR);
+    rigid_mul(TR, T, Tn);               // T = TR*T
     bool convergence = false;
-    if (st.itr_ctr > 0) convergence = (inorm < prm.delta_score);
-    if (st.itr_ctr > prm.itr_max) {
-        convergence = true;
-        st.ret = 0;
-        st.exit_code = 3;
-    }
-    st.itr_ctr++;
-    st.Teval = st.T;
-    if (convergence) { st.phase = PH_FINAL; st.with_h = 0; }
-    else { st.phase = PH_NEWTON; st.with_h = 1; }
+    if (itr_ctr > 0) convergence = (inorm < delta_score);
+    const bool capped = itr_ctr > itr_max;
+    if (capped) convergence = true;
+    for (int a = 0; a < 6; a++) { st.incr[a] = incr[a]; st.pose_local[a] = pl[a]; }
+    st.T = Tn;
+    st.Teval = Tn;
+    if (capped) { st.ret = 0; st.exit_code = 3; }
+    st.itr_ctr = itr_ctr + 1;
+    st.phase = convergence ? PH_FINAL : PH_NEWTON;
+    st.with_h = convergence ? 0 : 1;
 }
 
 // ---- one Newton iteration (fusion.h:857-1031) in STAGES ------------------------------------------------------
@@ -326,13 +341,24 @@ NDT_HD void newton_mask(double (&H)[6][6], double (&g)[6], const NdtMatchParamsD
 // stage 1: score, best pose, Hessian / gradient assembly (fusion.h:857-920), inactive dofs, gradient norm
 NDT_HDN void newton_assemble(MatchState &st, const double *sums, const double *fsums, const NdtMatchParamsDev &prm, NewtonWs &ws)
 {
-    st.fevals++;
-    st.score_here = sums[0];
-    if (st.use_feat) st.score_here += fsums[0];          // fusion.h:863-871: score_here_ndt + score_here_feat
-    if (st.use_prior) st.score_here += prior_score(st);   // fusion.h:875-890
-    if (!st.use_tikhonov && st.score_here < st.score_best) {   // fusion.h:914-920 (with Tikhonov: after its term, below)
-        st.Tbest = st.T;
-        st.score_best = st.score_here;
+    // (inputs first, see mt_request_trial: the 28 sums, the flags, the best score and the pose that may become the best one)
+    double s[28];
+#pragma unroll
+    for (int k = 0; k < 28; k++) s[k] = sums[k];
+    const int use_feat = st.use_feat, use_prior = st.use_prior, use_tikhonov = st.use_tikhonov, fevals = st.fevals;
+    const double score_best = st.score_best;
+    const rigid Tcur = st.T;
+    if (use_feat) {                                       // fusion.h:863-871: score, gradient and Hessian += those of the feature maps
+#pragma unroll
+        for (int k = 0; k < 28; k++) s[k] += fsums[k];
+    }
+    double score_here = s[0];
+    if (use_prior) score_here += prior_score(st);         // fusion.h:875-890
+    st.fevals = fevals + 1;
+    st.score_here = score_here;
+    if (!use_tikhonov && score_here < score_best) {       // fusion.h:914-920 (with Tikhonov: after its term, below)
+        st.Tbest = Tcur;
+        st.score_best = score_here;
     }
     // Hessian in registers (static indices).  Inactive dofs (NDTMatcherD2D_2D) are decoupled and given
     // the diagonal value of the first active dof, which leaves lambda_min / lambda_max of the active
@@ -344,12 +370,11 @@ NDT_HDN void newton_assemble(MatchState &st, const double *sums, const double *f
         for (int a = 0; a < 6; a++)
 #pragma unroll
             for (int b = a; b < 6; b++) {
-                double h = sums[o];
-                if (st.use_feat) h += fsums[o];     // Hessian += Hessian_feat
+                const double h = s[o];
                 H[a][b] = h; H[b][a] = h; o++;
             }
     }
-    if (st.use_prior) {                    // + computeHessianMahalanobis = Q + Q^T   (fusion.h:11-22)
+    if (use_prior) {                       // + computeHessianMahalanobis = Q + Q^T   (fusion.h:11-22)
 #pragma unroll
         for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -357,9 +382,8 @@ NDT_HDN void newton_assemble(MatchState &st, const double *sums, const double *f
     }
 #pragma unroll
     for (int a = 0; a < 6; a++) {
-        g[a] = sums[1 + a];
-        if (st.use_feat) g[a] += fsums[1 + a];
-        if (st.use_prior) {                // + computeGradientMahalanobis = (Q + Q^T) X   (fusion.h:29-32)
+        g[a] = s[1 + a];
+        if (use_prior) {                   // + computeGradientMahalanobis = (Q + Q^T) X   (fusion.h:29-32)
             double gp = 0;
 #pragma unroll
             for (int j = 0; j < 6; j++) gp += (st.Q[a * 6 + j] + st.Q[j * 6 + a]) * st.pose_local[j];
@@ -367,7 +391,7 @@ NDT_HDN void newton_assemble(MatchState &st, const double *sums, const double *f
         }
         ws.gpre[a] = g[a];
     }
-    if (st.use_tikhonov) {                 // (stage 1b takes over: the two matrices of H^T H do not fit beside this one)
+    if (use_tikhonov) {                    // (stage 1b takes over: the two matrices of H^T H do not fit beside this one)
 #pragma unroll
         for (int a = 0; a < 6; a++) {
             ws.g[a] = g[a];
@@ -474,15 +498,17 @@ NDT_HDN void newton_ldlt(NewtonWs &ws)
 // head of lineSearchMT (fusion.h:444-521) on the function whose value and gradient at the current pose are finit / g6:
 // direction test (the increment is negated IN PLACE when it points uphill, recovery step when it still does), then the
 // More-Thuente block.  NEXT_APPLY_STEP: the search is over (st.step_size = recovery step); NEXT_REQUEST_TRIAL: st.mt is set up.
-NDT_HD int mt_start(MatchState &st, double finit, const double *g6)
+// start of a More-Thuente search along `incr` (in registers; the caller stores it): fusion.h:444-521
+NDT_HD int mt_start_local(MatchState &st, double finit, const double *g6, double (&incr)[6])
 {
     MTState m;
     m.finit = finit;
     m.dginit = 0;
 #pragma unroll
-    for (int a = 0; a < 6; a++) m.dginit += st.incr[a] * g6[a];
+    for (int a = 0; a < 6; a++) m.dginit += incr[a] * g6[a];
     if (m.dginit >= 0.0) {                // fusion.h:456-479
-        for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
+#pragma unroll
+        for (int a = 0; a < 6; a++) incr[a] = -incr[a];
         m.dginit = -m.dginit;
         if (m.dginit >= 0.0) {
             st.step_size = 0.1;
@@ -496,28 +522,51 @@ NDT_HD int mt_start(MatchState &st, double finit, const double *g6)
     m.width1 = 2 * m.width;
     m.stx = 0.0; m.fx = m.finit; m.dgx = m.dginit;
     m.sty = 0.0; m.fy = m.finit; m.dgy = m.dginit;
+    m.stmin = 0.0; m.stmax = 0.0;         // (set by mt_request_trial before anybody reads them)
     st.mt = m;
     return NEXT_REQUEST_TRIAL;
+}
+NDT_HD int mt_start(MatchState &st, double finit, const double *g6)
+{
+    double incr[6];
+    for (int a = 0; a < 6; a++) incr[a] = st.incr[a];
+    const int next = mt_start_local(st, finit, g6, incr);
+    for (int a = 0; a < 6; a++) st.incr[a] = incr[a];
+    return next;
 }
 
 // stage 5: the increment, the direction tests and the start of the line search (fusion.h:966-1031, 444-521)
 NDT_HDN int newton_finish(MatchState &st, const double *sums, const NdtMatchParamsDev &prm, const NewtonWs &ws)
 {
+    // (inputs first, see mt_request_trial)
+    double dx[6], wg[6], gpre[6], gls[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        dx[a] = ws.dx[a]; wg[a] = ws.g[a]; gpre[a] = ws.gpre[a];
+        gls[a] = sums[1 + a] + st.ls_gconst[a];            // (+ 0 unless lineSearchMTFusion)
+    }
+    const double f0 = sums[0] + st.ls_fconst;
+    const int dof_mask = prm.dof_mask, step_control = prm.step_control, use_prior = st.use_prior;
+    double incr[6];
     double dginit = 0;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
-        bool on = (prm.dof_mask >> a) & 1;
-        double d = on ? -ws.dx[a] : 0.0;
-        st.incr[a] = d;
-        dginit += d * ws.g[a];
+        bool on = (dof_mask >> a) & 1;
+        double d = on ? -dx[a] : 0.0;
+        incr[a] = d;
+        dginit += d * wg[a];
     }
     if (dginit > 0) {                      // fusion.h:976-997
+#pragma unroll
+        for (int a = 0; a < 6; a++) st.incr[a] = incr[a];
         if (st.score_here > st.score_best) st.T = st.Tbest;
         st.exit_code = 2;
         st.done = 1;
         return NEXT_NONE;
     }
-    if (!prm.step_control) {
+    if (!step_control) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) st.incr[a] = incr[a];
         st.step_size = 1.0;
         return NEXT_APPLY_STEP;
     }
@@ -526,22 +575,22 @@ NDT_HDN int newton_finish(MatchState &st, const double *sums, const NdtMatchPara
     // which it takes by reference: when increment . (g_ndt + g_mahalanobis) >= 0 the increment is NEGATED IN PLACE
     // (fusion.h:89-95) before lineSearchMT sees it.  Without Tikhonov that gradient is the one dginit <= 0 was just
     // tested on (only dginit == 0 flips); with Tikhonov scg = H^T g + Q x0 is another vector and the flip is live.
-    if (st.use_prior) {
+    if (use_prior) {
         double dtcov = 0;
 #pragma unroll
-        for (int a = 0; a < 6; a++) dtcov += st.incr[a] * ws.gpre[a];
+        for (int a = 0; a < 6; a++) dtcov += incr[a] * gpre[a];
         if (dtcov >= 0.0) {
 #pragma unroll
-            for (int a = 0; a < 6; a++) st.incr[a] = -st.incr[a];
+            for (int a = 0; a < 6; a++) incr[a] = -incr[a];
         }
     }
     // lineSearchMT: its initial derivativesNDT(nextNDT) equals this evaluation (same cells), so the
     // score and gradient are reused instead of being recomputed (fusion.h:444-453).  The step is decided by the
     // NDT-only line search on the NDT-only score.
-    double gls[6];
+    const int next = mt_start_local(st, f0, gls, incr);
 #pragma unroll
-    for (int a = 0; a < 6; a++) gls[a] = sums[1 + a] + st.ls_gconst[a];        // (+ 0 unless lineSearchMTFusion)
-    return mt_start(st, sums[0] + st.ls_fconst, gls);
+    for (int a = 0; a < 6; a++) st.incr[a] = incr[a];
+    return next;
 }
 
 #if defined(NDT_SOLVER_STAGE_PROF) && defined(__HIP_DEVICE_COMPILE__)

@@ -214,7 +214,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.5.5 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.5.6 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -369,9 +369,10 @@ ndtgpu_status ndtgpu_mapset_info(const ndtgpu_mapset *s, size_t *n_maps, int32_t
     return NDTGPU_OK;
 }
 
-ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_dev, size_t n_points,
-                                  size_t stride_bytes, size_t map_stride_bytes, double range_limit,
-                                  const double *range_origins, const ndtgpu_cell_params *cell, ndtgpu_stream stream)
+// the build proper; `orig_dev`: per-map range origins already in device memory (or NULL: the grid centres)
+static ndtgpu_status mapset_build_core(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                                       size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                       const double *orig_dev, const ndtgpu_cell_params *cell, hipStream_t st)
 {
     if (!s || first + count > s->n_maps || (!xyz_dev && n_points) || stride_bytes < 12 || (stride_bytes & 3) ||
         n_points > 0xFFFFFFFFull)
@@ -379,14 +380,6 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
     ndtgpu_cell_params cp;
     ndtgpu_default_cell_params(&cp);
     if (cell) cp = *cell;
-    hipStream_t st = (hipStream_t)stream;
-    const double *orig_dev = nullptr;
-    if (range_origins && count) {
-        ndtgpu_status orc = s->origins_reserve(count * 3, st);
-        if (orc != NDTGPU_OK) return orc;
-        HIP_TRY(hipMemcpyAsync(s->origins_dev, range_origins, count * 3 * sizeof(double), hipMemcpyHostToDevice, st));
-        orig_dev = s->origins_dev;
-    }
     if (s->v.occ && count)   // a rebuilt map starts from cells without readings
         HIP_TRY(hipMemsetAsync(s->v.occ + first * (size_t)s->v.grid.slots, 0, count * (size_t)s->v.grid.slots * sizeof(float), st));
     if (s->profiling && !s->profile_span) HIP_TRY(hipEventRecord(s->ev[0], st));
@@ -394,9 +387,33 @@ ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, 
                          orig_dev, cp.n_min, cp.eval_factor, s->nice_range(first, count), st);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "mapset_build: launch", e);
     if (s->profiling && !s->profile_span) { HIP_TRY(hipEventRecord(s->ev[1], st)); s->ev_valid[0] = true; }
-    { ndtgpu_status trc = s->touch(st); if (trc != NDTGPU_OK) return trc; }
-    if (orig_dev) return s->origins_used(st);
+    return s->touch(st);
+}
+
+// per-map range origins from host memory into the set's buffer, ordered behind the last launch that read it
+static ndtgpu_status upload_origins(ndtgpu_mapset *s, const double *range_origins, size_t count, hipStream_t st, const double **orig_dev)
+{
+    *orig_dev = nullptr;
+    if (!range_origins || !count) return NDTGPU_OK;
+    ndtgpu_status orc = s->origins_reserve(count * 3, st);
+    if (orc != NDTGPU_OK) return orc;
+    HIP_TRY(hipMemcpyAsync(s->origins_dev, range_origins, count * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    *orig_dev = s->origins_dev;
     return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_build(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_dev, size_t n_points,
+                                  size_t stride_bytes, size_t map_stride_bytes, double range_limit,
+                                  const double *range_origins, const ndtgpu_cell_params *cell, ndtgpu_stream stream)
+{
+    if (!s || first + count > s->n_maps) return fail(NDTGPU_ERR_INVALID, "mapset_build: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const double *orig_dev = nullptr;
+    ndtgpu_status rc = upload_origins(s, range_origins, count, st, &orig_dev);
+    if (rc != NDTGPU_OK) return rc;
+    rc = mapset_build_core(s, first, count, xyz_dev, n_points, stride_bytes, map_stride_bytes, range_limit, orig_dev, cell, st);
+    if (orig_dev) { const ndtgpu_status urc = s->origins_used(st); if (rc == NDTGPU_OK) rc = urc; }
+    return rc;
 }
 
 ndtgpu_status ndtgpu_profiling_enable(ndtgpu_mapset *s, int on)
@@ -519,12 +536,19 @@ ndtgpu_status ndtgpu_mapset_build_host_async(ndtgpu_mapset *s, size_t first, siz
 {
     if (!s || (!xyz_host && n_points) || count == 0 || first + count > s->n_maps)
         return fail(NDTGPU_ERR_INVALID, "mapset_build_host: bad argument");
-    return stage_host_clouds(s, xyz_host, count, n_points, stride_bytes, map_stride_bytes, (hipStream_t)stream,
-                             [&](size_t c0, size_t cnt, const void *dev) {
-                                 return ndtgpu_mapset_build(s, first + c0, cnt, dev, n_points, stride_bytes, map_stride_bytes,
-                                                            range_limit, range_origins ? range_origins + 3 * c0 : nullptr, cell,
-                                                            stream);
-                             });
+    // (the range origins of ALL maps go up once, before the first chunk: a copy from pageable memory per chunk made the calling
+    //  thread wait behind the previous chunk's build every time)
+    hipStream_t st = (hipStream_t)stream;
+    const double *orig_dev = nullptr;
+    ndtgpu_status rc = upload_origins(s, range_origins, count, st, &orig_dev);
+    if (rc != NDTGPU_OK) return rc;
+    rc = stage_host_clouds(s, xyz_host, count, n_points, stride_bytes, map_stride_bytes, st,
+                           [&](size_t c0, size_t cnt, const void *dev) {
+                               return mapset_build_core(s, first + c0, cnt, dev, n_points, stride_bytes, map_stride_bytes,
+                                                        range_limit, orig_dev ? orig_dev + 3 * c0 : nullptr, cell, st);
+                           });
+    if (orig_dev) { const ndtgpu_status urc = s->origins_used(st); if (rc == NDTGPU_OK) rc = urc; }
+    return rc;
 }
 
 ndtgpu_status ndtgpu_mapset_build_host(ndtgpu_mapset *s, size_t first, size_t count, const void *xyz_host,

@@ -257,6 +257,18 @@ def test_host_clouds_through_the_pinned_ring(N, monkeypatch):
                 assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
                 assert np.max(np.abs(a[0] - b[0])) < 1e-12 and np.max(np.abs(a[1] - b[1])) < 1e-12
         assert np.array_equal(ms.num_cells_all(), ref.num_cells_all())
+    # per-map range origins with the chunked path (they go up once, before the first chunk; every chunk reads its own rows)
+    g = np.random.default_rng(3)
+    origins = g.uniform(-4.0, 4.0, size=(B, 3)) * np.array([1.0, 1.0, 0.0])
+    ref.build(scans_d, range_limit=12.0, range_origins=origins)
+    want_o, n_o = cells(ref), ref.num_cells_all()
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NDTGPU_HOST_PIPE", mode)
+        ms = N.MapSet(0.5, [0, 0, 0], [100, 100, 1], n_maps=B, max_cells=4096)
+        ms.build(scans, range_limit=12.0, range_origins=origins)
+        for a, b in zip(cells(ms), want_o):
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert np.array_equal(ms.num_cells_all(), n_o)
     # fused node maps from host clouds, chunked against one copy
     org = np.zeros((B, 3))
     outs = []
