@@ -159,11 +159,15 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
     # build; a map with more cells would be cut and flagged, and refused by the matcher like an overflowing build)
     build_local()
     cap_local = int(local_set.num_cells_all()[:n_local].max()) if n_local else 0
-    capt = torch.tensor([cap_local], dtype=torch.int64, device=dev)
+    occ_local = local_set.occupied_cells_max(0, n_local, stream=st) if n_local else 0
+    capt = torch.tensor([cap_local, occ_local], dtype=torch.int64, device=dev)
     if args.use_dist:
         dist.all_reduce(capt, op=dist.ReduceOp.MAX)
-    cells_cap = min(4096, (int(capt.item()) * 5 // 4 + 63) // 64 * 64)
-    stride = local_set.pack_bytes(cells_cap, True)
+    cells_cap = min(4096, (int(capt[0].item()) * 5 // 4 + 63) // 64 * 64)
+    # occupancies travel as (slot, value) pairs of the cells that have a reading (2-3 % of a node map's 80 000 slots)
+    occ_cap = (int(capt[1].item()) * 5 // 4 + 63) // 64 * 64
+    stride = local_set.pack_bytes(cells_cap, occ_cap=occ_cap)
+    stride_dense = local_set.pack_bytes(cells_cap, True)
     packed = torch.zeros((max(1, (n_nodes + world - 1) // world), stride), dtype=torch.uint8, device=dev)
 
     class Edges:
@@ -189,7 +193,7 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
             build_local()                                                            # phase A: this rank's node maps
         ev[1].record(st)
         if rebuild:
-            local_set.pack_cells(packed, 0, n_local, cells_cap=cells_cap, with_occupancy=True, stream=st)   # phase B
+            local_set.pack_cells(packed, 0, n_local, cells_cap=cells_cap, occ_cap=occ_cap, stream=st)       # phase B
             allrec = D.exchange_node_maps(packed[:n_local], n_nodes, rank, world)
             pool.unpack_cells(allrec, 0, n_nodes, with_occupancy=True, stream=st)
         ev[2].record(st)
@@ -291,13 +295,14 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "configs[3]: graph replay, %d nodes 2 m apart through %d rooms, every node a fused map of %d scans x %d pts "
                                   "(%.2f m cells); one step = A. build the node maps k %% world == rank (%d add_cloud calls), B. pack + ONE "
-                                  "all-gather + unpack of the cell records (%d B per node: %d cells + occupancies), C. register this rank's "
+                                  "all-gather + unpack of the cell records (%d B per node: %d cells + the (slot, occupancy) pairs of up to %d cells with a reading), C. register this rank's "
                                   "block-cyclic share (chunk 256) of the %d %s candidate edges with the edge preset (DELTA_SCORE 1e-3), "
                                   "D. all-gather of the edge results; %d rank(s)" % (
-                                      n_nodes, int(room.max()) + 1, S, NPn, res, S, stride, cells_cap, n_edges, what, world),
+                                      n_nodes, int(room.max()) + 1, S, NPn, res, S, stride, cells_cap, occ_cap, n_edges, what, world),
                       "nodes": n_nodes, "nodes_this_rank": int(n_local), "edges": n_edges, "edges_this_rank": int(len(E.mine)),
                       "edges_within_gate": n_gated, "gate_dist_m": args.gate_dist, "mean_cells_per_node_map": float(cells.mean()),
-                      "record_bytes_per_node": int(stride), "cells_cap": int(cells_cap)},
+                      "record_bytes_per_node": int(stride), "cells_cap": int(cells_cap), "occ_cap": int(occ_cap),
+                      "record_bytes_per_node_dense_occupancy": int(stride_dense)},
            "nodes_per_s_build": n_nodes / (build_ms * 1e-3) if world == 1 else n_local * world / (build_ms * 1e-3),
            "scans_per_s_fused": n_local * world * S / (build_ms * 1e-3),
            "edges_per_s_match": len(E.mine) / (match_ms * 1e-3) * world,

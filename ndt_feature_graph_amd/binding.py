@@ -122,7 +122,8 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_add_cloud_host", "ndtgpu_mapset_clear", "ndtgpu_mapset_export_occupancy",
            "ndtgpu_overlap_score_batch", "ndtgpu_covariance_batch", "ndtgpu_mapset_discard_cells", "ndtgpu_mapset_import_occupancy",
            "ndtgpu_match_fusion_feat_batch", "ndtgpu_match_aborted", "ndtgpu_mapset_pack_bytes",
-           "ndtgpu_mapset_pack_cells_device", "ndtgpu_mapset_unpack_cells_device", "ndtgpu_mapset_build_host_async",
+           "ndtgpu_mapset_pack_cells_device", "ndtgpu_mapset_unpack_cells_device", "ndtgpu_mapset_pack_bytes_sparse",
+           "ndtgpu_mapset_occupied_cells_max", "ndtgpu_mapset_pack_cells_sparse_device", "ndtgpu_mapset_build_host_async",
            "ndtgpu_mapset_add_cloud_host_async", "ndtgpu_registrar_create", "ndtgpu_registrar_destroy",
            "ndtgpu_register_batch_device", "ndtgpu_registrar_wait_stream", "ndtgpu_registrar_sync",
            "ndtgpu_registrar_profiling", "ndtgpu_registrar_kernel_ms", "ndtgpu_registrar_mapset", "ndtgpu_register_batch_host"]
@@ -194,6 +195,10 @@ def lib():
     L.ndtgpu_mapset_pack_bytes.argtypes = [vp, C.c_uint32, C.c_int]
     L.ndtgpu_mapset_pack_cells_device.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_int, vp]
     L.ndtgpu_mapset_unpack_cells_device.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_int, vp]
+    L.ndtgpu_mapset_pack_bytes_sparse.restype = C.c_size_t
+    L.ndtgpu_mapset_pack_bytes_sparse.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.ndtgpu_mapset_occupied_cells_max.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32), vp]
+    L.ndtgpu_mapset_pack_cells_sparse_device.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp]
     L.ndtgpu_registrar_create.argtypes = [C.POINTER(GridParams), C.c_size_t, C.c_int, C.POINTER(vp)]
     L.ndtgpu_registrar_destroy.argtypes = [vp]
     L.ndtgpu_register_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(CellParams),
@@ -358,18 +363,38 @@ class MapSet:
         _check(lib().ndtgpu_mapset_export_occupancy(self.h, int(i), out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
-    def pack_bytes(self, cells_cap, with_occupancy=False):
+    def pack_bytes(self, cells_cap, with_occupancy=False, occ_cap=None):
+        """Bytes of one exchange record.  occ_cap: the sparse form of the occupancy block (room for that many cells with a
+        reading, ndtgpu_mapset_pack_bytes_sparse) instead of one float per slot."""
+        if occ_cap is not None:
+            return int(lib().ndtgpu_mapset_pack_bytes_sparse(self.h, int(cells_cap), int(occ_cap)))
         return int(lib().ndtgpu_mapset_pack_bytes(self.h, int(cells_cap), int(bool(with_occupancy))))
 
-    def pack_cells(self, buf, first=0, count=None, cells_cap=None, with_occupancy=False, stream=None):
+    def occupied_cells_max(self, first=0, count=None, stream=None):
+        """The largest number of cells with an occupancy reading over maps [first, first+count): what the occ_cap of a
+        sparse exchange record must hold (ndtgpu_mapset_occupied_cells_max; synchronises the stream)."""
+        import torch
+        count = self.n_maps - first if count is None else count
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        out = C.c_uint32()
+        _check(lib().ndtgpu_mapset_occupied_cells_max(self.h, int(first), int(count), C.byref(out), _stream_ptr(stream)))
+        return int(out.value)
+
+    def pack_cells(self, buf, first=0, count=None, cells_cap=None, with_occupancy=False, stream=None, occ_cap=None):
         """Exchange records of maps [first, first+count) into the torch CUDA uint8 tensor buf [count, stride]
-        (ndtgpu_mapset_pack_cells_device; asynchronous)."""
+        (ndtgpu_mapset_pack_cells_device; asynchronous).  occ_cap: occupancies as (slot, value) pairs of the cells with a
+        reading (ndtgpu_mapset_pack_cells_sparse_device)."""
         import torch
         count = self.n_maps - first if count is None else count
         cap = self.info()["max_cells"] if cells_cap is None else cells_cap
         assert buf.dtype == torch.uint8 and buf.is_cuda and buf.is_contiguous() and buf.shape[0] >= count
         if stream is None:
             stream = torch.cuda.current_stream()
+        if occ_cap is not None:
+            _check(lib().ndtgpu_mapset_pack_cells_sparse_device(self.h, int(first), int(count), C.c_void_p(buf.data_ptr()),
+                                                                int(buf.stride(0)), int(cap), int(occ_cap), _stream_ptr(stream)))
+            return
         _check(lib().ndtgpu_mapset_pack_cells_device(self.h, int(first), int(count), C.c_void_p(buf.data_ptr()), int(buf.stride(0)),
                                                      int(cap), int(bool(with_occupancy)), _stream_ptr(stream)))
 

@@ -172,8 +172,11 @@ hipError_t ndt_launch_overlap(const NdtSetView &rset, const uint32_t *ridx_dev, 
 hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const NdtCell *cells_dev, size_t n_cells,
                                     hipStream_t stream);
 // exchange records of cell maps (csrc/ndt_pack.hip): header 16 B + cells_cap x NdtCell [+ slots x float]
+//   (with_occ 2: instead {n_occ, occ_cap} + occ_cap x {slot, float}: the cells with a reading)
 hipError_t ndt_launch_pack(const NdtSetView &set, size_t first, size_t count, void *buf_dev, size_t stride, unsigned cells_cap,
-                           int with_occ, hipStream_t stream);
+                           int with_occ, unsigned occ_cap, hipStream_t stream);
+size_t ndt_pack_sparse_occ_bytes(unsigned occ_cap);
+hipError_t ndt_launch_occ_count(const NdtSetView &set, size_t first, size_t count, unsigned *counts_dev, hipStream_t stream);
 hipError_t ndt_launch_unpack(const NdtSetView &set, size_t first, size_t count, const void *buf_dev, size_t stride, int with_occ,
                              hipStream_t stream);
 size_t ndt_match_work_bytes(size_t n_pairs, size_t n_slots);

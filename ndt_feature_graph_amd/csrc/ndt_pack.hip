@@ -7,33 +7,98 @@
 // all_gather moves all of them:
 //     ndtgpu_packed_header {n_cells, flags, n_dropped, cells_cap}            16 bytes
 //     cells_cap x ndtgpu_cell_record (= NdtCell, 80 bytes; the first n_cells are valid, in slot order)
-//     slots x float occupancy                                                  (with_occupancy only)
+//     slots x float occupancy                                                  (with_occupancy, dense form)
+//  or {n_occ, occ_cap} + occ_cap x {slot, occupancy}                            (sparse form: the cells that have a reading,
+//                                                                                in slot order -- a fused node map of the
+//                                                                                replay has readings in 2-3 % of its 80 k
+//                                                                                slots: 22 KB instead of 320 KB per node)
 // Unpacking installs the cells, rebuilds the rank map (the only index the matcher probes) and the counters: a map that
 // was unpacked is indistinguishable from the map that was packed.
 #include "ndt_math.h"
+#include "ndt_wave.h"
 
 #define NDT_PACK_THREADS 256
 #define NDT_PACK_F_OVERFLOW 1u      // the map overflowed max_cells where it was built, or holds more cells than cells_cap
 #define NDT_PACK_F_OCC 2u           // the record carries occupancies
 
+#define NDT_PACK_F_OCC_SPARSE 4u    // ... as (slot, value) pairs of the cells that have a reading
+
 struct NdtPackedHeader { uint32_t n_cells, flags, n_dropped, cells_cap; };
 static_assert(sizeof(NdtPackedHeader) == 16, "packed header");
+struct NdtPackedOccHead { uint32_t n_occ, occ_cap; };
+struct NdtPackedOcc { uint32_t slot; float occ; };
+static_assert(sizeof(NdtPackedOccHead) == 8 && sizeof(NdtPackedOcc) == 8, "sparse occupancy block");
+
+// Cells of a map that have a reading (occupancy != 0), counted by the 4 waves of a workgroup: wave w takes the w-th quarter
+// of the slots, 64 consecutive slots per step (coalesced), one ballot per step.  Returns the wave's count (wave-uniform).
+static __device__ __forceinline__ unsigned occ_count_quarter(const float *o, unsigned begin, unsigned end)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned n = 0;
+    for (unsigned b = begin; b < end; b += 64u) {
+        const unsigned s = b + lane;
+        const bool on = s < end && o[s] != 0.0f;
+        n += (unsigned)__popcll(ndt_ballot(on));
+    }
+    return n;
+}
+
+// one workgroup per map: counts[map - first] = its cells with a reading
+extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_occ_count_kernel(NdtSetView set, unsigned first,
+                                                                                   unsigned *__restrict__ counts)
+{
+    __shared__ unsigned s_n[NDT_PACK_THREADS / 64];
+    const unsigned map = first + blockIdx.x, wave = threadIdx.x >> 6;
+    const unsigned slots = (unsigned)set.grid.slots, q = ((slots + 3u) / 4u + 63u) & ~63u;
+    const float *o = set.occ + (size_t)map * slots;
+    const unsigned n = occ_count_quarter(o, min(slots, wave * q), min(slots, (wave + 1u) * q));
+    if ((threadIdx.x & 63u) == 0u) s_n[wave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+}
 
 // one workgroup per map
 extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_pack_kernel(NdtSetView set, unsigned first,
                                                                               char *__restrict__ buf, size_t stride,
-                                                                              unsigned cells_cap, int with_occ)
+                                                                              unsigned cells_cap, int with_occ, unsigned occ_cap)
 {
+    __shared__ unsigned s_n[NDT_PACK_THREADS / 64];
     const unsigned map = first + blockIdx.x, tid = threadIdx.x;
     const NdtGrid g = set.grid;
     char *rec = buf + (size_t)blockIdx.x * stride;
     const NdtMapCounters c = set.counters[map];
     const unsigned n = c.n_cells > g.max_cells ? g.max_cells : c.n_cells;
     const unsigned n_out = n > cells_cap ? cells_cap : n;
+    bool occ_cut = false;
+    if (with_occ == 2) {
+        // sparse occupancies: count per wave, then every wave writes its quarter's pairs behind those of the waves before it
+        // (slot order: the record's bytes do not depend on timing)
+        const unsigned slots = (unsigned)g.slots, q = ((slots + 3u) / 4u + 63u) & ~63u, wave = tid >> 6, lane = tid & 63u;
+        const float *o = set.occ + (size_t)map * slots;
+        const unsigned begin = min(slots, wave * q), end = min(slots, (wave + 1u) * q);
+        const unsigned mine = occ_count_quarter(o, begin, end);
+        if (lane == 0u) s_n[wave] = mine;
+        __syncthreads();
+        unsigned at = 0, total = 0;
+        for (unsigned w = 0; w < NDT_PACK_THREADS / 64; w++) { if (w < wave) at += s_n[w]; total += s_n[w]; }
+        occ_cut = total > occ_cap;
+        char *ob = rec + sizeof(NdtPackedHeader) + (size_t)cells_cap * sizeof(NdtCell);
+        if (tid == 0) *reinterpret_cast<NdtPackedOccHead *>(ob) = NdtPackedOccHead{occ_cut ? occ_cap : total, occ_cap};
+        NdtPackedOcc *pairs = reinterpret_cast<NdtPackedOcc *>(ob + sizeof(NdtPackedOccHead));
+        for (unsigned b = begin; b < end; b += 64u) {
+            const unsigned sl = b + lane;
+            const float v = sl < end ? o[sl] : 0.0f;
+            const unsigned long long m = ndt_ballot(v != 0.0f);
+            const unsigned pos = at + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (v != 0.0f && pos < occ_cap) pairs[pos] = NdtPackedOcc{sl, v};
+            at += (unsigned)__popcll(m);
+        }
+    }
     if (tid == 0) {
         NdtPackedHeader h;
         h.n_cells = n_out;
-        h.flags = ((c.overflow || n > cells_cap) ? NDT_PACK_F_OVERFLOW : 0u) | (with_occ ? NDT_PACK_F_OCC : 0u);
+        h.flags = ((c.overflow || n > cells_cap || occ_cut) ? NDT_PACK_F_OVERFLOW : 0u) | (with_occ ? NDT_PACK_F_OCC : 0u) |
+                  (with_occ == 2 ? NDT_PACK_F_OCC_SPARSE : 0u);
         h.n_dropped = c.n_dropped;
         h.cells_cap = cells_cap;
         *reinterpret_cast<NdtPackedHeader *>(rec) = h;
@@ -42,7 +107,7 @@ extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_pack_kernel(N
     const uint4 *src = reinterpret_cast<const uint4 *>(ndt_cells_of(set, map, set.cell_sel ? set.cell_sel[map] : 0u));
     uint4 *dst = reinterpret_cast<uint4 *>(rec + sizeof(NdtPackedHeader));
     for (unsigned i = tid; i < n_out * 5u; i += NDT_PACK_THREADS) dst[i] = src[i];
-    if (with_occ) {
+    if (with_occ == 1) {
         const float *o = set.occ + (size_t)map * g.slots;
         float *od = reinterpret_cast<float *>(rec + sizeof(NdtPackedHeader) + (size_t)cells_cap * sizeof(NdtCell));
         for (unsigned i = tid; i < (unsigned)g.slots; i += NDT_PACK_THREADS) od[i] = o[i];
@@ -64,7 +129,13 @@ extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_unpack_kernel
     const bool too_many = n > g.max_cells || n > cap_rec;
     if (n > cap_rec) n = cap_rec;
     if (n > g.max_cells) n = g.max_cells;
-    const bool occ_fits = sizeof(NdtPackedHeader) + (size_t)h.cells_cap * sizeof(NdtCell) + (size_t)g.slots * sizeof(float) <= stride;
+    const size_t occ_at = sizeof(NdtPackedHeader) + (size_t)h.cells_cap * sizeof(NdtCell);
+    const bool sparse = (h.flags & NDT_PACK_F_OCC_SPARSE) != 0u;
+    NdtPackedOccHead oh = {0u, 0u};
+    if (sparse && (h.flags & NDT_PACK_F_OCC) && occ_at + sizeof(NdtPackedOccHead) <= stride)
+        oh = *reinterpret_cast<const NdtPackedOccHead *>(rec + occ_at);
+    const bool occ_fits = sparse ? (occ_at + sizeof(NdtPackedOccHead) + (size_t)oh.occ_cap * sizeof(NdtPackedOcc) <= stride && oh.n_occ <= oh.occ_cap)
+                                 : (occ_at + (size_t)g.slots * sizeof(float) <= stride);
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     const unsigned bm_words = (unsigned)((g.slots + 31) >> 5);
     NdtCell *cells = set.cells + (size_t)map * g.max_cells;          // an installed map lives in the first cell array
@@ -85,9 +156,20 @@ extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_unpack_kernel
         if (i == 0 || (src[i - 1].slot >> 5) != (slot >> 5)) rankmap[slot >> 5].y = i;
     }
     if (with_occ && set.occ && (h.flags & NDT_PACK_F_OCC) && occ_fits) {
-        const float *o = reinterpret_cast<const float *>(rec + sizeof(NdtPackedHeader) + (size_t)h.cells_cap * sizeof(NdtCell));
         float *od = set.occ + (size_t)map * g.slots;
-        for (unsigned i = tid; i < (unsigned)g.slots; i += NDT_PACK_THREADS) od[i] = o[i];
+        if (sparse) {
+            // every cell without a reading, then the pairs (another thread's store to the same word: behind the barrier)
+            for (unsigned i = tid; i < (unsigned)g.slots; i += NDT_PACK_THREADS) od[i] = 0.0f;
+            __syncthreads();
+            const NdtPackedOcc *pairs = reinterpret_cast<const NdtPackedOcc *>(rec + occ_at + sizeof(NdtPackedOccHead));
+            for (unsigned i = tid; i < oh.n_occ; i += NDT_PACK_THREADS) {
+                const NdtPackedOcc pr = pairs[i];
+                if (pr.slot < (unsigned)g.slots) od[pr.slot] = pr.occ;
+            }
+        } else {
+            const float *o = reinterpret_cast<const float *>(rec + occ_at);
+            for (unsigned i = tid; i < (unsigned)g.slots; i += NDT_PACK_THREADS) od[i] = o[i];
+        }
     }
     if (tid == 0) {
         NdtMapCounters c = set.counters[map];
@@ -102,12 +184,22 @@ extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_unpack_kernel
     }
 }
 
+// with_occ: 0 no occupancies, 1 one float per slot, 2 (slot, value) pairs of the cells with a reading, at most occ_cap
 hipError_t ndt_launch_pack(const NdtSetView &set, size_t first, size_t count, void *buf_dev, size_t stride, unsigned cells_cap,
-                           int with_occ, hipStream_t stream)
+                           int with_occ, unsigned occ_cap, hipStream_t stream)
 {
     if (count == 0) return hipSuccess;
     hipLaunchKernelGGL(ndt_pack_kernel, dim3((unsigned)count), dim3(NDT_PACK_THREADS), 0, stream, set, (unsigned)first,
-                       (char *)buf_dev, stride, cells_cap, with_occ);
+                       (char *)buf_dev, stride, cells_cap, with_occ, occ_cap);
+    return hipGetLastError();
+}
+
+size_t ndt_pack_sparse_occ_bytes(unsigned occ_cap) { return sizeof(NdtPackedOccHead) + (size_t)occ_cap * sizeof(NdtPackedOcc); }
+
+hipError_t ndt_launch_occ_count(const NdtSetView &set, size_t first, size_t count, unsigned *counts_dev, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(ndt_occ_count_kernel, dim3((unsigned)count), dim3(NDT_PACK_THREADS), 0, stream, set, (unsigned)first, counts_dev);
     return hipGetLastError();
 }
 

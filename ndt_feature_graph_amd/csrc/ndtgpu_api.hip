@@ -214,7 +214,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.5.6 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.5.7 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1628,8 +1628,47 @@ ndtgpu_status ndtgpu_mapset_pack_cells_device(ndtgpu_mapset *s, size_t first, si
         stride < ndtgpu_mapset_pack_bytes(s, cells_cap, with_occupancy))
         return fail(NDTGPU_ERR_INVALID, "pack_cells: bad argument (16-byte aligned buffer, stride >= ndtgpu_mapset_pack_bytes)");
     if (with_occupancy && !s->v.occ) return fail(NDTGPU_ERR_INVALID, "pack_cells: the set carries no occupancies");
-    hipError_t e = ndt_launch_pack(s->v, first, count, buf_dev, stride, cells_cap, with_occupancy ? 1 : 0, (hipStream_t)stream);
+    hipError_t e = ndt_launch_pack(s->v, first, count, buf_dev, stride, cells_cap, with_occupancy ? 1 : 0, 0u, (hipStream_t)stream);
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "pack_cells: launch", e);
+    return NDTGPU_OK;
+}
+
+size_t ndtgpu_mapset_pack_bytes_sparse(const ndtgpu_mapset *s, uint32_t cells_cap, uint32_t occ_cap)
+{
+    if (!s) return 0;
+    const size_t b = sizeof(ndtgpu_packed_header) + (size_t)cells_cap * sizeof(NdtCell) + ndt_pack_sparse_occ_bytes(occ_cap);
+    return (b + 15u) & ~(size_t)15u;
+}
+
+ndtgpu_status ndtgpu_mapset_occupied_cells_max(ndtgpu_mapset *s, size_t first, size_t count, uint32_t *max_occupied,
+                                               ndtgpu_stream stream)
+{
+    if (!s || !max_occupied || first + count > s->n_maps) return fail(NDTGPU_ERR_INVALID, "occupied_cells_max: bad argument");
+    if (!s->v.occ) return fail(NDTGPU_ERR_INVALID, "occupied_cells_max: the set carries no occupancies");
+    *max_occupied = 0;
+    if (count == 0) return NDTGPU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned *counts_dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&counts_dev, count * sizeof(unsigned)));
+    std::vector<unsigned> counts(count);
+    hipError_t e = ndt_launch_occ_count(s->v, first, count, counts_dev, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), counts_dev, count * sizeof(unsigned), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(counts_dev);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "occupied_cells_max", e);
+    for (unsigned c : counts) *max_occupied = std::max<uint32_t>(*max_occupied, c);
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_mapset_pack_cells_sparse_device(ndtgpu_mapset *s, size_t first, size_t count, void *buf_dev, size_t stride,
+                                                     uint32_t cells_cap, uint32_t occ_cap, ndtgpu_stream stream)
+{
+    if (!s || first + count > s->n_maps || (count && !buf_dev) || ((uintptr_t)buf_dev & 15u) || (stride & 15u) ||
+        stride < ndtgpu_mapset_pack_bytes_sparse(s, cells_cap, occ_cap))
+        return fail(NDTGPU_ERR_INVALID, "pack_cells_sparse: bad argument (16-byte aligned buffer, stride >= ndtgpu_mapset_pack_bytes_sparse)");
+    if (!s->v.occ) return fail(NDTGPU_ERR_INVALID, "pack_cells_sparse: the set carries no occupancies");
+    hipError_t e = ndt_launch_pack(s->v, first, count, buf_dev, stride, cells_cap, 2, occ_cap, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "pack_cells_sparse: launch", e);
     return NDTGPU_OK;
 }
 

@@ -133,9 +133,29 @@ PACKED_CELL_DTYPE = np.dtype([("mean", "<f8", (3,)), ("cov", "<f8", (6,)), ("n",
 assert PACKED_HEADER_DTYPE.itemsize == 16 and PACKED_CELL_DTYPE.itemsize == 80
 
 
-def record_bytes(cells_cap, slots=0):
-    """ndtgpu_mapset_pack_bytes: bytes of one record (slots > 0: with the occupancy of every cell)."""
+PACKED_OCC_HEAD_DTYPE = np.dtype([("n_occ", "<u4"), ("occ_cap", "<u4")])      # sparse occupancy block: head, then pairs
+PACKED_OCC_DTYPE = np.dtype([("slot", "<u4"), ("occ", "<f4")])
+
+
+def record_bytes(cells_cap, slots=0, occ_cap=None):
+    """ndtgpu_mapset_pack_bytes: bytes of one record (slots > 0: with the occupancy of every cell); occ_cap:
+    ndtgpu_mapset_pack_bytes_sparse (the (slot, occupancy) pairs of up to occ_cap cells with a reading instead)."""
+    if occ_cap is not None:
+        return (16 + 80 * int(cells_cap) + 8 + 8 * int(occ_cap) + 15) // 16 * 16
     return (16 + 80 * int(cells_cap) + 4 * int(slots) + 15) // 16 * 16
+
+
+def sparse_occupancy_of_record(rec):
+    """(slots, values) of the sparse occupancy block of ONE exchange record (uint8 array), or None when the record carries
+    its occupancies densely or not at all (flags bit 2 clear)."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1)
+    h = rec[:16].view(PACKED_HEADER_DTYPE)[0]
+    if not (int(h["flags"]) & 4):
+        return None
+    at = 16 + 80 * int(h["cells_cap"])
+    oh = rec[at:at + 8].view(PACKED_OCC_HEAD_DTYPE)[0]
+    pairs = rec[at + 8:at + 8 + 8 * int(oh["n_occ"])].view(PACKED_OCC_DTYPE)
+    return pairs["slot"].copy(), pairs["occ"].copy()
 
 
 def record_from_cells(mean, cov, idx, npts, cells_per_axis, cells_cap, n_dropped=0):

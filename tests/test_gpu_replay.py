@@ -120,6 +120,46 @@ def test_replay_500_fused_nodes_sharded_build_and_exchange(N, O):
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
         assert np.max(np.abs(a[0] - b[0])) < 1e-12 and np.max(np.abs(a[1] - b[1])) < 1e-12
 
+    # the SPARSE form of the same exchange: occupancies as (slot, value) pairs of the cells with a reading, in slot order.
+    # Same maps after unpacking (into a set whose occupancies held something else before), a seventh of the bytes.
+    occ_cap = (max(loc.occupied_cells_max() for loc in locs) + 63) // 64 * 64
+    stride_s = direct.pack_bytes(cells_cap, occ_cap=occ_cap)
+    assert stride_s == D.record_bytes(cells_cap, occ_cap=occ_cap) and 5 * stride_s < stride
+    gathered_s = torch.zeros((world, n_max, stride_s), dtype=torch.uint8, device=dev)
+    for rank, loc in enumerate(locs):
+        mine = D.shard_nodes(n_nodes, rank, world)
+        loc.pack_cells(gathered_s[rank], 0, len(mine), cells_cap=cells_cap, occ_cap=occ_cap)
+        again = torch.zeros((len(mine), stride_s), dtype=torch.uint8, device=dev)
+        loc.pack_cells(again, 0, len(mine), cells_cap=cells_cap, occ_cap=occ_cap)
+        torch.cuda.synchronize()
+        assert torch.equal(again, gathered_s[rank, :len(mine)])            # slot order: the bytes do not depend on timing
+    allrec_s = D.records_to_node_order(gathered_s.view(world * n_max, stride_s), n_nodes, world)
+    pool_s = N.MapSet(res, [0, 0, 0], size, n_maps=n_nodes, max_cells=2048)
+    pool_s.enable_occupancy()
+    pool_s.unpack_cells(allrec[torch.arange(n_nodes - 1, -1, -1, device=dev)].contiguous(), 0, n_nodes, with_occupancy=True)   # (other maps' readings first)
+    pool_s.unpack_cells(allrec_s, 0, n_nodes, with_occupancy=True)
+    assert np.array_equal(pool_s.num_cells_all(), cells_per_map)
+    for k in (0, 3, 250, 498, 499):
+        for x, y in zip(pool_s.export_cells(k), pool.export_cells(k)):
+            assert np.array_equal(x, y)
+        occ = pool.occupancy(k)
+        assert np.array_equal(pool_s.occupancy(k), occ)
+        rec = allrec_s[k].cpu().numpy()
+        assert D.cells_from_record(rec)[4] == 6
+        sl, val = D.sparse_occupancy_of_record(rec)
+        flat = occ.reshape(-1)
+        assert np.array_equal(sl, np.flatnonzero(flat)) and np.array_equal(val, flat[sl])
+    # a record without room for every reading is cut and flagged, and the unpacked map refused like an overflowing build
+    small = torch.zeros((1, direct.pack_bytes(cells_cap, occ_cap=64)), dtype=torch.uint8, device=dev)
+    locs[0].pack_cells(small, 0, 1, cells_cap=cells_cap, occ_cap=64)
+    torch.cuda.synchronize()
+    assert D.cells_from_record(small[0].cpu().numpy())[4] == 7
+    pool_s.unpack_cells(small, 0, 1, with_occupancy=True)
+    with pytest.raises(N.NdtGpuError):
+        pool_s.num_cells(0)
+    pool_s.unpack_cells(allrec_s[:1].contiguous(), 0, 1, with_occupancy=True)
+    assert pool_s.num_cells(0) == cells_per_map[0]
+
     # phase C: gated candidates and all pairs, dealt block-cyclically to 8 shards, reassembled in edge order
     edges = D.all_pairs(n_nodes)
     assert len(edges) == 124750
@@ -331,10 +371,12 @@ def test_config4_full_size(N, O):
     # phase B: packed records, rank-major -> node order, ONE unpack
     cells_cap = min(4096, (cap_max * 5 // 4 + 63) // 64 * 64)
     n_max = (n_nodes + world - 1) // world
-    stride = locs[0].pack_bytes(cells_cap, True)
+    occ_cap = (max(loc.occupied_cells_max(stream=st) for loc in locs) * 5 // 4 + 63) // 64 * 64    # (the maximum over ranks)
+    stride = locs[0].pack_bytes(cells_cap, occ_cap=occ_cap)
+    assert 2 * stride < locs[0].pack_bytes(cells_cap, True)            # ~120 KB per node instead of 370 (sized by the node with the most readings)
     gathered = torch.zeros((world, n_max, stride), dtype=torch.uint8, device=dev)
     for rank, (loc, mine) in enumerate(zip(locs, mines)):
-        loc.pack_cells(gathered[rank], 0, len(mine), cells_cap=cells_cap, with_occupancy=True, stream=st)
+        loc.pack_cells(gathered[rank], 0, len(mine), cells_cap=cells_cap, occ_cap=occ_cap, stream=st)
     allrec = D.records_to_node_order(gathered.view(world * n_max, stride), n_nodes, world)
     pool = N.MapSet(res, [0, 0, 0], size, n_maps=n_nodes, max_cells=4096)
     pool.enable_occupancy()
