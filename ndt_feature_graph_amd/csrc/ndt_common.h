@@ -176,7 +176,14 @@ hipError_t ndt_launch_install_cells(const NdtSetView &set, size_t map, const Ndt
 hipError_t ndt_launch_pack(const NdtSetView &set, size_t first, size_t count, void *buf_dev, size_t stride, unsigned cells_cap,
                            int with_occ, unsigned occ_cap, hipStream_t stream);
 size_t ndt_pack_sparse_occ_bytes(unsigned occ_cap);
-hipError_t ndt_launch_occ_count(const NdtSetView &set, size_t first, size_t count, unsigned *counts_dev, hipStream_t stream);
+hipError_t ndt_launch_occ_count(const NdtSetView &set, size_t first, const uint32_t *maps_dev, size_t count, unsigned *counts_dev,
+                                hipStream_t stream);
+hipError_t ndt_launch_occ_list(const NdtSetView &set, const uint32_t *maps_dev, size_t count, const unsigned *offs_dev, void *pairs_dev,
+                               hipStream_t stream);
+hipError_t ndt_launch_overlap_lists(const NdtSetView &rset, const uint32_t *ridx_dev, const NdtSetView &mset,
+                                    const uint32_t *midx_dev, const uint32_t *list_of_link_dev, const unsigned *offs_dev,
+                                    const void *pairs_dev, const double *T16_dev, size_t n_links, double *score_dev,
+                                    long long *nb_dev, hipStream_t stream);
 hipError_t ndt_launch_unpack(const NdtSetView &set, size_t first, size_t count, const void *buf_dev, size_t stride, int with_occ,
                              hipStream_t stream);
 size_t ndt_match_work_bytes(size_t n_pairs, size_t n_slots);

@@ -552,6 +552,68 @@ extern "C" __global__ __launch_bounds__(256) void ndt_overlap_kernel(
     }
 }
 
+// The same score from LISTS of the moving maps' cells with a reading ((slot, occupancy) pairs in slot order: ndt_occ_list_kernel):
+// a fused node map has readings in 2-9 % of its slots, and every link of a replay read the whole dense array of its moving
+// map -- 320 KB per link, 6.4 GB for the 19 900 links of 200 nodes -- to find them.  list_of_link[link]: which list; the
+// pairs of list u are pairs[offs[u] .. offs[u + 1]).  Thread t takes entries t, t + 256, ... of the list (thread-local sums
+// in list order, then the fixed tree): run-to-run identical, and equal to the dense kernel's score up to the order of the sum.
+extern "C" __global__ __launch_bounds__(256) void ndt_overlap_lists_kernel(
+    NdtSetView rset, const uint32_t *__restrict__ ridx, NdtSetView mset, const uint32_t *__restrict__ midx,
+    const uint32_t *__restrict__ list_of_link, const unsigned *__restrict__ offs, const uint2 *__restrict__ pairs,
+    const double *__restrict__ T16, double *__restrict__ score, long long *__restrict__ nb_sum)
+{
+#pragma clang fp contract(off)
+    __shared__ double s_sum[256];
+    __shared__ unsigned s_cnt[256];
+    const unsigned link = blockIdx.x, tid = threadIdx.x;
+    const unsigned rm = ridx[link], mm = midx[link], u = list_of_link[link];
+    const NdtGrid gr = rset.grid, gm = mset.grid;
+    const float *occ_r = rset.occ + (size_t)rm * gr.slots;
+    const double *T = T16 + (size_t)link * 16;
+    const double mcx = mset.centres[mm * 3], mcy = mset.centres[mm * 3 + 1], mcz = mset.centres[mm * 3 + 2];
+    const double rcx = rset.centres[rm * 3], rcy = rset.centres[rm * 3 + 1], rcz = rset.centres[rm * 3 + 2];
+    double sum = 0.0;
+    unsigned cnt = 0;
+    const unsigned e1 = offs[u + 1u];
+    for (unsigned e = offs[u] + tid; e < e1; e += 256u) {
+        const uint2 pr = pairs[e];
+        const unsigned s = pr.x;
+        const double mov_occ = (double)occupancy_rescaled(__uint_as_float(pr.y));
+        if (mov_occ == 0.5) continue;
+        const int iz = s % gm.size[2], iy = (s / gm.size[2]) % gm.size[1], ix = s / (gm.size[2] * gm.size[1]);
+        // NDTCell::getCenter(): float
+        const float cfx = (float)(mcx + ((double)ix - (double)(gm.size[0] / 2)) * gm.res);
+        const float cfy = (float)(mcy + ((double)iy - (double)(gm.size[1] / 2)) * gm.res);
+        const float cfz = (float)(mcz + ((double)iz - (double)(gm.size[2] / 2)) * gm.res);
+        const double e0 = cfx, e1_ = cfy, e2 = cfz;
+        const float px = (float)(T[0] * e0 + T[4] * e1_ + T[8] * e2 + T[12]);
+        const float py = (float)(T[1] * e0 + T[5] * e1_ + T[9] * e2 + T[13]);
+        const float pz = (float)(T[2] * e0 + T[6] * e1_ + T[10] * e2 + T[14]);
+        const int jx = lazygrid_index((double)px, rcx, gr.res, gr.size[0]);
+        const int jy = lazygrid_index((double)py, rcy, gr.res, gr.size[1]);
+        const int jz = lazygrid_index((double)pz, rcz, gr.res, gr.size[2]);
+        if ((unsigned)jx >= (unsigned)gr.size[0] || (unsigned)jy >= (unsigned)gr.size[1] || (unsigned)jz >= (unsigned)gr.size[2]) continue;
+        const float orf = occ_r[(jx * gr.size[1] + jy) * gr.size[2] + jz];
+        const double ref_occ = (double)occupancy_rescaled(orf);
+        if (ref_occ != 0.5) {
+            cnt++;
+            const double diff = mov_occ - ref_occ;
+            sum += diff * diff;
+        }
+    }
+    s_sum[tid] = sum;
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    for (unsigned o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s_sum[tid] += s_sum[tid + o]; s_cnt[tid] += s_cnt[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        nb_sum[link] = (long long)s_cnt[0];
+        score[link] = s_cnt[0] ? s_sum[0] / (1. * (double)s_cnt[0]) : 1.;
+    }
+}
+
 // ndt_feature::discardCell(map, pt) (utils.h:229-236; fuser_hmt.cpp:229-232): the cells that hold the given points lose
 // their Gaussian.  One workgroup; the surviving cells are compacted in place in rank order (a cell never moves up, and a
 // chunk of 1024 records is read completely before any of it is rewritten), then the first ranks of the rank map's words
@@ -647,6 +709,17 @@ hipError_t ndt_launch_fuse(const NdtSetView &set, size_t first, size_t count, co
     hipLaunchKernelGGL(ndt_fuse_finalize_kernel, dim3((unsigned)count), dim3(NDT_FIN2_THREADS), 0, stream, set,
                        (unsigned)first, (unsigned)n_points, prm.n_min, prm.eval_factor, prm.maxnumpoints,
                        (float)prm.occupancy_limit, s1, s2);
+    return hipGetLastError();
+}
+
+hipError_t ndt_launch_overlap_lists(const NdtSetView &rset, const uint32_t *ridx_dev, const NdtSetView &mset,
+                                    const uint32_t *midx_dev, const uint32_t *list_of_link_dev, const unsigned *offs_dev,
+                                    const void *pairs_dev, const double *T16_dev, size_t n_links, double *score_dev,
+                                    long long *nb_dev, hipStream_t stream)
+{
+    if (n_links == 0) return hipSuccess;
+    hipLaunchKernelGGL(ndt_overlap_lists_kernel, dim3((unsigned)n_links), dim3(256), 0, stream, rset, ridx_dev, mset, midx_dev,
+                       list_of_link_dev, offs_dev, (const uint2 *)pairs_dev, T16_dev, score_dev, nb_dev);
     return hipGetLastError();
 }
 

@@ -43,18 +43,53 @@ static __device__ __forceinline__ unsigned occ_count_quarter(const float *o, uns
     return n;
 }
 
-// one workgroup per map: counts[map - first] = its cells with a reading
+// one workgroup per map: counts[blockIdx.x] = its cells with a reading (maps: first + blockIdx.x, or maps[blockIdx.x])
 extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_occ_count_kernel(NdtSetView set, unsigned first,
+                                                                                   const uint32_t *__restrict__ maps,
                                                                                    unsigned *__restrict__ counts)
 {
     __shared__ unsigned s_n[NDT_PACK_THREADS / 64];
-    const unsigned map = first + blockIdx.x, wave = threadIdx.x >> 6;
+    const unsigned map = maps ? maps[blockIdx.x] : first + blockIdx.x, wave = threadIdx.x >> 6;
     const unsigned slots = (unsigned)set.grid.slots, q = ((slots + 3u) / 4u + 63u) & ~63u;
     const float *o = set.occ + (size_t)map * slots;
     const unsigned n = occ_count_quarter(o, min(slots, wave * q), min(slots, (wave + 1u) * q));
     if ((threadIdx.x & 63u) == 0u) s_n[wave] = n;
     __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+}
+
+// The (slot, occupancy) pairs of the cells with a reading of map `map`, in slot order, to pairs[0 .. min(total, cap)); returns
+// the total (workgroup-uniform).  All NDT_PACK_THREADS threads; s_n: one word per wave.
+static __device__ __forceinline__ unsigned occ_compact(const NdtSetView &set, unsigned map, NdtPackedOcc *pairs, unsigned cap, unsigned *s_n)
+{
+    // count per wave, then every wave writes its quarter's pairs behind those of the waves before it
+    const unsigned tid = threadIdx.x, slots = (unsigned)set.grid.slots, q = ((slots + 3u) / 4u + 63u) & ~63u, wave = tid >> 6, lane = tid & 63u;
+    const float *o = set.occ + (size_t)map * slots;
+    const unsigned begin = min(slots, wave * q), end = min(slots, (wave + 1u) * q);
+    const unsigned mine = occ_count_quarter(o, begin, end);
+    if (lane == 0u) s_n[wave] = mine;
+    __syncthreads();
+    unsigned at = 0, total = 0;
+    for (unsigned w = 0; w < NDT_PACK_THREADS / 64; w++) { if (w < wave) at += s_n[w]; total += s_n[w]; }
+    for (unsigned b = begin; b < end; b += 64u) {
+        const unsigned sl = b + lane;
+        const float v = sl < end ? o[sl] : 0.0f;
+        const unsigned long long m = ndt_ballot(v != 0.0f);
+        const unsigned pos = at + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (v != 0.0f && pos < cap) pairs[pos] = NdtPackedOcc{sl, v};
+        at += (unsigned)__popcll(m);
+    }
+    return total;
+}
+
+// one workgroup per map maps[blockIdx.x]: its pairs to pairs + offs[blockIdx.x] (room for offs[blockIdx.x + 1] - offs[blockIdx.x])
+extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_occ_list_kernel(NdtSetView set, const uint32_t *__restrict__ maps,
+                                                                                  const unsigned *__restrict__ offs,
+                                                                                  uint2 *__restrict__ pairs)
+{
+    __shared__ unsigned s_n[NDT_PACK_THREADS / 64];
+    const unsigned o0 = offs[blockIdx.x], o1 = offs[blockIdx.x + 1u];
+    (void)occ_compact(set, maps[blockIdx.x], reinterpret_cast<NdtPackedOcc *>(pairs) + o0, o1 - o0, s_n);
 }
 
 // one workgroup per map
@@ -71,28 +106,11 @@ extern "C" __global__ __launch_bounds__(NDT_PACK_THREADS) void ndt_pack_kernel(N
     const unsigned n_out = n > cells_cap ? cells_cap : n;
     bool occ_cut = false;
     if (with_occ == 2) {
-        // sparse occupancies: count per wave, then every wave writes its quarter's pairs behind those of the waves before it
-        // (slot order: the record's bytes do not depend on timing)
-        const unsigned slots = (unsigned)g.slots, q = ((slots + 3u) / 4u + 63u) & ~63u, wave = tid >> 6, lane = tid & 63u;
-        const float *o = set.occ + (size_t)map * slots;
-        const unsigned begin = min(slots, wave * q), end = min(slots, (wave + 1u) * q);
-        const unsigned mine = occ_count_quarter(o, begin, end);
-        if (lane == 0u) s_n[wave] = mine;
-        __syncthreads();
-        unsigned at = 0, total = 0;
-        for (unsigned w = 0; w < NDT_PACK_THREADS / 64; w++) { if (w < wave) at += s_n[w]; total += s_n[w]; }
-        occ_cut = total > occ_cap;
+        // sparse occupancies, in slot order: the record's bytes do not depend on timing
         char *ob = rec + sizeof(NdtPackedHeader) + (size_t)cells_cap * sizeof(NdtCell);
+        const unsigned total = occ_compact(set, map, reinterpret_cast<NdtPackedOcc *>(ob + sizeof(NdtPackedOccHead)), occ_cap, s_n);
+        occ_cut = total > occ_cap;
         if (tid == 0) *reinterpret_cast<NdtPackedOccHead *>(ob) = NdtPackedOccHead{occ_cut ? occ_cap : total, occ_cap};
-        NdtPackedOcc *pairs = reinterpret_cast<NdtPackedOcc *>(ob + sizeof(NdtPackedOccHead));
-        for (unsigned b = begin; b < end; b += 64u) {
-            const unsigned sl = b + lane;
-            const float v = sl < end ? o[sl] : 0.0f;
-            const unsigned long long m = ndt_ballot(v != 0.0f);
-            const unsigned pos = at + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            if (v != 0.0f && pos < occ_cap) pairs[pos] = NdtPackedOcc{sl, v};
-            at += (unsigned)__popcll(m);
-        }
     }
     if (tid == 0) {
         NdtPackedHeader h;
@@ -196,10 +214,23 @@ hipError_t ndt_launch_pack(const NdtSetView &set, size_t first, size_t count, vo
 
 size_t ndt_pack_sparse_occ_bytes(unsigned occ_cap) { return sizeof(NdtPackedOccHead) + (size_t)occ_cap * sizeof(NdtPackedOcc); }
 
-hipError_t ndt_launch_occ_count(const NdtSetView &set, size_t first, size_t count, unsigned *counts_dev, hipStream_t stream)
+// maps_dev: the maps to count (count of them), or NULL for maps [first, first + count)
+hipError_t ndt_launch_occ_count(const NdtSetView &set, size_t first, const uint32_t *maps_dev, size_t count, unsigned *counts_dev,
+                                hipStream_t stream)
 {
     if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(ndt_occ_count_kernel, dim3((unsigned)count), dim3(NDT_PACK_THREADS), 0, stream, set, (unsigned)first, counts_dev);
+    hipLaunchKernelGGL(ndt_occ_count_kernel, dim3((unsigned)count), dim3(NDT_PACK_THREADS), 0, stream, set, (unsigned)first, maps_dev,
+                       counts_dev);
+    return hipGetLastError();
+}
+
+// the (slot, occupancy) pairs of maps_dev[u] to pairs_dev + offs_dev[u], u < count (offs_dev: count + 1 offsets)
+hipError_t ndt_launch_occ_list(const NdtSetView &set, const uint32_t *maps_dev, size_t count, const unsigned *offs_dev, void *pairs_dev,
+                               hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(ndt_occ_list_kernel, dim3((unsigned)count), dim3(NDT_PACK_THREADS), 0, stream, set, maps_dev, offs_dev,
+                       (uint2 *)pairs_dev);
     return hipGetLastError();
 }
 

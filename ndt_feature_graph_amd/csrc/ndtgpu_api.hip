@@ -869,17 +869,65 @@ ndtgpu_status ndtgpu_overlap_score_batch(ndtgpu_mapset *rs, const uint32_t *ridx
     hipStream_t st = (hipStream_t)stream;
     { ndtgpu_status wrc_ = rs->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     { ndtgpu_status wrc_ = ms->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
+    // Batches in which moving maps recur (a graph's links) go through LISTS of the moving maps' cells with a reading: every
+    // distinct moving map is scanned twice (count, then its (slot, occupancy) pairs in slot order), every link then walks a
+    // list of a few thousand pairs instead of the map's whole dense array.  NDTGPU_OVERLAP_DENSE=1: the dense kernel (A/B).
+    const char *dense_env = getenv("NDTGPU_OVERLAP_DENSE");
+    std::vector<uint32_t> list_of_link, list_maps;
+    if (!(dense_env && atoi(dense_env) != 0)) {
+        std::vector<int32_t> list_of_map(ms->n_maps, -1);
+        list_of_link.resize(n_links);
+        for (size_t k = 0; k < n_links; k++) {
+            int32_t &u = list_of_map[midx[k]];
+            if (u < 0) { u = (int32_t)list_maps.size(); list_maps.push_back(midx[k]); }
+            list_of_link[k] = (uint32_t)u;
+        }
+        if (3 * list_maps.size() > 2 * n_links) { list_of_link.clear(); list_maps.clear(); }   // (hardly any map twice: no gain)
+    }
+    const size_t U = list_maps.size();
     const size_t bT = n_links * 16 * sizeof(double), bI = n_links * sizeof(uint32_t), bS = n_links * sizeof(double);
     const size_t off_r = (bT + 255) & ~(size_t)255, off_m = (off_r + bI + 255) & ~(size_t)255,
-                 off_s = (off_m + bI + 255) & ~(size_t)255, off_n = (off_s + bS + 255) & ~(size_t)255;
-    ndtgpu_status rc = rs->ensure_stage(off_n + n_links * sizeof(long long));
+                 off_s = (off_m + bI + 255) & ~(size_t)255, off_n = (off_s + bS + 255) & ~(size_t)255,
+                 off_l = (off_n + n_links * sizeof(long long) + 255) & ~(size_t)255,          // list of every link
+                 off_u = (off_l + (U ? bI : 0) + 255) & ~(size_t)255,                          // the maps of the lists
+                 off_o = (off_u + U * sizeof(uint32_t) + 255) & ~(size_t)255,                  // counts, then offsets
+                 off_p = (off_o + (U + 1) * sizeof(unsigned) + 255) & ~(size_t)255;            // the pairs
+    ndtgpu_status rc = rs->ensure_stage(off_p);
     if (rc != NDTGPU_OK) return rc;
+    std::vector<unsigned> offs(U + 1, 0u);
+    if (U) {
+        // pass 1: how many cells with a reading every listed map has (before the buffer is laid out for good: it may move)
+        char *b0 = (char *)rs->stage;
+        HIP_TRY(hipMemcpyAsync(b0 + off_u, list_maps.data(), U * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        hipError_t e0 = ndt_launch_occ_count(ms->v, 0, (const uint32_t *)(b0 + off_u), U, (unsigned *)(b0 + off_o), st);
+        if (e0 != hipSuccess) return fail(NDTGPU_ERR_HIP, "overlap_score: count launch", e0);
+        HIP_TRY(hipMemcpyAsync(offs.data(), b0 + off_o, U * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        unsigned long long at = 0;
+        for (size_t u = 0; u < U; u++) { const unsigned c = offs[u]; offs[u] = (unsigned)at; at += c; }
+        if (at > 0xFFFFFFFFull) return fail(NDTGPU_ERR_CAPACITY, "overlap_score: too many occupied cells in one batch");
+        offs[U] = (unsigned)at;
+        rc = rs->ensure_stage(off_p + (size_t)at * 8u);
+        if (rc != NDTGPU_OK) return rc;
+    }
     char *base = (char *)rs->stage;
     HIP_TRY(hipMemcpyAsync(base, T16, bT, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + off_r, ridx, bI, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(base + off_m, midx, bI, hipMemcpyHostToDevice, st));
-    hipError_t e = ndt_launch_overlap(rs->v, (const uint32_t *)(base + off_r), ms->v, (const uint32_t *)(base + off_m),
-                                      (const double *)base, n_links, (double *)(base + off_s), (long long *)(base + off_n), st);
+    hipError_t e;
+    if (U) {
+        HIP_TRY(hipMemcpyAsync(base + off_l, list_of_link.data(), bI, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(base + off_u, list_maps.data(), U * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(base + off_o, offs.data(), (U + 1) * sizeof(unsigned), hipMemcpyHostToDevice, st));
+        e = ndt_launch_occ_list(ms->v, (const uint32_t *)(base + off_u), U, (const unsigned *)(base + off_o), base + off_p, st);
+        if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "overlap_score: list launch", e);
+        e = ndt_launch_overlap_lists(rs->v, (const uint32_t *)(base + off_r), ms->v, (const uint32_t *)(base + off_m),
+                                     (const uint32_t *)(base + off_l), (const unsigned *)(base + off_o), base + off_p,
+                                     (const double *)base, n_links, (double *)(base + off_s), (long long *)(base + off_n), st);
+    } else {
+        e = ndt_launch_overlap(rs->v, (const uint32_t *)(base + off_r), ms->v, (const uint32_t *)(base + off_m),
+                               (const double *)base, n_links, (double *)(base + off_s), (long long *)(base + off_n), st);
+    }
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "overlap_score: launch", e);
     HIP_TRY(hipMemcpyAsync(score, base + off_s, bS, hipMemcpyDeviceToHost, st));
     if (nb_sum) HIP_TRY(hipMemcpyAsync(nb_sum, base + off_n, n_links * sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -1651,7 +1699,7 @@ ndtgpu_status ndtgpu_mapset_occupied_cells_max(ndtgpu_mapset *s, size_t first, s
     unsigned *counts_dev = nullptr;
     HIP_TRY(hipMalloc((void **)&counts_dev, count * sizeof(unsigned)));
     std::vector<unsigned> counts(count);
-    hipError_t e = ndt_launch_occ_count(s->v, first, count, counts_dev, st);
+    hipError_t e = ndt_launch_occ_count(s->v, first, nullptr, count, counts_dev, st);
     if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), counts_dev, count * sizeof(unsigned), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(counts_dev);

@@ -267,7 +267,7 @@ def test_plain_build_leaves_occupancy(N, O):
     assert np.array_equal(ms.occupancy(0), om.occupancy())
 
 
-def test_overlap_score_parity(N, O):
+def test_overlap_score_parity(N, O, monkeypatch):
     """overlapNDTOccupancyScore over all ordered pairs of five fused node maps, at the true relative poses and at
     perturbed ones: nb_sum exact, score 1e-12; identical maps at the identity score 0; disjoint maps score 1."""
     from ndt_feature_graph_amd import synth
@@ -308,6 +308,14 @@ def test_overlap_score_parity(N, O):
         so, nbo = O.overlap_score(oms[ref[k]], oms[mov[k]], Ts[k])
         assert nb[k] == nbo, (k, nb[k], nbo)
         assert abs(score[k] - so) < 1e-6 * max(so, 1e-3), (k, score[k], so)
+    # (a batch in which moving maps recur goes through lists of their cells with a reading; the dense kernel on the same
+    #  batch: the same counts, the same score up to the order of one sum)
+    monkeypatch.setenv("NDTGPU_OVERLAP_DENSE", "1")
+    score_d, nb_d = N.overlap_score(ms, ref, ms, mov, Ts)
+    monkeypatch.delenv("NDTGPU_OVERLAP_DENSE")
+    assert np.array_equal(nb, nb_d) and np.max(np.abs(score - score_d)) <= 1e-13 * np.max(np.abs(score_d))
+    score_r, nb_r = N.overlap_score(ms, ref, ms, mov, Ts)
+    assert np.array_equal(score_r, score) and np.array_equal(nb_r, nb)          # run-to-run: the same bits
     same = [k for k in range(len(ref)) if ref[k] == mov[k] and k % 2 == 0]
     assert np.all(score[same] == 0.0) and np.all(nb[same] > 1000)
     far = np.eye(4); far[0, 3] = 500.0
