@@ -858,8 +858,14 @@ def main():
     }
     mk = kern["ndt_match_kernel"]
     mk["fp64_tflops"] = mk["fp64_gflop_per_launch"] / match_ms          # GFLOP / ms = TFLOP/s
-    mk["fp64_note"] = ("pair-term flops counted from csrc/ndt_match.hip: 130 per gradient term, 610 per Hessian term; "
-                       "MI355X fp64 vector peak 78.6 TFLOP/s (AMD datasheet) -> frac %.4f" % (mk["fp64_tflops"] / 78.6))
+    mk["fp64_note"] = ("pair-term flops: 130 per gradient term, 610 per Hessian term -- the per-term figures of the formulation in "
+                       "csrc/ndt_match.hip, the unit of every round's line (DESIGN.md 4.2); the shipped loops EXECUTE 145 / 487 fp64 "
+                       "flops per term (ISA count, fma = 2: since library 0.5.8 the Hessian term no longer issues its 42 "
+                       "multiplications by the structural zeros of e_k x v), i.e. %.2f GFLOP per launch; "
+                       "MI355X fp64 vector peak 78.6 TFLOP/s (AMD datasheet) -> frac %.4f"
+                       % ((145.0 * float(res_np["pair_terms_g"].sum()) + 487.0 * float(res_np["pair_terms_h"].sum())) / 1e9,
+                          mk["fp64_tflops"] / 78.6))
+    mk["fp64_gflop_executed_per_launch"] = (145.0 * float(res_np["pair_terms_g"].sum()) + 487.0 * float(res_np["pair_terms_h"].sum())) / 1e9
     dominant = "ndt_build_kernel" if iso_build_ms >= iso_match_ms else "ndt_match_kernel"   # by time alone on the chip
     dk = kern[dominant]
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
@@ -895,6 +901,8 @@ def main():
                     "unit": "TFLOP/s", "frac": mk["fp64_gflop_per_launch"] / mk["ms_isolated"] / 78.6, "traffic": traffic,
                     "achieved_timed_region": mk["fp64_tflops"], "frac_timed_region": mk["fp64_tflops"] / 78.6,
                     "frac_step": mk["fp64_gflop_per_launch"] / ms_per_step / 78.6,
+                    # the same launch priced by the fp64 flops its loops EXECUTE (ISA count; see kernels.ndt_match_kernel.fp64_note)
+                    "frac_executed_flops": mk["fp64_gflop_executed_per_launch"] / mk["ms_isolated"] / 78.6,
                     "note": note + "; frac_step = the same flops / ms_per_step (what the pipelined step sustains); fp64 vector work (no "
                                    "MFMA instruction is issued: every pair term has its own 3x3 inverse), counted against the fp64 peak"}
 

@@ -201,6 +201,25 @@ NDT_D double rcp_nr(double x)
 // With x = m - mu, B = (C + Cj)^-1, q = (B x, (m - C B x) x B x) [so that x^T B (dx/dp_a) ... = 2 q_a], s = -d1 exp(-d2/2 x^T B x):
 //   score += s,   gradient_a += 2 f q_a,   Hessian_ab += 2 f (h_ab - d2 q_a q_b),   f = -(d2 / 2) s,
 // h = half the second-order bracket of the reference formula (the factor 2 of every term is applied once, in 2 f).
+// a (e_K x v) and a . (e_K x v) without the component of e_K x v that is zero by construction: written with the vectors
+// {0, -v.z, v.y} etc. every such product is an instruction (x * 0 cannot be folded: it is NaN for an infinite x), 42 of the
+// 385 of a pair term with its Hessian.  The terms that are left come in the order they had: for finite operands the same
+// bits (a leading +-0 does not change the sum that follows it).
+template <int K>
+NDT_D d3 mul_ecross(const sym3 &a, d3 v)
+{
+    if constexpr (K == 0) return {a.xy * (-v.z) + a.xz * v.y, a.yy * (-v.z) + a.yz * v.y, a.yz * (-v.z) + a.zz * v.y};
+    else if constexpr (K == 1) return {a.xx * v.z + a.xz * (-v.x), a.xy * v.z + a.yz * (-v.x), a.xz * v.z + a.zz * (-v.x)};
+    else return {a.xx * (-v.y) + a.xy * v.x, a.xy * (-v.y) + a.yy * v.x, a.xz * (-v.y) + a.yz * v.x};
+}
+template <int K>
+NDT_D double dot_ecross(d3 a, d3 v)
+{
+    if constexpr (K == 0) return a.y * (-v.z) + a.z * v.y;
+    else if constexpr (K == 1) return a.x * v.z + a.z * (-v.x);
+    else return a.x * (-v.y) + a.y * v.x;
+}
+
 template <bool WITH_H>
 NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, double *acc)
 {
@@ -235,16 +254,17 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
     if (!WITH_H) return;
 
     const sym3 B = {A.xx * id, A.xy * id, A.xz * id, A.yy * id, A.yz * id, A.zz * id};
-    d3 j[3] = {ex_cross(m), ey_cross(m), ez_cross(m)};
-    d3 Bj[3], p[3], r[3], u[3];
-    p[0] = ex_cross(xB); p[1] = ey_cross(xB); p[2] = ez_cross(xB);
-    d3 qv[3] = {ex_cross(w), ey_cross(w), ez_cross(w)};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        Bj[k] = mul(B, j[k]);
-        r[k] = qv[k] - mul(C, p[k]);                 // Z_k (B x)
-        u[k] = mul(B, r[k]);
+    // j_k = e_k x m, p_k = e_k x (B x), q_k = e_k x w: never formed (see mul_ecross)
+    d3 Bj[3], r[3], u[3];
+    Bj[0] = mul_ecross<0>(B, m); Bj[1] = mul_ecross<1>(B, m); Bj[2] = mul_ecross<2>(B, m);
+    {
+        const d3 c0 = mul_ecross<0>(C, xB), c1 = mul_ecross<1>(C, xB), c2 = mul_ecross<2>(C, xB);
+        r[0] = d3{0.0 - c0.x, -w.z - c0.y, w.y - c0.z};          // Z_k (B x) = e_k x w - C (e_k x B x)
+        r[1] = d3{w.z - c1.x, 0.0 - c1.y, -w.x - c1.z};
+        r[2] = d3{-w.y - c2.x, w.x - c2.y, 0.0 - c2.z};
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) u[k] = mul(B, r[k]);
     const double Bm[3][3] = {{B.xx, B.xy, B.xz}, {B.xy, B.yy, B.yz}, {B.xz, B.yz, B.zz}};
     const double Bjv[3][3] = {{Bj[0].x, Bj[0].y, Bj[0].z}, {Bj[1].x, Bj[1].y, Bj[1].z}, {Bj[2].x, Bj[2].y, Bj[2].z}};
     const double uv[3][3] = {{u[0].x, u[0].y, u[0].z}, {u[1].x, u[1].y, u[1].z}, {u[2].x, u[2].y, u[2].z}};
@@ -266,8 +286,13 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
             } else if (a < 3) {
                 h = Bjv[b - 3][a] - uv[b - 3][a];
             } else {
-                int i = a - 3, k = b - 3;
-                h = dot(j[i], Bj[k]) + xBH[i][k] - (dot(u[i], j[k]) + dot(u[k], j[i])) + dot(u[i], r[k]) + dot(p[i], r[k]);
+                const int i = a - 3, k = b - 3;
+                // dot(j_i, B j_k) + x^T B H_ik - (dot(u_i, j_k) + dot(u_k, j_i)) + dot(u_i, r_k) + dot(p_i, r_k)
+                const double jBj = i == 0 ? dot_ecross<0>(Bj[k], m) : i == 1 ? dot_ecross<1>(Bj[k], m) : dot_ecross<2>(Bj[k], m);
+                const double uj_ik = k == 0 ? dot_ecross<0>(u[i], m) : k == 1 ? dot_ecross<1>(u[i], m) : dot_ecross<2>(u[i], m);
+                const double uj_ki = i == 0 ? dot_ecross<0>(u[k], m) : i == 1 ? dot_ecross<1>(u[k], m) : dot_ecross<2>(u[k], m);
+                const double pr = i == 0 ? dot_ecross<0>(r[k], xB) : i == 1 ? dot_ecross<1>(r[k], xB) : dot_ecross<2>(r[k], xB);
+                h = jBj + xBH[i][k] - (uj_ik + uj_ki) + dot(u[i], r[k]) + pr;
             }
             acc[o++] += f2 * (h - qk[a] * q[b]);
         }
