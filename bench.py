@@ -859,13 +859,14 @@ def main():
     mk = kern["ndt_match_kernel"]
     mk["fp64_tflops"] = mk["fp64_gflop_per_launch"] / match_ms          # GFLOP / ms = TFLOP/s
     mk["fp64_note"] = ("pair-term flops: 130 per gradient term, 610 per Hessian term -- the per-term figures of the formulation in "
-                       "csrc/ndt_match.hip, the unit of every round's line (DESIGN.md 4.2); the shipped loops EXECUTE 145 / 487 fp64 "
+                       "csrc/ndt_match.hip, the unit of every round's line (DESIGN.md 4.2); the shipped loops EXECUTE 145 / 394 fp64 "
                        "flops per term (ISA count, fma = 2: since library 0.5.8 the Hessian term no longer issues its 42 "
-                       "multiplications by the structural zeros of e_k x v), i.e. %.2f GFLOP per launch; "
+                       "multiplications by the structural zeros of e_k x v, since 0.5.9 its rotational blocks are d_i^T B d_k with "
+                       "d_k = j_k - r_k), i.e. %.2f GFLOP per launch; "
                        "MI355X fp64 vector peak 78.6 TFLOP/s (AMD datasheet) -> frac %.4f"
-                       % ((145.0 * float(res_np["pair_terms_g"].sum()) + 487.0 * float(res_np["pair_terms_h"].sum())) / 1e9,
+                       % ((145.0 * float(res_np["pair_terms_g"].sum()) + 394.0 * float(res_np["pair_terms_h"].sum())) / 1e9,
                           mk["fp64_tflops"] / 78.6))
-    mk["fp64_gflop_executed_per_launch"] = (145.0 * float(res_np["pair_terms_g"].sum()) + 487.0 * float(res_np["pair_terms_h"].sum())) / 1e9
+    mk["fp64_gflop_executed_per_launch"] = (145.0 * float(res_np["pair_terms_g"].sum()) + 394.0 * float(res_np["pair_terms_h"].sum())) / 1e9
     dominant = "ndt_build_kernel" if iso_build_ms >= iso_match_ms else "ndt_match_kernel"   # by time alone on the chip
     dk = kern[dominant]
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command

@@ -214,7 +214,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.5.8 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.5.9 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1412,6 +1412,24 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
                 double share = (M + B) > 0 ? M / (M + B) : 0.5;
                 share = std::min(0.9, std::max(0.25, share));
                 r->stream_groups = std::max(8u, ((unsigned)(share * n_cu + 4.0) / 8u) * 8u);
+                // ... refined by what the build side really does with the CUs it is left: a build launch is one workgroup per
+                // map, four to a CU, so on F CUs it takes ceil(maps / 4F) ROUNDS of the mean workgroup time -- 2048 maps take
+                // four rounds on 128 CUs and five on 120, 112 or 104.  Of the splits around the proportional one, take the one
+                // whose slower side is fastest (the bench halls after the round's matcher savings: 136 by proportion, 573 k
+                // registrations/s; 128 by this rule, 624 k; 120: 585 k, 144: 544 k).
+                if (B > 0 && M > 0) {
+                    const double wg = 4.0 * B / (2.0 * (double)p);            // mean clocks of a build workgroup
+                    double best_t = 0;
+                    unsigned best_g = r->stream_groups;
+                    for (int g8 = (int)r->stream_groups - 32; g8 <= (int)r->stream_groups + 32; g8 += 8) {
+                        if (g8 < 16 || g8 > n_cu - 16) continue;
+                        const double slots = 4.0 * (n_cu - g8);
+                        const double t = std::max(M / g8, std::ceil(2.0 * (double)p / slots) * wg);
+                        const bool closer = std::abs(g8 - (int)r->stream_groups) < std::abs((int)best_g - (int)r->stream_groups);
+                        if (best_t == 0 || t < 0.99 * best_t || (t <= 1.01 * best_t && closer && t <= best_t)) { best_t = t; best_g = (unsigned)g8; }
+                    }
+                    r->stream_groups = best_g;
+                }
                 if (getenv("NDTGPU_REG_VERBOSE")) fprintf(stderr, "ndtgpu registrar: build %.3g, registrations %.3g CU-clocks per sub-batch -> matcher instances of %u workgroups\n", B, M, r->stream_groups);
                 r->submitted++;
                 if (ticket) *ticket = (uint64_t)r->submitted;

@@ -620,7 +620,23 @@ def test_match_parity_sweep(N, O, res, n_pts, nn, step_control):
         for Tx, rx in ((Tc[b], rc), (Tp[b], rp)):
             dt, dr = pose_close(Tx, To)
             assert dt <= POSE_TOL_M and dr <= POSE_TOL_RAD, (b, dt, dr)
-            assert bool(rx["converged"][b]) == ro["converged"] and rx["iterations"][b] == ro["iterations"]
+            same_flow = bool(rx["converged"][b]) == ro["converged"] and rx["iterations"][b] == ro["iterations"]
+            if not same_flow:
+                # One iteration more or less at the convergence test |dp| < DELTA_SCORE is accepted only where the ORACLE ALONE
+                # does the same when its own sums are taken in another order or moved by a few ulp (oracle_set_sum_mode, as in
+                # test_gpu_fullsize.py): rounding decides there, not the formulas.
+                assert ro["iterations"] > 1 and abs(int(rx["iterations"][b]) - ro["iterations"]) <= 1, (b, rx["iterations"][b], ro["iterations"])
+                base, fragile = (ro["iterations"], ro["converged"]), False
+                for mode in list(range(16, 28)) + list(range(1, 16)):
+                    O.set_sum_mode(mode)
+                    try:
+                        Tq, rq = O.match_d2d(om[b][0], om[b][1], T0[b], **kw)
+                    finally:
+                        O.set_sum_mode(0)
+                    if (rq["iterations"], rq["converged"]) != base:
+                        fragile = True
+                        break
+                assert fragile, (b, rx["iterations"][b], ro["iterations"], "the oracle's flow is stable under other summation orders and ulp noise")
 
 
 def test_full_size_properties(N):
