@@ -239,12 +239,14 @@ NDT_HDN void mt_request_trial(MatchState &st)
     pose_to_rigid(pincr, ps);
     rigid_mul(ps, T, Te);              // trial cells = ps * nextNDT (fusion.h:556-589)
     // Which trials are evaluated WITH their Hessian: the first one while first trials keep being accepted (spec_ok), and every
-    // trial from the third on -- a search that gets that far ends there nine times in ten (tools/spec_stats.py, 128 bench pairs:
-    // trials per search 1 / 2 / 3 / 4+: 434 / 454 / 244 / 24; the second trial ends 63 % of the searches that reach it, the third
-    // 91 %), and an evaluation with the Hessian that is consumed saves a whole gradient-only one (9.3 k against 11.5 k wave
-    // instructions lost when it is not: worth it above 55 %).  NDT_SPEC_FROM: the trial from which on (experiments).
+    // trial from the SECOND on (tools/spec_stats.py, 128 bench pairs: trials per search 1 / 2 / 3 / 4+: 434 / 454 / 244 / 24; the
+    // second trial ends 63 % of the searches that reach it, the third 91 %).  An evaluation with the Hessian that is consumed
+    // saves a whole gradient-only one; one that is not costs the difference -- worth it above 47 % now that a share task
+    // with the Hessian is 1.9 times a gradient-only one (it was 2.4 times, break-even 55 %, before the round's leaner Hessian
+    // term: from the third trial on then).  Measured, 100 steps of the bench: from the second trial 646 k registrations/s,
+    // from the third 620 k.  NDT_SPEC_FROM: the number of trials before the first speculated one (experiments).
 #ifndef NDT_SPEC_FROM
-#define NDT_SPEC_FROM 2
+#define NDT_SPEC_FROM 1
 #endif
     int spec = ((nfev == 0 && spec_ok) || (!use_feat && nfev >= NDT_SPEC_FROM)) ? 1 : 0;
     if (spec && !use_feat) {
