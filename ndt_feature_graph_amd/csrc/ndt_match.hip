@@ -181,6 +181,8 @@ NDT_D double exp_nonpos(double x)
     p = fma(p, r, sgpr_const(5.00000000000000000e-01));   // 1/2!
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
+    // (Estrin's scheme -- the same polynomial in 16 instructions of depth 5 -- was measured in round 5: 643 against 647 k
+    //  registrations/s on the bench; the chain through the exponential is not what the gradient term waits for)
     const double v = ldexp(p, (int)fmax(kf, -1100.0));
     return x < -745.2 ? 0.0 : v;
 }
