@@ -374,17 +374,18 @@ def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_c
     # the same steps through the registrar (ONE ndtgpu_register_batch_device call per step, three internal map sets / streams):
     # the builds and the first registrations of step k + 1 fill the CUs that the long registrations of step k have left
     ms.profiling(False)
-    reg = N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=B, depth=4, max_cells=4096)
-    outs = [(T_init_cm.clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev), [0]) for _ in range(4)]
+    D = max(1, min(8, int(args.buffers)))
+    reg = N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=B, depth=D, max_cells=4096)
+    outs = [(T_init_cm.clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev), [0]) for _ in range(D)]
     n_pipe = 12
 
     def pstep(k):
-        T_k, r_k, tk = outs[k % 4]
+        T_k, r_k, tk = outs[k % D]
         if tk[0]:
             reg.wait_stream(st, ticket=tk[0])
         T_k.copy_(T_init_cm)
         tk[0] = reg.submit(both[:B], both[B:], T_k, r_k, range_limit=rng_lim, stream=st)
-    for k in range(4):
+    for k in range(D):
         pstep(k)
     reg.sync(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -392,7 +393,7 @@ def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_c
         pstep(k)
     reg.sync(); torch.cuda.synchronize()
     elapsed_pipe = time.perf_counter() - t0
-    same = bool(torch.equal(outs[(n_pipe - 1) % 4][0], T16) and torch.equal(outs[(n_pipe - 1) % 4][1][:, :32], results[:, :32]))
+    same = bool(torch.equal(outs[(n_pipe - 1) % D][0], T16) and torch.equal(outs[(n_pipe - 1) % D][1][:, :32], results[:, :32]))
     reg.close()
     out = {"value": B * n_pipe / elapsed_pipe, "unit": "registrations/s", "pairs": B, "steps": n_pipe,
            "ms_per_step": 1e3 * elapsed_pipe / n_pipe, "value_serial": B * n_steps / elapsed,
@@ -613,7 +614,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--dense-pairs", type=int, default=384, help="pairs of the dense-scene leg (0 = skip it)")
     ap.add_argument("--dense-cpu-sample", type=int, default=16, help="pairs of the dense-scene leg timed on the CPU")
-    ap.add_argument("--buffers", type=int, default=4, help="pipeline depth (the registrar's internal map sets)")
+    ap.add_argument("--buffers", type=int, default=8, help="pipeline depth (the registrar's internal map sets; at most 8)")
     ap.add_argument("--cu-split", type=int, default=0, help="CUs given to the build streams (hipExtStreamCreateWithCUMask), the "
                     "matcher streams get the rest; 0: every stream sees the whole chip")
     ap.add_argument("--sub-batch", type=int, default=0, help="pairs per internal sub-batch of the registrar (0: --pairs, one sub-batch per call)")
@@ -676,6 +677,9 @@ def main():
     n_buf = 1 if args.no_pipeline else args.buffers
     n_cu_dev = torch.cuda.get_device_properties(dev).multi_processor_count
     legacy = args.legacy_pipeline or args.cu_split > 0
+    if legacy:
+        n_buf = min(n_buf, 4)                  # (the round-4 choreography: a whole map set per buffer)
+    n_buf = max(1, min(n_buf, 8))              # (the registrar's ring holds at most eight map sets)
     if args.cu_split > 0 and n_buf > 1:
         os.environ["NDTGPU_MATCH_GROUPS"] = str(n_cu_dev - args.cu_split)
 
