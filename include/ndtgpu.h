@@ -372,7 +372,7 @@ ndtgpu_status ndtgpu_mapset_pack_cells_sparse_device(ndtgpu_mapset *set, size_t 
  * Results are bit for bit those of ndtgpu_mapset_build + ndtgpu_match_batch_device on the same scans. */
 typedef struct ndtgpu_registrar ndtgpu_registrar;
 /* grid: as ndtgpu_mapset_create (grid->max_cells applies per scan).  pairs_per_batch: registrations per internal sub-batch
- * (1024 fills an MI355X: two registrations per CU in flight); depth: internal map sets in flight, 1 .. 8 (a batch is
+ * (1024 fills an MI355X: two registrations per CU in flight); depth: internal map sets in flight, 1 .. 16 (the stream-fed matcher serves up to 8; a batch is
  * complete 3-5 ms after its publication and its set is busy until then: 8 keeps the builds from waiting for that, 4 costs ~5 %
  * on the bench; memory per map set: see ndtgpu_mapset_create x 2 x pairs_per_batch maps). */
 ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pairs_per_batch, int depth,
