@@ -85,6 +85,8 @@ struct NdtSetView {            // what kernels see of a mapset
     float *occ;                // [n_maps][slots]      NDTCell::occ of every cell (NDTMap::initialize: all cells exist)
     long long *occ_delta;      // [n_maps][slots]      beam evidence of one addPointCloud, exact sums in units of 2^-32
                                //                      (all 0 between calls)
+    unsigned char *occ_touched;// [n_maps][ceil(slots / 256)]  1: a beam left evidence in this block of 256 slots (the finalise
+                               //                      pass looks at those blocks only; all 0 between calls)
     NdtCell *cells_alt;        // [n_maps][max_cells]  second cell array: an incremental update reads the old cells
                                //                      while it writes the new ranking
     uint32_t *cell_sel;        // [n_maps]             0: the map's cells are in `cells`, 1: in `cells_alt`

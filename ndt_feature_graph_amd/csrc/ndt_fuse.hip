@@ -157,6 +157,7 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
     const uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);
     const NdtCell *cells = ndt_cells_of(set, map, set.cell_sel[map]);
     long long *delta = set.occ_delta + (size_t)map * g.slots;
+    unsigned char *touched = set.occ_touched + (size_t)map * (((size_t)g.slots + 255) >> 8);
     int iox = 0, ioy = 0, ioz = 0;                    // idxo = idyo = idzo = 0 like upstream
     const unsigned lane = threadIdx.x & 63u;
     // Cell index of a sample.  The reference rounds the sample to float, p = (float)(origin + f s), and takes
@@ -241,7 +242,10 @@ extern "C" __global__ __launch_bounds__(256) void ndt_raytrace_kernel(
                 const long long mv = mine ? val : 0ll;
                 v = ((long long)wave_sum_i32((int)(mv >> 20)) << 20) + (long long)wave_sum_i32((int)(mv & 0xFFFFF));
             }
-            if ((int)lane == leader) atomicAdd(reinterpret_cast<unsigned long long *>(delta + s0), (unsigned long long)v);
+            if ((int)lane == leader) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(delta + s0), (unsigned long long)v);
+                touched[(unsigned)s0 >> 8] = 1;      // (a plain byte store: everybody writes the same 1)
+            }
             todo &= ~m_mine;
         }
     }
@@ -277,17 +281,36 @@ extern "C" __global__ __launch_bounds__(NDT_FIN2_THREADS) void ndt_fuse_finalize
     if (tid == 0) s_binned = 0;
 
     // ---- 1. the beams' evidence: occupancy = clamp(occupancy + sum of the updates) ---------------------------------
-    for (unsigned s = tid; s < (unsigned)g.slots; s += nthreads) {
-        const long long d = delta[s];
-        if (d != 0) {
-            float o = (float)((double)occ[s] + (double)d * (1.0 / 4294967296.0));
-            o = o > occupancy_limit ? occupancy_limit : (o < -occupancy_limit ? -occupancy_limit : o);
-            occ[s] = o;
-            delta[s] = 0;
+    // Only the blocks of 256 slots that a beam marked (ndt_raytrace_kernel): a scan leaves evidence in a few per cent of a node
+    // map's slots, and reading all of them was 640 KB per map and scan.  64 block flags per load; the k-th marked block of a
+    // group goes to wave k mod nwaves.
+    {
+        const unsigned nblk = ((unsigned)g.slots + 255u) >> 8;
+        unsigned char *touched = set.occ_touched + (size_t)map * nblk;
+        for (unsigned b0 = 0; b0 < nblk; b0 += 64u) {
+            const unsigned bi = b0 + lane;
+            unsigned long long marked = ndt_ballot(bi < nblk && touched[bi] != 0);
+            for (unsigned k = 0; marked; k++) {
+                const unsigned b = b0 + (unsigned)__builtin_ctzll(marked);
+                marked &= marked - 1ull;
+                if (k % nwaves != wave) continue;
+                const unsigned s_end = min((unsigned)g.slots, (b + 1u) << 8);
+                for (unsigned s = (b << 8) + lane; s < s_end; s += 64u) {
+                    const long long d = delta[s];
+                    if (d != 0) {
+                        float o = (float)((double)occ[s] + (double)d * (1.0 / 4294967296.0));
+                        o = o > occupancy_limit ? occupancy_limit : (o < -occupancy_limit ? -occupancy_limit : o);
+                        occ[s] = o;
+                        delta[s] = 0;
+                    }
+                }
+            }
         }
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // accumulator atomics bypass the L1
+        __syncthreads();                                                   // (every wave has read the flags)
+        for (unsigned i = tid; i < nblk; i += nthreads)
+            if (touched[i] != 0) touched[i] = 0;
     }
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // accumulator atomics bypass the L1
-    __syncthreads();
 
     // ---- 2. computeGaussian of every cell that received points --------------------------------------------------
     unsigned n_alloc = ctr->n_alloc;

@@ -214,7 +214,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.5.10 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.5.11 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -336,6 +336,7 @@ ndtgpu_status ndtgpu_mapset_destroy(ndtgpu_mapset *s)
     if (s->v.centres) (void)hipFree(s->v.centres);
     if (s->v.occ) (void)hipFree(s->v.occ);
     if (s->v.occ_delta) (void)hipFree(s->v.occ_delta);
+    if (s->v.occ_touched) (void)hipFree(s->v.occ_touched);
     if (s->v.cells_alt) (void)hipFree(s->v.cells_alt);
     if (s->v.cell_sel) (void)hipFree(s->v.cell_sel);
     if (s->stage) (void)hipFree(s->stage);
@@ -737,9 +738,13 @@ ndtgpu_status ndtgpu_mapset_enable_occupancy(ndtgpu_mapset *s)
     long long *delta = nullptr;
     NdtCell *alt = nullptr;
     uint32_t *sel = nullptr;
+    unsigned char *touched = nullptr;
+    const size_t blocks = (slots + 255) / 256;
     hipError_t e;
     if ((e = hipMalloc((void **)&occ, n * slots * sizeof(float))) != hipSuccess ||
         (e = hipMalloc((void **)&delta, n * slots * sizeof(long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&touched, n * blocks)) != hipSuccess ||
+        (e = hipMemset(touched, 0, n * blocks)) != hipSuccess ||
         (e = hipMalloc((void **)&alt, n * cap * sizeof(NdtCell))) != hipSuccess ||
         (e = hipMalloc((void **)&sel, n * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemset(occ, 0, n * slots * sizeof(float))) != hipSuccess ||
@@ -747,11 +752,12 @@ ndtgpu_status ndtgpu_mapset_enable_occupancy(ndtgpu_mapset *s)
         (e = hipMemset(sel, 0, n * sizeof(uint32_t))) != hipSuccess) {
         if (occ) (void)hipFree(occ);
         if (delta) (void)hipFree(delta);
+        if (touched) (void)hipFree(touched);
         if (alt) (void)hipFree(alt);
         if (sel) (void)hipFree(sel);
         return fail(NDTGPU_ERR_ALLOC, "enable_occupancy: device memory", e);
     }
-    s->v.occ = occ; s->v.occ_delta = delta; s->v.cells_alt = alt; s->v.cell_sel = sel;
+    s->v.occ = occ; s->v.occ_delta = delta; s->v.occ_touched = touched; s->v.cells_alt = alt; s->v.cell_sel = sel;
     return NDTGPU_OK;
 }
 
