@@ -554,7 +554,7 @@ class Registrar:
     """ndtgpu_registrar: scans in, poses out -- grid builds + D2D matcher of batches of scan pairs as ONE asynchronous call,
     pipelined over the library's own streams (include/ndtgpu.h)."""
 
-    def __init__(self, res, centre, size_m, pairs_per_batch=1024, depth=3, max_cells=0):
+    def __init__(self, res, centre, size_m, pairs_per_batch=1024, depth=8, max_cells=0):
         gp = GridParams()
         gp.res = float(res)
         gp.centre[:] = [float(x) for x in centre]

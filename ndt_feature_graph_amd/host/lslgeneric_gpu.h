@@ -637,7 +637,7 @@ namespace ndtgpu_host {
 // are padded with NaN points, which loadPointCloud drops.
 class ScanRegistrar {
 public:
-    ScanRegistrar(double res, const double centre[3], const double size_m[3], size_t pairs_per_batch = 1024, int depth = 3,
+    ScanRegistrar(double res, const double centre[3], const double size_m[3], size_t pairs_per_batch = 1024, int depth = 8,
                   uint32_t max_cells = 0)
     {
         ndtgpu_grid_params g;
