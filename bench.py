@@ -923,8 +923,10 @@ def main():
                    "entry": ("ndtgpu_mapset_build + ndtgpu_match_batch_device per step, streams and events driven by bench.py" if legacy
                              else "ONE ndtgpu_register_batch_device call per step (scans in HBM -> poses); reg.sync() ends the timed region"),
                    "pipeline": ("serial: one stream" if n_buf == 1 else
-                                "%d internal map sets / streams: builds of step k+1 start when the builds of step k are done and run "
-                                "on the CUs the matcher's finished workgroups have left" % n_buf),
+                                ("%d map sets / steps in flight, three streams, matcher launches on the CUs the builds leave" % n_buf if legacy else
+                                 "%d internal map sets in flight: the grid builds of later steps run on two streams beside ONE running "
+                                 "instance of the stream-fed matcher, which holds the share of the CUs the registrar measured on its "
+                                 "first batch" % n_buf)),
                    "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2)},
         "roofline": roofline, "kernels": kern,
         # SURVEY.md 8d (config 4): node maps and edges are separate units when node maps are reused across edges
