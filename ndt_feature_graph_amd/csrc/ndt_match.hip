@@ -1966,7 +1966,7 @@ NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &epoch, unsigned G)
 // `a += load` the compiler waits for every load before it issues the next (they are atomic accesses and stay in program
 // order), and a registration of 96 chunks paid six dependent round trips across the fabric per evaluation.  Same order
 // of additions as the plain loop.
-NDT_D double sum_rows_16x32(const double *rows, unsigned NC, unsigned r, unsigned k)
+static __device__ __noinline__ double sum_rows_16x32(const double *rows, unsigned NC, unsigned r, unsigned k)
 {
     auto ldd = [](const double *q) {
         return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
