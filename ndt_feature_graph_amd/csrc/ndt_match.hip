@@ -222,7 +222,11 @@ NDT_D double dot_ecross(d3 a, d3 v)
     else return a.x * (-v.y) + a.y * v.x;
 }
 
-template <bool WITH_H>
+// PLANAR: the term of NDTMatcherD2D_2D ({x, y, yaw}, dof_mask 0x23): of the gradient the entries 0, 1, 5, of the Hessian the six
+// entries among them -- the expressions of the full term for those entries (the same bits), nothing else (the other sums stay 0;
+// newton_mask decouples their dofs anyway).  One rotational vector d_2 instead of three: ~135 instead of 276 instructions per
+// 64 terms with the Hessian.  Only where nobody reads the inactive entries: not under the Tikhonov term (H^T H mixes them in).
+template <bool WITH_H, bool PLANAR = false>
 NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, double *acc)
 {
     const d3 x = m - mu;
@@ -248,6 +252,28 @@ NDT_D void pair_term(d3 m, sym3 C, d3 mu, sym3 Cj, double lfd1, double lfd2, dou
 #endif
     const double f2 = -lfd2 * sh;                    // 2 f
     const d3 w = mul(C, xB);
+    if constexpr (PLANAR) {
+        const d3 mw = m - w;
+        const double q5 = mw.x * xB.y - mw.y * xB.x;         // (cross(m - w, B x)).z
+        acc[0] += sh;
+        acc[1] += f2 * xB.x; acc[2] += f2 * xB.y; acc[6] += f2 * q5;
+        if (!WITH_H) return;
+        const sym3 B = {A.xx * id, A.xy * id, A.xz * id, A.yy * id, A.yz * id, A.zz * id};
+        const d3 c2 = mul_ecross<2>(C, xB);
+        const d3 r2 = d3{-w.y - c2.x, w.x - c2.y, 0.0 - c2.z};
+        const d3 d2 = d3{c2.x - mw.y, c2.y + mw.x, c2.z};
+        const d3 Bd2 = mul(B, d2);
+        const double xBH22 = -(xB.x * m.x + xB.y * m.y);
+        const double qk0 = lfd2 * xB.x, qk1 = lfd2 * xB.y, qk5 = lfd2 * q5;
+        const double h55 = dot(d2, Bd2) + xBH22 + dot_ecross<2>(r2, xB);
+        acc[7] += f2 * (B.xx - qk0 * xB.x);      // (0, 0)
+        acc[8] += f2 * (B.xy - qk0 * xB.y);      // (0, 1)
+        acc[12] += f2 * (Bd2.x - qk0 * q5);      // (0, 5)
+        acc[13] += f2 * (B.yy - qk1 * xB.y);     // (1, 1)
+        acc[17] += f2 * (Bd2.y - qk1 * q5);      // (1, 5)
+        acc[27] += f2 * (h55 - qk5 * q5);        // (5, 5)
+        return;
+    }
     const d3 qr = cross(m - w, xB);                  // x^T B j_k - x^T B Z_k B x / 2,  j_k = e_k x m
     const double q[6] = {xB.x, xB.y, xB.z, qr.x, qr.y, qr.z};
     acc[0] += sh;
@@ -382,7 +408,7 @@ NDT_D unsigned wave_incl_scan_u32(unsigned v)
 
 // TERM stage: the n (source lane, target cell) pairs at the head of the wave's list, 64 at a time; every lane does one
 // dense pair term.  Without a Hessian the target cells of the next batch are fetched while this one is computed.
-template <bool WITH_H>
+template <bool WITH_H, bool PLANAR = false>
 NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double lfd2, unsigned n)
 {
     const unsigned lane = threadIdx.x & 63u;
@@ -415,7 +441,7 @@ NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double
         for (unsigned e0 = 0; e0 < n; e0 += 64u) {
             fetch(e0 + 64u, en1, mu1, Cj1);
             __builtin_amdgcn_sched_barrier(0);       // (the loads stay above the arithmetic)
-            if (e0 + lane < n) pair_term<true>(tile_m(en0 >> 24), tile_C(en0 >> 24), mu0, Cj0, lfd1, lfd2, w.acc);
+            if (e0 + lane < n) pair_term<true, PLANAR>(tile_m(en0 >> 24), tile_C(en0 >> 24), mu0, Cj0, lfd1, lfd2, w.acc);
             en0 = en1; mu0 = mu1; Cj0 = Cj1;
         }
     } else {
@@ -428,10 +454,10 @@ NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double
         for (unsigned e0 = 0; e0 < n; e0 += 128u) {
             fetch(e0 + 64u, enB, muB, CjB);
             __builtin_amdgcn_sched_barrier(0);
-            if (e0 + lane < n) pair_term<false>(tile_m(enA >> 24), tile_C(enA >> 24), muA, CjA, lfd1, lfd2, w.acc);
+            if (e0 + lane < n) pair_term<false, PLANAR>(tile_m(enA >> 24), tile_C(enA >> 24), muA, CjA, lfd1, lfd2, w.acc);
             fetch(e0 + 128u, enA, muA, CjA);
             __builtin_amdgcn_sched_barrier(0);
-            if (e0 + 64u + lane < n) pair_term<false>(tile_m(enB >> 24), tile_C(enB >> 24), muB, CjB, lfd1, lfd2, w.acc);
+            if (e0 + 64u + lane < n) pair_term<false, PLANAR>(tile_m(enB >> 24), tile_C(enB >> 24), muB, CjB, lfd1, lfd2, w.acc);
         }
     }
     w.terms += n;
@@ -452,7 +478,7 @@ NDT_D void term_list(WaveEval<WITH_H> &w, const MapView &tg, double lfd1, double
 // matcher -- and every segment gets its own hit list, its own pass over the pair terms and its own row of wave totals
 // (seg_rows + segment * seg_stride; the accumulators are zero again afterwards): TRANSFORM and PROBE run once for all 64
 // cells, while the sums of a segment are bit for bit those of a group that holds that segment's cells alone.
-template <int NN, bool WITH_H, int QL, bool SEG = false, bool KEEP_RUNS = false>
+template <int NN, bool WITH_H, int QL, bool SEG = false, bool KEEP_RUNS = false, bool PLANAR = false>
 NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int base, int stride, int end,
                       const rigid &T, double lfd1, double lfd2, unsigned cache_key, unsigned seg_lanes = 64u,
                       double *seg_rows = nullptr, unsigned seg_stride = 0u)
@@ -666,7 +692,7 @@ NDT_D void eval_group(WaveEval<WITH_H> &w, const MapView &tg, gcell_ptr src, int
             if (!(filled && p0 == 0u)) fill(off_l, cnt_l, p0, p1);
             ndt_wave_sync();                             // list entries and tile columns were written by other lanes
             NDT_PROF_T(2)
-            term_list<WITH_H>(w, tg, lfd1, lfd2, p1 - p0);
+            term_list<WITH_H, PLANAR>(w, tg, lfd1, lfd2, p1 - p0);
             NDT_PROF_T(3)
             ndt_wave_sync();                             // the next pass (or group) overwrites the list and the tile
         }
@@ -941,7 +967,7 @@ struct MatchSlot {
 };
 
 // one share of one evaluation: on return the wave's row of partial sums is in S.part
-template <int NN, bool WITH_H, int QL>
+template <int NN, bool WITH_H, int QL, bool PLANAR = false>
 NDT_D void run_share(MatchSlot<QL> &S, unsigned v, double *wsrc, uint2 *wwin, double lfd1, double lfd2)
 {
     constexpr int NACC = WaveEval<WITH_H>::NACC, SH = WITH_H ? 1 : 3;
@@ -961,7 +987,7 @@ NDT_D void run_share(MatchSlot<QL> &S, unsigned v, double *wsrc, uint2 *wwin, do
     const int msrc = S.sv.n_cells;
     const unsigned key = msrc <= 64 * NDT_VW ? S.session : 0u;   // a share remembers the hit list of ONE group
     for (int base = (int)v; base < msrc; base += 64 * NDT_VW)
-        eval_group<NN, WITH_H, QL>(w, S.tg, S.sv.cells, base, NDT_VW, msrc, S.st.Teval, lfd1, lfd2, key);
+        eval_group<NN, WITH_H, QL, false, false, PLANAR>(w, S.tg, S.sv.cells, base, NDT_VW, msrc, S.st.Teval, lfd1, lfd2, key);
     const double tot = wave_totals<WITH_H>(w);
     if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) S.part[v * 32 + (lane >> SH)] = tot;
     if (lane == 0) S.part[v * 32 + 28] = (double)w.terms;
@@ -1310,7 +1336,12 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // the request was published before `next`
             const long long c0 = __builtin_readcyclecounter();
             const int with_h = S.with_h;
-            if (with_h) run_share<NN, true, QL>(S, v, wsrc, wwin, s_prm.lfd1, s_prm.lfd2);
+            // (NDTMatcherD2D_2D without the Tikhonov term: the planar pair term, see pair_term)
+            const bool planar = (s_prm.dof_mask & 0x3f) == 0x23 && !(s_prm.fusion_flags & 2);
+            if (planar) {
+                if (with_h) run_share<NN, true, QL, true>(S, v, wsrc, wwin, s_prm.lfd1, s_prm.lfd2);
+                else run_share<NN, false, QL, true>(S, v, wsrc, wwin, s_prm.lfd1, s_prm.lfd2);
+            } else if (with_h) run_share<NN, true, QL>(S, v, wsrc, wwin, s_prm.lfd1, s_prm.lfd2);
             else run_share<NN, false, QL>(S, v, wsrc, wwin, s_prm.lfd1, s_prm.lfd2);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the row of partial sums before the count
             unsigned d = 0;
@@ -1659,7 +1690,11 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const long long c0 = __builtin_readcyclecounter();
             const int with_h = S.with_h;
-            if (with_h) run_share<NN, true, QL>(S, v, wsrc, wwin, E.prm.lfd1, E.prm.lfd2);
+            const bool planar = (E.prm.dof_mask & 0x3f) == 0x23 && !(E.prm.fusion_flags & 2);
+            if (planar) {
+                if (with_h) run_share<NN, true, QL, true>(S, v, wsrc, wwin, E.prm.lfd1, E.prm.lfd2);
+                else run_share<NN, false, QL, true>(S, v, wsrc, wwin, E.prm.lfd1, E.prm.lfd2);
+            } else if (with_h) run_share<NN, true, QL>(S, v, wsrc, wwin, E.prm.lfd1, E.prm.lfd2);
             else run_share<NN, false, QL>(S, v, wsrc, wwin, E.prm.lfd1, E.prm.lfd2);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             unsigned d = 0;

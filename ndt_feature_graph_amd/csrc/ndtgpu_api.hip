@@ -214,7 +214,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.5.12 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.5.13 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
