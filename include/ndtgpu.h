@@ -371,12 +371,46 @@ ndtgpu_status ndtgpu_mapset_pack_cells_sparse_device(ndtgpu_mapset *set, size_t 
  * the CUs that the long registrations of sub-batch k do not occupy (the pipeline that bench.py drove by hand until round 4).
  * Results are bit for bit those of ndtgpu_mapset_build + ndtgpu_match_batch_device on the same scans. */
 typedef struct ndtgpu_registrar ndtgpu_registrar;
-/* grid: as ndtgpu_mapset_create (grid->max_cells applies per scan).  pairs_per_batch: registrations per internal sub-batch
- * (1024 fills an MI355X: two registrations per CU in flight); depth: internal map sets in flight, 1 .. 16 (the stream-fed matcher serves up to 8; a batch is
- * complete 3-5 ms after its publication and its set is busy until then: 8 keeps the builds from waiting for that, 4 costs ~5 %
- * on the bench; memory per map set: see ndtgpu_mapset_create x 2 x pairs_per_batch maps). */
+/* What a caller may decide about a registrar -- one POD struct, defaults from
+ * ndtgpu_default_registrar_params; a field left at 0 means "the library's choice".  (The NDTGPU_REG_* environment variables of
+ * earlier rounds survive as EXPERIMENT switches only: they fill in fields the caller left at 0.) */
+enum { NDTGPU_MATCHER_AUTO = 0,        /* stream-fed where it applies (2 <= depth <= 8, max_cells < 16384, a device with more than
+                                        * one stream priority), else one launch per sub-batch */
+       NDTGPU_MATCHER_PER_BATCH = 1,   /* one matcher launch per sub-batch on the sub-batch's stream, ordered by events */
+       NDTGPU_MATCHER_STREAM_FED = 2   /* ONE running matcher instance serves batch after batch from a queue in device memory;
+                                        * create fails with NDTGPU_ERR_INVALID where it cannot be had */ };
+typedef struct {
+    size_t pairs_per_batch;   /* registrations per internal sub-batch (1024 fills an MI355X: two registrations per CU in flight) */
+    int32_t depth;            /* internal map sets in flight, 1 .. 16 (the stream-fed matcher serves up to 8; a batch is complete
+                               * 3-5 ms after its publication and its set is busy until then: 8 keeps the builds from waiting for
+                               * that, 4 costs ~5 % on the bench; memory: ndtgpu_mapset_create x 2 x pairs_per_batch maps each) */
+    int32_t matcher_form;     /* NDTGPU_MATCHER_* */
+    uint32_t matcher_groups;  /* CUs (workgroups) the matcher side holds while builds run beside it; 0 = MEASURED: the first
+                               * sub-batch runs alone on the chip, the kernels' own clocks give the CU-time of builds and
+                               * registrations, and the chip is split in that proportion */
+    int32_t build_streams;    /* stream-fed form: 1 or 2 build streams that take the sub-batches in turn; 0 = 2 when depth >= 3 */
+    uint32_t linger_us;       /* stream-fed form: how long a matcher instance that has worked stays when it runs dry */
+    int32_t recalibrate_pct;  /* measured split only: when the mean number of Gaussian cells per map over the last sub-batches
+                               * differs from the figure the split was measured at by more than this many percent, the pipeline is
+                               * drained once and the split measured again (a registrar that moves from halls to clutter).
+                               * 0 = 25; negative = never */
+} ndtgpu_registrar_params;
+void ndtgpu_default_registrar_params(ndtgpu_registrar_params *p);
+typedef struct {
+    int32_t matcher_form;     /* the form in use: NDTGPU_MATCHER_PER_BATCH or NDTGPU_MATCHER_STREAM_FED */
+    uint32_t matcher_groups;  /* current CUs of the matcher side (0: stream-fed and not measured yet) */
+    int32_t build_streams;
+    int32_t calibrations;     /* how often the split has been measured */
+    uint64_t submitted;       /* sub-batches so far */
+    double cells_per_map;     /* mean Gaussian cells per map of the sub-batch the split was last measured on */
+} ndtgpu_registrar_info;
+/* grid: as ndtgpu_mapset_create (grid->max_cells applies per scan). */
+ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const ndtgpu_registrar_params *params,
+                                         ndtgpu_registrar **out);
+/* ... with the default parameters but for the two that every caller has to think about */
 ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pairs_per_batch, int depth,
                                       ndtgpu_registrar **out);
+ndtgpu_status ndtgpu_registrar_get_info(const ndtgpu_registrar *reg, ndtgpu_registrar_info *info);
 ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *reg);
 /* n_pairs registrations: pair k builds the target map from cloud k of targets_dev and the source map from cloud k of
  * sources_dev (DEVICE pointers; n_points records each, stride_bytes apart, clouds map_stride_bytes apart; range filter as
@@ -402,14 +436,20 @@ ndtgpu_status ndtgpu_register_batch_host(ndtgpu_registrar *reg, const void *targ
                                          const ndtgpu_cell_params *cell, double *T16, size_t n_pairs,
                                          const ndtgpu_match_params *prm, ndtgpu_match_result *results);
 /* `stream` waits (on the device, the host does not) for the call `ticket` names and every call before it; ticket 0: for
- * every call submitted so far */
+ * every call submitted so far.  Stream-fed form: the wait is a device-side kernel that ends when the running matcher instance
+ * has completed the batch, so `stream` must not share the matcher stream's hardware queue -- a stream created with the HIGHEST
+ * priority the device offers is refused (NDTGPU_ERR_INVALID); streams of default priority and the null stream are fine. */
 ndtgpu_status ndtgpu_registrar_wait_stream(ndtgpu_registrar *reg, uint64_t ticket, ndtgpu_stream stream);
-/* the host waits for every batch submitted so far; NDTGPU_ERR_HIP if a matcher launch gave up (ndtgpu_match_aborted) */
+/* the host waits for every batch submitted so far; NDTGPU_ERR_HIP if a matcher launch gave up (ndtgpu_match_aborted).  In the
+ * stream-fed form that is reported once: registrations of the batches that were cut short carry exit_code -4 (every result of a
+ * batch is set to "not run" when the batch is published), and the registrar can be used again afterwards. */
 ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *reg);
-/* Profiling: when enabled every sub-batch's build and matcher launch is bracketed by HIP events on the internal stream it
- * runs on.  ndtgpu_registrar_kernel_ms waits for the recorded sub-batches, returns their number and the mean durations
- * (mean_ms[0] build launch, mean_ms[1] matcher launch; under a pipeline these include the time a launch shares the chip with
- * its neighbours), and forgets them. */
+/* Profiling: when enabled every sub-batch's build launch is bracketed by HIP events on the internal stream it runs on, and so
+ * is its matcher launch in the per-batch form.  In the stream-fed form there is no launch per batch: mean_ms[1] is then what
+ * the queue saw of the batch -- from its publication (maps built) until its last registration finished, on the device's 100 MHz
+ * clock -- for the last 64 sub-batches.  ndtgpu_registrar_kernel_ms waits for the recorded sub-batches (stream-fed: for
+ * everything submitted), returns their number and the mean durations (mean_ms[0] build, mean_ms[1] matcher side; under a
+ * pipeline these include the time the work shares the chip with its neighbours), and forgets them. */
 ndtgpu_status ndtgpu_registrar_profiling(ndtgpu_registrar *reg, int on);
 ndtgpu_status ndtgpu_registrar_kernel_ms(ndtgpu_registrar *reg, float mean_ms[2], int32_t *launches);
 /* the internal map set a sub-batch slot uses (tests: cell-by-cell parity of what the registrar built; slot < depth).  Owned by

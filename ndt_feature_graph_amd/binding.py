@@ -126,7 +126,8 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_occupied_cells_max", "ndtgpu_mapset_pack_cells_sparse_device", "ndtgpu_mapset_build_host_async",
            "ndtgpu_mapset_add_cloud_host_async", "ndtgpu_registrar_create", "ndtgpu_registrar_destroy",
            "ndtgpu_register_batch_device", "ndtgpu_registrar_wait_stream", "ndtgpu_registrar_sync",
-           "ndtgpu_registrar_profiling", "ndtgpu_registrar_kernel_ms", "ndtgpu_registrar_mapset", "ndtgpu_register_batch_host"]
+           "ndtgpu_registrar_profiling", "ndtgpu_registrar_kernel_ms", "ndtgpu_registrar_mapset", "ndtgpu_register_batch_host",
+           "ndtgpu_default_registrar_params", "ndtgpu_registrar_create_ex", "ndtgpu_registrar_get_info"]
 
 _lib = None
 
@@ -201,6 +202,10 @@ def lib():
     L.ndtgpu_mapset_pack_cells_sparse_device.argtypes = [vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_uint32, C.c_uint32, vp]
     L.ndtgpu_registrar_create.argtypes = [C.POINTER(GridParams), C.c_size_t, C.c_int, C.POINTER(vp)]
     L.ndtgpu_registrar_destroy.argtypes = [vp]
+    L.ndtgpu_default_registrar_params.argtypes = [C.POINTER(RegistrarParams)]
+    L.ndtgpu_default_registrar_params.restype = None
+    L.ndtgpu_registrar_create_ex.argtypes = [C.POINTER(GridParams), C.POINTER(RegistrarParams), C.POINTER(vp)]
+    L.ndtgpu_registrar_get_info.argtypes = [vp, C.POINTER(RegistrarInfo)]
     L.ndtgpu_register_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(CellParams),
                                                vp, C.c_size_t, C.POINTER(MatchParams), vp, vp, C.POINTER(C.c_uint64)]
     L.ndtgpu_register_batch_host.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(CellParams),
@@ -550,19 +555,45 @@ class _BorrowedMapSet(MapSet):
         self.h = None
 
 
+class RegistrarParams(C.Structure):
+    _fields_ = [("pairs_per_batch", C.c_size_t), ("depth", C.c_int32), ("matcher_form", C.c_int32), ("matcher_groups", C.c_uint32),
+                ("build_streams", C.c_int32), ("linger_us", C.c_uint32), ("recalibrate_pct", C.c_int32)]
+
+
+class RegistrarInfo(C.Structure):
+    _fields_ = [("matcher_form", C.c_int32), ("matcher_groups", C.c_uint32), ("build_streams", C.c_int32), ("calibrations", C.c_int32),
+                ("submitted", C.c_uint64), ("cells_per_map", C.c_double)]
+
+
+MATCHER_AUTO, MATCHER_PER_BATCH, MATCHER_STREAM_FED = 0, 1, 2
+
+
 class Registrar:
     """ndtgpu_registrar: scans in, poses out -- grid builds + D2D matcher of batches of scan pairs as ONE asynchronous call,
-    pipelined over the library's own streams (include/ndtgpu.h)."""
+    pipelined over the library's own streams (include/ndtgpu.h).  Keyword arguments beyond pairs_per_batch / depth are the
+    fields of ndtgpu_registrar_params (matcher_form, matcher_groups, build_streams, linger_us, recalibrate_pct)."""
 
-    def __init__(self, res, centre, size_m, pairs_per_batch=1024, depth=8, max_cells=0):
+    def __init__(self, res, centre, size_m, pairs_per_batch=1024, depth=8, max_cells=0, **fields):
         gp = GridParams()
         gp.res = float(res)
         gp.centre[:] = [float(x) for x in centre]
         gp.size[:] = [float(x) for x in size_m]
         gp.max_cells = int(max_cells)
+        rp = RegistrarParams()
+        lib().ndtgpu_default_registrar_params(C.byref(rp))
+        rp.pairs_per_batch, rp.depth = int(pairs_per_batch), int(depth)
+        for k, v in fields.items():
+            if k not in dict(RegistrarParams._fields_):
+                raise TypeError("Registrar: no parameter %r" % k)
+            setattr(rp, k, int(v))
         h = C.c_void_p()
-        _check(lib().ndtgpu_registrar_create(C.byref(gp), int(pairs_per_batch), int(depth), C.byref(h)))
+        _check(lib().ndtgpu_registrar_create_ex(C.byref(gp), C.byref(rp), C.byref(h)))
         self.h, self.depth, self.per, self.res = h, int(depth), int(pairs_per_batch), float(res)
+
+    def info(self):
+        i = RegistrarInfo()
+        _check(lib().ndtgpu_registrar_get_info(self.h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in RegistrarInfo._fields_}
 
     def close(self):
         if getattr(self, "h", None):

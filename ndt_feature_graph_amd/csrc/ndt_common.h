@@ -216,6 +216,9 @@ size_t ndt_stream_ring_offset();
 hipError_t ndt_stream_wait(void *queue_dev, unsigned ring, unsigned seq, hipStream_t stream);   // `stream` waits until batch `seq` is complete
 hipError_t ndt_stream_skip(void *queue_dev, unsigned seq, hipStream_t stream);
 hipError_t ndt_launch_match_stream(void *queue_dev, int n_neighbours, unsigned n_groups, hipStream_t stream);
+unsigned ndt_stream_stamps();
+hipError_t ndt_stream_reset(void *queue_dev, unsigned submitted, unsigned ring);                 // after an abort, streams idle
+hipError_t ndt_stream_read_stamps(const void *queue_dev, unsigned seq, unsigned long long out[2]);   // 100 MHz: published, complete
 size_t ndt_match_pool_ctrl_bytes();
 size_t ndt_match_pool_head_bytes();
 size_t ndt_match_pool_pair_bytes(size_t n_chunks);

@@ -1431,13 +1431,19 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
 //   * Two registrations per workgroup, as above.  Measured with three (half the hit list each): best 562 k registrations/s at 128
 //     workgroups against 578 k with two at 144 (100 steps of the bench).
 #define NDT_STREAM_RING 8
+#define NDT_STREAM_STAMPS 64
 struct NdtStreamBatch {
     NdtSetView set;                  // targets in maps [0, n_pairs), sources in [n_pairs, 2 n_pairs)
     double *T16;
     NdtMatchResultDev *res;
     NdtMatchParamsDev prm;
     unsigned n_pairs, seq;
-    unsigned fresh, done;            // tickets drawn, registrations finished
+    // (seq + 1) << 32 | tickets drawn.  The generation names the batch a ticket belongs to: a draw that lands on an entry that
+    // is being re-published (a slot held up for longer than a whole batch takes) carries the OLD generation, is recognised
+    // by that and thrown away -- the publisher's single store of the new word erases it without losing a ticket of the new
+    // batch (zeroing `fresh` in two steps could hand a ticket out twice).
+    unsigned long long fresh;
+    unsigned done, pad_;             // registrations finished
 };
 struct NdtStreamQueue {
     unsigned published;              // batches published so far (their descriptors are complete)
@@ -1446,14 +1452,37 @@ struct NdtStreamQueue {
     unsigned abort;
     unsigned ring;                   // entries in use (= the registrar's depth: entry e always describes map set e; set by the host)
     unsigned linger;                 // 100 MHz ticks an instance that has worked stays when it runs dry (set by the host)
-    unsigned pad_[2];
+    unsigned live;                   // workgroups of matcher instances that are resident
+    unsigned pad_;
     unsigned done_seq[NDT_STREAM_RING];   // ring entry e: seq + 1 of the last batch that completed in it
+    // 100 MHz time stamps of the last NDT_STREAM_STAMPS batches: [seq % N][0] published, [1] last registration finished
+    // (ndtgpu_registrar_kernel_ms: the matcher side of a sub-batch as the queue saw it)
+    unsigned long long stamp[NDT_STREAM_STAMPS][2];
     NdtStreamBatch b[NDT_STREAM_RING];
 };
 size_t ndt_stream_queue_bytes() { return sizeof(NdtStreamQueue); }
 size_t ndt_stream_abort_offset() { return offsetof(NdtStreamQueue, abort); }
 size_t ndt_stream_ring_offset() { return offsetof(NdtStreamQueue, ring); }     // {ring, linger}: two words the host sets
 unsigned ndt_stream_ring() { return NDT_STREAM_RING; }
+unsigned ndt_stream_stamps() { return NDT_STREAM_STAMPS; }
+// After an abort (and with every stream of the registrar idle): the queue as if all `submitted` batches were complete.
+hipError_t ndt_stream_reset(void *queue_dev, unsigned submitted, unsigned ring)
+{
+    struct { unsigned published, first_open, completed, abort; } head = {submitted, submitted, submitted, 0u};
+    hipError_t e = hipMemcpy(queue_dev, &head, sizeof head, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    unsigned live = 0u, done_seq[NDT_STREAM_RING] = {};
+    for (unsigned j = submitted > ring ? submitted - ring : 0u; j < submitted; j++) done_seq[j % ring] = j + 1u;
+    e = hipMemcpy((char *)queue_dev + offsetof(NdtStreamQueue, live), &live, sizeof live, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+    return hipMemcpy((char *)queue_dev + offsetof(NdtStreamQueue, done_seq), done_seq, sizeof done_seq, hipMemcpyHostToDevice);
+}
+// the two stamps of batch `seq` (valid while fewer than NDT_STREAM_STAMPS batches have been published since)
+hipError_t ndt_stream_read_stamps(const void *queue_dev, unsigned seq, unsigned long long out[2])
+{
+    return hipMemcpy(out, (const char *)queue_dev + offsetof(NdtStreamQueue, stamp) + (size_t)(seq % NDT_STREAM_STAMPS) * 16u, 16u,
+                     hipMemcpyDeviceToHost);
+}
 
 namespace {
 NDT_D unsigned sys_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -1470,12 +1499,28 @@ struct StreamSlotExt {               // what a slot of the stream-fed matcher kn
 };
 }  // namespace
 
+// 256 threads.  Every result of the batch starts as "not run" (exit_code -4, converged 0): a batch that an abort cuts short
+// describes itself, registration by registration.  Then the descriptor -- everything but the ticket word --, and the ticket
+// word (new generation, no tickets drawn) with ONE store: from then on draws are valid.
 __global__ void ndt_stream_publish_kernel(NdtStreamQueue *q, NdtStreamBatch desc)
 {
-    NdtStreamBatch *b = &q->b[desc.seq % q->ring];
-    *b = desc;
-    b->fresh = 0u; b->done = 0u;
+    for (unsigned i = threadIdx.x; i < desc.n_pairs; i += blockDim.x) {
+        NdtMatchResultDev *o = desc.res + i;
+        o->converged = 0; o->iterations = 0; o->fevals = 0; o->exit_code = -4;
+        o->score = 0.0; o->n_source = 0; o->n_target = 0;
+        o->cycles_eval = 0; o->cycles_solver = 0; o->pair_terms_g = 0; o->pair_terms_h = 0;
+    }
     __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    NdtStreamBatch *b = &q->b[desc.seq % q->ring];
+    b->set = desc.set; b->T16 = desc.T16; b->res = desc.res; b->prm = desc.prm;
+    b->n_pairs = desc.n_pairs; b->seq = desc.seq;
+    b->done = 0u;
+    q->stamp[desc.seq % NDT_STREAM_STAMPS][0] = wall_clock64();
+    q->stamp[desc.seq % NDT_STREAM_STAMPS][1] = 0ull;
+    __threadfence_system();
+    __hip_atomic_store(&b->fresh, (unsigned long long)(desc.seq + 1u) << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&q->published, desc.seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1486,16 +1531,22 @@ __global__ void ndt_stream_publish_kernel(NdtStreamQueue *q, NdtStreamBatch desc
 __global__ void ndt_stream_wait_kernel(NdtStreamQueue *q, unsigned entry, unsigned value)
 {
     unsigned spins = 0u, seen = 0u;
+    bool gave_up = false;
     while ((int)(sys_load(&q->done_seq[entry]) - value) < 0) {
         __builtin_amdgcn_s_sleep(32);
         if ((++spins & 255u) == 0u) {
             unsigned progress = sys_load(&q->completed);
             for (unsigned e = 0; e < q->ring; e++) progress += sys_load(&q->b[e].done);
             if (progress != seen) { seen = progress; spins = 0u; }
-            if (spins > (1u << 25)) { sys_store(&q->abort, 2u); break; }      // ~30 s without any progress
-            if (sys_load(&q->abort)) break;
+            if (spins > (1u << 25)) sys_store(&q->abort, 2u);                 // ~30 s without any progress
+            if (sys_load(&q->abort)) { gave_up = true; break; }
         }
     }
+    // What follows this kernel on its stream rebuilds a map set (or reads a batch's outputs).  After an abort the batch is not
+    // complete: the instances stop drawing tickets, but registrations that are under way still read their maps -- the stream is
+    // held until every resident workgroup has left (they finish what they hold: milliseconds; bounded all the same).
+    if (gave_up)
+        for (unsigned k = 0; k < (1u << 22) && sys_load(&q->live) != 0u; k++) __builtin_amdgcn_s_sleep(64);
 }
 
 template <int NN>
@@ -1507,12 +1558,15 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
     __shared__ StreamSlotExt ext[R];
     __shared__ double w_src[NDT_MATCH_WAVES * 9 * 64];
     __shared__ uint2 w_win[NDT_MATCH_WAVES * 7 * 64];
-    __shared__ unsigned s_session, s_closed, s_seen;
+    __shared__ unsigned s_session, s_closed, s_seen, s_left;
 
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned ring = sys_load(&q->ring);
-    if (tid == 0) { s_session = 0u; s_closed = 0u; s_seen = 0u; }
+    if (tid == 0) {
+        s_session = 0u; s_closed = 0u; s_seen = 0u; s_left = 0u;
+        __hip_atomic_fetch_add(&q->live, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (tid < (unsigned)R) {
         Slot &S = slots[tid];
         S.state = SLOT_FREE; S.next = NDT_VW; S.done = 0u; S.retry = clock_lo(); S.preset = -1; S.resumed = 0;
@@ -1555,14 +1609,25 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
             if (task == TASK_NONE && lds_load(&s_closed) >= (unsigned)R) task = TASK_EXIT;
         }
         task = __builtin_amdgcn_readfirstlane(task);
-        if (task == TASK_EXIT) return;
+        if (task == TASK_EXIT) {
+            // (the last wave out takes the workgroup off the queue's count of resident workgroups)
+            if (lane == 0 && atomicAdd(&s_left, 1u) == (unsigned)NDT_MATCH_WAVES - 1u)
+                __hip_atomic_fetch_sub(&q->live, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
         if (task == TASK_NONE) {
             if (__builtin_amdgcn_readfirstlane(running ? 1 : 0)) __builtin_amdgcn_s_sleep(2);
             else __builtin_amdgcn_s_sleep(16);
             idle_spins += 1u;
             if ((idle_spins & 1023u) == 0u) {
                 if (idle_spins > (1u << 26)) sys_store(&q->abort, 1u);          // ~30 s without work
-                if (sys_load(&q->abort)) return;
+                // (an abort: nothing new is drawn -- the loader below closes the slots.  A wave leaves when no registration of its
+                //  workgroup is under way; registrations that are finish first, a second at most)
+                if (sys_load(&q->abort) && (!__builtin_amdgcn_readfirstlane(running ? 1 : 0) || idle_spins > (1u << 22))) {
+                    if (lane == 0 && atomicAdd(&s_left, 1u) == (unsigned)NDT_MATCH_WAVES - 1u)
+                        __hip_atomic_fetch_sub(&q->live, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
             }
             continue;
         }
@@ -1583,6 +1648,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                     const unsigned fo = sys_load(&q->first_open);
                     const unsigned pub = sys_load(&q->published);
                     const unsigned comp = sys_load(&q->completed);
+                    if (sys_load(&q->abort)) { new_state = SLOT_CLOSED; break; }     // nothing new after an abort
                     if ((int)(c - fo) < 0) c = fo;
                     E.cur = c;
                     if ((int)(c - pub) >= 0) {
@@ -1609,7 +1675,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                     // takes the batch's number from there (a workgroup that was held up between the queue words and the draw
                     // for longer than a whole batch takes would otherwise file the registration under the old number).
                     const volatile NdtStreamBatch *Bv = B;
-                    const unsigned f = __hip_atomic_fetch_add(&B->fresh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long ticket = __hip_atomic_fetch_add(&B->fresh, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned f = (unsigned)ticket;
                     // (the whole descriptor in one round trip, before the first of its words is looked at)
                     const unsigned n = Bv->n_pairs, bseq = Bv->seq;
                     const int d_nn = Bv->prm.n_neighbours, d_itr = Bv->prm.itr_max, d_sc = Bv->prm.step_control, d_dof = Bv->prm.dof_mask;
@@ -1617,6 +1684,9 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                     const double d_ds = Bv->prm.delta_score, d_l1 = Bv->prm.lfd1, d_l2 = Bv->prm.lfd2;
                     double *const d_T16 = Bv->T16;
                     NdtMatchResultDev *const d_res = Bv->res;
+                    // a ticket of another generation than the descriptor's: the entry is being re-published (this slot was held up
+                    // for longer than a whole batch takes).  The draw is void -- the publisher's store erases it -- : look again
+                    if ((unsigned)(ticket >> 32) != bseq + 1u) continue;
                     if (f >= n) {
                         if (bseq == c) {
                             __hip_atomic_fetch_max(&q->first_open, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1657,6 +1727,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                         const unsigned d = __hip_atomic_fetch_add(E.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         if (d + 1u == n) {
                             __hip_atomic_fetch_max(&q->first_open, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            q->stamp[c % NDT_STREAM_STAMPS][1] = wall_clock64();
                             sys_store(&q->done_seq[c % ring], c + 1u);
                             __hip_atomic_fetch_add(&q->completed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
@@ -1727,6 +1798,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                 if (d + 1u == E.n_pairs) {
                     // (a complete batch has no tickets left: nobody looks at its ring entry again, it may be re-published)
                     __hip_atomic_fetch_max(&q->first_open, E.seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    q->stamp[E.seq % NDT_STREAM_STAMPS][1] = wall_clock64();
                     sys_store(&q->done_seq[E.seq % ring], E.seq + 1u);
                     __hip_atomic_fetch_add(&q->completed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
@@ -1761,8 +1833,8 @@ hipError_t ndt_stream_publish(void *queue_dev, const NdtSetView &set, double *T1
                               const NdtMatchParamsDev &prm, unsigned n_pairs, unsigned seq, hipStream_t stream)
 {
     NdtStreamBatch d;
-    d.set = set; d.T16 = T16_dev; d.res = res_dev; d.prm = prm; d.n_pairs = n_pairs; d.seq = seq; d.fresh = 0u; d.done = 0u;
-    hipLaunchKernelGGL(ndt_stream_publish_kernel, dim3(1), dim3(1), 0, stream, (NdtStreamQueue *)queue_dev, d);
+    d.set = set; d.T16 = T16_dev; d.res = res_dev; d.prm = prm; d.n_pairs = n_pairs; d.seq = seq; d.fresh = 0ull; d.done = 0u; d.pad_ = 0u;
+    hipLaunchKernelGGL(ndt_stream_publish_kernel, dim3(1), dim3(256), 0, stream, (NdtStreamQueue *)queue_dev, d);
     return hipGetLastError();
 }
 

@@ -214,7 +214,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.5.13 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.6.0 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -875,9 +875,11 @@ ndtgpu_status ndtgpu_overlap_score_batch(ndtgpu_mapset *rs, const uint32_t *ridx
     hipStream_t st = (hipStream_t)stream;
     { ndtgpu_status wrc_ = rs->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     { ndtgpu_status wrc_ = ms->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
-    // Batches in which moving maps recur (a graph's links) go through LISTS of the moving maps' cells with a reading: every
-    // distinct moving map is scanned twice (count, then its (slot, occupancy) pairs in slot order), every link then walks a
-    // list of a few thousand pairs instead of the map's whole dense array.  NDTGPU_OVERLAP_DENSE=1: the dense kernel (A/B).
+    // Every link walks a LIST of its moving map's cells with a reading: every distinct moving map of the batch is scanned twice
+    // (count, then its (slot, occupancy) pairs in slot order), a link then visits a few thousand pairs instead of the map's whole
+    // dense array.  Which kernel serves a link does NOT depend on the other links of its batch (the dense kernel adds in
+    // another order: a link's score must not change with the way links are chunked or sharded over ranks).
+    // NDTGPU_OVERLAP_DENSE=1: the dense kernel for every link (A/B).
     const char *dense_env = getenv("NDTGPU_OVERLAP_DENSE");
     std::vector<uint32_t> list_of_link, list_maps;
     if (!(dense_env && atoi(dense_env) != 0)) {
@@ -888,7 +890,6 @@ ndtgpu_status ndtgpu_overlap_score_batch(ndtgpu_mapset *rs, const uint32_t *ridx
             if (u < 0) { u = (int32_t)list_maps.size(); list_maps.push_back(midx[k]); }
             list_of_link[k] = (uint32_t)u;
         }
-        if (3 * list_maps.size() > 2 * n_links) { list_of_link.clear(); list_maps.clear(); }   // (hardly any map twice: no gain)
     }
     const size_t U = list_maps.size();
     const size_t bT = n_links * 16 * sizeof(double), bI = n_links * sizeof(uint32_t), bS = n_links * sizeof(double);
@@ -1165,6 +1166,7 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
 struct ndtgpu_registrar {
     size_t per = 0;
     int depth = 0;
+    ndtgpu_registrar_params prm{};     // as given to ndtgpu_registrar_create_ex (zeros resolved)
     std::vector<ndtgpu_mapset *> sets;
     std::vector<hipStream_t> streams;
     std::vector<hipEvent_t> built;
@@ -1175,15 +1177,32 @@ struct ndtgpu_registrar {
     int last_built = -1;
     uint32_t *iota = nullptr;          // device: 0 .. 2 per - 1 (target indices: iota, source indices: iota + p)
     size_t submitted = 0;              // sub-batches so far
-    // stream-fed form (csrc/ndt_match.hip, ndt_match_stream_kernel): ONE build stream, ONE matcher stream on which an instance of
+    // stream-fed form (csrc/ndt_match.hip, ndt_match_stream_kernel): build streams, ONE matcher stream on which an instance of
     // the matcher serves batch after batch from a queue in device memory
     void *queue = nullptr;
     hipStream_t bst = nullptr, bst2 = nullptr, pst = nullptr, mst = nullptr;   // builds (two, in turn), publishes (in order), matcher
+    int mst_prio = 0;                  // the matcher stream's priority: a stream of the caller's at this priority may share its hardware queue
     hipStream_t hst = nullptr;         // the drain helper of ndtgpu_registrar_sync
     size_t helped = 0;                 // sub-batches submitted when the last helper was launched
     std::vector<hipEvent_t> pub_ev;
-    unsigned stream_groups = 0;        // workgroups (= CUs) of a matcher instance; 0: not calibrated yet
+    unsigned stream_groups = 0;        // workgroups (= CUs) of a matcher instance; 0: to be measured on the next sub-batch
     int stream_nn = -1;
+    int n_cu = 256;
+    // the split of the chip is measured on a sub-batch and re-measured when the maps change: per slot the map counters of
+    // the last build travel to pinned host memory on a side stream; a later call looks at what has arrived (no waiting)
+    int calibrations = 0;
+    double calib_cells = 0.0;          // mean Gaussian cells per map the split stands for: of the sub-batch it was first measured
+                                       // on; after a re-measurement, of the recent sub-batches that asked for it (a registrar
+                                       // that is fed two kinds of scenes in turn settles on their mean instead of measuring
+                                       // again at every change)
+    double recal_ref = 0.0;
+    size_t calib_at = 0;               // ... and its number
+    hipStream_t sst = nullptr;
+    NdtMapCounters *stat_host = nullptr;     // [depth][2 per], pinned
+    std::vector<hipEvent_t> stat_ev;
+    std::vector<long long> stat_seq;   // sub-batch whose counters slot k holds (-1: none / consumed)
+    std::vector<unsigned> stat_maps;
+    std::vector<double> recent_cells;  // mean cells per map of the last sub-batches seen (at most `depth`)
     // host clouds (ndtgpu_register_batch_host): per slot a device staging area for the scans of a sub-batch, one for the
     // poses / results of a call, a copy stream
     std::vector<void *> hstage;
@@ -1192,15 +1211,25 @@ struct ndtgpu_registrar {
     size_t hio_bytes = 0;
     hipStream_t hcopy = nullptr;
     bool profiling = false;
-    std::vector<hipEvent_t> marks;     // 4 per profiled sub-batch: build start / end, matcher start / end
+    struct ProfMark { hipEvent_t e[4]; long long seq; };   // build start / end, matcher start / end (events), or the queue's stamps of `seq`
+    std::vector<ProfMark> marks;
 };
+
+static int device_cus()
+{
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    return n_cu;
+}
 
 ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
 {
     if (!r) return NDTGPU_OK;
     for (hipStream_t st : r->streams)
         if (st) (void)hipStreamSynchronize(st);
-    for (hipEvent_t e : r->marks) (void)hipEventDestroy(e);
+    for (auto &m : r->marks)
+        for (hipEvent_t e : m.e) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->built) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->done) if (e) (void)hipEventDestroy(e);
     if (r->in_ev) (void)hipEventDestroy(r->in_ev);
@@ -1210,9 +1239,12 @@ ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
     if (r->pst) { (void)hipStreamSynchronize(r->pst); (void)hipStreamDestroy(r->pst); }
     if (r->hst) { (void)hipStreamSynchronize(r->hst); (void)hipStreamDestroy(r->hst); }
     if (r->mst) { (void)hipStreamSynchronize(r->mst); (void)hipStreamDestroy(r->mst); }
+    if (r->sst) { (void)hipStreamSynchronize(r->sst); (void)hipStreamDestroy(r->sst); }
     if (r->bst) (void)hipStreamDestroy(r->bst);
     if (r->bst2) (void)hipStreamDestroy(r->bst2);
     for (hipEvent_t e : r->pub_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->stat_ev) if (e) (void)hipEventDestroy(e);
+    if (r->stat_host) (void)hipHostFree(r->stat_host);
     if (r->queue) (void)hipFree(r->queue);
     for (void *q : r->hstage) if (q) (void)hipFree(q);
     if (r->hio) (void)hipFree(r->hio);
@@ -1224,15 +1256,48 @@ ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
     return NDTGPU_OK;
 }
 
-ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pairs_per_batch, int depth, ndtgpu_registrar **out)
+void ndtgpu_default_registrar_params(ndtgpu_registrar_params *p)
 {
-    if (!grid || !out || pairs_per_batch == 0 || pairs_per_batch > (1u << 30) || depth < 1 || depth > 16)
+    if (!p) return;
+    p->pairs_per_batch = 1024;
+    p->depth = 8;
+    p->matcher_form = NDTGPU_MATCHER_AUTO;
+    p->matcher_groups = 0;
+    p->build_streams = 0;
+    p->linger_us = 0;
+    p->recalibrate_pct = 25;
+}
+
+// An experiment's environment variable overrides a field the caller LEFT AT ITS DEFAULT (0 / auto); what a caller sets wins.
+static int env_int(const char *name, int fallback)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : fallback;
+}
+
+ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const ndtgpu_registrar_params *params, ndtgpu_registrar **out)
+{
+    if (!grid || !params || !out) return fail(NDTGPU_ERR_INVALID, "registrar_create: null argument");
+    ndtgpu_registrar_params P = *params;
+    const size_t pairs_per_batch = P.pairs_per_batch;
+    const int depth = P.depth;
+    if (pairs_per_batch == 0 || pairs_per_batch > (1u << 30) || depth < 1 || depth > 16)
         return fail(NDTGPU_ERR_INVALID, "registrar_create: bad argument (pairs_per_batch >= 1, 1 <= depth <= 16)");
+    if (P.matcher_form < NDTGPU_MATCHER_AUTO || P.matcher_form > NDTGPU_MATCHER_STREAM_FED || P.build_streams < 0 || P.build_streams > 2)
+        return fail(NDTGPU_ERR_INVALID, "registrar_create: matcher_form must be 0..2, build_streams 0..2");
     if (!have_device()) return fail(NDTGPU_ERR_NO_DEVICE, "registrar_create: no HIP device");
+    // experiments (tools/, A/B runs): only where the caller asked for the default
+    if (P.matcher_form == NDTGPU_MATCHER_AUTO && getenv("NDTGPU_REG_STREAM"))
+        P.matcher_form = env_int("NDTGPU_REG_STREAM", 1) ? NDTGPU_MATCHER_AUTO : NDTGPU_MATCHER_PER_BATCH;
+    if (P.matcher_groups == 0) P.matcher_groups = (unsigned)std::max(0, env_int("NDTGPU_REG_GROUPS", 0));
+    if (P.build_streams == 0) P.build_streams = std::min(2, std::max(0, env_int("NDTGPU_REG_BUILD_STREAMS", 0)));
+    if (P.linger_us == 0) P.linger_us = (unsigned)std::max(0, env_int("NDTGPU_REG_LINGER_US", 0));
+    if (P.recalibrate_pct == 0) P.recalibrate_pct = 25;
     ndtgpu_registrar *r = new (std::nothrow) ndtgpu_registrar();
     if (!r) return fail(NDTGPU_ERR_ALLOC, "registrar_create: host alloc");
     r->per = pairs_per_batch;
     r->depth = depth;
+    r->n_cu = device_cus();
     r->sets.assign(depth, nullptr);
     r->streams.assign(depth, nullptr);
     r->built.assign(depth, nullptr);
@@ -1244,55 +1309,65 @@ ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pai
         if (rc != NDTGPU_OK) break;
         // Pipelined (depth > 1), a matcher launch keeps to half of the CUs: its persistent workgroups hold a CU each, whole, until
         // their registrations are done, and with all CUs taken the next sub-batch's builds would wait for the launch's first
-        // exits (measured, 1024 pairs per sub-batch: 470 k registrations/s with 256 workgroups, 488 k with 128..160;
-        // NDTGPU_REG_GROUPS overrides)
-        if (depth > 1) {
-            int dev = 0, n_cu = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                n_cu = 256;
-            const char *ge = getenv("NDTGPU_REG_GROUPS");
-            r->sets[k]->match_groups = ge && atoi(ge) > 0 ? (unsigned)atoi(ge) : (unsigned)(n_cu / 2);
-        }
+        // exits (measured, 1024 pairs per sub-batch: 470 k registrations/s with 256 workgroups, 488 k with 128..160)
+        if (depth > 1) r->sets[k]->match_groups = P.matcher_groups ? P.matcher_groups : (unsigned)(r->n_cu / 2);
         e = hipStreamCreateWithFlags(&r->streams[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&r->built[k], hipEventDisableTiming);
     }
     for (size_t k = 0; k < r->done.size() && rc == NDTGPU_OK && e == hipSuccess; k++)
         e = hipEventCreateWithFlags(&r->done[k], hipEventDisableTiming);
-    // The stream-fed matcher (NDTGPU_REG_STREAM=0 keeps one matcher launch per sub-batch): pipelined registrars of small maps
-    {
-        const char *se = getenv("NDTGPU_REG_STREAM");
-        const bool want = se ? atoi(se) != 0 : true;
-        if (rc == NDTGPU_OK && e == hipSuccess && want && depth > 1 && (unsigned)depth <= ndt_stream_ring() &&
-            r->sets[0]->v.grid.max_cells < 16384u) {
-            int dev = 0, n_cu = 0, lo = 0, hi = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                n_cu = 256;
-            const char *ge = getenv("NDTGPU_REG_GROUPS");
-            r->stream_groups = ge && atoi(ge) > 0 ? (unsigned)atoi(ge) : 0u;        // 0: measured on the first sub-batch
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // The stream-fed matcher: pipelined registrars of small maps.  It needs a hardware queue of its own for the matcher stream:
+    // the registrar orders map-set reuse with device-side wait kernels that only end when the running instance makes progress,
+    // so an instance launch must never sit in a queue behind such a kernel.  What keeps the streams apart is a priority of
+    // their own each -- a device that offers one priority level only (lo == hi) keeps the form with one matcher launch per
+    // sub-batch (ordered by events), as does NDTGPU_REG_PRIO=0.
+    if (rc == NDTGPU_OK && e == hipSuccess) {
+        int lo = 0, hi = 0;
+        const bool prio_ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi && env_int("NDTGPU_REG_PRIO", 1) != 0;
+        const bool can = depth > 1 && (unsigned)depth <= ndt_stream_ring() && r->sets[0]->v.grid.max_cells < 16384u && prio_ok;
+        if (P.matcher_form == NDTGPU_MATCHER_STREAM_FED && !can) {
+            ndtgpu_registrar_destroy(r);
+            return fail(NDTGPU_ERR_INVALID, "registrar_create: the stream-fed matcher needs 2 <= depth <= 8, max_cells < 16384 and a device "
+                                            "with more than one stream priority");
+        }
+        if (P.matcher_form != NDTGPU_MATCHER_PER_BATCH && can) {
+            r->stream_groups = P.matcher_groups;            // 0: measured on the first sub-batch
             e = hipMalloc(&r->queue, ndt_stream_queue_bytes());
             if (e == hipSuccess) e = hipMemset(r->queue, 0, ndt_stream_queue_bytes());
-            const char *le = getenv("NDTGPU_REG_LINGER_US");
-            const unsigned ring_linger[2] = {(unsigned)depth, (unsigned)(100 * (le ? std::max(0, atoi(le)) : 0))};   // 100 MHz ticks (measured: no gain from 300 / 1000 us; default 0)
+            const unsigned ring_linger[2] = {(unsigned)depth, 100u * P.linger_us};   // 100 MHz ticks (measured: no gain from 300 / 1000 us; default 0)
             if (e == hipSuccess) e = hipMemcpy((char *)r->queue + ndt_stream_ring_offset(), ring_linger, sizeof ring_linger, hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->bst, hipStreamNonBlocking);
-            // Two build streams that take the sub-batches in turn (NDTGPU_REG_BUILD_STREAMS=1: one): a build launch is one
+            // Two build streams that take the sub-batches in turn (build_streams = 1: one): a build launch is one
             // workgroup per map and every map costs about the same, so on F free CUs it takes ceil(maps / 4 F) whole rounds
             // (measured: 1.47 ms beside a matcher instance on 128 CUs, 1.85 ms beside one on 129); with the next launch's
             // workgroups filling the last, nearly empty round the build side runs at its average rate whatever F is.
             // Publishes stay in order on a stream of their own.
-            const char *bse = getenv("NDTGPU_REG_BUILD_STREAMS");
-            if (e == hipSuccess && !(bse && atoi(bse) == 1) && depth >= 3) e = hipStreamCreateWithFlags(&r->bst2, hipStreamNonBlocking);
+            if (P.build_streams == 0) P.build_streams = depth >= 3 ? 2 : 1;
+            if (depth < 3) P.build_streams = 1;
+            if (e == hipSuccess && P.build_streams == 2) e = hipStreamCreateWithFlags(&r->bst2, hipStreamNonBlocking);
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->pst, hipStreamNonBlocking, lo);
             // (a priority of its own: the runtime then never maps the two streams onto one hardware queue, where the build of
             //  batch k + 1 would sit behind the running matcher instance)
-            const char *pe_ = getenv("NDTGPU_REG_PRIO");                    // (experiment: 0 = every stream at the default priority)
-            if (pe_ && atoi(pe_) == 0) lo = hi = 0;
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&r->mst, hipStreamNonBlocking, hi);
+            r->mst_prio = hi;
+            if (e == hipSuccess) (void)hipStreamGetPriority(r->mst, &r->mst_prio);
             r->pub_ev.assign(depth, nullptr);
             for (int k = 0; k < depth && e == hipSuccess; k++) e = hipEventCreateWithFlags(&r->pub_ev[k], hipEventDisableTiming);
+            // the side channel of the map statistics
+            if (e == hipSuccess && P.matcher_groups == 0 && P.recalibrate_pct > 0) {
+                e = hipStreamCreateWithFlags(&r->sst, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipHostMalloc((void **)&r->stat_host, (size_t)depth * 2 * pairs_per_batch * sizeof(NdtMapCounters), hipHostMallocDefault);
+                r->stat_ev.assign(depth, nullptr);
+                r->stat_seq.assign(depth, -1);
+                r->stat_maps.assign(depth, 0u);
+                for (int k = 0; k < depth && e == hipSuccess; k++) e = hipEventCreateWithFlags(&r->stat_ev[k], hipEventDisableTiming);
+            }
+        } else {
+            P.build_streams = 0;
         }
+        P.matcher_form = r->queue ? NDTGPU_MATCHER_STREAM_FED : NDTGPU_MATCHER_PER_BATCH;
     }
+    r->prm = P;
     if (rc == NDTGPU_OK && e == hipSuccess) e = hipEventCreateWithFlags(&r->in_ev, hipEventDisableTiming);
     if (rc == NDTGPU_OK && e == hipSuccess) e = hipMalloc((void **)&r->iota, (2 * pairs_per_batch + 4) * sizeof(uint32_t));
     if (rc == NDTGPU_OK && e == hipSuccess) {
@@ -1306,6 +1381,27 @@ ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pai
         return fail(rc != NDTGPU_OK ? rc : NDTGPU_ERR_HIP, why.c_str());
     }
     *out = r;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pairs_per_batch, int depth, ndtgpu_registrar **out)
+{
+    ndtgpu_registrar_params p;
+    ndtgpu_default_registrar_params(&p);
+    p.pairs_per_batch = pairs_per_batch;
+    p.depth = depth;
+    return ndtgpu_registrar_create_ex(grid, &p, out);
+}
+
+ndtgpu_status ndtgpu_registrar_get_info(const ndtgpu_registrar *r, ndtgpu_registrar_info *info)
+{
+    if (!r || !info) return fail(NDTGPU_ERR_INVALID, "registrar_get_info: null argument");
+    info->matcher_form = r->prm.matcher_form;
+    info->matcher_groups = r->queue ? r->stream_groups : r->sets[0]->match_groups;
+    info->build_streams = r->prm.build_streams;
+    info->calibrations = r->calibrations;
+    info->submitted = (uint64_t)r->submitted;
+    info->cells_per_map = r->calib_cells;
     return NDTGPU_OK;
 }
 
@@ -1326,21 +1422,35 @@ ndtgpu_status ndtgpu_registrar_profiling(ndtgpu_registrar *r, int on)
 ndtgpu_status ndtgpu_registrar_kernel_ms(ndtgpu_registrar *r, float mean_ms[2], int32_t *launches)
 {
     if (!r || !mean_ms || !launches) return fail(NDTGPU_ERR_INVALID, "registrar_kernel_ms: bad argument");
-    const size_t n = r->marks.size() / 4;
+    const size_t n = r->marks.size();
     double sum[2] = {0.0, 0.0};
+    size_t cnt[2] = {0, 0};
+    if (r->queue && n) {                    // the stamps are complete once the matcher side is
+        ndtgpu_status rc = ndtgpu_registrar_sync(r);
+        if (rc != NDTGPU_OK) return rc;
+    }
     for (size_t k = 0; k < n; k++) {
-        HIP_TRY(hipEventSynchronize(r->marks[4 * k + 3]));
-        for (int w = 0; w < 2; w++) {
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, r->marks[4 * k + 2 * w], r->marks[4 * k + 2 * w + 1]));
-            sum[w] += ms;
+        ndtgpu_registrar::ProfMark &m = r->marks[k];
+        HIP_TRY(hipEventSynchronize(m.e[m.seq >= 0 ? 1 : 3]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, m.e[0], m.e[1]));
+        sum[0] += ms; cnt[0]++;
+        if (m.seq < 0) {
+            HIP_TRY(hipEventElapsedTime(&ms, m.e[2], m.e[3]));
+            sum[1] += ms; cnt[1]++;
+        } else if ((size_t)m.seq + ndt_stream_stamps() > r->submitted) {
+            // stream-fed form: what the queue saw of the sub-batch -- published (its maps built) until its last registration finished
+            unsigned long long st[2] = {0, 0};
+            HIP_TRY(ndt_stream_read_stamps(r->queue, (unsigned)m.seq, st));
+            if (st[1] > st[0]) { sum[1] += (double)(st[1] - st[0]) * 1e-5; cnt[1]++; }
         }
     }
-    for (hipEvent_t e : r->marks) (void)hipEventDestroy(e);
+    for (auto &m : r->marks)
+        for (hipEvent_t e : m.e) if (e) (void)hipEventDestroy(e);
     r->marks.clear();
     *launches = (int32_t)n;
-    mean_ms[0] = n ? (float)(sum[0] / (double)n) : 0.f;
-    mean_ms[1] = n ? (float)(sum[1] / (double)n) : 0.f;
+    mean_ms[0] = cnt[0] ? (float)(sum[0] / (double)cnt[0]) : 0.f;
+    mean_ms[1] = cnt[1] ? (float)(sum[1] / (double)cnt[1]) : 0.f;
     return NDTGPU_OK;
 }
 
@@ -1360,15 +1470,36 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
     if (pdev.n_neighbours < 0 || pdev.n_neighbours > 3 || (pdev.dof_mask & 0x3f) == 0)
         return fail(NDTGPU_ERR_INVALID, "match: n_neighbours must be 0..3 and dof_mask non-empty");
     HIP_TRY(hipEventRecord(r->in_ev, (hipStream_t)stream));
+    auto new_mark = [&](long long seq, ndtgpu_registrar::ProfMark **out_mark) -> ndtgpu_status {
+        ndtgpu_registrar::ProfMark m{};
+        m.seq = seq;
+        for (int k = 0; k < (seq >= 0 ? 2 : 4); k++) HIP_TRY(hipEventCreate(&m.e[k]));
+        r->marks.push_back(m);
+        *out_mark = &r->marks.back();
+        return NDTGPU_OK;
+    };
+    // one build launch when the sources follow the targets in memory, else two
+    auto build_pairs = [&](ndtgpu_mapset *set, size_t off, size_t p, hipStream_t st) -> ndtgpu_status {
+        const char *tg = (const char *)targets_dev + off * map_stride_bytes, *sc = (const char *)sources_dev + off * map_stride_bytes;
+        if (sc == tg + p * map_stride_bytes)
+            return ndtgpu_mapset_build(set, 0, 2 * p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+        ndtgpu_status rc = ndtgpu_mapset_build(set, 0, p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+        if (rc == NDTGPU_OK)
+            rc = ndtgpu_mapset_build(set, p, p, sc, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
+        return rc;
+    };
     if (r->queue) {
         // ---- stream-fed form: builds on one stream, batches published to the running matcher instance -------------------
+        auto drain = [&]() -> ndtgpu_status {
+            HIP_TRY(hipStreamSynchronize(r->bst));
+            if (r->bst2) HIP_TRY(hipStreamSynchronize(r->bst2));
+            HIP_TRY(hipStreamSynchronize(r->pst));
+            HIP_TRY(hipStreamSynchronize(r->mst));
+            if (r->hst) HIP_TRY(hipStreamSynchronize(r->hst));
+            return NDTGPU_OK;
+        };
         if (r->stream_nn != pdev.n_neighbours) {                 // (an instance is compiled for one neighbourhood size)
-            if (r->stream_nn >= 0) {
-                HIP_TRY(hipStreamSynchronize(r->bst));
-                if (r->bst2) HIP_TRY(hipStreamSynchronize(r->bst2));
-                HIP_TRY(hipStreamSynchronize(r->pst));
-                HIP_TRY(hipStreamSynchronize(r->mst));
-            }
+            if (r->stream_nn >= 0) { ndtgpu_status drc = drain(); if (drc != NDTGPU_OK) return drc; }
             r->stream_nn = pdev.n_neighbours;
         }
         for (size_t off = 0; off < n_pairs; off += r->per) {
@@ -1377,28 +1508,54 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
             const int slot = (int)(j % (size_t)r->depth);
             ndtgpu_mapset *set = r->sets[slot];
             hipStream_t st = (r->bst2 && (j & 1u)) ? r->bst2 : r->bst;
+            // ---- have the maps changed?  The counters of earlier builds that have arrived on the host say how many Gaussian
+            // cells a map holds now; when the mean over the last sub-batches has left the figure the split was measured at by
+            // more than recalibrate_pct, the pipeline is drained once and this sub-batch measures the split again (a
+            // registrar that moves from halls to clutter would otherwise keep 128 matcher CUs where 200 are right).
+            if (r->sst && r->stream_groups != 0u) {
+                for (int k = 0; k < r->depth; k++) {
+                    if (r->stat_seq[k] < 0 || hipEventQuery(r->stat_ev[k]) != hipSuccess) continue;
+                    const NdtMapCounters *c = r->stat_host + (size_t)k * 2 * r->per;
+                    double cells = 0;
+                    for (unsigned m = 0; m < r->stat_maps[k]; m++) cells += (double)c[m].n_cells;
+                    if (r->stat_maps[k]) {
+                        if (r->recent_cells.size() >= (size_t)r->depth) r->recent_cells.erase(r->recent_cells.begin());
+                        r->recent_cells.push_back(cells / (double)r->stat_maps[k]);
+                    }
+                    r->stat_seq[k] = -1;
+                }
+                if (r->recent_cells.size() >= (size_t)std::min(r->depth, 4) && r->calib_cells > 0 && j >= r->calib_at + 2 * (size_t)r->depth) {
+                    double mean = 0;
+                    for (double v : r->recent_cells) mean += v;
+                    mean /= (double)r->recent_cells.size();
+                    if (std::fabs(mean / r->calib_cells - 1.0) * 100.0 > (double)r->prm.recalibrate_pct) {
+                        if (getenv("NDTGPU_REG_VERBOSE"))
+                            fprintf(stderr, "ndtgpu registrar: %.0f cells per map where the split was measured at %.0f: measuring again\n", mean, r->calib_cells);
+                        ndtgpu_status drc = drain();
+                        if (drc != NDTGPU_OK) return drc;
+                        r->stream_groups = 0u;
+                        r->recal_ref = mean;
+                    }
+                }
+            }
             HIP_TRY(hipStreamWaitEvent(st, r->in_ev, 0));
             if (r->stream_groups == 0u) {
-                // ---- the first sub-batch of a registrar's life measures the split of the chip: its maps are built and its
-                // pairs registered with nothing else on the device (the whole chip each; the same bits), the host reads the
-                // kernels' own clocks -- CU-time of the builds B and of the registrations M -- and a matcher instance gets
-                // n_cu M / (M + B) CUs from then on: 144 of 256 on the bench's halls, 220 on a cluttered scene whose maps
-                // hold five times the cells.  Costs one synchronisation, once.
-                const char *tg0 = (const char *)targets_dev + off * map_stride_bytes, *sc0 = (const char *)sources_dev + off * map_stride_bytes;
-                ndtgpu_status rc0;
-                if (sc0 == tg0 + p * map_stride_bytes) {
-                    rc0 = ndtgpu_mapset_build(set, 0, 2 * p, tg0, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-                } else {
-                    rc0 = ndtgpu_mapset_build(set, 0, p, tg0, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-                    if (rc0 == NDTGPU_OK)
-                        rc0 = ndtgpu_mapset_build(set, p, p, sc0, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-                }
+                // ---- a sub-batch that measures the split of the chip (the first of a registrar's life; later ones after a
+                // drain, see above): its maps are built and its pairs registered with nothing else on the device (the whole
+                // chip each; the same bits), the host reads the kernels' own clocks -- CU-time of the builds B and of the
+                // registrations M -- and a matcher instance gets n_cu M / (M + B) CUs from then on: 128 of 256 on the bench's
+                // halls, 200 on a cluttered scene whose maps hold five times the cells.  Costs one synchronisation.
+                ndtgpu_registrar::ProfMark *mk0 = nullptr;
+                if (r->profiling) { ndtgpu_status mrc = new_mark(-1, &mk0); if (mrc != NDTGPU_OK) return mrc; HIP_TRY(hipEventRecord(mk0->e[0], st)); }
+                ndtgpu_status rc0 = build_pairs(set, off, p, st);
                 if (rc0 != NDTGPU_OK) return rc0;
+                if (mk0) { HIP_TRY(hipEventRecord(mk0->e[1], st)); HIP_TRY(hipEventRecord(mk0->e[2], st)); }
                 const unsigned saved_groups = set->match_groups;
                 set->match_groups = 0;                            // (the whole chip)
                 rc0 = ndtgpu_match_batch_device(set, r->iota, set, r->iota + p, T16_dev + off * 16, p, prm, results_dev + off, st);
                 set->match_groups = saved_groups;
                 if (rc0 != NDTGPU_OK) return rc0;
+                if (mk0) HIP_TRY(hipEventRecord(mk0->e[3], st));
                 hipError_t se = ndt_stream_skip(r->queue, (unsigned)j, st);
                 if (se != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: calibration", se);
                 HIP_TRY(hipEventRecord(r->built[slot], st));
@@ -1407,8 +1564,11 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
                 std::vector<ndtgpu_match_result> res(p);
                 HIP_TRY(hipMemcpy(ctr.data(), set->v.counters, 2 * p * sizeof(NdtMapCounters), hipMemcpyDeviceToHost));
                 HIP_TRY(hipMemcpy(res.data(), results_dev + off, p * sizeof(ndtgpu_match_result), hipMemcpyDeviceToHost));
-                double B = 0, M = 0;
-                for (const NdtMapCounters &c : ctr) B += (double)c.cyc[0] + (double)c.cyc[1] + (double)c.cyc[2] + (double)c.cyc[3];
+                double B = 0, M = 0, cells = 0;
+                for (const NdtMapCounters &c : ctr) {
+                    B += (double)c.cyc[0] + (double)c.cyc[1] + (double)c.cyc[2] + (double)c.cyc[3];
+                    cells += (double)c.n_cells;
+                }
                 B /= 4.0;                                         // a build workgroup shares its CU with three others
                 // (a clock sum outside any plausible range -- seen once in six runs on the cluttered scene: 2^63 in one result -- is
                 //  left out: the split is a heuristic, one registration does not move it; NDTGPU_REG_VERBOSE reports it)
@@ -1425,9 +1585,7 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
                 }
                 if (m_bad < res.size()) M *= (double)res.size() / (double)(res.size() - m_bad);
                 M *= 1.125;                                       // (measured optimum on the bench scene: 144 of 256 CUs where the raw clocks say 138)
-                int dev = 0, n_cu = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                    n_cu = 256;
+                const int n_cu = r->n_cu;
                 double share = (M + B) > 0 ? M / (M + B) : 0.5;
                 share = std::min(0.9, std::max(0.25, share));
                 r->stream_groups = std::max(8u, ((unsigned)(share * n_cu + 4.0) / 8u) * 8u);
@@ -1449,39 +1607,38 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
                     }
                     r->stream_groups = best_g;
                 }
-                if (getenv("NDTGPU_REG_VERBOSE")) fprintf(stderr, "ndtgpu registrar: build %.3g, registrations %.3g CU-clocks per sub-batch -> matcher instances of %u workgroups\n", B, M, r->stream_groups);
+                r->calibrations++;
+                r->calib_cells = r->recal_ref > 0 ? r->recal_ref : cells / (double)(2 * p);
+                r->recal_ref = 0.0;
+                r->calib_at = j;
+                r->recent_cells.clear();
+                for (long long &q : r->stat_seq) q = -1;
+                if (getenv("NDTGPU_REG_VERBOSE")) fprintf(stderr, "ndtgpu registrar: build %.3g, registrations %.3g CU-clocks per sub-batch, %.0f cells per map -> matcher instances of %u workgroups\n", B, M, r->calib_cells, r->stream_groups);
                 r->submitted++;
                 if (ticket) *ticket = (uint64_t)r->submitted;
                 continue;
             }
-            // this map set was last used by sub-batch j - depth: its registrations must be complete before it is rebuilt
-            // (depth 4 is what the pipeline wants: two builds in flight beside the registrations of the two batches before them.
-            //  Measured with deeper rings, 5 / 6 / 8 map sets: 478 / 485 / 524 k registrations/s against 538 k -- the two build
-            //  streams then run in lockstep, two batches are published together, and the matcher instance runs dry in between)
+            // This map set was last used by sub-batch j - depth: its registrations must be complete before it is rebuilt.
+            // (Depth: a batch is complete 3-5 ms after its publication; with 8 map sets the builds never wait for that, 4 cost
+            //  ~5 % on the bench -- include/ndtgpu.h.)
             if (j >= (size_t)r->depth) {
                 hipError_t we = ndt_stream_wait(r->queue, (unsigned)r->depth, (unsigned)(j - (size_t)r->depth), st);
                 if (we != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: wait launch", we);
             }
-            hipEvent_t *mk = nullptr;
-            if (r->profiling) {
-                const size_t at = r->marks.size();
-                r->marks.resize(at + 4, nullptr);
-                for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreate(&r->marks[at + k]));
-                mk = &r->marks[at];
-                HIP_TRY(hipEventRecord(mk[0], st));
-            }
-            const char *tg = (const char *)targets_dev + off * map_stride_bytes, *sc = (const char *)sources_dev + off * map_stride_bytes;
-            ndtgpu_status rc;
-            if (sc == tg + p * map_stride_bytes) {
-                rc = ndtgpu_mapset_build(set, 0, 2 * p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-            } else {
-                rc = ndtgpu_mapset_build(set, 0, p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-                if (rc == NDTGPU_OK)
-                    rc = ndtgpu_mapset_build(set, p, p, sc, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-            }
+            ndtgpu_registrar::ProfMark *mk = nullptr;
+            if (r->profiling) { ndtgpu_status mrc = new_mark((long long)j, &mk); if (mrc != NDTGPU_OK) return mrc; HIP_TRY(hipEventRecord(mk->e[0], st)); }
+            ndtgpu_status rc = build_pairs(set, off, p, st);
             if (rc != NDTGPU_OK) return rc;
-            if (mk) { HIP_TRY(hipEventRecord(mk[1], st)); HIP_TRY(hipEventRecord(mk[2], st)); HIP_TRY(hipEventRecord(mk[3], st)); }
+            if (mk) HIP_TRY(hipEventRecord(mk->e[1], st));
             HIP_TRY(hipEventRecord(r->built[slot], st));
+            if (r->sst && r->stat_seq[slot] < 0) {
+                // (the counters of this build travel to the host behind it, on a stream of their own)
+                HIP_TRY(hipStreamWaitEvent(r->sst, r->built[slot], 0));
+                HIP_TRY(hipMemcpyAsync(r->stat_host + (size_t)slot * 2 * r->per, set->v.counters, 2 * p * sizeof(NdtMapCounters), hipMemcpyDeviceToHost, r->sst));
+                HIP_TRY(hipEventRecord(r->stat_ev[slot], r->sst));
+                r->stat_seq[slot] = (long long)j;
+                r->stat_maps[slot] = (unsigned)(2 * p);
+            }
             HIP_TRY(hipStreamWaitEvent(r->pst, r->built[slot], 0));
             hipError_t pe = ndt_stream_publish(r->queue, set->v, T16_dev + off * 16, reinterpret_cast<NdtMatchResultDev *>(results_dev + off),
                                                pdev, (unsigned)p, (unsigned)j, r->pst);
@@ -1504,25 +1661,11 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
         ndtgpu_mapset *set = r->sets[slot];
         HIP_TRY(hipStreamWaitEvent(st, r->in_ev, 0));
         if (r->last_built >= 0 && r->last_built != slot) HIP_TRY(hipStreamWaitEvent(st, r->built[r->last_built], 0));
-        hipEvent_t *mk = nullptr;
-        if (r->profiling) {
-            const size_t at = r->marks.size();
-            r->marks.resize(at + 4, nullptr);
-            for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreate(&r->marks[at + k]));
-            mk = &r->marks[at];
-            HIP_TRY(hipEventRecord(mk[0], st));
-        }
-        const char *tg = (const char *)targets_dev + off * map_stride_bytes, *sc = (const char *)sources_dev + off * map_stride_bytes;
-        ndtgpu_status rc;
-        if (sc == tg + p * map_stride_bytes) {
-            rc = ndtgpu_mapset_build(set, 0, 2 * p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-        } else {
-            rc = ndtgpu_mapset_build(set, 0, p, tg, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-            if (rc == NDTGPU_OK)
-                rc = ndtgpu_mapset_build(set, p, p, sc, n_points, stride_bytes, map_stride_bytes, range_limit, nullptr, cell, st);
-        }
+        ndtgpu_registrar::ProfMark *mk = nullptr;
+        if (r->profiling) { ndtgpu_status mrc = new_mark(-1, &mk); if (mrc != NDTGPU_OK) return mrc; HIP_TRY(hipEventRecord(mk->e[0], st)); }
+        ndtgpu_status rc = build_pairs(set, off, p, st);
         if (rc != NDTGPU_OK) return rc;
-        if (mk) { HIP_TRY(hipEventRecord(mk[1], st)); HIP_TRY(hipEventRecord(mk[2], st)); }
+        if (mk) { HIP_TRY(hipEventRecord(mk->e[1], st)); HIP_TRY(hipEventRecord(mk->e[2], st)); }
         HIP_TRY(hipEventRecord(r->built[slot], st));
         r->last_built = slot;
         // `built` releases the next sub-batch's build AND, on this stream, this sub-batch's matcher.  The matcher's persistent
@@ -1531,13 +1674,12 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
         // rate (measured: 430 k against 470 k registrations/s).  Two 4-byte fills keep this stream busy for the few
         // microseconds the next build's dispatch needs to get ahead (NDTGPU_REG_GAP: their number).
         if (r->depth > 1) {
-            const char *gap = getenv("NDTGPU_REG_GAP");
-            const int n_gap = gap ? atoi(gap) : 2;
+            const int n_gap = env_int("NDTGPU_REG_GAP", 2);
             for (int g = 0; g < n_gap; g++) HIP_TRY(hipMemsetAsync(r->iota + 2 * r->per, 0, 4, st));
         }
         rc = ndtgpu_match_batch_device(set, r->iota, set, r->iota + p, T16_dev + off * 16, p, prm, results_dev + off, st);
         if (rc != NDTGPU_OK) return rc;
-        if (mk) HIP_TRY(hipEventRecord(mk[3], st));
+        if (mk) HIP_TRY(hipEventRecord(mk->e[3], st));
         HIP_TRY(hipEventRecord(r->done[r->submitted % r->done.size()], st));
         r->submitted++;
         if (ticket) *ticket = (uint64_t)r->submitted;      // "every sub-batch before this count"
@@ -1550,6 +1692,15 @@ ndtgpu_status ndtgpu_registrar_wait_stream(ndtgpu_registrar *r, uint64_t ticket,
     if (!r || ticket > (uint64_t)r->submitted) return fail(NDTGPU_ERR_INVALID, "registrar_wait_stream: bad argument");
     const size_t end = ticket ? (size_t)ticket : r->submitted;
     if (r->queue) {
+        // The wait is a device-side kernel that ends when the running matcher instance has made the batch complete: it must not
+        // sit in the hardware queue the instance launches go through.  The runtime keeps streams of different priorities on
+        // different queues; a stream of the matcher stream's priority (the highest the device offers) is refused.
+        if (stream) {
+            int prio = 0;
+            if (hipStreamGetPriority((hipStream_t)stream, &prio) == hipSuccess && prio == r->mst_prio)
+                return fail(NDTGPU_ERR_INVALID, "registrar_wait_stream: a stream of the highest priority may share the matcher's hardware queue; "
+                                                "wait on a stream of default priority (or use ndtgpu_registrar_sync)");
+        }
         // the last `depth` sub-batches before `end` (a sub-batch is only published once the one `depth` before it is complete)
         for (size_t j = end > (size_t)r->depth ? end - (size_t)r->depth : 0; j < end; j++) {
             hipError_t we = ndt_stream_wait(r->queue, (unsigned)r->depth, (unsigned)j, (hipStream_t)stream);
@@ -1570,9 +1721,7 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
         // Nothing more is coming before this call returns: once the last sub-batch has been published the CUs that were kept
         // for the builds are free, and a second instance on those takes its share of what is left to register.
         if (r->submitted > r->helped && r->stream_groups && r->stream_nn >= 0 && !getenv("NDTGPU_REG_NO_HELPER")) {
-            int dev = 0, n_cu = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                n_cu = 256;
+            const int n_cu = r->n_cu;
             if ((unsigned)n_cu > r->stream_groups + 8u) {
                 if (!r->hst) HIP_TRY(hipStreamCreateWithFlags(&r->hst, hipStreamNonBlocking));
                 HIP_TRY(hipStreamWaitEvent(r->hst, r->pub_ev[(r->submitted - 1) % (size_t)r->depth], 0));
@@ -1588,7 +1737,14 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
         if (r->hst) HIP_TRY(hipStreamSynchronize(r->hst));
         unsigned aborted = 0;
         HIP_TRY(hipMemcpy(&aborted, (char *)r->queue + ndt_stream_abort_offset(), sizeof aborted, hipMemcpyDeviceToHost));
-        if (aborted) return fail(NDTGPU_ERR_HIP, "registrar: the stream-fed matcher gave up (no work, or no progress behind a wait, for ~30 s)");
+        if (aborted) {
+            // Reported ONCE: the registrations of the batches that were cut short carry exit_code -4 (every result starts as
+            // "not run" when its batch is published), the queue is put back to "everything submitted is over", and the
+            // registrar can be used again.
+            HIP_TRY(ndt_stream_reset(r->queue, (unsigned)r->submitted, (unsigned)r->depth));
+            return fail(NDTGPU_ERR_HIP, "registrar: the stream-fed matcher gave up (no work, or no progress behind a wait, for ~30 s); "
+                                        "registrations that did not run report exit_code -4");
+        }
         return NDTGPU_OK;
     }
     for (int k = 0; k < r->depth; k++) HIP_TRY(hipStreamSynchronize(r->streams[k]));

@@ -219,15 +219,19 @@ def valid_links(edges, T_links, node_T, scores=None, max_score=0.1, max_dist=1.0
     the filter the reference applies to the REGISTERED links before it optimises: a link (ref, mov, T) stays when its
     score <= max_score (skipped when `scores` is None), its nodes are at least min_idx_dist indices apart and the pose it
     predicts for the moving node, node_T[ref] * T, lies within max_dist / max_angle of the node's own pose
-    (distanceBetweenAffine3d: translation norm, rotation angle).  Returns the indices of the links that stay."""
+    (distanceBetweenAffine3d, utils.h:43-48: norm of the translation of own^-1 * pred, and |getRobustYawFromAffine3d| =
+    acos of the (0, 0) entry of its rotation -- the angle of the rotated x axis IN THE XY PLANE, not the 3D rotation angle, and
+    unclipped as upstream: an entry a rounding above 1 gives NaN, NaN < max_angle is false, the link is rejected).
+    Returns the indices of the links that stay."""
     edges = np.asarray(edges)
     T_links = np.asarray(T_links, dtype=np.float64).reshape(-1, 4, 4)
     node_T = np.asarray(node_T, dtype=np.float64)
     pred = np.einsum("eij,ejk->eik", node_T[edges[:, 0]], T_links)
     own = node_T[edges[:, 1]]
     dist = np.linalg.norm(pred[:, :3, 3] - own[:, :3, 3], axis=1)
-    rel = np.einsum("eji,ejk->eik", own[:, :3, :3], pred[:, :3, :3])
-    ang = np.arccos(np.clip((np.trace(rel, axis1=1, axis2=2) - 1.0) / 2.0, -1.0, 1.0))
+    r00 = np.einsum("ej,ej->e", own[:, :3, 0], pred[:, :3, 0])          # (own_R^T pred_R)(0, 0)
+    with np.errstate(invalid="ignore"):
+        ang = np.abs(np.arccos(r00))
     keep = (np.abs(edges[:, 1].astype(np.int64) - edges[:, 0].astype(np.int64)) >= min_idx_dist) & (dist < max_dist) & (ang < max_angle)
     if scores is not None:
         keep &= np.asarray(scores) <= max_score

@@ -30,11 +30,13 @@ struct Pose2dCov {
     Eigen::Matrix3d cov;
 };
 
-// getRobustYawFromAffine3d (utils.h:30-41)
-inline double getRobustYawFromAffine3d(const Eigen::Affine3d &a)
+// getRobustYawFromAffine3d (utils.h:30-41).  `clamped`: the cosine is brought into [-1, 1] first -- upstream does not, so a
+// rotation whose (0, 0) entry is a rounding above 1 yields NaN there: kept as written where it only rejects a link
+// (distanceBetweenAffine3d -> getValidLinks), not where it would turn a pose into NaN (force2D).
+inline double getRobustYawFromAffine3d(const Eigen::Affine3d &a, bool clamped = true)
 {
-    const double dot = a(0, 0);                       // v1 = (1,0,0), v2 = R v1: v1.v2 in the xy plane
-    const double angle = std::acos(std::fmax(-1.0, std::fmin(1.0, dot)));
+    const double c = clamped ? std::fmax(-1.0, std::fmin(1.0, a(0, 0))) : a(0, 0);   // x axis . rotated x axis, in the xy plane
+    const double angle = std::acos(c);
     return (a(1, 0) > 0) ? angle : -angle;
 }
 // distanceBetweenAffine3d (utils.h:43-48)
@@ -42,7 +44,7 @@ inline void distanceBetweenAffine3d(const Eigen::Affine3d &p1, const Eigen::Affi
 {
     Eigen::Affine3d tmp = p1.inverse() * p2;
     dist = tmp.translation().norm();
-    angularDist = std::fabs(getRobustYawFromAffine3d(tmp));
+    angularDist = std::fabs(getRobustYawFromAffine3d(tmp, false));
 }
 // forceEigenAffine3dTo2dInPlace (utils.h:50-72)
 inline void forceEigenAffine3dTo2dInPlace(Eigen::Affine3d &a3d)

@@ -58,7 +58,9 @@ def cells_equal(gpu, cpu, res):
 
 
 def test_config3_batch_1024_pairs_100k_points(N, O):
-    """configs[2] exactly as bench.py runs it: scans resident in HBM, two 1024-map sets, ONE device-pointer batch."""
+    """configs[2] through the TWO-CALL path (ndtgpu_mapset_build, then ONE ndtgpu_match_batch_device): scans resident in HBM,
+    two 1024-map sets.  bench.py times the one-call registrar instead; that entry has its own full-size test
+    (tests/test_gpu_registrar_fullsize.py), which asserts the bits of this path."""
     import torch
     from ndt_feature_graph_amd import binding, synth
     dev = torch.device("cuda", 0)

@@ -181,7 +181,12 @@ def test_registrar_rejects_bad_arguments(N, scene):
         N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=0, depth=3)
     with pytest.raises(N.NdtGpuError):
         N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=0)
+    with pytest.raises(N.NdtGpuError):                           # the stream-fed form cannot be had with one map set
+        N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=1, matcher_form=2)
+    with pytest.raises(N.NdtGpuError):
+        N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=2, matcher_form=7)
     reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=1, max_cells=4096)
+    assert reg.info()["matcher_form"] == 1 and reg.info()["calibrations"] == 0
     reg.sync()                                                   # nothing submitted: returns at once
     assert reg.kernel_ms() == (0.0, 0.0, 0)
     reg.close()
@@ -217,20 +222,21 @@ def test_registrar_host_form(N, scene):
     reg.close()
 
 
-@pytest.mark.parametrize("mode,groups", [("stream", None), ("stream", "8"), ("launch_per_batch", None)])
-def test_registrar_long_run_both_matcher_forms(N, scene, monkeypatch, mode, groups):
+@pytest.mark.parametrize("mode,groups", [("stream", None), ("stream", 8), ("launch_per_batch", None)])
+def test_registrar_long_run_both_matcher_forms(N, scene, mode, groups):
     """Twelve calls (36 sub-batches: many turns of the ring of four map sets) without a host wait, four output buffers in
     rotation guarded by tickets -- through the stream-fed matcher (one running instance serves batch after batch; its CU share
     measured on the first sub-batch, or forced to 8 workgroups) and through the form with one matcher launch per sub-batch
-    (NDTGPU_REG_STREAM=0): every call returns the bits of ndtgpu_mapset_build + ndtgpu_match_batch_device."""
+    (ndtgpu_registrar_params.matcher_form): every call returns the bits of ndtgpu_mapset_build + ndtgpu_match_batch_device."""
     import torch
     from ndt_feature_graph_amd import binding
-    monkeypatch.setenv("NDTGPU_REG_STREAM", "1" if mode == "stream" else "0")
+    fields = {"matcher_form": binding.MATCHER_STREAM_FED if mode == "stream" else binding.MATCHER_PER_BATCH}
     if groups:
-        monkeypatch.setenv("NDTGPU_REG_GROUPS", groups)
+        fields["matcher_groups"] = groups
     B, both, dev = scene["B"], scene["both"], scene["dev"]
     T_ref, r_ref = two_call_reference(N, scene, 32)
-    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=32, depth=4, max_cells=4096)
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=32, depth=4, max_cells=4096, **fields)
+    assert reg.info()["matcher_form"] == fields["matcher_form"]
     st = torch.cuda.Stream(device=dev)
     outs = [(scene["T0"].clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev)) for _ in range(4)]
     tickets = [0] * 4
