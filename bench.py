@@ -617,6 +617,8 @@ def main():
     ap.add_argument("--buffers", type=int, default=8, help="pipeline depth (the registrar's internal map sets; at most 8)")
     ap.add_argument("--cu-split", type=int, default=0, help="CUs given to the build streams (hipExtStreamCreateWithCUMask), the "
                     "matcher streams get the rest; 0: every stream sees the whole chip")
+    ap.add_argument("--registrar", type=str, default="", help="fields of ndtgpu_registrar_params for the timed registrar, e.g. "
+                    "'matcher_groups=128,recalibrate_pct=-1' (experiments; the default registrar is what the headline is quoted on)")
     ap.add_argument("--sub-batch", type=int, default=0, help="pairs per internal sub-batch of the registrar (0: --pairs, one sub-batch per call)")
     ap.add_argument("--legacy-pipeline", action="store_true",
                     help="the round-4 form: bench.py itself drives mapset pairs, streams and events (ndtgpu_mapset_build + "
@@ -686,7 +688,8 @@ def main():
     class Buf:
         pass
     bufs = []
-    reg = None if legacy else N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=(args.sub_batch or B), depth=n_buf, max_cells=4096)
+    reg_fields = {kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in args.registrar.split(",") if "=" in kv}
+    reg = None if legacy else N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=(args.sub_batch or B), depth=n_buf, max_cells=4096, **reg_fields)
     main_stream = torch.cuda.current_stream()
     if os.environ.get("BENCH_MAIN_SIDE"):      # (experiment: the caller's stream is not the null stream)
         main_stream = torch.cuda.Stream(device=dev)
@@ -927,7 +930,8 @@ def main():
                                  "%d internal map sets in flight: the grid builds of later steps run on two streams beside ONE running "
                                  "instance of the stream-fed matcher, which holds the share of the CUs the registrar measured on its "
                                  "first batch" % n_buf)),
-                   "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2)},
+                   "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2),
+                   "registrar": (reg.info() if reg is not None else None)},
         "roofline": roofline, "kernels": kern,
         # SURVEY.md 8d (config 4): node maps and edges are separate units when node maps are reused across edges
         # north_star: scans/s and achieved HBM-bandwidth fraction (algorithmic bytes / time / 8 TB/s), per kernel

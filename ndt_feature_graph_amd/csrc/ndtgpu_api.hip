@@ -1163,6 +1163,24 @@ ndtgpu_status ndtgpu_match_batch_device(ndtgpu_mapset *ts, const uint32_t *tidx_
 // builds among themselves -- sub-batch k + 1 builds once sub-batch k's build has finished, i.e. while matcher k runs: the
 // matcher's workgroups leave their CUs as soon as no registration is left to start (csrc/ndt_match.hip), so the next builds
 // fill the CUs that the few long registrations do not hold --, (iii) a map set against its own previous use (same stream).
+// the Gaussian cells of n_maps maps, summed, to two words of pinned host memory: {cells, seq + 1}
+__global__ void ndt_reg_stats_kernel(const NdtMapCounters *ctr, unsigned n_maps, unsigned long long seq, unsigned long long *out)
+{
+    __shared__ unsigned long long part[256];
+    unsigned long long c = 0;
+    for (unsigned i = threadIdx.x; i < n_maps; i += 256u) c += ctr[i].n_cells;
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (unsigned o = 128u; o > 0u; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&out[0], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&out[1], seq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 struct ndtgpu_registrar {
     size_t per = 0;
     int depth = 0;
@@ -1197,10 +1215,10 @@ struct ndtgpu_registrar {
                                        // again at every change)
     double recal_ref = 0.0;
     size_t calib_at = 0;               // ... and its number
-    hipStream_t sst = nullptr;
-    NdtMapCounters *stat_host = nullptr;     // [depth][2 per], pinned
-    std::vector<hipEvent_t> stat_ev;
-    std::vector<long long> stat_seq;   // sub-batch whose counters slot k holds (-1: none / consumed)
+    unsigned long long *stat_host = nullptr; // [depth][2], pinned: {Gaussian cells of the slot's maps, sub-batch + 1} written by a
+                                             // one-workgroup kernel behind the build (no copy engine, no event: a device-to-host
+                                             // copy per sub-batch cost the pipeline a quarter of its rate, measured)
+    std::vector<long long> stat_seq;   // sub-batch whose counters slot k was asked for (-1: none / consumed)
     std::vector<unsigned> stat_maps;
     std::vector<double> recent_cells;  // mean cells per map of the last sub-batches seen (at most `depth`)
     // host clouds (ndtgpu_register_batch_host): per slot a device staging area for the scans of a sub-batch, one for the
@@ -1239,11 +1257,9 @@ ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
     if (r->pst) { (void)hipStreamSynchronize(r->pst); (void)hipStreamDestroy(r->pst); }
     if (r->hst) { (void)hipStreamSynchronize(r->hst); (void)hipStreamDestroy(r->hst); }
     if (r->mst) { (void)hipStreamSynchronize(r->mst); (void)hipStreamDestroy(r->mst); }
-    if (r->sst) { (void)hipStreamSynchronize(r->sst); (void)hipStreamDestroy(r->sst); }
     if (r->bst) (void)hipStreamDestroy(r->bst);
     if (r->bst2) (void)hipStreamDestroy(r->bst2);
     for (hipEvent_t e : r->pub_ev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : r->stat_ev) if (e) (void)hipEventDestroy(e);
     if (r->stat_host) (void)hipHostFree(r->stat_host);
     if (r->queue) (void)hipFree(r->queue);
     for (void *q : r->hstage) if (q) (void)hipFree(q);
@@ -1355,12 +1371,10 @@ ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const n
             for (int k = 0; k < depth && e == hipSuccess; k++) e = hipEventCreateWithFlags(&r->pub_ev[k], hipEventDisableTiming);
             // the side channel of the map statistics
             if (e == hipSuccess && P.matcher_groups == 0 && P.recalibrate_pct > 0) {
-                e = hipStreamCreateWithFlags(&r->sst, hipStreamNonBlocking);
-                if (e == hipSuccess) e = hipHostMalloc((void **)&r->stat_host, (size_t)depth * 2 * pairs_per_batch * sizeof(NdtMapCounters), hipHostMallocDefault);
-                r->stat_ev.assign(depth, nullptr);
+                e = hipHostMalloc((void **)&r->stat_host, (size_t)depth * 2 * sizeof(unsigned long long), hipHostMallocDefault);
+                if (e == hipSuccess) memset(r->stat_host, 0, (size_t)depth * 2 * sizeof(unsigned long long));
                 r->stat_seq.assign(depth, -1);
                 r->stat_maps.assign(depth, 0u);
-                for (int k = 0; k < depth && e == hipSuccess; k++) e = hipEventCreateWithFlags(&r->stat_ev[k], hipEventDisableTiming);
             }
         } else {
             P.build_streams = 0;
@@ -1512,15 +1526,17 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
             // cells a map holds now; when the mean over the last sub-batches has left the figure the split was measured at by
             // more than recalibrate_pct, the pipeline is drained once and this sub-batch measures the split again (a
             // registrar that moves from halls to clutter would otherwise keep 128 matcher CUs where 200 are right).
-            if (r->sst && r->stream_groups != 0u) {
+            if (r->stat_host && r->stream_groups != 0u) {
+                // (back-pressure: the host runs at most `depth` sub-batches ahead of the builds -- without it a caller that
+                //  never waits would have submitted everything before the first counters arrive)
+                if (j >= (size_t)r->depth) HIP_TRY(hipEventSynchronize(r->built[slot]));
                 for (int k = 0; k < r->depth; k++) {
-                    if (r->stat_seq[k] < 0 || hipEventQuery(r->stat_ev[k]) != hipSuccess) continue;
-                    const NdtMapCounters *c = r->stat_host + (size_t)k * 2 * r->per;
-                    double cells = 0;
-                    for (unsigned m = 0; m < r->stat_maps[k]; m++) cells += (double)c[m].n_cells;
+                    volatile unsigned long long *sh = r->stat_host + 2 * k;
+                    if (r->stat_seq[k] < 0 || sh[1] != (unsigned long long)r->stat_seq[k] + 1ull) continue;
+                    std::atomic_thread_fence(std::memory_order_acquire);
                     if (r->stat_maps[k]) {
                         if (r->recent_cells.size() >= (size_t)r->depth) r->recent_cells.erase(r->recent_cells.begin());
-                        r->recent_cells.push_back(cells / (double)r->stat_maps[k]);
+                        r->recent_cells.push_back((double)sh[0] / (double)r->stat_maps[k]);
                     }
                     r->stat_seq[k] = -1;
                 }
@@ -1630,15 +1646,17 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
             ndtgpu_status rc = build_pairs(set, off, p, st);
             if (rc != NDTGPU_OK) return rc;
             if (mk) HIP_TRY(hipEventRecord(mk->e[1], st));
-            HIP_TRY(hipEventRecord(r->built[slot], st));
-            if (r->sst && r->stat_seq[slot] < 0) {
-                // (the counters of this build travel to the host behind it, on a stream of their own)
-                HIP_TRY(hipStreamWaitEvent(r->sst, r->built[slot], 0));
-                HIP_TRY(hipMemcpyAsync(r->stat_host + (size_t)slot * 2 * r->per, set->v.counters, 2 * p * sizeof(NdtMapCounters), hipMemcpyDeviceToHost, r->sst));
-                HIP_TRY(hipEventRecord(r->stat_ev[slot], r->sst));
+            if (r->stat_host && r->stat_seq[slot] < 0 && j % 3u == 0u) {
+                // (how many Gaussian cells the maps of this build hold: one small kernel behind it writes the sum to the host.
+                //  Every third sub-batch: the launch costs the build stream a few microseconds -- 2 % of the bench's rate when
+                //  every sub-batch had one -- and an odd period does not lock onto callers that alternate between two scenes)
+                hipLaunchKernelGGL(ndt_reg_stats_kernel, dim3(1), dim3(256), 0, st, set->v.counters, (unsigned)(2 * p), (unsigned long long)j,
+                                   r->stat_host + 2 * slot);
+                HIP_TRY(hipGetLastError());
                 r->stat_seq[slot] = (long long)j;
                 r->stat_maps[slot] = (unsigned)(2 * p);
             }
+            HIP_TRY(hipEventRecord(r->built[slot], st));
             HIP_TRY(hipStreamWaitEvent(r->pst, r->built[slot], 0));
             hipError_t pe = ndt_stream_publish(r->queue, set->v, T16_dev + off * 16, reinterpret_cast<NdtMatchResultDev *>(results_dev + off),
                                                pdev, (unsigned)p, (unsigned)j, r->pst);
