@@ -456,6 +456,84 @@ ndtgpu_status ndtgpu_registrar_kernel_ms(ndtgpu_registrar *reg, float mean_ms[2]
  * the registrar. */
 ndtgpu_status ndtgpu_registrar_mapset(ndtgpu_registrar *reg, int slot, ndtgpu_mapset **set);
 
+/* ---- the fuser's call as ONE entry: NDTFeatureFuserHMT::update for a batch of independent fusers ---------------------------
+ * NDTFeatureFuserHMT::update (ndt_feature/src/ndt_feature_src/ndt_feature_fuser_hmt.cpp:108-512) is, per scan: move the scan
+ * into the node map's frame (:186-190), build its NDT map on the node map's lattice (:201-227), matchFusion against the node
+ * map with the odometry soft constraint / Tikhonov term / odometry cells (:291-357), the matcher's covariance (:399-413), the
+ * consistency gate and the pose update (:415-474), move the raw scan by the new pose and ray-trace it into the node map
+ * (:479-486) -- three host-synchronous C-ABI calls (build, match, add_cloud) with host arithmetic in between.  A fuser bank
+ * holds B independent fusers (robots, bags, the node fusers of a graph: they share nothing) and does all of it for a range of
+ * its slots in ONE asynchronous call: one upload of what the host derives from the odometry increments, then device work only --
+ * the pose a registration yields goes into the fuse-in without visiting the host.  Results are bit for bit those of the calls
+ * it replaces on the same inputs (tests/test_gpu_fuser_bank.py).
+ * Covers the production configuration of the fuser -- globalTransf and loadCentroid (their defaults; the launch files never
+ * change them), beHMT / visualisation / the FLIRT feature map outside the path. */
+typedef struct ndtgpu_fuser_bank ndtgpu_fuser_bank;
+typedef struct {
+    /* NDTFeatureFuserHMT::Params (ndt_feature_fuser_hmt.h:58-207): the fields the path reads, same names in snake case */
+    double resolution, map_size_x, map_size_y, map_size_z, sensor_range;
+    double max_translation_norm, max_rotation_norm;
+    int32_t check_consistency, fuse_incomplete;
+    int32_t use_odom;              /* the 40 odometry cell pairs (:322-334) join the registration (matchFusion's useFeat) */
+    int32_t neighbours, stepcontrol, itr_max;
+    double delta_score;
+    int32_t force_odom_as_est, fusion2d, all_matches_valid, use_soft_constraints, compute_cov, step_control_fusion, use_tikhonov;
+    int32_t covariance_mode;       /* `mode` of ndtgpu_covariance_batch */
+    /* MotionModel2d::Params (motion_model.hpp:123-136) */
+    double motion_Cd, motion_Ct, motion_Dd, motion_Dt, motion_Td, motion_Tt;
+    double sensor_pose[16];        /* setSensorPose: column-major like every pose of this header */
+    uint32_t max_cells;            /* cell capacity of the node and scan maps (ndtgpu_grid_params.max_cells) */
+} ndtgpu_fuser_params;
+void ndtgpu_default_fuser_params(ndtgpu_fuser_params *p);   /* Params() and MotionModel2d::Params() of the reference, sensor at the origin */
+/* What the host derives from (current pose, odometry increment) before the device takes over -- a pure function, exposed so
+ * that a caller (or a test) can drive the three separate calls with exactly the inputs the bank uses. */
+typedef struct {
+    double Tscan[16];            /* Tinit * sensor_pose: raw scan -> node map frame (:186-190) */
+    double scan_centre[3];       /* loadPointCloudCentroid's grid centre (:201-202) */
+    double range_origin[3];      /* the sensor position the range limit is measured from */
+    double Tcov[36];             /* TmotionCov, row-major (:137-146) */
+    double odom_cov[9];          /* covariance of the odometry cells (:127-130) */
+    double feat_src_mean[3];     /* the 40 correspondences of ndtgpu_match_fusion_feat_batch: source cell i ... */
+    double feat_tgt_mean[3];     /* ... target cell i, */
+    double feat_cov_rotated[6];  /* the covariance of all of them (xx xy xz yy yz zz) */
+    double feat_cov_plain[6];    /* but the LAST source cell, which keeps the un-rotated one (:336-339) */
+} ndtgpu_fuser_prepared;
+ndtgpu_status ndtgpu_fuser_prepare(const ndtgpu_fuser_params *prm, const double Tnow16[16], const double Tmotion16[16],
+                                   const double node_centre[3], ndtgpu_fuser_prepared *out);
+typedef struct {
+    double Tnow[16];             /* the fuser's pose after the update: what update() returns */
+    double Tmotion_est[16];      /* the registered increment */
+    double spose[16];            /* Tnow * sensor_pose: the frame the raw scan was fused in at */
+    ndtgpu_match_result match;
+    int32_t match_ok;            /* converged, or fuseIncomplete / allMatchesValid */
+    int32_t registration_failure;/* the consistency gate fired: the pose is the odometry's */
+    int32_t cov_singular, pad_;
+    double posecov_mean[3];      /* current_posecov */
+    double posecov[9];           /* column-major 3x3 */
+} ndtgpu_fuser_result;
+/* node_maps: the map set whose maps [0, n_fusers) are the fusers' node maps (a graph's pool: the caller keeps ownership), or
+ * NULL: the bank makes its own with prm's map sizes.  Enables occupancy on it. */
+ndtgpu_status ndtgpu_fuser_bank_create(const ndtgpu_fuser_params *prm, size_t n_fusers, ndtgpu_mapset *node_maps,
+                                       ndtgpu_fuser_bank **out);
+ndtgpu_status ndtgpu_fuser_bank_destroy(ndtgpu_fuser_bank *bank);
+/* the node maps and the scan maps of the last update (borrowed) */
+ndtgpu_status ndtgpu_fuser_bank_mapsets(ndtgpu_fuser_bank *bank, ndtgpu_mapset **node_maps, ndtgpu_mapset **scan_maps);
+/* NDTFeatureFuserHMT::initialize(initPos, cloud, ...) (:65-102) for slots [first, first + count): pose initPose16[k] (HOST), the
+ * node map centred on it, the first cloud (DEVICE, sensor frame; n_points records `stride_bytes` apart, clouds
+ * `map_stride_bytes` apart) ray-traced in.  Asynchronous on `stream`. */
+ndtgpu_status ndtgpu_fuser_initialize_batch(ndtgpu_fuser_bank *bank, size_t first, size_t count, const double *initPose16,
+                                            const void *xyz_dev, size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                            ndtgpu_stream stream);
+/* NDTFeatureFuserHMT::update(Tmotion, cloud, pts, updateFeatureMap, updateNDTMap) for slots [first, first + count): Tmotion16
+ * HOST (count x 16), clouds DEVICE in the sensor frame.  Asynchronous on `stream`; a call waits (on the host) for the bank's
+ * previous call first: it starts from the poses that one left.  Scans of unequal length: pad with NaN points. */
+ndtgpu_status ndtgpu_fuser_update_batch(ndtgpu_fuser_bank *bank, size_t first, size_t count, const double *Tmotion16,
+                                        const void *xyz_dev, size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                        int update_ndt_map, ndtgpu_stream stream);
+/* waits for the bank's last call; Tnow16: HOST, count x 16; results (may be NULL): the records of the last update call for the
+ * slots it covered, zeroes for the others */
+ndtgpu_status ndtgpu_fuser_poses(ndtgpu_fuser_bank *bank, size_t first, size_t count, double *Tnow16, ndtgpu_fuser_result *results);
+
 /* single pair convenience == graph.cpp:273 */
 ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *target_set, size_t target_map, ndtgpu_mapset *source_set,
                                size_t source_map, double T16[16], const ndtgpu_match_params *prm,

@@ -8,5 +8,5 @@ mirror of the reference classes lives in ndt_feature_graph_amd/host/.
 There is no CPU fallback: importing works anywhere (the build check runs without a GPU), but
 every compute call raises NdtGpuError when the HIP library or a device is missing.
 """
-from .binding import (MapSet, Registrar, covariance, MatchParams, NdtGpuError, build_library, derivatives, device_count, lib,  # noqa: F401
+from .binding import (MapSet, Registrar, FuserBank, fuser_params, fuser_prepare, covariance, MatchParams, NdtGpuError, build_library, derivatives, device_count, lib,  # noqa: F401
                       library_path, match_batch, match_d2d, match_fusion_batch, overlap_score)

@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_HERE, "libndtgpu.so")
-_SOURCES = ["ndt_build.hip", "ndt_build_flat.hip", "ndt_match.hip", "ndt_fuse.hip", "ndt_pack.hip", "ndtgpu_api.hip"]
+_SOURCES = ["ndt_build.hip", "ndt_build_flat.hip", "ndt_match.hip", "ndt_fuse.hip", "ndt_pack.hip", "ndt_fuser.hip", "ndtgpu_api.hip"]
 
 STATUS = {0: "OK", -1: "ERR_INVALID", -2: "ERR_HIP", -3: "ERR_NO_DEVICE", -4: "ERR_CAPACITY", -5: "ERR_ALLOC"}
 
@@ -127,7 +127,9 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_mapset_add_cloud_host_async", "ndtgpu_registrar_create", "ndtgpu_registrar_destroy",
            "ndtgpu_register_batch_device", "ndtgpu_registrar_wait_stream", "ndtgpu_registrar_sync",
            "ndtgpu_registrar_profiling", "ndtgpu_registrar_kernel_ms", "ndtgpu_registrar_mapset", "ndtgpu_register_batch_host",
-           "ndtgpu_default_registrar_params", "ndtgpu_registrar_create_ex", "ndtgpu_registrar_get_info"]
+           "ndtgpu_default_registrar_params", "ndtgpu_registrar_create_ex", "ndtgpu_registrar_get_info",
+           "ndtgpu_default_fuser_params", "ndtgpu_fuser_prepare", "ndtgpu_fuser_bank_create", "ndtgpu_fuser_bank_destroy",
+           "ndtgpu_fuser_bank_mapsets", "ndtgpu_fuser_initialize_batch", "ndtgpu_fuser_update_batch", "ndtgpu_fuser_poses"]
 
 _lib = None
 
@@ -206,6 +208,15 @@ def lib():
     L.ndtgpu_default_registrar_params.restype = None
     L.ndtgpu_registrar_create_ex.argtypes = [C.POINTER(GridParams), C.POINTER(RegistrarParams), C.POINTER(vp)]
     L.ndtgpu_registrar_get_info.argtypes = [vp, C.POINTER(RegistrarInfo)]
+    L.ndtgpu_default_fuser_params.argtypes = [C.POINTER(FuserParams)]
+    L.ndtgpu_default_fuser_params.restype = None
+    L.ndtgpu_fuser_prepare.argtypes = [C.POINTER(FuserParams), dp, dp, dp, C.POINTER(FuserPrepared)]
+    L.ndtgpu_fuser_bank_create.argtypes = [C.POINTER(FuserParams), C.c_size_t, vp, C.POINTER(vp)]
+    L.ndtgpu_fuser_bank_destroy.argtypes = [vp]
+    L.ndtgpu_fuser_bank_mapsets.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.ndtgpu_fuser_initialize_batch.argtypes = [vp, C.c_size_t, C.c_size_t, dp, vp, C.c_size_t, C.c_size_t, C.c_size_t, vp]
+    L.ndtgpu_fuser_update_batch.argtypes = [vp, C.c_size_t, C.c_size_t, dp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, vp]
+    L.ndtgpu_fuser_poses.argtypes = [vp, C.c_size_t, C.c_size_t, dp, vp]
     L.ndtgpu_register_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(CellParams),
                                                vp, C.c_size_t, C.POINTER(MatchParams), vp, vp, C.POINTER(C.c_uint64)]
     L.ndtgpu_register_batch_host.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(CellParams),
@@ -657,6 +668,110 @@ class Registrar:
         h = C.c_void_p()
         _check(lib().ndtgpu_registrar_mapset(self.h, int(slot), C.byref(h)))
         return _BorrowedMapSet(h, 2 * self.per, self.res)
+
+
+class FuserParams(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("map_size_x", C.c_double), ("map_size_y", C.c_double), ("map_size_z", C.c_double),
+                ("sensor_range", C.c_double), ("max_translation_norm", C.c_double), ("max_rotation_norm", C.c_double),
+                ("check_consistency", C.c_int32), ("fuse_incomplete", C.c_int32), ("use_odom", C.c_int32), ("neighbours", C.c_int32),
+                ("stepcontrol", C.c_int32), ("itr_max", C.c_int32), ("delta_score", C.c_double), ("force_odom_as_est", C.c_int32),
+                ("fusion2d", C.c_int32), ("all_matches_valid", C.c_int32), ("use_soft_constraints", C.c_int32), ("compute_cov", C.c_int32),
+                ("step_control_fusion", C.c_int32), ("use_tikhonov", C.c_int32), ("covariance_mode", C.c_int32),
+                ("motion_Cd", C.c_double), ("motion_Ct", C.c_double), ("motion_Dd", C.c_double), ("motion_Dt", C.c_double),
+                ("motion_Td", C.c_double), ("motion_Tt", C.c_double), ("sensor_pose", C.c_double * 16), ("max_cells", C.c_uint32)]
+
+
+class FuserPrepared(C.Structure):
+    _fields_ = [("Tscan", C.c_double * 16), ("scan_centre", C.c_double * 3), ("range_origin", C.c_double * 3), ("Tcov", C.c_double * 36),
+                ("odom_cov", C.c_double * 9), ("feat_src_mean", C.c_double * 3), ("feat_tgt_mean", C.c_double * 3),
+                ("feat_cov_rotated", C.c_double * 6), ("feat_cov_plain", C.c_double * 6)]
+
+
+FUSER_RESULT_DTYPE = np.dtype([("Tnow", "<f8", (16,)), ("Tmotion_est", "<f8", (16,)), ("spose", "<f8", (16,)), ("match", RESULT_DTYPE),
+                               ("match_ok", "<i4"), ("registration_failure", "<i4"), ("cov_singular", "<i4"), ("pad_", "<i4"),
+                               ("posecov_mean", "<f8", (3,)), ("posecov", "<f8", (9,))])
+
+
+def fuser_params(**fields):
+    """ndtgpu_default_fuser_params with fields overridden; sensor_pose: 4x4 (row-major NumPy) or 16 column-major numbers."""
+    p = FuserParams()
+    lib().ndtgpu_default_fuser_params(C.byref(p))
+    for k, v in fields.items():
+        if k == "sensor_pose":
+            a = np.asarray(v, dtype=np.float64)
+            p.sensor_pose[:] = list(a.T.reshape(16) if a.shape == (4, 4) else a.reshape(16))
+        elif k not in dict(FuserParams._fields_):
+            raise TypeError("fuser_params: no field %r" % k)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def fuser_prepare(params, Tnow, Tmotion, node_centre):
+    """ndtgpu_fuser_prepare: what the host derives from (pose, odometry increment).  Tnow / Tmotion: 4x4 row-major NumPy."""
+    out = FuserPrepared()
+    tn = np.ascontiguousarray(np.asarray(Tnow, dtype=np.float64).T).reshape(16).copy()
+    tm = np.ascontiguousarray(np.asarray(Tmotion, dtype=np.float64).T).reshape(16).copy()
+    nc = _f64(node_centre).reshape(3)
+    _check(lib().ndtgpu_fuser_prepare(C.byref(params), _dp(tn), _dp(tm), _dp(nc), C.byref(out)))
+    return {k: np.array(getattr(out, k)) for k, _ in FuserPrepared._fields_}
+
+
+class FuserBank:
+    """ndtgpu_fuser_bank: NDTFeatureFuserHMT::initialize / update for a batch of independent fusers, one asynchronous call
+    each (include/ndtgpu.h).  Poses are 4x4 row-major NumPy arrays on this side."""
+
+    def __init__(self, params, n_fusers, node_maps=None):
+        h = C.c_void_p()
+        _check(lib().ndtgpu_fuser_bank_create(C.byref(params), int(n_fusers), node_maps.h if node_maps is not None else None, C.byref(h)))
+        self.h, self.n, self.params = h, int(n_fusers), params
+        self._node_maps = node_maps       # (kept alive)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ndtgpu_fuser_bank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def mapsets(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(lib().ndtgpu_fuser_bank_mapsets(self.h, C.byref(a), C.byref(b)))
+        return _BorrowedMapSet(a, self.n, self.params.resolution), _BorrowedMapSet(b, self.n, self.params.resolution)
+
+    @staticmethod
+    def _poses16(T, n):
+        return np.ascontiguousarray(np.transpose(np.asarray(T, dtype=np.float64).reshape(n, 4, 4), (0, 2, 1))).reshape(n, 16).copy()
+
+    def _cloud_args(self, xyz):
+        import torch
+        assert xyz.dtype == torch.float32 and xyz.is_cuda and xyz.stride(2) == 1 and xyz.stride(1) == xyz.shape[2]
+        return C.c_void_p(xyz.data_ptr()), int(xyz.shape[1]), 4 * int(xyz.shape[2]), 4 * int(xyz.stride(0))
+
+    def initialize(self, init_poses, xyz, first=0, stream=None):
+        n = int(xyz.shape[0])
+        T = self._poses16(init_poses, n)
+        ptr, npts, stride, mstride = self._cloud_args(xyz)
+        _check(lib().ndtgpu_fuser_initialize_batch(self.h, int(first), n, _dp(T), ptr, npts, stride, mstride, _stream_ptr(stream)))
+
+    def update(self, Tmotion, xyz, first=0, update_ndt_map=True, stream=None):
+        n = int(xyz.shape[0])
+        T = self._poses16(Tmotion, n)
+        ptr, npts, stride, mstride = self._cloud_args(xyz)
+        _check(lib().ndtgpu_fuser_update_batch(self.h, int(first), n, _dp(T), ptr, npts, stride, mstride, 1 if update_ndt_map else 0,
+                                               _stream_ptr(stream)))
+
+    def poses(self, first=0, count=None):
+        """-> (Tnow [n,4,4] row-major, results of the last update call: FUSER_RESULT_DTYPE [n]); waits for the bank"""
+        n = self.n - first if count is None else int(count)
+        T = np.zeros((n, 16))
+        res = np.zeros(n, dtype=FUSER_RESULT_DTYPE)
+        _check(lib().ndtgpu_fuser_poses(self.h, int(first), n, _dp(T), C.c_void_p(res.ctypes.data)))
+        return np.transpose(T.reshape(n, 4, 4), (0, 2, 1)).copy(), res
 
 
 def match_d2d(target_set, tmap, source_set, smap, T, **params):

@@ -4,6 +4,7 @@
 #include "../../include/ndtgpu.h"
 #include "ndt_math.h"
 #include "ndt_solver.h"
+#include "ndt_pose.h"
 
 #include <algorithm>
 #include <cmath>
@@ -2277,6 +2278,464 @@ ndtgpu_status ndtgpu_match_d2d(ndtgpu_mapset *ts, size_t tmap, ndtgpu_mapset *ss
 {
     uint32_t ti = (uint32_t)tmap, si = (uint32_t)smap;
     return ndtgpu_match_batch(ts, &ti, ss, &si, T16, 1, prm, result, nullptr);
+}
+
+
+// ---- the fuser bank: NDTFeatureFuserHMT::update for a batch of independent fusers as ONE call (include/ndtgpu.h) ----------
+// Per call and slot: [host] the odometry model, the soft-constraint covariance, the odometry cells, the scan frame and the scan
+// map's centre (ndtgpu_fuser_prepare) -> ONE upload -> [device] scan into the node map's frame, scan map build, matchFusion
+// against the slot's node map, the matcher's covariance, the post-registration step (pose, gates, accumulated covariance),
+// scan into the frame of the new pose, ray-traced fuse-in.  No host round trip in between; the host looks at the poses when it
+// asks for them (ndtgpu_fuser_poses) or at the next call, which needs them.
+
+struct ndtgpu_fuser_bank {
+    ndtgpu_fuser_params prm{};
+    size_t n = 0;
+    ndtgpu_mapset *nodes = nullptr, *scans = nullptr;
+    bool own_nodes = false;
+    struct HostState {
+        NdtFuserState s{};
+        double Todom[16];
+        bool is_init = false;
+    };
+    std::vector<HostState> st;
+    NdtFuserState *st_dev = nullptr;
+    double *sensor_pose_dev = nullptr;
+    // staging of one call: a pinned block and its device twin
+    //   [count] Tscan16 | Tmotion16 | Test16 | Q36 | origins3 | centres3 | feat cells (40 x 18) | feat offsets | idx | spose16 | fuse origins3 |
+    //   match results | cov36 | cov flags | results
+    char *pin = nullptr, *dev = nullptr;
+    size_t stage_bytes = 0;
+    float *xyz_a = nullptr, *xyz_b = nullptr;     // the scans in the node frame before / after the registration (packed xyz)
+    size_t xyz_cap = 0;
+    hipEvent_t done_ev = nullptr;
+    bool in_flight = false;
+    size_t fl_first = 0, fl_count = 0;
+    size_t off_res = 0, off_pin_res = 0;          // where the in-flight call's results sit in the staging block
+    hipStream_t fl_stream = nullptr;
+};
+
+namespace {
+struct FuserLayout {
+    size_t Tscan, Tmotion, Test, Q, origin, centre, feat, foff, idx, spose, forigin, match, cov, covflag, res, total;
+};
+FuserLayout fuser_layout(size_t count, bool feat)
+{
+    FuserLayout L;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
+    L.Tscan = take(count * 16 * sizeof(double));
+    L.Tmotion = take(count * 16 * sizeof(double));
+    L.Test = take(count * 16 * sizeof(double));
+    L.Q = take(count * 36 * sizeof(double));
+    L.origin = take(count * 3 * sizeof(double));
+    L.centre = take(count * 3 * sizeof(double));
+    L.feat = take(feat ? count * 40 * 18 * sizeof(double) : 0);
+    L.foff = take((count + 1) * sizeof(uint32_t));
+    L.idx = take(count * sizeof(uint32_t));
+    L.spose = take(count * 16 * sizeof(double));
+    L.forigin = take(count * 3 * sizeof(double));
+    L.match = take(count * sizeof(NdtMatchResultDev));
+    L.cov = take(count * 36 * sizeof(double));
+    L.covflag = take(count * sizeof(int));
+    L.res = take(count * sizeof(NdtFuserResultDev));
+    L.total = at;
+    return L;
+}
+void pose_identity(double *T) { for (int q = 0; q < 16; q++) T[q] = (q % 5 == 0) ? 1.0 : 0.0; }
+}  // namespace
+
+static_assert(sizeof(ndtgpu_fuser_result) == sizeof(NdtFuserResultDev), "fuser result layouts must agree");
+
+void ndtgpu_default_fuser_params(ndtgpu_fuser_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    // NDTFeatureFuserHMT::Params() (ndt_feature_fuser_hmt.h:58-101)
+    p->resolution = 1.0;
+    p->map_size_x = 40.0; p->map_size_y = 40.0; p->map_size_z = 10.0;
+    p->sensor_range = 3.0;
+    p->max_translation_norm = 1.0;
+    p->max_rotation_norm = M_PI / 4.0;
+    p->check_consistency = 0;
+    p->fuse_incomplete = 0;
+    p->use_odom = 1;
+    p->neighbours = 0;
+    p->stepcontrol = 1;
+    p->itr_max = 30;
+    p->delta_score = 10e-4;
+    p->force_odom_as_est = 0;
+    p->fusion2d = 0;
+    p->all_matches_valid = 0;
+    p->use_soft_constraints = 1;
+    p->compute_cov = 1;
+    p->step_control_fusion = 1;
+    p->use_tikhonov = 1;
+    p->covariance_mode = 0;
+    // MotionModel2d::Params() (motion_model.hpp:128-136)
+    p->motion_Cd = 0.001; p->motion_Ct = 0.001; p->motion_Dd = 0.005; p->motion_Dt = 0.005; p->motion_Td = 0.001; p->motion_Tt = 0.001;
+    pose_identity(p->sensor_pose);
+    p->max_cells = 0;
+}
+
+ndtgpu_status ndtgpu_fuser_prepare(const ndtgpu_fuser_params *prm, const double Tnow16[16], const double Tmotion16[16],
+                                   const double node_centre[3], ndtgpu_fuser_prepared *out)
+{
+    if (!prm || !Tnow16 || !Tmotion16 || !node_centre || !out) return fail(NDTGPU_ERR_INVALID, "fuser_prepare: null argument");
+    if (!(prm->resolution > 0)) return fail(NDTGPU_ERR_INVALID, "fuser_prepare: resolution");
+    // fuser_hmt.cpp:124-146 -- the odometry "constraints" (MotionModel2d::getMeasurementCov, motion_model.cpp:190-207)
+    double e3[3];
+    ndt_euler012(Tmotion16, e3);
+    const double rx = Tmotion16[12], ry = Tmotion16[13], rot = e3[2];
+    const double dist = std::sqrt(rx * rx + ry * ry);
+    const double R00 = prm->motion_Dd * dist * dist + prm->motion_Dt * rot * rot;
+    const double R11 = prm->motion_Cd * dist * dist + prm->motion_Ct * rot * rot;
+    const double R22 = prm->motion_Td * dist * dist + prm->motion_Tt * rot * rot;
+    for (double &v : out->odom_cov) v = 0.0;
+    out->odom_cov[0] = R00; out->odom_cov[4] = R11;
+    out->odom_cov[8] = 0.01;                       // "the height in the ndt feature vec and not rotational variance"
+    for (double &v : out->Tcov) v = 0.0;
+    for (int a = 0; a < 6; a++) out->Tcov[a * 6 + a] = 1.0;
+    out->Tcov[0] = R00; out->Tcov[7] = R11; out->Tcov[35] = R22;     // getCovMatrix6; (2,2) = (3,3) = (4,4) = 1 (:144-146)
+    // :166-190 (globalTransf): the scan goes to the node map's frame by Tinit * sensor_pose, Tinit = Tnow
+    ndt_pose_mul(Tnow16, prm->sensor_pose, out->Tscan);
+    for (int a = 0; a < 3; a++) {
+        out->range_origin[a] = out->Tscan[12 + a];
+        // loadPointCloudCentroid (:201-202): the scan map's centre on the lattice of the node map's
+        const double diff = out->range_origin[a] - node_centre[a];
+        out->scan_centre[a] = node_centre[a] + std::floor(diff / prm->resolution) * prm->resolution;
+    }
+    // :291-334 -- the odometry cells: a pair (previous pose + motion | current pose), both moved into the node map's frame
+    // by Tnow (pseudoTransformNDTMap: mean' = T mean, cov' = R cov R^T); the LAST current cell keeps the un-rotated covariance
+    double RC[9], RCRt[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s2 = 0;
+            for (int k = 0; k < 3; k++) s2 += Tnow16[k * 4 + i] * out->odom_cov[k * 3 + j];
+            RC[i * 3 + j] = s2;
+        }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s2 = 0;
+            for (int k = 0; k < 3; k++) s2 += RC[i * 3 + k] * Tnow16[k * 4 + j];
+            RCRt[i * 3 + j] = s2;
+        }
+    const int ij[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+    for (int k = 0; k < 6; k++) {
+        out->feat_cov_rotated[k] = RCRt[ij[k][0] * 3 + ij[k][1]];
+        out->feat_cov_plain[k] = out->odom_cov[ij[k][0] * 3 + ij[k][1]];
+    }
+    for (int a = 0; a < 3; a++) {
+        out->feat_src_mean[a] = Tnow16[12 + a];                                                        // Tinit * 0
+        out->feat_tgt_mean[a] = Tnow16[a] * Tmotion16[12] + Tnow16[4 + a] * Tmotion16[13] + Tnow16[8 + a] * Tmotion16[14] + Tnow16[12 + a];
+    }
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_fuser_bank_destroy(ndtgpu_fuser_bank *b)
+{
+    if (!b) return NDTGPU_OK;
+    if (b->in_flight && b->done_ev) (void)hipEventSynchronize(b->done_ev);
+    if (b->done_ev) (void)hipEventDestroy(b->done_ev);
+    if (b->scans) (void)ndtgpu_mapset_destroy(b->scans);
+    if (b->own_nodes && b->nodes) (void)ndtgpu_mapset_destroy(b->nodes);
+    if (b->st_dev) (void)hipFree(b->st_dev);
+    if (b->sensor_pose_dev) (void)hipFree(b->sensor_pose_dev);
+    if (b->pin) (void)hipHostFree(b->pin);
+    if (b->dev) (void)hipFree(b->dev);
+    if (b->xyz_a) (void)hipFree(b->xyz_a);
+    if (b->xyz_b) (void)hipFree(b->xyz_b);
+    delete b;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_fuser_bank_create(const ndtgpu_fuser_params *prm, size_t n_fusers, ndtgpu_mapset *node_maps, ndtgpu_fuser_bank **out)
+{
+    if (!prm || !out || n_fusers == 0) return fail(NDTGPU_ERR_INVALID, "fuser_bank_create: bad argument");
+    if (!(prm->resolution > 0) || !(prm->sensor_range > 0) || prm->neighbours < 0 || prm->neighbours > 3 || prm->itr_max < 0)
+        return fail(NDTGPU_ERR_INVALID, "fuser_bank_create: resolution / sensor_range must be positive, neighbours 0..3");
+    if (!have_device()) return fail(NDTGPU_ERR_NO_DEVICE, "fuser_bank_create: no HIP device");
+    if (node_maps && node_maps->n_maps < n_fusers) return fail(NDTGPU_ERR_INVALID, "fuser_bank_create: node_maps holds fewer maps than fusers");
+    if (node_maps && node_maps->v.grid.res != prm->resolution) return fail(NDTGPU_ERR_INVALID, "fuser_bank_create: node_maps has another cell size");
+    ndtgpu_fuser_bank *b = new (std::nothrow) ndtgpu_fuser_bank();
+    if (!b) return fail(NDTGPU_ERR_ALLOC, "fuser_bank_create: host alloc");
+    b->prm = *prm;
+    b->n = n_fusers;
+    b->st.resize(n_fusers);
+    for (auto &h : b->st) { pose_identity(h.s.Tnow); pose_identity(h.s.Tlast_fuse); pose_identity(h.Todom); }
+    ndtgpu_status rc = NDTGPU_OK;
+    if (node_maps) {
+        b->nodes = node_maps;
+    } else {
+        ndtgpu_grid_params g{};
+        g.res = prm->resolution;
+        g.size[0] = prm->map_size_x; g.size[1] = prm->map_size_y; g.size[2] = prm->map_size_z;
+        g.max_cells = prm->max_cells;
+        rc = ndtgpu_mapset_create(&g, n_fusers, &b->nodes);
+        b->own_nodes = rc == NDTGPU_OK;
+    }
+    if (rc == NDTGPU_OK) rc = ndtgpu_mapset_enable_occupancy(b->nodes);
+    if (rc == NDTGPU_OK) {
+        // the scan maps: localMapSize (ndt_feature_fuser_hmt.h:224-226), centres set per update
+        ndtgpu_grid_params g{};
+        g.res = prm->resolution;
+        g.size[0] = g.size[1] = prm->sensor_range + 3.0 * prm->resolution;
+        g.size[2] = prm->map_size_z;
+        g.max_cells = prm->max_cells;
+        rc = ndtgpu_mapset_create(&g, n_fusers, &b->scans);
+    }
+    hipError_t e = hipSuccess;
+    if (rc == NDTGPU_OK) e = hipMalloc((void **)&b->st_dev, n_fusers * sizeof(NdtFuserState));
+    if (rc == NDTGPU_OK && e == hipSuccess) e = hipMalloc((void **)&b->sensor_pose_dev, 16 * sizeof(double));
+    if (rc == NDTGPU_OK && e == hipSuccess) e = hipMemcpy(b->sensor_pose_dev, prm->sensor_pose, 16 * sizeof(double), hipMemcpyHostToDevice);
+    if (rc == NDTGPU_OK && e == hipSuccess) e = hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming);
+    if (rc != NDTGPU_OK || e != hipSuccess) {
+        const std::string why = rc != NDTGPU_OK ? g_err : std::string("fuser_bank_create: ") + hipGetErrorString(e);
+        ndtgpu_fuser_bank_destroy(b);
+        return fail(rc != NDTGPU_OK ? rc : NDTGPU_ERR_HIP, why.c_str());
+    }
+    *out = b;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_fuser_bank_mapsets(ndtgpu_fuser_bank *b, ndtgpu_mapset **node_maps, ndtgpu_mapset **scan_maps)
+{
+    if (!b) return fail(NDTGPU_ERR_INVALID, "fuser_bank_mapsets: null");
+    if (node_maps) *node_maps = b->nodes;
+    if (scan_maps) *scan_maps = b->scans;
+    return NDTGPU_OK;
+}
+
+// the host's copy of the pose state catches up with the device: waits for the call in flight
+static ndtgpu_status fuser_catch_up(ndtgpu_fuser_bank *b)
+{
+    if (!b->in_flight) return NDTGPU_OK;
+    HIP_TRY(hipEventSynchronize(b->done_ev));
+    b->in_flight = false;
+    if (b->fl_count) {
+        std::vector<NdtFuserState> tmp(b->fl_count);
+        HIP_TRY(hipMemcpy(tmp.data(), b->st_dev + b->fl_first, b->fl_count * sizeof(NdtFuserState), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < b->fl_count; k++) b->st[b->fl_first + k].s = tmp[k];
+    }
+    return NDTGPU_OK;
+}
+
+static ndtgpu_status fuser_stage(ndtgpu_fuser_bank *b, size_t bytes, size_t count, size_t n_points)
+{
+    if (bytes > b->stage_bytes) {
+        if (b->pin) (void)hipHostFree(b->pin);
+        if (b->dev) (void)hipFree(b->dev);
+        b->pin = b->dev = nullptr;
+        b->stage_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&b->pin, bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&b->dev, bytes));
+        b->stage_bytes = bytes;
+    }
+    const size_t need = count * n_points * 3;
+    if (need > b->xyz_cap) {
+        if (b->xyz_a) (void)hipFree(b->xyz_a);
+        if (b->xyz_b) (void)hipFree(b->xyz_b);
+        b->xyz_a = b->xyz_b = nullptr;
+        b->xyz_cap = 0;
+        HIP_TRY(hipMalloc((void **)&b->xyz_a, need * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&b->xyz_b, need * sizeof(float)));
+        b->xyz_cap = need;
+    }
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_fuser_initialize_batch(ndtgpu_fuser_bank *b, size_t first, size_t count, const double *initPose16,
+                                            const void *xyz_dev, size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                            ndtgpu_stream stream)
+{
+    if (!b || first + count > b->n || (count && (!initPose16 || (n_points && !xyz_dev))) || stride_bytes < 12 || (stride_bytes & 3) ||
+        n_points > 0xFFFFFFFFull)
+        return fail(NDTGPU_ERR_INVALID, "fuser_initialize: bad argument");
+    if (count == 0) return NDTGPU_OK;
+    ndtgpu_status rc = fuser_catch_up(b);
+    if (rc != NDTGPU_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const FuserLayout L = fuser_layout(count, false);
+    rc = fuser_stage(b, L.total, count, n_points);
+    if (rc != NDTGPU_OK) return rc;
+    // fuser_hmt.cpp:65-102: the first cloud goes through the sensor pose, then through the initial pose (two roundings to float);
+    // Tnow = initPos; the map is centred on it (z = 0) and receives the cloud from where the sensor stood
+    rc = ndtgpu_mapset_clear(b->nodes, first, count);
+    if (rc != NDTGPU_OK) return rc;
+    double *Tinit = (double *)(b->pin + L.Tscan), *orig = (double *)(b->pin + L.forigin), *Tsens = (double *)(b->pin + L.Tmotion);
+    for (size_t k = 0; k < count; k++) {
+        ndtgpu_fuser_bank::HostState &h = b->st[first + k];
+        const double *T0 = initPose16 + 16 * k;
+        memcpy(h.s.Tnow, T0, sizeof h.s.Tnow);
+        memcpy(h.s.Tlast_fuse, T0, sizeof h.s.Tlast_fuse);
+        memcpy(h.Todom, T0, sizeof h.Todom);
+        for (double &v : h.s.cov_mean) v = 0.0;
+        for (double &v : h.s.cov) v = 0.0;
+        h.is_init = true;
+        const double centre[3] = {T0[12], T0[13], 0.0};
+        rc = ndtgpu_mapset_set_centre(b->nodes, first + k, centre);
+        if (rc != NDTGPU_OK) return rc;
+        memcpy(Tinit + 16 * k, T0, 16 * sizeof(double));
+        memcpy(Tsens + 16 * k, b->prm.sensor_pose, 16 * sizeof(double));
+        double Ts[16];
+        ndt_pose_mul(T0, b->prm.sensor_pose, Ts);              // Tnow_sensor: the origin the readings were taken from
+        for (int a = 0; a < 3; a++) orig[3 * k + a] = Ts[12 + a];
+    }
+    HIP_TRY(hipMemcpyAsync(b->dev, b->pin, L.total, hipMemcpyHostToDevice, st));
+    {
+        std::vector<NdtFuserState> tmp(count);
+        for (size_t k = 0; k < count; k++) tmp[k] = b->st[first + k].s;
+        HIP_TRY(hipMemcpy(b->st_dev + first, tmp.data(), count * sizeof(NdtFuserState), hipMemcpyHostToDevice));
+    }
+    hipError_t e = ndt_launch_cloud_transform(xyz_dev, count, n_points, stride_bytes, map_stride_bytes, (const double *)(b->dev + L.Tmotion),
+                                              (const double *)(b->dev + L.Tscan), 16, b->xyz_b, st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "fuser_initialize: transform", e);
+    NdtFuseParams fp;
+    fp.maxz = 100.0; fp.sensor_noise = 0.1; fp.maxnumpoints = 1e5; fp.occupancy_limit = 255.0; fp.eval_factor = 1000.0; fp.n_min = 3;   // :92-94
+    e = ndt_launch_fuse(b->nodes->v, first, count, b->xyz_b, n_points, 12, n_points * 12, (const double *)(b->dev + L.forigin), fp,
+                        b->nodes->nice_range(first, count), st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "fuser_initialize: fuse launch", e);
+    { ndtgpu_status trc = b->nodes->touch(st); if (trc != NDTGPU_OK) return trc; }
+    HIP_TRY(hipEventRecord(b->done_ev, st));
+    b->in_flight = true;
+    b->fl_first = first; b->fl_count = 0;                      // (the host state is already what the device holds)
+    b->fl_stream = st;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_fuser_update_batch(ndtgpu_fuser_bank *b, size_t first, size_t count, const double *Tmotion16, const void *xyz_dev,
+                                        size_t n_points, size_t stride_bytes, size_t map_stride_bytes, int update_ndt_map,
+                                        ndtgpu_stream stream)
+{
+    if (!b || first + count > b->n || (count && (!Tmotion16 || (n_points && !xyz_dev))) || stride_bytes < 12 || (stride_bytes & 3) ||
+        n_points > 0xFFFFFFFFull)
+        return fail(NDTGPU_ERR_INVALID, "fuser_update: bad argument");
+    if (count == 0) return NDTGPU_OK;
+    ndtgpu_status rc = fuser_catch_up(b);          // this call starts from the poses the previous one left
+    if (rc != NDTGPU_OK) return rc;
+    for (size_t k = 0; k < count; k++)
+        if (!b->st[first + k].is_init) return fail(NDTGPU_ERR_INVALID, "fuser_update: call ndtgpu_fuser_initialize_batch first (NDT-FuserHMT: Call Initialize first!!)");
+    const ndtgpu_fuser_params &P = b->prm;
+    hipStream_t st = (hipStream_t)stream;
+    const bool feat = P.use_odom != 0 && !P.fusion2d;
+    const int flags = P.fusion2d ? 0 : ((P.use_soft_constraints ? 1 : 0) | (P.use_tikhonov ? 2 : 0));
+    const FuserLayout L = fuser_layout(count, feat);
+    rc = fuser_stage(b, L.total, count, n_points);
+    if (rc != NDTGPU_OK) return rc;
+    // ---- host: what depends on the odometry increment and the current pose only -----------------------------------------
+    double *Tscan = (double *)(b->pin + L.Tscan), *Tm = (double *)(b->pin + L.Tmotion), *Te = (double *)(b->pin + L.Test),
+           *Q = (double *)(b->pin + L.Q), *orig = (double *)(b->pin + L.origin), *cen = (double *)(b->pin + L.centre),
+           *fc = (double *)(b->pin + L.feat);
+    uint32_t *foff = (uint32_t *)(b->pin + L.foff), *idx = (uint32_t *)(b->pin + L.idx);
+    for (size_t k = 0; k < count; k++) {
+        ndtgpu_fuser_bank::HostState &h = b->st[first + k];
+        const double *T = Tmotion16 + 16 * k;
+        ndtgpu_fuser_prepared pp;
+        rc = ndtgpu_fuser_prepare(&P, h.s.Tnow, T, &b->nodes->centres_host[(first + k) * 3], &pp);
+        if (rc != NDTGPU_OK) return rc;
+        memcpy(Tscan + 16 * k, pp.Tscan, sizeof pp.Tscan);
+        memcpy(Tm + 16 * k, T, 16 * sizeof(double));
+        memcpy(Te + 16 * k, T, 16 * sizeof(double));          // Tmotion_est starts as the odometry increment (:166-170)
+        if (flags && !invert6(pp.Tcov, Q + 36 * k)) return fail(NDTGPU_ERR_INVALID, "fuser_update: singular odometry covariance");
+        for (int a = 0; a < 3; a++) { orig[3 * k + a] = pp.range_origin[a]; cen[3 * k + a] = pp.scan_centre[a]; }
+        if (feat) {
+            for (int i = 0; i < 40; i++) {
+                double *c = fc + (k * 40 + i) * 18;          // {source mean, cov | target mean, cov}: NDTMatcherFeatureD2D pairs (i, i)
+                for (int a = 0; a < 3; a++) { c[a] = pp.feat_src_mean[a]; c[9 + a] = pp.feat_tgt_mean[a]; }
+                for (int a = 0; a < 6; a++) { c[3 + a] = i == 39 ? pp.feat_cov_plain[a] : pp.feat_cov_rotated[a]; c[12 + a] = pp.feat_cov_rotated[a]; }
+            }
+        }
+        foff[k] = (uint32_t)(40 * k);
+        idx[k] = (uint32_t)(first + k);
+        double To[16];
+        ndt_pose_mul(h.Todom, T, To);                          // "we track this only for display purposes!"
+        memcpy(h.Todom, To, sizeof To);
+        // the scan map's centre: the launcher picks its kernel by what the host knows of the centres
+        for (int a = 0; a < 3; a++) b->scans->centres_host[(first + k) * 3 + a] = pp.scan_centre[a];
+        b->scans->nice_host[first + k] = ndt_grid_is_nice(b->scans->v.grid, pp.scan_centre) ? 1 : 0;
+    }
+    foff[count] = (uint32_t)(40 * count);
+    HIP_TRY(hipMemcpyAsync(b->dev, b->pin, L.res, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->scans->v.centres + first * 3, b->dev + L.centre, count * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    // ---- device -------------------------------------------------------------------------------------------------------
+    // the scan in the node map's frame (:190), its NDT map on the node map's lattice (:201-227)
+    hipError_t e = ndt_launch_cloud_transform(xyz_dev, count, n_points, stride_bytes, map_stride_bytes, (const double *)(b->dev + L.Tscan),
+                                              nullptr, 16, b->xyz_a, st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "fuser_update: transform", e);
+    rc = mapset_build_core(b->scans, first, count, b->xyz_a, n_points, 12, n_points * 12, P.sensor_range, (const double *)(b->dev + L.origin),
+                           nullptr, st);
+    if (rc != NDTGPU_OK) return rc;
+    // matchFusion / matchFusion2d of the scan map against the slot's node map (:353-357)
+    ndtgpu_match_params mp;
+    ndtgpu_default_match_params(&mp);
+    mp.n_neighbours = P.neighbours; mp.itr_max = P.itr_max; mp.delta_score = P.delta_score; mp.step_control = P.stepcontrol ? 1 : 0;
+    mp.dof_mask = P.fusion2d ? 0x23 : 0x3f;
+    mp.use_initial_guess = 1;
+    NdtMatchParamsDev pd = to_dev(&mp);
+    pd.fusion_flags = feat ? (flags | (P.step_control_fusion ? 4 : 0)) : flags;
+    const uint32_t *idx_dev = (const uint32_t *)(b->dev + L.idx);
+    rc = match_device_core(b->nodes, idx_dev, b->scans, idx_dev, (double *)(b->dev + L.Test), count, pd,
+                           (ndtgpu_match_result *)(b->dev + L.match), flags ? (const double *)(b->dev + L.Q) : nullptr, st,
+                           feat ? (const unsigned *)(b->dev + L.foff) : nullptr, feat ? (const double *)(b->dev + L.feat) : nullptr);
+    if (rc != NDTGPU_OK) return rc;
+    // NDTMatcherD2D::covariance at the registered pose (:403-405; a default-constructed matcher: n_neighbours 2)
+    if (P.compute_cov) {
+        ndtgpu_match_params cp;
+        ndtgpu_default_match_params(&cp);
+        e = ndt_launch_covariance(b->nodes->v, idx_dev, b->scans->v, idx_dev, (const double *)(b->dev + L.Test), count, cp.n_neighbours,
+                                  cp.lfd1, cp.lfd2, P.covariance_mode, (double *)(b->dev + L.cov), (int *)(b->dev + L.covflag), st);
+        if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "fuser_update: covariance launch", e);
+    }
+    // the post-registration step (:361-480), the scan in the frame of the new pose, the fuse-in (:485-486)
+    NdtFuserPolicy pol;
+    pol.max_translation_norm = P.max_translation_norm; pol.max_rotation_norm = P.max_rotation_norm;
+    pol.translation_fuse_delta = 0.05; pol.rotation_fuse_delta = 0.01;                   // ndt_feature_fuser_hmt.h:222-223
+    pol.check_consistency = P.check_consistency; pol.fuse_incomplete = P.fuse_incomplete; pol.all_matches_valid = P.all_matches_valid;
+    pol.force_odom_as_est = P.force_odom_as_est; pol.compute_cov = P.compute_cov;
+    e = ndt_launch_fuser_post(pol, b->sensor_pose_dev, b->st_dev + first, (const double *)(b->dev + L.Tmotion), (const double *)(b->dev + L.Test),
+                              (const NdtMatchResultDev *)(b->dev + L.match), P.compute_cov ? (const double *)(b->dev + L.cov) : nullptr,
+                              P.compute_cov ? (const int *)(b->dev + L.covflag) : nullptr, count, (double *)(b->dev + L.spose),
+                              (double *)(b->dev + L.forigin), (NdtFuserResultDev *)(b->dev + L.res), st);
+    if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "fuser_update: post launch", e);
+    if (update_ndt_map) {
+        e = ndt_launch_cloud_transform(xyz_dev, count, n_points, stride_bytes, map_stride_bytes, (const double *)(b->dev + L.spose), nullptr, 16,
+                                       b->xyz_b, st);
+        if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "fuser_update: transform", e);
+        NdtFuseParams fp;
+        fp.maxz = 25.0; fp.sensor_noise = 0.06; fp.maxnumpoints = 1e5; fp.occupancy_limit = 255.0; fp.eval_factor = 1000.0; fp.n_min = 3;   // :485-486
+        e = ndt_launch_fuse(b->nodes->v, first, count, b->xyz_b, n_points, 12, n_points * 12, (const double *)(b->dev + L.forigin), fp,
+                            b->nodes->nice_range(first, count), st);
+        if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "fuser_update: fuse launch", e);
+        { ndtgpu_status trc = b->nodes->touch(st); if (trc != NDTGPU_OK) return trc; }
+    }
+    HIP_TRY(hipMemcpyAsync(b->pin + L.res, b->dev + L.res, count * sizeof(NdtFuserResultDev), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(b->done_ev, st));
+    b->in_flight = true;
+    b->fl_first = first; b->fl_count = count;
+    b->off_pin_res = L.res;
+    b->fl_stream = st;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_fuser_poses(ndtgpu_fuser_bank *b, size_t first, size_t count, double *Tnow16, ndtgpu_fuser_result *results)
+{
+    if (!b || first + count > b->n || (count && !Tnow16)) return fail(NDTGPU_ERR_INVALID, "fuser_poses: bad argument");
+    const bool had = b->in_flight && b->fl_count > 0;
+    const size_t f0 = b->fl_first, fc = b->fl_count, off = b->off_pin_res;
+    ndtgpu_status rc = fuser_catch_up(b);
+    if (rc != NDTGPU_OK) return rc;
+    for (size_t k = 0; k < count; k++) memcpy(Tnow16 + 16 * k, b->st[first + k].s.Tnow, 16 * sizeof(double));
+    if (results) {
+        // the records of the LAST update call, for the slots it covered (zeroes elsewhere)
+        memset(results, 0, count * sizeof *results);
+        (void)had;
+        if (fc)
+            for (size_t k = 0; k < count; k++) {
+                const size_t slot = first + k;
+                if (slot >= f0 && slot < f0 + fc) memcpy(&results[k], b->pin + off + (slot - f0) * sizeof(NdtFuserResultDev), sizeof(NdtFuserResultDev));
+            }
+    }
+    return NDTGPU_OK;
 }
 
 }  // extern "C"
