@@ -479,6 +479,8 @@ typedef struct {
     double delta_score;
     int32_t force_odom_as_est, fusion2d, all_matches_valid, use_soft_constraints, compute_cov, step_control_fusion, use_tikhonov;
     int32_t covariance_mode;       /* `mode` of ndtgpu_covariance_batch */
+    int32_t discard_cells;         /* the scan map's cells that hold the scan's first and last point lose their Gaussian (:229-232) */
+    int32_t pad_;
     /* MotionModel2d::Params (motion_model.hpp:123-136) */
     double motion_Cd, motion_Ct, motion_Dd, motion_Dt, motion_Td, motion_Tt;
     double sensor_pose[16];        /* setSensorPose: column-major like every pose of this header */
@@ -530,6 +532,13 @@ ndtgpu_status ndtgpu_fuser_initialize_batch(ndtgpu_fuser_bank *bank, size_t firs
 ndtgpu_status ndtgpu_fuser_update_batch(ndtgpu_fuser_bank *bank, size_t first, size_t count, const double *Tmotion16,
                                         const void *xyz_dev, size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
                                         int update_ndt_map, ndtgpu_stream stream);
+/* the same with the clouds in HOST memory (pcl::PointCloud: 16-byte records), copied to the device on a stream of the bank's own;
+ * asynchronous once the caller's memory has been read */
+ndtgpu_status ndtgpu_fuser_initialize_batch_host(ndtgpu_fuser_bank *bank, size_t first, size_t count, const double *initPose16,
+                                                 const void *xyz_host, size_t n_points, size_t stride_bytes, size_t map_stride_bytes);
+ndtgpu_status ndtgpu_fuser_update_batch_host(ndtgpu_fuser_bank *bank, size_t first, size_t count, const double *Tmotion16,
+                                             const void *xyz_host, size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                             int update_ndt_map);
 /* waits for the bank's last call; Tnow16: HOST, count x 16; results (may be NULL): the records of the last update call for the
  * slots it covered, zeroes for the others */
 ndtgpu_status ndtgpu_fuser_poses(ndtgpu_fuser_bank *bank, size_t first, size_t count, double *Tnow16, ndtgpu_fuser_result *results);

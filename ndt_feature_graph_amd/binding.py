@@ -129,7 +129,8 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_registrar_profiling", "ndtgpu_registrar_kernel_ms", "ndtgpu_registrar_mapset", "ndtgpu_register_batch_host",
            "ndtgpu_default_registrar_params", "ndtgpu_registrar_create_ex", "ndtgpu_registrar_get_info",
            "ndtgpu_default_fuser_params", "ndtgpu_fuser_prepare", "ndtgpu_fuser_bank_create", "ndtgpu_fuser_bank_destroy",
-           "ndtgpu_fuser_bank_mapsets", "ndtgpu_fuser_initialize_batch", "ndtgpu_fuser_update_batch", "ndtgpu_fuser_poses"]
+           "ndtgpu_fuser_bank_mapsets", "ndtgpu_fuser_initialize_batch", "ndtgpu_fuser_update_batch", "ndtgpu_fuser_poses",
+           "ndtgpu_fuser_initialize_batch_host", "ndtgpu_fuser_update_batch_host"]
 
 _lib = None
 
@@ -677,6 +678,7 @@ class FuserParams(C.Structure):
                 ("stepcontrol", C.c_int32), ("itr_max", C.c_int32), ("delta_score", C.c_double), ("force_odom_as_est", C.c_int32),
                 ("fusion2d", C.c_int32), ("all_matches_valid", C.c_int32), ("use_soft_constraints", C.c_int32), ("compute_cov", C.c_int32),
                 ("step_control_fusion", C.c_int32), ("use_tikhonov", C.c_int32), ("covariance_mode", C.c_int32),
+                ("discard_cells", C.c_int32), ("pad_", C.c_int32),
                 ("motion_Cd", C.c_double), ("motion_Ct", C.c_double), ("motion_Dd", C.c_double), ("motion_Dt", C.c_double),
                 ("motion_Td", C.c_double), ("motion_Tt", C.c_double), ("sensor_pose", C.c_double * 16), ("max_cells", C.c_uint32)]
 

@@ -2308,6 +2308,9 @@ struct ndtgpu_fuser_bank {
     size_t stage_bytes = 0;
     float *xyz_a = nullptr, *xyz_b = nullptr;     // the scans in the node frame before / after the registration (packed xyz)
     size_t xyz_cap = 0;
+    void *xyz_in = nullptr;                       // host clouds (the *_host entries) on their way in
+    size_t xyz_in_bytes = 0;
+    hipStream_t own_st = nullptr;
     hipEvent_t done_ev = nullptr;
     bool in_flight = false;
     size_t fl_first = 0, fl_count = 0;
@@ -2445,6 +2448,8 @@ ndtgpu_status ndtgpu_fuser_bank_destroy(ndtgpu_fuser_bank *b)
     if (b->dev) (void)hipFree(b->dev);
     if (b->xyz_a) (void)hipFree(b->xyz_a);
     if (b->xyz_b) (void)hipFree(b->xyz_b);
+    if (b->xyz_in) (void)hipFree(b->xyz_in);
+    if (b->own_st) { (void)hipStreamSynchronize(b->own_st); (void)hipStreamDestroy(b->own_st); }
     delete b;
     return NDTGPU_OK;
 }
@@ -2665,6 +2670,16 @@ ndtgpu_status ndtgpu_fuser_update_batch(ndtgpu_fuser_bank *b, size_t first, size
     rc = mapset_build_core(b->scans, first, count, b->xyz_a, n_points, 12, n_points * 12, P.sensor_range, (const double *)(b->dev + L.origin),
                            nullptr, st);
     if (rc != NDTGPU_OK) return rc;
+    if (P.discard_cells && n_points > 0) {
+        // :229-232 -- ndt_feature::discardCell(ndglobal, cloud.front()) and (.., cloud.back()): the cells of the scan map that hold the
+        // first and the last point of the (moved) scan lose their Gaussian
+        for (size_t k = 0; k < count; k++) {
+            const float *c0 = b->xyz_a + k * n_points * 3;
+            e = ndt_launch_discard(b->scans->v, first + k, c0, 1, st);
+            if (e == hipSuccess) e = ndt_launch_discard(b->scans->v, first + k, c0 + (n_points - 1) * 3, 1, st);
+            if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "fuser_update: discard launch", e);
+        }
+    }
     // matchFusion / matchFusion2d of the scan map against the slot's node map (:353-357)
     ndtgpu_match_params mp;
     ndtgpu_default_match_params(&mp);
@@ -2715,6 +2730,50 @@ ndtgpu_status ndtgpu_fuser_update_batch(ndtgpu_fuser_bank *b, size_t first, size
     b->off_pin_res = L.res;
     b->fl_stream = st;
     return NDTGPU_OK;
+}
+
+// the clouds of a *_host entry travel to a device buffer of the bank on a stream of its own; the device entry follows there
+static ndtgpu_status fuser_clouds_in(ndtgpu_fuser_bank *b, size_t count, const void *xyz_host, size_t n_points, size_t stride_bytes,
+                                     size_t map_stride_bytes, const void **xyz_dev)
+{
+    *xyz_dev = nullptr;
+    if (!count || !n_points) return NDTGPU_OK;
+    if (count > 1 && map_stride_bytes < n_points * stride_bytes) return fail(NDTGPU_ERR_INVALID, "fuser: clouds must not overlap");
+    ndtgpu_status rc = fuser_catch_up(b);          // (the previous call may still read the buffer)
+    if (rc != NDTGPU_OK) return rc;
+    if (!b->own_st) HIP_TRY(hipStreamCreateWithFlags(&b->own_st, hipStreamNonBlocking));
+    const size_t bytes = (count - 1) * map_stride_bytes + n_points * stride_bytes;
+    if (bytes > b->xyz_in_bytes) {
+        if (b->xyz_in) (void)hipFree(b->xyz_in);
+        b->xyz_in = nullptr; b->xyz_in_bytes = 0;
+        HIP_TRY(hipMalloc(&b->xyz_in, bytes));
+        b->xyz_in_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(b->xyz_in, xyz_host, bytes, hipMemcpyHostToDevice, b->own_st));
+    *xyz_dev = b->xyz_in;
+    return NDTGPU_OK;
+}
+
+ndtgpu_status ndtgpu_fuser_initialize_batch_host(ndtgpu_fuser_bank *b, size_t first, size_t count, const double *initPose16,
+                                                 const void *xyz_host, size_t n_points, size_t stride_bytes, size_t map_stride_bytes)
+{
+    if (!b || (count && n_points && !xyz_host)) return fail(NDTGPU_ERR_INVALID, "fuser_initialize_host: bad argument");
+    const void *dev = nullptr;
+    ndtgpu_status rc = fuser_clouds_in(b, count, xyz_host, n_points, stride_bytes, map_stride_bytes, &dev);
+    if (rc != NDTGPU_OK) return rc;
+    return ndtgpu_fuser_initialize_batch(b, first, count, initPose16, dev, n_points, stride_bytes, map_stride_bytes, (ndtgpu_stream)b->own_st);
+}
+
+ndtgpu_status ndtgpu_fuser_update_batch_host(ndtgpu_fuser_bank *b, size_t first, size_t count, const double *Tmotion16,
+                                             const void *xyz_host, size_t n_points, size_t stride_bytes, size_t map_stride_bytes,
+                                             int update_ndt_map)
+{
+    if (!b || (count && n_points && !xyz_host)) return fail(NDTGPU_ERR_INVALID, "fuser_update_host: bad argument");
+    const void *dev = nullptr;
+    ndtgpu_status rc = fuser_clouds_in(b, count, xyz_host, n_points, stride_bytes, map_stride_bytes, &dev);
+    if (rc != NDTGPU_OK) return rc;
+    return ndtgpu_fuser_update_batch(b, first, count, Tmotion16, dev, n_points, stride_bytes, map_stride_bytes, update_ndt_map,
+                                     (ndtgpu_stream)b->own_st);
 }
 
 ndtgpu_status ndtgpu_fuser_poses(ndtgpu_fuser_bank *b, size_t first, size_t count, double *Tnow16, ndtgpu_fuser_result *results)

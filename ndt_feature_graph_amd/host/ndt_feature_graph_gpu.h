@@ -1,18 +1,22 @@
-// ndt_feature_graph_gpu.h -- host mirror of the ndt_feature classes that drive the hot path:
+// ndt_feature_graph_gpu.h -- host front door of the ndt_feature classes that drive the hot path, over the C-ABI of libndtgpu.so:
 //   ndt_feature::MotionModel2d        motion_model.hpp:123-163, motion_model.cpp:166-207
 //   ndt_feature::matchFusion / matchFusion2d   ndt_matcher_d2d_fusion.h:797-1155, 1159-1176
-//   ndt_feature::NDTFeatureFuserHMT   ndt_feature_fuser_hmt.h:36-334, ndt_feature_fuser_hmt.cpp:65-102 (initialize), 108-512 (update)
+//   ndt_feature::NDTFeatureFuserHMT   ndt_feature_fuser_hmt.h:36-334 (Params, initialize, update)
 //   ndt_feature::NDTFeatureLink / NDTFeatureNode / overlapNDTOccupancyScore   ndt_feature_link.h:9-56, ndt_feature_node.h:38-252
-//   ndt_feature::NDTFeatureGraph      ndt_feature_graph.h:20-280, ndt_feature_graph.cpp:24-144 (initialize, update),
-//                                     :260-353 (updateLink[s]UsingNDTRegistration), :395-405, :527-556
-// Same class, member and parameter names and the same control flow as the reference; the lslgeneric:: calls go to the
-// GPU through lslgeneric_gpu.h.  The ROS / iSAM / FLIRT members stay where they are (out of scope):
-// InterestPointVec is an empty placeholder, and a configuration that asks for the feature or odometry-cell terms
-// (Params::useFeat / useOdom) is rejected loudly instead of being silently ignored.
-//
-// What changes against the reference: updateLinksUsingNDTRegistration registers ALL links in one batched GPU call
-// (matcher, covariance and overlap score: three calls per batch instead of three per link), never blocks on stdin
-// (graph.cpp:318-328) and reports non-convergence in NDTFeatureLink::converged; node maps live in one device pool.
+//   ndt_feature::NDTFeatureGraph      ndt_feature_graph.h:20-280 (initialize, update, updateLink[s]UsingNDTRegistration, ...)
+// Class, member and parameter names are the reference's, so that its callers compile against this header.  What is behind them
+// is not the reference's control flow retyped but the batched device entries:
+//   * NDTFeatureFuserHMT::initialize / update are ONE C-ABI call each (ndtgpu_fuser_initialize_batch / ndtgpu_fuser_update_batch
+//     on the fuser's slot of a ndtgpu_host::FuserBank): scan -> scan map -> matchFusion -> covariance -> pose -> ray-traced
+//     fuse-in run on the device without a host round trip.  A graph's node fusers are the slots of one bank over the pool its
+//     node maps live in, so several graphs / robots / bags can also be stepped with one call (FuserBank::update).
+//   * NDTFeatureGraph::updateLinksUsingNDTRegistration registers ALL links in one batched call each for the matcher, the
+//     covariance and the overlap score (three calls per batch instead of three per link), never blocks on stdin
+//     (graph.cpp:318-328) and reports non-convergence in NDTFeatureLink::converged.
+// Configurations the device path does not cover are rejected loudly (ndtgpu_host::Error), never silently ignored: the FLIRT
+// interest points (InterestPointVec is an empty placeholder: out of scope), globalTransf = false,
+// loadCentroid = false.  In a catkin build that needs those the reference's own ndt_feature_fuser_hmt.cpp runs against
+// lslgeneric_gpu.h instead.
 #pragma once
 #include "lslgeneric_gpu.h"
 
@@ -201,6 +205,84 @@ inline bool matchFusion2d(lslgeneric::NDTMap &targetNDT, lslgeneric::NDTMap &sou
     return matcher_d2d_2d.match(targetNDT, sourceNDT, T, useInitialGuess);
 }
 
+}  // namespace ndt_feature
+
+namespace ndtgpu_host {
+
+// B independent fusers stepped by ONE call (ndtgpu_fuser_bank): the slots' node maps are the maps of a MapPool.
+class FuserBank {
+public:
+    FuserBank(const ndtgpu_fuser_params &p, std::shared_ptr<MapPool> pool) : pool_(std::move(pool)), prm_(p)
+    {
+        check(ndtgpu_fuser_bank_create(&p, pool_->size(), pool_->handle(), &bank_), "ndtgpu_fuser_bank_create");
+    }
+    ~FuserBank() { ndtgpu_fuser_bank_destroy(bank_); }
+    FuserBank(const FuserBank &) = delete;
+    FuserBank &operator=(const FuserBank &) = delete;
+    const ndtgpu_fuser_params &params() const { return prm_; }
+    const std::shared_ptr<MapPool> &pool() const { return pool_; }
+
+    // slots [first, first + clouds.size()): poses and first clouds (sensor frame)
+    void initialize(size_t first, const std::vector<Eigen::Affine3d> &initPos, const std::vector<const pcl::PointCloud<pcl::PointXYZ> *> &clouds)
+    {
+        pack(clouds);
+        std::vector<double> T = flat(initPos);
+        check(ndtgpu_fuser_initialize_batch_host(bank_, first, clouds.size(), T.data(), pts_.data(), np_, 16, np_ * 16), "ndtgpu_fuser_initialize_batch_host");
+    }
+    // one update of every slot of the range; returns the records of the call (pose, registered increment, matcher report)
+    std::vector<ndtgpu_fuser_result> update(size_t first, const std::vector<Eigen::Affine3d> &Tmotion,
+                                            const std::vector<const pcl::PointCloud<pcl::PointXYZ> *> &clouds, bool updateNDTMap = true)
+    {
+        if (Tmotion.size() != clouds.size()) throw Error(NDTGPU_ERR_INVALID, "FuserBank::update: one odometry increment per cloud");
+        pack(clouds);
+        std::vector<double> T = flat(Tmotion);
+        check(ndtgpu_fuser_update_batch_host(bank_, first, clouds.size(), T.data(), pts_.data(), np_, 16, np_ * 16, updateNDTMap ? 1 : 0),
+              "ndtgpu_fuser_update_batch_host");
+        std::vector<ndtgpu_fuser_result> res(clouds.size());
+        std::vector<double> now(16 * clouds.size());
+        check(ndtgpu_fuser_poses(bank_, first, clouds.size(), now.data(), res.data()), "ndtgpu_fuser_poses");
+        return res;
+    }
+    Eigen::Affine3d pose(size_t slot)
+    {
+        Eigen::Affine3d T;
+        check(ndtgpu_fuser_poses(bank_, slot, 1, T.data(), nullptr), "ndtgpu_fuser_poses");
+        return T;
+    }
+
+private:
+    static std::vector<double> flat(const std::vector<Eigen::Affine3d> &T)
+    {
+        std::vector<double> o(16 * T.size());
+        for (size_t k = 0; k < T.size(); k++)
+            for (int e = 0; e < 16; e++) o[16 * k + e] = T[k].data()[e];
+        return o;
+    }
+    // clouds of unequal length side by side, padded with NaN points (which the binning drops)
+    void pack(const std::vector<const pcl::PointCloud<pcl::PointXYZ> *> &clouds)
+    {
+        static_assert(sizeof(pcl::PointXYZ) == 16, "pcl::PointXYZ is four floats");
+        np_ = 0;
+        for (const auto *c : clouds) np_ = std::max(np_, c->size());
+        pts_.assign(clouds.size() * np_ * 4, std::nanf(""));
+        for (size_t k = 0; k < clouds.size(); k++)
+            for (size_t i = 0; i < clouds[k]->size(); i++) {
+                const pcl::PointXYZ &q = clouds[k]->points[i];
+                float *o = &pts_[(k * np_ + i) * 4];
+                o[0] = q.x; o[1] = q.y; o[2] = q.z;
+            }
+    }
+    std::shared_ptr<MapPool> pool_;
+    ndtgpu_fuser_params prm_;
+    ndtgpu_fuser_bank *bank_ = nullptr;
+    std::vector<float> pts_;
+    size_t np_ = 0;
+};
+
+}  // namespace ndtgpu_host
+
+namespace ndt_feature {
+
 class NDTFeatureFuserHMT {
 public:
     Eigen::Affine3d Tnow, Tlast_fuse, Todom;   ///< current pose
@@ -261,21 +343,37 @@ public:
     Params params_;
     MotionModel2d::Params motion_params_;
     ndtgpu_match_result last_match{};        // (added) what the device matcher reported for the last update
+    ndtgpu_fuser_result last_update{};       // (added) the whole record of the last update
 
-    NDTFeatureFuserHMT(const NDTFeatureFuserHMT::Params &params) : map(NULL), params_(params)
+    // the fields of Params / MotionModel2d::Params / the sensor pose that the device path reads, as the C-ABI wants them.
+    // Throws for the configurations it does not cover.
+    static ndtgpu_fuser_params bankParams(const Params &p, const MotionModel2d::Params &m, const Eigen::Affine3d &sensor_pose)
     {
-        isInit = false;
-        translation_fuse_delta = 0.05;
-        rotation_fuse_delta = 0.01;
-        localMapSize = Eigen::Vector3d(params.sensor_range + 3 * params.resolution, params.sensor_range + 3 * params.resolution, params.map_size_z);
+        if (!p.globalTransf || !p.loadCentroid)
+            throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: the device path covers globalTransf = loadCentroid = true (the "
+                                                         "defaults); run the reference's own update against lslgeneric_gpu.h for the others");
+        if (!p.useNDT) throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: useNDT == false leaves nothing to match");
+        ndtgpu_fuser_params q;
+        ndtgpu_default_fuser_params(&q);
+        q.resolution = p.resolution;
+        q.map_size_x = p.map_size_x; q.map_size_y = p.map_size_y; q.map_size_z = p.map_size_z;
+        q.sensor_range = p.sensor_range;
+        q.max_translation_norm = p.max_translation_norm; q.max_rotation_norm = p.max_rotation_norm;
+        q.check_consistency = p.checkConsistency; q.fuse_incomplete = p.fuseIncomplete;
+        q.use_odom = p.useOdom;               // (useFeat: without FLIRT interest points there are no feature matches to add)
+        q.neighbours = p.neighbours; q.stepcontrol = p.stepcontrol; q.itr_max = p.ITR_MAX; q.delta_score = p.DELTA_SCORE;
+        q.force_odom_as_est = p.forceOdomAsEst; q.fusion2d = p.fusion2d; q.all_matches_valid = p.allMatchesValid;
+        q.use_soft_constraints = p.useSoftConstraints; q.compute_cov = p.computeCov; q.step_control_fusion = p.stepControlFusion;
+        q.use_tikhonov = p.useTikhonovRegularization; q.discard_cells = p.discardCells;
+        q.motion_Cd = m.Cd; q.motion_Ct = m.Ct; q.motion_Dd = m.Dd; q.motion_Dt = m.Dt; q.motion_Td = m.Td; q.motion_Tt = m.Tt;
+        for (int e = 0; e < 16; e++) q.sensor_pose[e] = sensor_pose.data()[e];
+        return q;
     }
-    // the node map lives in a device pool shared with the other nodes of a graph (batched edge registration)
-    NDTFeatureFuserHMT(const NDTFeatureFuserHMT::Params &params, std::shared_ptr<ndtgpu_host::MapPool> pool, size_t slot)
-        : NDTFeatureFuserHMT(params)
-    {
-        pool_ = std::move(pool);
-        pool_slot_ = slot;
-    }
+
+    NDTFeatureFuserHMT(const NDTFeatureFuserHMT::Params &params) : map(NULL), params_(params), isInit(false) {}
+    // a fuser that is slot `slot` of a bank shared with other fusers (the node fusers of a graph)
+    NDTFeatureFuserHMT(const NDTFeatureFuserHMT::Params &params, std::shared_ptr<ndtgpu_host::FuserBank> bank, size_t slot)
+        : map(NULL), params_(params), isInit(false), bank_(std::move(bank)), slot_(slot) {}
     ~NDTFeatureFuserHMT()
     {
         if (map != NULL) delete map;
@@ -289,25 +387,25 @@ public:
     const NDTFeatureFuserHMT::Params &getParam() const { return params_; }
     Eigen::Matrix3d &getCov() { return current_posecov.cov; }
 
-    /** Set the initial position and set the first scan to the map (ndt_feature_fuser_hmt.cpp:65-102) */
+    /** initialize(initPos, cloud, pts, preLoad) -- ndt_feature_fuser_hmt.cpp:65-102 -- as ONE device call */
     void initialize(Eigen::Affine3d initPos, const pcl::PointCloud<pcl::PointXYZ> &cloudOrig, const InterestPointVec & /*pts*/, bool /*preLoad*/ = false)
     {
-        pcl::PointCloud<pcl::PointXYZ> cloud(cloudOrig);
-        ndtgpu_host::transformPointCloudInPlace(sensor_pose, cloud);
-        ndtgpu_host::transformPointCloudInPlace(initPos, cloud);
-        Tnow = initPos;
+        if (!bank_) {     // a fuser on its own: a bank of one over a pool of one
+            const double c[3] = {0, 0, 0}, sz[3] = {params_.map_size_x, params_.map_size_y, params_.map_size_z};
+            auto pool = std::make_shared<ndtgpu_host::MapPool>(params_.resolution, c, sz, 1);
+            bank_ = std::make_shared<ndtgpu_host::FuserBank>(bankParams(params_, motion_params_, sensor_pose), pool);
+            slot_ = 0;
+        }
         if (map != NULL) delete map;
-        map = pool_ ? new lslgeneric::NDTMap(pool_, pool_slot_) : new lslgeneric::NDTMap(new lslgeneric::LazyGrid(params_.resolution));
-        map->initialize(Tnow.translation()(0), Tnow.translation()(1), 0., params_.map_size_x, params_.map_size_y, params_.map_size_z);
-        Eigen::Affine3d Tnow_sensor = Tnow * sensor_pose;   // the origin from where the sensor readings occured
-        map->addPointCloud(Tnow_sensor.translation(), cloud, 0.1, 100.0, 0.1);
-        map->computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE, 1e5, 255, Tnow_sensor.translation(), 0.1);
+        map = new lslgeneric::NDTMap(bank_->pool(), slot_);
+        // (the host object learns where the map sits; the device call below fills it)
+        map->initialize(initPos.translation()(0), initPos.translation()(1), 0., params_.map_size_x, params_.map_size_y, params_.map_size_z);
+        bank_->initialize(slot_, {initPos}, {&cloudOrig});
+        Tnow = Tlast_fuse = Todom = initPos;
         isInit = true;
-        Tlast_fuse = Tnow;
-        Todom = Tnow;
     }
 
-    /** ndt_feature_fuser_hmt.cpp:108-512 */
+    /** update(Tmotion, cloud, pts, updateFeatureMap, updateNDTMap) -- ndt_feature_fuser_hmt.cpp:108-512 -- as ONE device call */
     Eigen::Affine3d update(Eigen::Affine3d Tmotion, const pcl::PointCloud<pcl::PointXYZ> &cloudOrig, const InterestPointVec & /*pts*/,
                            bool /*updateFeatureMap*/ = true, bool updateNDTMap = true)
     {
@@ -315,171 +413,28 @@ public:
             fprintf(stderr, "NDT-FuserHMT: Call Initialize first!!\n");
             return Tnow;
         }
-        // (useFeat: the FLIRT interest points are the ROS layer's; without them the RANSAC of fuser_hmt.cpp:250 finds no
-        //  matches, consistent_features is false and no feature cell is made -- which is what this mirror does)
-        pcl::PointCloud<pcl::PointXYZ> cloud(cloudOrig);
-        pcl::PointCloud<pcl::PointXYZ> cloud_orig(cloudOrig);
-
-        Eigen::Vector3d map_centroid;
-        map->getCentroid(map_centroid[0], map_centroid[1], map_centroid[2]);
-
-        // Odometry 'constraints'
-        MotionModel2d motion(motion_params_);
-        Pose2d relpose(Tmotion.translation()[0], Tmotion.translation()[1], Tmotion.rotation().eulerAngles(0, 1, 2)[2]);
-        Pose2dCov relposecov = motion.getPose2dCov(relpose);
-        Eigen::Matrix3d odom_cov = relposecov.cov;
-        odom_cov(2, 0) = 0.; odom_cov(2, 1) = 0.; odom_cov(0, 2) = 0.; odom_cov(1, 2) = 0.;
-        odom_cov(2, 2) = 0.01;   // This is the height in the ndt feature vec and not rotational variance.
-        lslgeneric::NDTCell ndt_odom_cell;
-        ndt_odom_cell.setMean(Eigen::Vector3d(0., 0., 0.));
-        ndt_odom_cell.setCov(odom_cov);
-        lslgeneric::NDTCell ndt_odom_cell_prev;
-        ndt_odom_cell_prev.setMean(Tmotion.translation());
-        ndt_odom_cell_prev.setCov(odom_cov);
-        Eigen::MatrixXd TmotionCov = motion.getCovMatrix6(relpose);
-        TmotionCov(2, 2) = 1;   // z
-        TmotionCov(3, 3) = 1;   // roll
-        TmotionCov(4, 4) = 1;   // pitch
-
-        Todom = Todom * Tmotion;   // we track this only for display purposes!
-
-        Eigen::Affine3d Tinit;
-        if (params_.globalTransf) Tinit = Tnow;
-        else Tinit.setIdentity();
-        Eigen::Affine3d Tmotion_est;
-        if (params_.globalTransf) Tmotion_est = Tmotion;
-        else Tmotion_est = Tnow * Tmotion;
-
-        Eigen::Affine3d global_rotation;
-        Eigen::Affine3d Tinit_sensor_pose = Tinit * sensor_pose;
-        ndtgpu_host::transformPointCloudInPlace(Tinit_sensor_pose, cloud);   // Cloud -> transformed in to the vehicle origin!
-
-        // the map of the current scan ("ndglobal"); the device arena is kept between updates
-        const double lsx = params_.loadCentroid ? localMapSize(0) : params_.sensor_range;
-        const double lsy = params_.loadCentroid ? localMapSize(1) : params_.sensor_range;
-        const double lsz = params_.loadCentroid ? localMapSize(2) : params_.map_size_z;
-        if (!scan_pool_) {
-            const double c[3] = {0, 0, 0}, s[3] = {lsx, lsy, lsz};
-            scan_pool_ = std::make_shared<ndtgpu_host::MapPool>(params_.resolution, c, s, 1);
-        }
-        lslgeneric::NDTMap ndglobal(scan_pool_, 0);
-
-        if (params_.loadCentroid) {
-            if (params_.globalTransf) {
-                ndglobal.loadPointCloudCentroid(cloud, Tinit_sensor_pose.translation(), map_centroid, localMapSize, params_.sensor_range);
-            } else {
-                // 1) rotate the cloud to be aligned with a global frame (Tmotion_est)
-                // 2) a translation (new map_centroid) that aligns the current local map
-                global_rotation = Tmotion_est;
-                Tmotion_est = ndtgpu_host::affine_from_pose(global_rotation.translation()(0), global_rotation.translation()(1),
-                                                            global_rotation.translation()(2), 0, 0, 0);
-                global_rotation.data()[12] = 0.; global_rotation.data()[13] = 0.; global_rotation.data()[14] = 0.;
-                ndtgpu_host::transformPointCloudInPlace(global_rotation, cloud);
-                Eigen::Vector3d local_centroid = computeLocalCentroid(map_centroid, Tmotion_est.translation(), params_.resolution);
-                ndglobal.loadPointCloudCentroid(cloud, Tinit_sensor_pose.translation(), local_centroid, localMapSize, params_.sensor_range);
-            }
-        } else {
-            if (!params_.globalTransf) ndglobal.guessSize(0, 0, 0, params_.sensor_range, params_.sensor_range, params_.map_size_z);
-            else throw ndtgpu_host::Error(NDTGPU_ERR_INVALID, "NDTFeatureFuserHMT: globalTransf without loadCentroid sizes the scan map from "
-                                                             "the cloud (4 x its radius): not implemented for the reusable scan arena");
-            ndglobal.loadPointCloud(cloud, params_.sensor_range);
-        }
-        ndglobal.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE);
-        if (params_.discardCells && cloud.size() > 0) {   // fuser_hmt.cpp:229-232
-            discardCell(ndglobal, cloud.front());
-            discardCell(ndglobal, cloud.back());
-        }
-
-        // NDT based feature matching (fuser_hmt.cpp:291-334): two CellVector maps with known correspondence
-        std::vector<std::pair<int, int> > corr;
-        const bool consistent_features = false;        // no interest points, no matches (see above)
-        lslgeneric::CellVector *cv_prev_sensor_frame = new lslgeneric::CellVector();
-        lslgeneric::CellVector *cv_curr_sensor_frame = new lslgeneric::CellVector();
-        bool use_odom_or_features = true;
-        lslgeneric::NDTMap ndt_feat_prev_sensor_frame(cv_prev_sensor_frame, true);
-        lslgeneric::NDTMap ndt_feat_curr_sensor_frame(cv_curr_sensor_frame, true);
-        std::unique_ptr<lslgeneric::NDTMap> ndt_feat_prev_vehicle_frame(ndt_feat_prev_sensor_frame.pseudoTransformNDTMap(sensor_pose));
-        // The current frame is always in vehicle frame (to be moved Tinit in registration)
-        std::unique_ptr<lslgeneric::NDTMap> ndt_feat_curr_vehicle_frame(ndt_feat_curr_sensor_frame.pseudoTransformNDTMap(sensor_pose));
-        if (params_.useOdom) {
-            for (int i = 0; i < 40; i++) {   // "Quick HACK HERE."
-                addNDTCellToMap(ndt_feat_prev_vehicle_frame.get(), &ndt_odom_cell_prev);
-                addNDTCellToMap(ndt_feat_curr_vehicle_frame.get(), &ndt_odom_cell);
-                int tmp_size = (int)corr.size();
-                corr.push_back(std::pair<int, int>(tmp_size, tmp_size));
-            }
-        }
-        std::unique_ptr<lslgeneric::NDTMap> ndt_feat_prev(ndt_feat_prev_vehicle_frame->pseudoTransformNDTMap(Tnow /* *Tmotion */));
-        std::unique_ptr<lslgeneric::NDTMap> ndt_feat_curr(ndt_feat_curr_vehicle_frame->pseudoTransformNDTMap(Tinit));
-        // Remove the covariance rotation from the odometry (done when pseudo moving): the LAST cell only, like the reference
-        if (params_.useOdom) {
-            lslgeneric::CellVector *cl = ndt_feat_curr->getMyIndex();
-            cl->getCellIdx(cl->size() - 1)->setCov(odom_cov);
-        }
-        if (!params_.useFeat && !params_.useOdom) use_odom_or_features = false;   // both odom and feature are in the same pot
-        if (!params_.useOdom && !consistent_features) use_odom_or_features = false;
-
-        bool match_ok = true;
-        if (params_.fusion2d) {
-            match_ok = matchFusion2d(*map, ndglobal, *ndt_feat_prev, *ndt_feat_curr, corr, Tmotion_est, true, params_.useNDT, use_odom_or_features,
-                                     params_.stepcontrol, params_.ITR_MAX, params_.neighbours, params_.DELTA_SCORE) || params_.fuseIncomplete;
-        } else {
-            match_ok = matchFusion(*map, ndglobal, *ndt_feat_prev, *ndt_feat_curr, corr, Tmotion_est, TmotionCov, true, params_.useNDT,
-                                   use_odom_or_features, params_.stepcontrol, params_.ITR_MAX, params_.neighbours, params_.DELTA_SCORE,
-                                   params_.useSoftConstraints, params_.stepControlFusion, params_.useTikhonovRegularization, &last_match) ||
-                       params_.fuseIncomplete;
-        }
-        if (params_.allMatchesValid) match_ok = true;
-
-        if (match_ok) {
-            if (params_.computeCov) {   // recompute the covariance (based on the matching)
-                lslgeneric::NDTMatcherD2D matcher_d2d;
-                Eigen::MatrixXd matching_cov(6, 6);
-                matcher_d2d.covariance(*map, ndglobal, Tmotion_est, matching_cov);
-                Pose2dCov posecov;
-                posecov.mean = pose2dFromAffine3d(Tmotion_est);
-                posecov.cov = cov6toCov3(matching_cov);
-                pose2dClearDependence(posecov);
-                current_posecov.mean = pose2dFromAffine3d(Tmotion_est);
-                Eigen::Matrix3d prev_cov = current_posecov.cov;
-                current_posecov.cov = prev_cov + posecov.cov;
-            }
-            Eigen::Affine3d diff = (Tmotion_est).inverse() * Tmotion;
-            if ((diff.translation().norm() > params_.max_translation_norm ||
-                 diff.rotation().eulerAngles(0, 1, 2).norm() > params_.max_rotation_norm) && params_.checkConsistency) {
-                fprintf(stderr, "****  NDTFuserHMT -- ALMOST DEFINATELY A REGISTRATION FAILURE *****\n");
-                Tnow = Tnow * Tmotion;
-            } else {
-                if (params_.forceOdomAsEst) Tnow = Tnow * Tmotion;
-                else if (params_.globalTransf) Tnow = Tnow * Tmotion_est;
-                else if (params_.loadCentroid) Tnow = Tmotion_est * global_rotation;   // global_rotation, used with centroids
-                else Tnow = Tmotion_est;
-                Eigen::Affine3d diff_fuse = Tlast_fuse.inverse() * Tnow;
-                if (diff_fuse.translation().norm() > translation_fuse_delta ||
-                    diff_fuse.rotation().eulerAngles(0, 1, 2).norm() > rotation_fuse_delta)
-                    Tlast_fuse = Tnow;
-            }
-        } else {
-            Tnow = Tnow * Tmotion;
-        }
-
-        Eigen::Affine3d spose = Tnow * sensor_pose;
-        ndtgpu_host::transformPointCloudInPlace(spose, cloud_orig);
-        if (updateNDTMap) {
-            map->addPointCloud(spose.translation(), cloud_orig, 0.06, 25);   // keep the raw cloud and add it here
-            map->computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE, 1e5, 255, spose.translation(), 0.1);
-        }
+        absorb(bank_->update(slot_, {Tmotion}, {&cloudOrig}, updateNDTMap)[0], Tmotion);
         return Tnow;
     }
+    // (added) what a batched caller does after FuserBank::update on this fuser's slot
+    void absorb(const ndtgpu_fuser_result &r, const Eigen::Affine3d &Tmotion)
+    {
+        last_update = r;
+        last_match = r.match;
+        for (int e = 0; e < 16; e++) Tnow.data()[e] = r.Tnow[e];
+        Todom = Todom * Tmotion;
+        for (int a = 0; a < 3; a++) current_posecov.mean(a) = r.posecov_mean[a];
+        for (int e = 0; e < 9; e++) current_posecov.cov.data()[e] = r.posecov[e];
+    }
+    const std::shared_ptr<ndtgpu_host::FuserBank> &bank() const { return bank_; }
+    size_t slot() const { return slot_; }
 
 private:
     bool isInit;
-    double translation_fuse_delta, rotation_fuse_delta;
     Eigen::Affine3d sensor_pose;
-    Eigen::Vector3d localMapSize;
     Pose2dCov current_posecov;
-    std::shared_ptr<ndtgpu_host::MapPool> pool_, scan_pool_;
-    size_t pool_slot_ = 0;
+    std::shared_ptr<ndtgpu_host::FuserBank> bank_;
+    size_t slot_ = 0;
 };
 
 // interfaces.h:10-48 -- what the iSAM layer consumes (ndt_offline_mapper.h:40 takes NDTFeatureGraphInterface&)
@@ -650,63 +605,41 @@ public:
         return true;
     }
 
-    // Initialize the first entry of the map (graph.cpp:24-55)
+    // initialize(initPose, cloud, pts, preLoad) -- ndt_feature_graph.cpp:24-55: the first node.  A node keeps its map in its
+    // own frame (node.T places it in the world), so its fuser starts at the identity.
     void initialize(Eigen::Affine3d initPose, pcl::PointCloud<pcl::PointXYZ> &cloud, const InterestPointVec &pts, bool preLoad = false)
     {
-        NDTFeatureNode node;
-        node.map = new_fuser();
-        node.T = initPose;
-        node.map->setMotionParams(motion_params_);
-        node.map->setSensorPose(sensor_pose_);
-        initPose.setIdentity();   // keep each map in it's own ref frame (that is node.T)
-        node.map->initialize(initPose, cloud, pts, preLoad);
-        if (params_.storePtsInNodes) {   // Add the cloud...
-            Eigen::Affine3d Tnow_local_sensor = initPose * sensor_pose_;
-            node.addCloud(Tnow_local_sensor, cloud);
-        }
-        nodes_.push_back(node);
-        Tnow = node.T;
+        open_node(initPose, cloud, pts, preLoad);
+        Tnow = initPose;
     }
 
-    // Update the map with new readings, return the current pose in global coordinates (graph.cpp:60-144)
+    // update(Tmotion, cloud, pts) -- ndt_feature_graph.cpp:60-144: the scan goes to the current node's fuser; once the robot
+    // has moved newNodeTranslDist inside a node, the scan is only LOCALISED there (no fuse-in) and becomes the first scan of
+    // a new node at the pose that localisation gave.  Returns the pose in world coordinates.
     Eigen::Affine3d update(Eigen::Affine3d Tmotion, pcl::PointCloud<pcl::PointXYZ> &cloud, const InterestPointVec &pts)
     {
-        NDTFeatureNode &node = nodes_.back();
         distance_moved_in_last_node_ += Tmotion.translation().norm();
-        if (distance_moved_in_last_node_ > params_.newNodeTranslDist) {   // start on a new map
+        const bool leave = distance_moved_in_last_node_ > params_.newNodeTranslDist;
+        NDTFeatureNode &cur = nodes_.back();
+        const Eigen::Affine3d local = cur.map->update(Tmotion, cloud, pts, !leave, !leave);
+        Tnow = cur.T * local;
+        cur.Tlocal_odom = cur.Tlocal_odom * Tmotion;
+        cur.Tlocal_fuse = local;
+        if (leave) {
             distance_moved_in_last_node_ = 0.;
-            // the returned pose is the local map coord; do not update the maps in this step
-            Eigen::Affine3d Tnow_local = node.map->update(Tmotion, cloud, pts, false, false);
-            Tnow = node.T * Tnow_local;
-            node.Tlocal_odom = node.Tlocal_odom * Tmotion;
-            node.Tlocal_fuse = Tnow_local;
-            NDTFeatureNode new_node;
-            if (params_.popNodes) {
+            if (params_.popNodes) {          // (only the newest node is kept)
                 delete nodes_.back().map;
                 nodes_.pop_back();
                 pool_->release_last();
             }
-            new_node.map = new_fuser();
-            new_node.map->setMotionParams(motion_params_);
-            new_node.map->setSensorPose(sensor_pose_);
-            new_node.T = Tnow;
-            Eigen::Affine3d init_pose;
-            init_pose.setIdentity();
-            new_node.map->initialize(init_pose, cloud, pts, false);   // add the first data
-            nodes_.push_back(new_node);
+            open_node(Tnow, cloud, pts, false);
             return Tnow;
         }
-        Eigen::Affine3d Tnow_local = node.map->update(Tmotion, cloud, pts);
-        Tnow = node.T * Tnow_local;
-        node.Tlocal_odom = node.Tlocal_odom * Tmotion;
-        node.Tlocal_fuse = Tnow_local;
-        if (params_.storePtsInNodes) {
-            if (node.nbUpdates % params_.storePtsInNodesIncr == 0) {
-                Eigen::Affine3d Tnow_local_sensor = Tnow_local * sensor_pose_;
-                node.addCloud(Tnow_local_sensor, cloud);
-            }
+        if (params_.storePtsInNodes && cur.nbUpdates % params_.storePtsInNodesIncr == 0) {
+            Eigen::Affine3d in_node = local * sensor_pose_;
+            cur.addCloud(in_node, cloud);
         }
-        node.nbUpdates++;
+        cur.nbUpdates++;
         return Tnow;
     }
 
@@ -819,13 +752,30 @@ public:
     MotionModel2d::Params motion_params_;
 
 protected:
+    // the node fusers are the slots of ONE bank over the pool the node maps live in
     NDTFeatureFuserHMT *new_fuser()
     {
         if (!pool_) {
             const double c[3] = {0, 0, 0}, s[3] = {fuser_params_.map_size_x, fuser_params_.map_size_y, fuser_params_.map_size_z};
             pool_ = std::make_shared<ndtgpu_host::MapPool>(fuser_params_.resolution, c, s, params_.maxNodes);
+            bank_ = std::make_shared<ndtgpu_host::FuserBank>(NDTFeatureFuserHMT::bankParams(fuser_params_, motion_params_, sensor_pose_), pool_);
         }
-        return new NDTFeatureFuserHMT(fuser_params_, pool_, pool_->allocate());
+        return new NDTFeatureFuserHMT(fuser_params_, bank_, pool_->allocate());
+    }
+    // a new node at world pose `at`, its map started from `cloud`
+    void open_node(const Eigen::Affine3d &at, pcl::PointCloud<pcl::PointXYZ> &cloud, const InterestPointVec &pts, bool preLoad)
+    {
+        NDTFeatureNode node;
+        node.T = at;
+        node.map = new_fuser();
+        node.map->setMotionParams(motion_params_);
+        node.map->setSensorPose(sensor_pose_);
+        node.map->initialize(Eigen::Affine3d::Identity(), cloud, pts, preLoad);
+        if (params_.storePtsInNodes && nodes_.empty()) {
+            Eigen::Affine3d in_node = sensor_pose_;
+            node.addCloud(in_node, cloud);
+        }
+        nodes_.push_back(node);
     }
     void score_links(std::vector<NDTFeatureLink> &links)
     {
@@ -845,6 +795,7 @@ protected:
     }
 
     std::shared_ptr<ndtgpu_host::MapPool> pool_;
+    std::shared_ptr<ndtgpu_host::FuserBank> bank_;
     std::vector<NDTFeatureNode> nodes_;
     std::vector<NDTFeatureLink> links_;
     Eigen::Affine3d sensor_pose_, Tnow;

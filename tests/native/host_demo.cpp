@@ -260,7 +260,7 @@ int main()
     fp.resolution = 0.5; fp.map_size_x = 60; fp.map_size_y = 60; fp.map_size_z = 1.0; fp.sensor_range = 30;
     fp.useNDT = true; fp.useFeat = false; fp.useOdom = false;
     fp.neighbours = 2; fp.stepcontrol = true; fp.ITR_MAX = 30; fp.DELTA_SCORE = 1e-6;
-    fp.globalTransf = false; fp.loadCentroid = false; fp.fusion2d = false;
+    fp.globalTransf = true; fp.loadCentroid = true; fp.fusion2d = false;      // (the defaults: what the one-call device path covers)
     fp.useSoftConstraints = true; fp.useTikhonovRegularization = false; fp.computeCov = true;
     NDTFeatureGraph::Params gp;
     gp.newNodeTranslDist = 1.0;
@@ -568,6 +568,95 @@ int main()
         std::printf("F: %d scan pairs in one call: poses within %.2e of the pair-at-a-time sequence (%d of %d with its iteration count), "
                     "within %.3f m of the true motion\n", P, worst, same_iters, P, worst_gt);
         CHECK(worst < 1e-6 && same_iters >= P - 1 && worst_gt < 0.08, "the batch call disagrees with the pair-at-a-time sequence");
+    }
+    // ---- G. NDTFeatureFuserHMT::update as ONE device call == the sequence of lslgeneric calls it stands for ---------------
+    // (the sequence a catkin build runs when the reference's own ndt_feature_fuser_hmt.cpp is compiled against lslgeneric_gpu.h:
+    //  scan into the node frame, scan map on the node map's lattice, odometry cells, matchFusion, covariance, pose, fuse-in)
+    {
+        NDTFeatureFuserHMT::Params p = fp;
+        p.useOdom = true; p.useSoftConstraints = true; p.useTikhonovRegularization = true; p.stepControlFusion = true;
+        const Eigen::Affine3d sensor = ndtgpu_host::affine_from_pose(0.2, -0.03, 0, 0, 0, 0.01);
+        NDTFeatureFuserHMT one(p);
+        one.setSensorPose(sensor);
+        const Eigen::Affine3d start = ndtgpu_host::affine_from_pose(0.05, -0.02, 0, 0, 0, 0.004);
+        const pcl::PointCloud<pcl::PointXYZ> first = corridor_scan(gt[0] * sensor, 600);
+        one.initialize(start, first, no_pts);
+        // call by call: the node map
+        lslgeneric::NDTMap node(new lslgeneric::LazyGrid(p.resolution));
+        node.initialize(start.translation()(0), start.translation()(1), 0., p.map_size_x, p.map_size_y, p.map_size_z);
+        {
+            pcl::PointCloud<pcl::PointXYZ> c(first);
+            ndtgpu_host::transformPointCloudInPlace(sensor, c);
+            ndtgpu_host::transformPointCloudInPlace(start, c);
+            const Eigen::Affine3d at = start * sensor;
+            node.addPointCloud(at.translation(), c, 0.1, 100.0, 0.1);
+            node.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE, 1e5, 255, at.translation(), 0.1);
+        }
+        CHECK(node.numberOfActiveCells() == one.map->numberOfActiveCells(), "G: node maps differ after initialize: %d / %d cells",
+              node.numberOfActiveCells(), one.map->numberOfActiveCells());
+        Eigen::Affine3d pose = start;
+        const Eigen::Vector3d local_size(p.sensor_range + 3 * p.resolution, p.sensor_range + 3 * p.resolution, p.map_size_z);
+        double worst = 0;
+        int same_iters = 0;
+        const int steps = 3;
+        for (int k = 1; k <= steps; k++) {
+            const Eigen::Affine3d inc = gt[k - 1].inverse() * gt[k];
+            const Eigen::Affine3d Tmotion = ndtgpu_host::affine_from_pose(inc(0, 3) + 0.004 * k, inc(1, 3) - 0.003 * k, 0, 0, 0,
+                                                                          std::atan2(inc(1, 0), inc(0, 0)) + 0.001 * k);
+            const pcl::PointCloud<pcl::PointXYZ> scan = corridor_scan(gt[k] * sensor, 600 + k);
+            const Eigen::Affine3d Ta = one.update(Tmotion, scan, no_pts);
+            // -- the same scan, call by call
+            const Eigen::Affine3d into_node = pose * sensor;
+            pcl::PointCloud<pcl::PointXYZ> c(scan);
+            ndtgpu_host::transformPointCloudInPlace(into_node, c);
+            Eigen::Vector3d node_centre;
+            node.getCentroid(node_centre[0], node_centre[1], node_centre[2]);
+            lslgeneric::NDTMap scan_map(new lslgeneric::LazyGrid(p.resolution));
+            scan_map.loadPointCloudCentroid(c, into_node.translation(), node_centre, local_size, p.sensor_range);
+            scan_map.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE);
+            MotionModel2d model;                                             // (default parameters, like `one`)
+            const Pose2d rel(Tmotion.translation()[0], Tmotion.translation()[1], Tmotion.rotation().eulerAngles(0, 1, 2)[2]);
+            Eigen::Matrix3d cell_cov = model.getPose2dCov(rel).cov;
+            cell_cov(2, 2) = 0.01;
+            Eigen::MatrixXd Tcov = model.getCovMatrix6(rel);
+            Tcov(2, 2) = 1; Tcov(3, 3) = 1; Tcov(4, 4) = 1;
+            lslgeneric::NDTCell was, is;                                     // the odometry cell pair: where the robot was + motion | where it is
+            was.setMean(Tmotion.translation()); was.setCov(cell_cov);
+            is.setMean(Eigen::Vector3d(0, 0, 0)); is.setCov(cell_cov);
+            lslgeneric::NDTMap prev_local(new lslgeneric::CellVector(), true), curr_local(new lslgeneric::CellVector(), true);
+            std::vector<std::pair<int, int> > corr;
+            for (int i = 0; i < 40; i++) {
+                addNDTCellToMap(&prev_local, &was);
+                addNDTCellToMap(&curr_local, &is);
+                corr.push_back(std::make_pair(i, i));
+            }
+            std::unique_ptr<lslgeneric::NDTMap> prev(prev_local.pseudoTransformNDTMap(pose)), curr(curr_local.pseudoTransformNDTMap(pose));
+            curr->getMyIndex()->getCellIdx(39)->setCov(cell_cov);            // (the last one keeps the un-rotated covariance)
+            Eigen::Affine3d est = Tmotion;
+            ndtgpu_match_result mr;
+            const bool ok = ndt_feature::matchFusion(node, scan_map, *prev, *curr, corr, est, Tcov, true, true, true, p.stepcontrol, p.ITR_MAX,
+                                                     p.neighbours, p.DELTA_SCORE, true, true, true, &mr);
+            pose = pose * (ok ? est : Tmotion);
+            const Eigen::Affine3d at = pose * sensor;
+            pcl::PointCloud<pcl::PointXYZ> raw(scan);
+            ndtgpu_host::transformPointCloudInPlace(at, raw);
+            node.addPointCloud(at.translation(), raw, 0.06, 25);
+            node.computeNDTCells(lslgeneric::CELL_UPDATE_MODE_SAMPLE_VARIANCE, 1e5, 255, at.translation(), 0.1);
+            double d = 0;
+            for (int e = 0; e < 16; e++) d = std::fmax(d, std::fabs(Ta.data()[e] - pose.data()[e]));
+            worst = std::fmax(worst, d);
+            same_iters += mr.iterations == one.last_match.iterations && ok == (one.last_match.converged != 0);
+            CHECK(node.numberOfActiveCells() == one.map->numberOfActiveCells(), "G: node maps differ after update %d: %d / %d cells", k,
+                  node.numberOfActiveCells(), one.map->numberOfActiveCells());
+        }
+        std::printf("G: %d updates: the one-call fuser and the call-by-call sequence agree to %.2e on the pose (%d of %d with the same matcher report)\n",
+                    steps, worst, same_iters, steps);
+        CHECK(worst < 1e-9 && same_iters == steps, "the one-call fuser disagrees with the call-by-call sequence: %.3e", worst);
+        // a configuration the device path does not cover is refused, not approximated
+        NDTFeatureFuserHMT::Params q = fp;
+        q.globalTransf = false;
+        NDTFeatureFuserHMT other(q);
+        CHECK(throws_invalid([&] { other.initialize(start, first, no_pts); }), "globalTransf = false accepted by the one-call fuser");
     }
     std::printf("%d failures in total\n", g_fails);
     return g_fails ? 1 : 0;
