@@ -52,7 +52,13 @@ static pcl::PointCloud<pcl::PointXYZ> corridor_scan(const Eigen::Affine3d &senso
     return pc;
 }
 
-static void pose_error(const Eigen::Affine3d &a, const Eigen::Affine3d &b, double &d, double &ang) { distanceBetweenAffine3d(a, b, d, ang); }
+// (not distanceBetweenAffine3d: that one keeps upstream's unclamped acos, NaN for two poses that agree to the last bit)
+static void pose_error(const Eigen::Affine3d &a, const Eigen::Affine3d &b, double &d, double &ang)
+{
+    const Eigen::Affine3d rel = a.inverse() * b;
+    d = rel.translation().norm();
+    ang = std::fabs(getRobustYawFromAffine3d(rel, true));
+}
 
 // ---- C: the reference's host loop, re-typed ------------------------------------------------------------------
 namespace retyped {
