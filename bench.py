@@ -325,6 +325,99 @@ def config4(args, torch, dist, N, binding, synth, rank, world, dev, size_m, rng_
         dist.destroy_process_group()
 
 
+def fuser_leg(torch, N, binding, synth, dev, with_cpu, n_fusers=64, n_points=100000, n_updates=6):
+    """NDTFeatureFuserHMT::update (ndt_feature_fuser_hmt.cpp:108-512) as the fuser bank runs it: ONE ndtgpu_fuser_update_batch
+    call per scan step for `n_fusers` independent fusers (scan -> scan map on the node map's lattice -> matchFusion with the
+    soft constraint, the Tikhonov term and the 40 odometry cells -> covariance -> pose -> ray-traced fuse-in), 100 k points per
+    scan, 0.5 m cells, the fuser preset; beside it one fuser alone (the reference's call shape) and the CPU oracle walking one
+    fuser's update.  A labelled extra of the bench line, outside the timed region."""
+    import math
+    res, rng_lim, size = 0.5, 30.0, [100.0, 100.0, 1.0]
+    prm = N.fuser_params(resolution=res, map_size_x=size[0], map_size_y=size[1], map_size_z=size[2], sensor_range=rng_lim,
+                         neighbours=2, itr_max=30, delta_score=1e-6, max_cells=4096)
+    gen = np.random.default_rng(11)
+    seeds = torch.arange(9001, 9001 + n_fusers, dtype=torch.int64, device=dev)
+    poses = np.zeros((n_updates + 1, n_fusers, 3))
+    for s in range(1, n_updates + 1):
+        step = np.stack([gen.uniform(0.15, 0.3, n_fusers), gen.uniform(-0.05, 0.05, n_fusers), gen.uniform(-0.04, 0.04, n_fusers)], axis=1)
+        c, sn = np.cos(poses[s - 1, :, 2]), np.sin(poses[s - 1, :, 2])
+        poses[s, :, 0] = poses[s - 1, :, 0] + c * step[:, 0] - sn * step[:, 1]
+        poses[s, :, 1] = poses[s - 1, :, 1] + sn * step[:, 0] + c * step[:, 1]
+        poses[s, :, 2] = poses[s - 1, :, 2] + step[:, 2]
+    scans = [synth.scan_2d(seeds, torch.as_tensor(poses[s], device=dev), n_points, noise_stream=s).contiguous() for s in range(n_updates + 1)]
+
+    def T2(p):
+        T = np.tile(np.eye(4), (p.shape[0], 1, 1))
+        T[:, 0, 0] = np.cos(p[:, 2]); T[:, 0, 1] = -np.sin(p[:, 2]); T[:, 1, 0] = np.sin(p[:, 2]); T[:, 1, 1] = np.cos(p[:, 2])
+        T[:, 0, 3], T[:, 1, 3] = p[:, 0], p[:, 1]
+        return T
+    Tm = []
+    for s in range(n_updates):
+        true = np.linalg.inv(T2(poses[s])) @ T2(poses[s + 1])
+        noise = T2(np.stack([gen.normal(0, 0.01, n_fusers), gen.normal(0, 0.01, n_fusers), gen.normal(0, 0.003, n_fusers)], axis=1))
+        Tm.append(true @ noise)
+    st = torch.cuda.current_stream()
+
+    def run(count):
+        bank = N.FuserBank(prm, count)
+        bank.initialize(T2(poses[0][:count]), scans[0][:count], stream=st)
+        bank.update(Tm[0][:count], scans[1][:count], stream=st)         # (warm: code objects, staging buffers)
+        bank.poses()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(1, n_updates):
+            bank.update(Tm[s][:count], scans[s + 1][:count], stream=st)
+            T, r = bank.poses()                                         # the pose is what update() returns: fetched every step
+        dt = (time.perf_counter() - t0) / (n_updates - 1)
+        bank.close()
+        return dt, T, r
+    dt_all, T_all, r_all = run(n_fusers)
+    dt_one, T_one, r_one = run(1)
+    true_last = T2(poses[n_updates])
+    err = float(np.max(np.linalg.norm(T_all[:, :2, 3] - true_last[:, :2, 3], axis=1)))
+    out = {"unit": "fuser updates/s", "value": n_fusers / dt_all, "fusers_per_call": n_fusers, "ms_per_call": 1e3 * dt_all,
+           "one_fuser_ms_per_update": 1e3 * dt_one, "one_fuser_equals_batch_bits": bool(np.array_equal(T_one[0], T_all[0])),
+           "worst_position_error_vs_ground_truth_m": err, "matcher_iterations_mean": float(r_all["match"]["iterations"].mean()),
+           "workload": "%d independent fusers x %d points per scan, 0.5 m cells, node maps 100 x 100 x 1 m, default Params() of the fuser "
+                       "(useOdom, useSoftConstraints, useTikhonovRegularization, computeCov) with the fuser preset of the matcher; "
+                       "ONE ndtgpu_fuser_update_batch call + ndtgpu_fuser_poses per scan step (host wall clock, poses fetched every "
+                       "step like update() returns them)" % (n_fusers, n_points)}
+    if with_cpu:
+        import oracle as O
+        # the CPU oracle walks ONE update of fuser 0 from the same state (node map after initialize + first update is rebuilt there)
+        k = 0
+        sens = np.eye(4)
+        Tn = T2(poses[0][:1])[0]
+        om = O.OracleMap(res, [Tn[0, 3], Tn[1, 3], 0.0], size)
+
+        def mv(T, xyz):
+            x, y, z = (xyz[:, a].astype(np.float64) for a in range(3))
+            return np.stack([(T[r, 0] * x + T[r, 1] * y + T[r, 2] * z + T[r, 3]).astype(np.float32) for r in range(3)], axis=1)
+        sc0 = scans[0][k].cpu().numpy()
+        om.add_point_cloud((Tn @ sens)[:3, 3], mv(Tn, sc0), maxz=100.0, sensor_noise=0.1, order_free=True)
+        om.compute_cells_full()
+        sc1 = scans[1][k].cpu().numpy()
+        c0 = time.perf_counter()
+        pp = N.fuser_prepare(prm, Tn, Tm[0][k], [Tn[0, 3], Tn[1, 3], 0.0])
+        local = rng_lim + 3 * res
+        os_ = O.OracleMap(res, pp["scan_centre"], [local, local, size[2]])
+        os_.load_points(mv(pp["Tscan"].reshape(4, 4).T, sc1), rng_lim, range_origin=pp["range_origin"])
+        os_.compute_cells()
+        sm = np.tile(pp["feat_src_mean"], (40, 1)); tm = np.tile(pp["feat_tgt_mean"], (40, 1))
+        scv = np.tile(pp["feat_cov_rotated"], (40, 1)); scv[39] = pp["feat_cov_plain"]; tcv = np.tile(pp["feat_cov_rotated"], (40, 1))
+        To, ro = O.match_fusion_feat(om, os_, Tm[0][k], pp["Tcov"].reshape(6, 6), (sm, scv, tm, tcv), use_soft_constraints=True, tikhonov=True,
+                                     step_control_fusion=True, n_neighbours=2, itr_max=30, delta_score=1e-6, step_control=1)
+        O.covariance(om, os_, To, n_neighbours=2)
+        Tn2 = Tn @ (To if ro["converged"] else Tm[0][k])
+        om.add_point_cloud((Tn2 @ sens)[:3, 3], mv(Tn2 @ sens, sc1), maxz=25.0, sensor_noise=0.06, order_free=True)
+        om.compute_cells_full()
+        t_cpu = time.perf_counter() - c0
+        out["cpu_oracle_one_update_ms"] = 1e3 * t_cpu
+        out["one_fuser_speedup_vs_cpu_1thread"] = t_cpu / dt_one
+        out["batch_speedup_vs_cpu_1thread"] = t_cpu * n_fusers / dt_all
+    return out
+
+
 def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_cpu):
     """The headline configuration (100 k points, 0.5 m cells, fuser preset) on the DENSE scene of synth.room_2d -- ~2 k Gaussian
     cells per map, the size SURVEY.md 8(a, d) gives a 2D map, against ~370 in the plain room the headline runs on: the same two
@@ -874,6 +967,14 @@ def main():
                        % ((145.0 * float(res_np["pair_terms_g"].sum()) + 394.0 * float(res_np["pair_terms_h"].sum())) / 1e9,
                           mk["fp64_tflops"] / 78.6))
     mk["fp64_gflop_executed_per_launch"] = (145.0 * float(res_np["pair_terms_g"].sum()) + 394.0 * float(res_np["pair_terms_h"].sum())) / 1e9
+    # What the REFERENCE's loop needs: per registration one evaluation with the Hessian per Newton iteration
+    # (fusion.h:856) and gradient-only evaluations for everything else it runs -- every line-search trial, the re-evaluation of
+    # the Newton pose that opens a line search (fusion.h:444; the kernel reuses the Newton sums and neither runs nor counts it),
+    # the score at the returned pose (fusion.h:1085): `fevals` + `iterations` evaluations, `iterations` of them with the Hessian.
+    # Terms per evaluation of a registration: its own mean.  Hessians the kernel evaluates on speculation (trials from the second
+    # on, the first trial while first trials are accepted) are NOT in this figure.
+    ev_terms = (res_np["pair_terms_g"] + res_np["pair_terms_h"]).astype(np.float64) / np.maximum(1, res_np["fevals"]).astype(np.float64)
+    mk["fp64_gflop_needed_per_launch"] = float((ev_terms * (610.0 * res_np["iterations"] + 130.0 * res_np["fevals"])).sum()) / 1e9
     dominant = "ndt_build_kernel" if iso_build_ms >= iso_match_ms else "ndt_match_kernel"   # by time alone on the chip
     dk = kern[dominant]
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command
@@ -911,6 +1012,8 @@ def main():
                     "frac_step": mk["fp64_gflop_per_launch"] / ms_per_step / 78.6,
                     # the same launch priced by the fp64 flops its loops EXECUTE (ISA count; see kernels.ndt_match_kernel.fp64_note)
                     "frac_executed_flops": mk["fp64_gflop_executed_per_launch"] / mk["ms_isolated"] / 78.6,
+                    # ... and by the evaluations the reference's loop needs (speculated Hessians are no credit)
+                    "frac_needed": mk["fp64_gflop_needed_per_launch"] / mk["ms_isolated"] / 78.6,
                     "note": note + "; frac_step = the same flops / ms_per_step (what the pipelined step sustains); fp64 vector work (no "
                                    "MFMA instruction is issued: every pair term has its own 3x3 inverse), counted against the fp64 peak"}
 
@@ -1085,6 +1188,8 @@ def main():
         del both, fixed, moving
         torch.cuda.empty_cache()
         out["dense_scene"] = dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, not args.no_cpu)
+        torch.cuda.empty_cache()
+        out["fuser_update"] = fuser_leg(torch, N, binding, synth, dev, not args.no_cpu)
     if rank == 0:
         print(json.dumps(out))
     if use_dist:
