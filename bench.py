@@ -38,7 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-ROUND_TAG = "r05"
+ROUND_TAG = "r06"
 PMC_FILE = ROUND_TAG + "_pmc_traffic.json"
 
 

@@ -24,11 +24,11 @@ for c in 5 fuse; do
 done
 python bench.py > gpurun_out/bench_full.log 2>&1
 # summarise here (the raw traces and per-dispatch counter tables exceed what travels back), keep the small tables only
-python tools/summarize_profiles.py r05 gpurun_out/r05_profiles > gpurun_out/r05_summarize.log 2>&1
-python tools/kernel_resources.py > gpurun_out/r05_profiles/r05_kernel_resources.txt 2>&1
-for d in prof_kt prof_kt_serial prof_kt_5 prof_kt_fuse; do mkdir -p gpurun_out/r05_raw/$d; cp gpurun_out/$d/bench_kernel_stats.csv gpurun_out/r05_raw/$d/ 2>/dev/null; done
+python tools/summarize_profiles.py r06 gpurun_out/r06_profiles > gpurun_out/r06_summarize.log 2>&1
+python tools/kernel_resources.py > gpurun_out/r06_profiles/r06_kernel_resources.txt 2>&1
+for d in prof_kt prof_kt_serial prof_kt_5 prof_kt_fuse; do mkdir -p gpurun_out/r06_raw/$d; cp gpurun_out/$d/bench_kernel_stats.csv gpurun_out/r06_raw/$d/ 2>/dev/null; done
 rm -rf gpurun_out/prof_*
 tail -1 gpurun_out/bench_full.log | cut -c1-400
 tail -1 gpurun_out/bench_c5.log | cut -c1-400
 tail -1 gpurun_out/bench_cfuse.log | cut -c1-400
-ls gpurun_out/r05_profiles; tail -3 gpurun_out/r05_summarize.log | cut -c1-300
+ls gpurun_out/r06_profiles; tail -3 gpurun_out/r06_summarize.log | cut -c1-300
