@@ -70,7 +70,7 @@ hipError_t ndt_launch_cloud_transform(const void *xyz_dev, size_t count, size_t 
 
 // One thread per fuser slot: what NDTFeatureFuserHMT::update does between the registration and the fuse-in
 // (fuser_hmt.cpp:361-480), on the device so that the fuse-in follows without the host.
-__global__ void ndt_fuser_post_kernel(NdtFuserPolicy pol, const double *__restrict__ sensor_pose16, NdtFuserState *__restrict__ state,
+__global__ __launch_bounds__(64) void ndt_fuser_post_kernel(NdtFuserPolicy pol, const double *__restrict__ sensor_pose16, NdtFuserState *__restrict__ state,
                                       const double *__restrict__ Tmotion16, const double *__restrict__ Test16,
                                       const NdtMatchResultDev *__restrict__ match, const double *__restrict__ cov36,
                                       const int *__restrict__ cov_singular, unsigned count, double *__restrict__ spose16,
