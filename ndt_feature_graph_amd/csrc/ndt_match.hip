@@ -2210,7 +2210,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         }
         __syncthreads();
         if (s_done) break;
-        const rigid Te = s_T;
+        const rigid &Te = s_T;            // (read from LDS where the transform needs it, see ndt_match_pool_kernel)
         long long c0 = __builtin_readcyclecounter();
 #pragma unroll 1
         for (unsigned q = g; q < NQ; q += G) {
@@ -2589,7 +2589,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_pool_kernel(
             const MapView sv = map_view_uniform(sset, sidx[pair]);
             const unsigned NC = s_task[6], CH = s_task[7];
             const int per = (int)s_task[8];
-            const rigid Te = s_T;
+            const rigid &Te = s_T;        // (read from LDS where the transform needs it: as a register copy it lived across the pair terms, partly in scratch memory)
             const unsigned c = task * CH;
             const int begin = min(sv.n_cells, (int)c * per), count = min(sv.n_cells - begin, (int)CH * per);
             if (CH > 1u) {
