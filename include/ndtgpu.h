@@ -411,6 +411,10 @@ ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const n
 ndtgpu_status ndtgpu_registrar_create(const ndtgpu_grid_params *grid, size_t pairs_per_batch, int depth,
                                       ndtgpu_registrar **out);
 ndtgpu_status ndtgpu_registrar_get_info(const ndtgpu_registrar *reg, ndtgpu_registrar_info *info);
+/* TEST AID (stream-fed form): raises the matcher's abort word, as a workgroup that found no work for ~30 s would -- the give-up
+ * protocol (results "not run", map sets held until the instances have left, one error from ndtgpu_registrar_sync, a registrar
+ * that works again afterwards) is otherwise only reachable by starving the device for half a minute. */
+ndtgpu_status ndtgpu_registrar_inject_abort(ndtgpu_registrar *reg);
 ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *reg);
 /* n_pairs registrations: pair k builds the target map from cloud k of targets_dev and the source map from cloud k of
  * sources_dev (DEVICE pointers; n_points records each, stride_bytes apart, clouds map_stride_bytes apart; range filter as

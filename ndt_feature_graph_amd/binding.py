@@ -130,7 +130,7 @@ EXPORTS = ["ndtgpu_version", "ndtgpu_last_error", "ndtgpu_device_count", "ndtgpu
            "ndtgpu_default_registrar_params", "ndtgpu_registrar_create_ex", "ndtgpu_registrar_get_info",
            "ndtgpu_default_fuser_params", "ndtgpu_fuser_prepare", "ndtgpu_fuser_bank_create", "ndtgpu_fuser_bank_destroy",
            "ndtgpu_fuser_bank_mapsets", "ndtgpu_fuser_initialize_batch", "ndtgpu_fuser_update_batch", "ndtgpu_fuser_poses",
-           "ndtgpu_fuser_initialize_batch_host", "ndtgpu_fuser_update_batch_host"]
+           "ndtgpu_fuser_initialize_batch_host", "ndtgpu_fuser_update_batch_host", "ndtgpu_registrar_inject_abort"]
 
 _lib = None
 
@@ -209,6 +209,7 @@ def lib():
     L.ndtgpu_default_registrar_params.restype = None
     L.ndtgpu_registrar_create_ex.argtypes = [C.POINTER(GridParams), C.POINTER(RegistrarParams), C.POINTER(vp)]
     L.ndtgpu_registrar_get_info.argtypes = [vp, C.POINTER(RegistrarInfo)]
+    L.ndtgpu_registrar_inject_abort.argtypes = [vp]
     L.ndtgpu_default_fuser_params.argtypes = [C.POINTER(FuserParams)]
     L.ndtgpu_default_fuser_params.restype = None
     L.ndtgpu_fuser_prepare.argtypes = [C.POINTER(FuserParams), dp, dp, dp, C.POINTER(FuserPrepared)]
@@ -601,6 +602,10 @@ class Registrar:
         h = C.c_void_p()
         _check(lib().ndtgpu_registrar_create_ex(C.byref(gp), C.byref(rp), C.byref(h)))
         self.h, self.depth, self.per, self.res = h, int(depth), int(pairs_per_batch), float(res)
+
+    def inject_abort(self):
+        """test aid: the stream-fed matcher's give-up word (include/ndtgpu.h)"""
+        _check(lib().ndtgpu_registrar_inject_abort(self.h))
 
     def info(self):
         i = RegistrarInfo()

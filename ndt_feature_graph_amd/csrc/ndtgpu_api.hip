@@ -215,7 +215,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.6.0 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.6.1 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1417,6 +1417,16 @@ ndtgpu_status ndtgpu_registrar_get_info(const ndtgpu_registrar *r, ndtgpu_regist
     info->calibrations = r->calibrations;
     info->submitted = (uint64_t)r->submitted;
     info->cells_per_map = r->calib_cells;
+    return NDTGPU_OK;
+}
+
+// test aid: raises the stream-fed matcher's abort word, as a workgroup that found no work for ~30 s would
+ndtgpu_status ndtgpu_registrar_inject_abort(ndtgpu_registrar *r)
+{
+    if (!r) return fail(NDTGPU_ERR_INVALID, "registrar_inject_abort: null");
+    if (!r->queue) return fail(NDTGPU_ERR_INVALID, "registrar_inject_abort: not the stream-fed form");
+    const unsigned one = 1u;
+    HIP_TRY(hipMemcpy((char *)r->queue + ndt_stream_abort_offset(), &one, sizeof one, hipMemcpyHostToDevice));
     return NDTGPU_OK;
 }
 

@@ -306,5 +306,49 @@ def test_registrar_stream_form_edges(N, scene):
     same_bits(binding, Tb, resb, T_ref, r_ref)
 
 
+def test_registrar_gives_up_cleanly_and_works_again(N, scene):
+    """The give-up protocol of the stream-fed matcher, reached through the test aid ndtgpu_registrar_inject_abort:
+    registrations that did not run report exit_code -4 with their pose untouched, every other one carries the bits of the
+    two-call path, ndtgpu_registrar_sync reports the abort ONCE, and the same registrar then registers everything again."""
+    import torch
+    from ndt_feature_graph_amd import binding
+    B, both, dev = scene["B"], scene["both"], scene["dev"]
+    T_ref, r_ref = two_call_reference(N, scene, 32)
+    reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=32, depth=4, max_cells=4096, matcher_form=binding.MATCHER_STREAM_FED)
+    st = torch.cuda.current_stream()
+    T0 = scene["T0"]
+    outs = [(T0.clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev)) for _ in range(6)]
+    torch.cuda.synchronize()
+    for T16, res in outs[:1]:                                   # (the measuring sub-batch and two more run to the end)
+        reg.submit(both[:B], both[B:], T16, res, range_limit=RNG, stream=st)
+    reg.sync()
+    for T16, res in outs[1:]:
+        reg.submit(both[:B], both[B:], T16, res, range_limit=RNG, stream=st)
+    reg.inject_abort()
+    with pytest.raises(N.NdtGpuError):
+        reg.sync()
+    torch.cuda.synchronize()
+    same_bits(binding, outs[0][0], outs[0][1], T_ref, r_ref)
+    not_run = 0
+    for T16, res in outs[1:]:
+        r = res.cpu().numpy().view(binding.RESULT_DTYPE).reshape(B)
+        T = T16.cpu().numpy()
+        skipped = r["exit_code"] == -4
+        not_run += int(skipped.sum())
+        assert not r["converged"][skipped].any() and np.array_equal(T[skipped], T0.cpu().numpy()[skipped])
+        assert np.array_equal(T[~skipped], T_ref[~skipped])
+        for f in DET_FIELDS:
+            assert np.array_equal(r[f][~skipped], r_ref[f][~skipped]), f
+    assert not_run > 0, "the abort came after everything had run: nothing was tested"
+    reg.sync()                                                  # reported once; the registrar is usable again
+    T16, res = T0.clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        T16.copy_(T0)
+        reg.submit(both[:B], both[B:], T16, res, range_limit=RNG, stream=st)
+        reg.sync()
+        same_bits(binding, T16, res, T_ref, r_ref)
+    reg.close()
+
+
 def pose_dist(a16, b16):
     return float(np.max(np.abs(np.asarray(a16) - np.asarray(b16))))
