@@ -142,7 +142,7 @@ __global__ __launch_bounds__(NDT_FLAT_THREADS) __attribute__((amdgpu_waves_per_e
     // region 0: the waves' reduction scratch during phase A (NDT_FLAT_LDSRED), the Gaussian-cell bitmap from phase B on
     const unsigned region0_words = NDT_FLAT_LDSRED ? max(bm_words, (unsigned)(NDT_FLAT_WAVES * NDT_FLAT_RED_DOUBLES * 2)) : bm_words;
     unsigned *s_bits = s_dyn;                      // [bm_words]   Gaussian-cell bit per slot (phase B on)
-    double *s_red = reinterpret_cast<double *>(s_dyn);   // [waves][9][64] (phase A)
+    [[maybe_unused]] double *s_red = reinterpret_cast<double *>(s_dyn);   // [waves][9][64] (phase A)
     unsigned *s_hash = s_dyn + region0_words;      // [hash_entries] (slot + 1) << 13 | id; compacted per wave after phase A
 
     uint2 *rankmap = set.rankmap + (size_t)map * ndt_rm_stride(g);

@@ -406,6 +406,9 @@ NDT_D unsigned wave_incl_scan_u32(unsigned v)
     return (unsigned)x;
 }
 
+template <bool WITH_H>
+NDT_D double wave_totals(const WaveEval<WITH_H> &w);      // (defined below, used by eval_group's segment rows)
+
 // TERM stage: the n (source lane, target cell) pairs at the head of the wave's list, 64 at a time; every lane does one
 // dense pair term.  Without a Hessian the target cells of the next batch are fetched while this one is computed.
 template <bool WITH_H, bool PLANAR = false>
