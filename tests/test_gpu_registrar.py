@@ -350,5 +350,16 @@ def test_registrar_gives_up_cleanly_and_works_again(N, scene):
     reg.close()
 
 
+def test_registrar_soak_short(N):
+    """tools/registrar_soak.py for 12 s: hundreds of calls of random sizes through small registrars (ring entries re-published every
+    few hundred microseconds), two registrars alive at once, callers that sometimes wait: every call the two-call path's bits.
+    (The long form, 180 s on one MI355X: 48 838 calls, 284 705 sub-batches, no difference, no stall -- profiles/README.md.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "registrar_soak.py"), "12"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "every call the bits of the two-call path" in out.stdout
+
+
 def pose_dist(a16, b16):
     return float(np.max(np.abs(np.asarray(a16) - np.asarray(b16))))
