@@ -45,6 +45,24 @@ __device__ long long g_solver_prof[16];
 
 namespace {
 
+// How many of the NDT_VW shares of an evaluation hold cells (the others deliver rows of zeros): a property of the source map alone.
+// Maps of 257..448 cells -- the bench's halls hold 372 -- are dealt to 5..7 shares of 52..64 cells instead of eight at 32..56 of
+// the 64 lanes: TRANSFORM, PROBE, the hit list and the wave sum are paid per share, and the pair terms of a share come in batches
+// of 64 (eight shares of 238 terms: 32 batches, six of 318: 30).  Round 6, measured (bench, 100 steps): 642 k -> 664-671 k
+// registrations/s; the isolated launch of 1024 pairs 2.16-2.26 -> 2.08-2.13 ms on the same box (a lone registration's six
+// waves share four SIMDs with less contention than eight do).  -DNDT_FIXED_SHARES: eight shares always (A/B).
+NDT_D unsigned ndt_shares_of(int msrc)
+{
+#ifndef NDT_FIXED_SHARES
+    if (msrc <= 256) return (unsigned)NDT_VW;          // (small maps keep all eight waves: a lone registration's latency)
+    const unsigned n = ((unsigned)msrc + 63u) / 64u;
+    return n < (unsigned)NDT_VW ? n : (unsigned)NDT_VW;
+#else
+    (void)msrc;
+    return (unsigned)NDT_VW;
+#endif
+}
+
 // cell records and rank bitmaps live in device (global) memory: said in the pointer types, so that pointers that went
 // through an LDS copy of a MapView are still dereferenced with global_load, not flat_load
 typedef const NdtCell __attribute__((address_space(1))) *gcell_ptr;
@@ -818,7 +836,8 @@ NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &
     wave_eval_init<NW, WITH_H>(w, sh);
     // cells are dealt to the shares in turn (cell i -> share i mod 8): cells are ranked in slot order, so a contiguous
     // part would be one strip of the map, and strips differ a lot in how many neighbours their cells have
-    const unsigned key = msrc <= 64 * NDT_VW ? cache_key : 0u;   // a share remembers the hit list of ONE group
+    const unsigned nsh = ndt_shares_of(msrc);
+    const unsigned key = msrc <= 64 * (int)nsh ? cache_key : 0u;   // a share remembers the hit list of ONE group
 #pragma unroll 1
     for (unsigned v = wave; v < (unsigned)NDT_VW; v += (unsigned)NW) {
         w.myq = sh.queue + v * QL;
@@ -827,8 +846,9 @@ NDT_D void eval_derivs(const MapView &tg, gcell_ptr src, int msrc, const rigid &
         w.terms = 0;
 #pragma unroll
         for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
-        for (int base = (int)v; base < msrc; base += 64 * NDT_VW)
-            eval_group<NN, WITH_H, QL, false, true>(w, tg, src, base, NDT_VW, msrc, T, lfd1, lfd2, key);
+        if (v < nsh)
+            for (int base = (int)v; base < msrc; base += 64 * (int)nsh)
+                eval_group<NN, WITH_H, QL, false, true>(w, tg, src, base, (int)nsh, msrc, T, lfd1, lfd2, key);
         const double tot = wave_totals<WITH_H>(w);
         if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) sh.part[v * 32 + (lane >> SH)] = tot;
         if (lane == 0) sh.part[v * 32 + 28] = (double)w.terms;
@@ -988,9 +1008,14 @@ NDT_D void run_share(MatchSlot<QL> &S, unsigned v, double *wsrc, uint2 *wwin, do
 #pragma unroll
     for (int k = 0; k < NACC; k++) w.acc[k] = 0.0;
     const int msrc = S.sv.n_cells;
-    const unsigned key = msrc <= 64 * NDT_VW ? S.session : 0u;   // a share remembers the hit list of ONE group
-    for (int base = (int)v; base < msrc; base += 64 * NDT_VW)
-        eval_group<NN, WITH_H, QL, false, false, PLANAR>(w, S.tg, S.sv.cells, base, NDT_VW, msrc, S.st.Teval, lfd1, lfd2, key);
+    const unsigned nsh = ndt_shares_of(msrc);
+    if (v >= nsh) {                                              // (a share without cells: a row of zeros, no butterfly)
+        if (lane < 29u) S.part[v * 32 + lane] = 0.0;
+        return;
+    }
+    const unsigned key = msrc <= 64 * (int)nsh ? S.session : 0u;   // a share remembers the hit list of ONE group
+    for (int base = (int)v; base < msrc; base += 64 * (int)nsh)
+        eval_group<NN, WITH_H, QL, false, false, PLANAR>(w, S.tg, S.sv.cells, base, (int)nsh, msrc, S.st.Teval, lfd1, lfd2, key);
     const double tot = wave_totals<WITH_H>(w);
     if ((lane & ((1u << SH) - 1u)) == 0u && (lane >> SH) < (unsigned)NACC) S.part[v * 32 + (lane >> SH)] = tot;
     if (lane == 0) S.part[v * 32 + 28] = (double)w.terms;

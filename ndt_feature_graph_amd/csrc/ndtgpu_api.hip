@@ -215,7 +215,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.6.1 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.6.2 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
