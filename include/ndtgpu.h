@@ -389,7 +389,9 @@ typedef struct {
                                * sub-batch runs alone on the chip, the kernels' own clocks give the CU-time of builds and
                                * registrations, and the chip is split in that proportion */
     int32_t build_streams;    /* stream-fed form: 1 or 2 build streams that take the sub-batches in turn; 0 = 2 when depth >= 3 */
-    uint32_t linger_us;       /* stream-fed form: how long a matcher instance that has worked stays when it runs dry */
+    uint32_t linger_us;       /* stream-fed form: how long a matcher instance that has worked stays when it runs dry (0 = 1000: where
+                               * the builds are the slower side an instance that leaves has to be placed again among build
+                               * workgroups that keep arriving; ndtgpu_registrar_sync does not wait for it) */
     int32_t recalibrate_pct;  /* measured split only: when the mean number of Gaussian cells per map over the last sub-batches
                                * differs from the figure the split was measured at by more than this many percent, the pipeline is
                                * drained once and the split measured again (a registrar that moves from halls to clutter).

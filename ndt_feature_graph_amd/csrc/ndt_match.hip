@@ -1483,7 +1483,8 @@ struct NdtStreamQueue {
     unsigned ring;                   // entries in use (= the registrar's depth: entry e always describes map set e; set by the host)
     unsigned linger;                 // 100 MHz ticks an instance that has worked stays when it runs dry (set by the host)
     unsigned live;                   // workgroups of matcher instances that are resident
-    unsigned pad_;
+    unsigned final_pub;              // the host is waiting for everything: an instance that finds `published` at this value complete
+                                     // does not linger (ndtgpu_registrar_sync)
     unsigned done_seq[NDT_STREAM_RING];   // ring entry e: seq + 1 of the last batch that completed in it
     // 100 MHz time stamps of the last NDT_STREAM_STAMPS batches: [seq % N][0] published, [1] last registration finished
     // (ndtgpu_registrar_kernel_ms: the matcher side of a sub-batch as the queue saw it)
@@ -1690,7 +1691,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                         new_state = SLOT_FREE;
                         if (comp == pub) {
                             const unsigned now = (unsigned)wall_clock64() | 1u;
-                            if (!E.worked || linger == 0u) new_state = SLOT_CLOSED;
+                            if (!E.worked || linger == 0u || sys_load(&q->final_pub) == pub) new_state = SLOT_CLOSED;
                             else if (E.dry_since == 0u) E.dry_since = now;
                             else if (now - E.dry_since > linger) new_state = SLOT_CLOSED;
                         } else {
@@ -1852,6 +1853,13 @@ __global__ void ndt_stream_skip_kernel(NdtStreamQueue *q, unsigned seq)
     sys_store(&q->done_seq[seq % q->ring], seq + 1u);
     __threadfence_system();
     __hip_atomic_store(&q->published, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// "nothing more is coming until the host says so": instances that find batch `published` - 1 complete leave without lingering
+__global__ void ndt_stream_final_kernel(NdtStreamQueue *q, unsigned published) { sys_store(&q->final_pub, published); }
+hipError_t ndt_stream_final(void *queue_dev, unsigned published, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ndt_stream_final_kernel, dim3(1), dim3(1), 0, stream, (NdtStreamQueue *)queue_dev, published);
+    return hipGetLastError();
 }
 hipError_t ndt_stream_skip(void *queue_dev, unsigned seq, hipStream_t stream)
 {

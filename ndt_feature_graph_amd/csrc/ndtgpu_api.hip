@@ -215,7 +215,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.6.2 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.6.3 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1308,7 +1308,13 @@ ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const n
         P.matcher_form = env_int("NDTGPU_REG_STREAM", 1) ? NDTGPU_MATCHER_AUTO : NDTGPU_MATCHER_PER_BATCH;
     if (P.matcher_groups == 0) P.matcher_groups = (unsigned)std::max(0, env_int("NDTGPU_REG_GROUPS", 0));
     if (P.build_streams == 0) P.build_streams = std::min(2, std::max(0, env_int("NDTGPU_REG_BUILD_STREAMS", 0)));
-    if (P.linger_us == 0) P.linger_us = (unsigned)std::max(0, env_int("NDTGPU_REG_LINGER_US", 0));
+    // An instance that has worked stays for `linger` when it runs dry.  Where the builds are the slower side (a split that gives the
+    // matcher more than its share) a batch is complete before the next one is published; an instance that leaves then has to be
+    // placed again -- 144 whole CUs among build workgroups that keep arriving -- and the pipeline falls into lockstep: measured on the
+    // bench with 144 matcher CUs forced, 259 k registrations/s without linger, 560 k with 1 ms; at the measured split (128) linger
+    // changes nothing (0 / 200 / 1000 us: 664 / 666 / 661 k).  Default 1 ms; ndtgpu_registrar_sync switches it off for what is
+    // already submitted, so a waiting host does not pay for it.
+    if (P.linger_us == 0) P.linger_us = (unsigned)std::max(0, env_int("NDTGPU_REG_LINGER_US", 1000));
     if (P.recalibrate_pct == 0) P.recalibrate_pct = 25;
     ndtgpu_registrar *r = new (std::nothrow) ndtgpu_registrar();
     if (!r) return fail(NDTGPU_ERR_ALLOC, "registrar_create: host alloc");
@@ -1749,6 +1755,11 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
     if (r->queue) {
         // Nothing more is coming before this call returns: once the last sub-batch has been published the CUs that were kept
         // for the builds are free, and a second instance on those takes its share of what is left to register.
+        // (nothing more is coming before this call returns: instances do not linger behind the last published batch)
+        if (r->submitted) {
+            hipError_t fe = ndt_stream_final(r->queue, (unsigned)r->submitted, r->pst);
+            if (fe != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: final launch", fe);
+        }
         if (r->submitted > r->helped && r->stream_groups && r->stream_nn >= 0 && !getenv("NDTGPU_REG_NO_HELPER")) {
             const int n_cu = r->n_cu;
             if ((unsigned)n_cu > r->stream_groups + 8u) {
