@@ -912,9 +912,13 @@ def main():
     if reg is not None:
         build_ms_ev, match_ms_ev, n_prof = reg.kernel_ms()
         assert n_prof >= args.steps
-        stream_fed = match_ms_ev <= 0.05       # the stream-fed matcher: ONE instance serves batch after batch, there is no launch per step
+        # the stream-fed matcher: ONE instance serves batch after batch, there is no launch per step -- what the registrar reports as
+        # its matcher side is then the queue's own stamp of a batch: publication until its last registration finished (a latency, not
+        # a share of the chip's time)
+        stream_fed = reg.info()["matcher_form"] == binding.MATCHER_STREAM_FED
+        batch_latency_ms = match_ms_ev if stream_fed else None
         if stream_fed:
-            match_ms_ev = ms_per_step_hint = None
+            match_ms_ev = None
         k_build, k_match = [build_ms_ev], [match_ms_ev if match_ms_ev is not None else 1e3 * elapsed / args.steps]
         reg.profiling(False)
     else:
@@ -1034,7 +1038,8 @@ def main():
                                  "instance of the stream-fed matcher, which holds the share of the CUs the registrar measured on its "
                                  "first batch" % n_buf)),
                    "mean_cells_per_map": float((m_t.mean() + m_s.mean()) / 2),
-                   "registrar": (reg.info() if reg is not None else None)},
+                   "registrar": (reg.info() if reg is not None else None),
+                   "batch_latency_ms": (batch_latency_ms if reg is not None else None)},
         "roofline": roofline, "kernels": kern,
         # SURVEY.md 8d (config 4): node maps and edges are separate units when node maps are reused across edges
         # north_star: scans/s and achieved HBM-bandwidth fraction (algorithmic bytes / time / 8 TB/s), per kernel
