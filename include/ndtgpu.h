@@ -396,6 +396,10 @@ typedef struct {
                                * differs from the figure the split was measured at by more than this many percent, the pipeline is
                                * drained once and the split measured again (a registrar that moves from halls to clutter).
                                * 0 = 25; negative = never */
+    int32_t matcher_slots;    /* stream-fed form: registrations in flight per workgroup of a matcher instance, 2 (hit lists of 1024 entries
+                               * per share) or 3 (512: maps of up to ~450 cells; the one-lane solver steps of a registration are then covered
+                               * by two others, +8 % on the bench); 0 = chosen with the split by the measured cells per map (2 with a
+                               * forced split).  The same bits either way. */
 } ndtgpu_registrar_params;
 void ndtgpu_default_registrar_params(ndtgpu_registrar_params *p);
 typedef struct {
@@ -405,6 +409,8 @@ typedef struct {
     int32_t calibrations;     /* how often the split has been measured */
     uint64_t submitted;       /* sub-batches so far */
     double cells_per_map;     /* mean Gaussian cells per map of the sub-batch the split was last measured on */
+    int32_t matcher_slots;    /* registrations in flight per workgroup of a matcher instance */
+    int32_t pad_;
 } ndtgpu_registrar_info;
 /* grid: as ndtgpu_mapset_create (grid->max_cells applies per scan). */
 ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const ndtgpu_registrar_params *params,

@@ -570,12 +570,12 @@ class _BorrowedMapSet(MapSet):
 
 class RegistrarParams(C.Structure):
     _fields_ = [("pairs_per_batch", C.c_size_t), ("depth", C.c_int32), ("matcher_form", C.c_int32), ("matcher_groups", C.c_uint32),
-                ("build_streams", C.c_int32), ("linger_us", C.c_uint32), ("recalibrate_pct", C.c_int32)]
+                ("build_streams", C.c_int32), ("linger_us", C.c_uint32), ("recalibrate_pct", C.c_int32), ("matcher_slots", C.c_int32)]
 
 
 class RegistrarInfo(C.Structure):
     _fields_ = [("matcher_form", C.c_int32), ("matcher_groups", C.c_uint32), ("build_streams", C.c_int32), ("calibrations", C.c_int32),
-                ("submitted", C.c_uint64), ("cells_per_map", C.c_double)]
+                ("submitted", C.c_uint64), ("cells_per_map", C.c_double), ("matcher_slots", C.c_int32), ("pad_", C.c_int32)]
 
 
 MATCHER_AUTO, MATCHER_PER_BATCH, MATCHER_STREAM_FED = 0, 1, 2

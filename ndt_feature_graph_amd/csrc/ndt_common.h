@@ -215,7 +215,7 @@ hipError_t ndt_stream_publish(void *queue_dev, const NdtSetView &set, double *T1
 size_t ndt_stream_ring_offset();
 hipError_t ndt_stream_wait(void *queue_dev, unsigned ring, unsigned seq, hipStream_t stream);   // `stream` waits until batch `seq` is complete
 hipError_t ndt_stream_skip(void *queue_dev, unsigned seq, hipStream_t stream);
-hipError_t ndt_launch_match_stream(void *queue_dev, int n_neighbours, unsigned n_groups, hipStream_t stream);
+hipError_t ndt_launch_match_stream(void *queue_dev, int n_neighbours, int slots, unsigned n_groups, hipStream_t stream);
 unsigned ndt_stream_stamps();
 hipError_t ndt_stream_final(void *queue_dev, unsigned published, hipStream_t stream);     // instances stop lingering once `published` batches are complete
 hipError_t ndt_stream_reset(void *queue_dev, unsigned submitted, unsigned ring);                 // after an abort, streams idle

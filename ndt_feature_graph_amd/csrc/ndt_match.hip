@@ -1580,10 +1580,14 @@ __global__ void ndt_stream_wait_kernel(NdtStreamQueue *q, unsigned entry, unsign
         for (unsigned k = 0; k < (1u << 22) && sys_load(&q->live) != 0u; k++) __builtin_amdgcn_s_sleep(64);
 }
 
-template <int NN>
+// R registrations in flight per workgroup: two with hit lists of 1024 entries per share, or THREE with 512 -- enough for maps of up
+// to ~450 cells (62 cells x 5 neighbours per share), whose registrations spend 40 % of their time in one-lane solver steps that
+// a third registration covers (round 6, bench: 666 -> 722 k registrations/s; the cluttered scene, 1 085 hits per share in three
+// passes: 90-97 against 99 k -- the registrar picks by the cells per map it measured).  Same shares, same sums: the same bits.
+template <int NN, int R>
 __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ndt_match_stream_kernel(NdtStreamQueue *q)
 {
-    constexpr int R = 2, QL = 1024;
+    constexpr int QL = R >= 3 ? 512 : 1024;
     typedef MatchSlot<QL> Slot;
     __shared__ Slot slots[R];
     __shared__ StreamSlotExt ext[R];
@@ -1882,16 +1886,22 @@ hipError_t ndt_stream_wait(void *queue_dev, unsigned ring, unsigned seq, hipStre
     return hipGetLastError();
 }
 
-hipError_t ndt_launch_match_stream(void *queue_dev, int n_neighbours, unsigned n_groups, hipStream_t stream)
+hipError_t ndt_launch_match_stream(void *queue_dev, int n_neighbours, int slots, unsigned n_groups, hipStream_t stream)
 {
     NdtStreamQueue *q = (NdtStreamQueue *)queue_dev;
+#define NDT_LAUNCH_STREAM(NN_)                                                                                                   \
+    do {                                                                                                                         \
+        if (slots >= 3) hipLaunchKernelGGL((ndt_match_stream_kernel<NN_, 3>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); \
+        else hipLaunchKernelGGL((ndt_match_stream_kernel<NN_, 2>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q);         \
+    } while (0)
     switch (n_neighbours) {
-    case 0: hipLaunchKernelGGL(ndt_match_stream_kernel<0>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); break;
-    case 1: hipLaunchKernelGGL(ndt_match_stream_kernel<1>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); break;
-    case 2: hipLaunchKernelGGL(ndt_match_stream_kernel<2>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); break;
-    case 3: hipLaunchKernelGGL(ndt_match_stream_kernel<3>, dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); break;
+    case 0: NDT_LAUNCH_STREAM(0); break;
+    case 1: NDT_LAUNCH_STREAM(1); break;
+    case 2: NDT_LAUNCH_STREAM(2); break;
+    case 3: NDT_LAUNCH_STREAM(3); break;
     default: return hipErrorInvalidValue;
     }
+#undef NDT_LAUNCH_STREAM
     return hipGetLastError();
 }
 

@@ -215,7 +215,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.6.3 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.6.4 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1205,6 +1205,7 @@ struct ndtgpu_registrar {
     size_t helped = 0;                 // sub-batches submitted when the last helper was launched
     std::vector<hipEvent_t> pub_ev;
     unsigned stream_groups = 0;        // workgroups (= CUs) of a matcher instance; 0: to be measured on the next sub-batch
+    int stream_slots = 2;              // registrations in flight per workgroup of an instance (2, or 3 with half the hit list each)
     int stream_nn = -1;
     int n_cu = 256;
     // the split of the chip is measured on a sub-batch and re-measured when the maps change: per slot the map counters of
@@ -1283,6 +1284,7 @@ void ndtgpu_default_registrar_params(ndtgpu_registrar_params *p)
     p->build_streams = 0;
     p->linger_us = 0;
     p->recalibrate_pct = 25;
+    p->matcher_slots = 0;
 }
 
 // An experiment's environment variable overrides a field the caller LEFT AT ITS DEFAULT (0 / auto); what a caller sets wins.
@@ -1316,6 +1318,9 @@ ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const n
     // already submitted, so a waiting host does not pay for it.
     if (P.linger_us == 0) P.linger_us = (unsigned)std::max(0, env_int("NDTGPU_REG_LINGER_US", 1000));
     if (P.recalibrate_pct == 0) P.recalibrate_pct = 25;
+    if (P.matcher_slots != 0 && P.matcher_slots != 2 && P.matcher_slots != 3)
+        return fail(NDTGPU_ERR_INVALID, "registrar_create: matcher_slots must be 0 (auto), 2 or 3");
+    if (P.matcher_slots == 0) { const int es = env_int("NDTGPU_REG_SLOTS", 0); if (es == 2 || es == 3) P.matcher_slots = es; }
     ndtgpu_registrar *r = new (std::nothrow) ndtgpu_registrar();
     if (!r) return fail(NDTGPU_ERR_ALLOC, "registrar_create: host alloc");
     r->per = pairs_per_batch;
@@ -1355,6 +1360,7 @@ ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const n
         }
         if (P.matcher_form != NDTGPU_MATCHER_PER_BATCH && can) {
             r->stream_groups = P.matcher_groups;            // 0: measured on the first sub-batch
+            r->stream_slots = P.matcher_slots ? P.matcher_slots : 2;   // (auto: decided with the split, by the cells per map)
             e = hipMalloc(&r->queue, ndt_stream_queue_bytes());
             if (e == hipSuccess) e = hipMemset(r->queue, 0, ndt_stream_queue_bytes());
             const unsigned ring_linger[2] = {(unsigned)depth, 100u * P.linger_us};   // 100 MHz ticks (measured: no gain from 300 / 1000 us; default 0)
@@ -1423,6 +1429,8 @@ ndtgpu_status ndtgpu_registrar_get_info(const ndtgpu_registrar *r, ndtgpu_regist
     info->calibrations = r->calibrations;
     info->submitted = (uint64_t)r->submitted;
     info->cells_per_map = r->calib_cells;
+    info->matcher_slots = r->queue ? r->stream_slots : 2;
+    info->pad_ = 0;
     return NDTGPU_OK;
 }
 
@@ -1641,6 +1649,9 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
                     r->stream_groups = best_g;
                 }
                 r->calibrations++;
+                // three registrations per workgroup where the hit lists of a share fit 512 entries (maps of up to ~450 cells: 64 cells
+                // x 5-6 neighbours, with room), two with lists of 1024 entries otherwise
+                if (r->prm.matcher_slots == 0) r->stream_slots = (cells / (double)(2 * p) <= 448.0) ? 3 : 2;
                 r->calib_cells = r->recal_ref > 0 ? r->recal_ref : cells / (double)(2 * p);
                 r->recal_ref = 0.0;
                 r->calib_at = j;
@@ -1682,7 +1693,7 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
             // every published batch is followed by an instance launch: it starts when the running instance has ended (and
             // then serves this batch and whatever is published while it runs), or finds the batch taken and leaves
             HIP_TRY(hipStreamWaitEvent(r->mst, r->pub_ev[slot], 0));
-            pe = ndt_launch_match_stream(r->queue, pdev.n_neighbours, r->stream_groups, r->mst);
+            pe = ndt_launch_match_stream(r->queue, pdev.n_neighbours, r->stream_slots, r->stream_groups, r->mst);
             if (pe != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: matcher launch", pe);
             r->submitted++;
             if (ticket) *ticket = (uint64_t)r->submitted;
@@ -1765,7 +1776,7 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
             if ((unsigned)n_cu > r->stream_groups + 8u) {
                 if (!r->hst) HIP_TRY(hipStreamCreateWithFlags(&r->hst, hipStreamNonBlocking));
                 HIP_TRY(hipStreamWaitEvent(r->hst, r->pub_ev[(r->submitted - 1) % (size_t)r->depth], 0));
-                hipError_t he = ndt_launch_match_stream(r->queue, r->stream_nn, (unsigned)n_cu - r->stream_groups, r->hst);
+                hipError_t he = ndt_launch_match_stream(r->queue, r->stream_nn, r->stream_slots, (unsigned)n_cu - r->stream_groups, r->hst);
                 if (he != hipSuccess) return fail(NDTGPU_ERR_HIP, "registrar: helper launch", he);
             }
             r->helped = r->submitted;
