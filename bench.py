@@ -810,6 +810,9 @@ def main():
         bufs.append(b)
     state = {"k": 0, "match_started": None}
 
+    # (experiment: BENCH_ITR_MAX=1 leaves the matcher next to nothing to do -- what the build side alone delivers at the split)
+    exp_params = {"itr_max": int(os.environ["BENCH_ITR_MAX"])} if os.environ.get("BENCH_ITR_MAX") else {}
+
     def step_registrar(ev=None):
         b = bufs[state["k"] % n_buf]
         state["k"] += 1
@@ -818,7 +821,7 @@ def main():
         if b.gathered_ev is not None:
             main_stream.wait_event(b.gathered_ev)      # ... and its all-gather read them
         b.T16.copy_(T_init_cm)
-        b.ticket = reg.submit(both[:B], both[B:], b.T16, b.results, range_limit=rng_lim, stream=main_stream)
+        b.ticket = reg.submit(both[:B], both[B:], b.T16, b.results, range_limit=rng_lim, stream=main_stream, **exp_params)
         if use_dist:   # final gather of the edge transforms (the only collective on the path)
             reg.wait_stream(comm_stream, ticket=b.ticket)
             with torch.cuda.stream(comm_stream):

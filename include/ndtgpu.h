@@ -410,7 +410,8 @@ typedef struct {
     uint64_t submitted;       /* sub-batches so far */
     double cells_per_map;     /* mean Gaussian cells per map of the sub-batch the split was last measured on */
     int32_t matcher_slots;    /* registrations in flight per workgroup of a matcher instance */
-    int32_t pad_;
+    int32_t resident_groups;  /* workgroups of matcher instances on the device at the time of the call (stream-fed form; a 4-byte
+                               * device read on the null stream) */
 } ndtgpu_registrar_info;
 /* grid: as ndtgpu_mapset_create (grid->max_cells applies per scan). */
 ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const ndtgpu_registrar_params *params,

@@ -575,7 +575,7 @@ class RegistrarParams(C.Structure):
 
 class RegistrarInfo(C.Structure):
     _fields_ = [("matcher_form", C.c_int32), ("matcher_groups", C.c_uint32), ("build_streams", C.c_int32), ("calibrations", C.c_int32),
-                ("submitted", C.c_uint64), ("cells_per_map", C.c_double), ("matcher_slots", C.c_int32), ("pad_", C.c_int32)]
+                ("submitted", C.c_uint64), ("cells_per_map", C.c_double), ("matcher_slots", C.c_int32), ("resident_groups", C.c_int32)]
 
 
 MATCHER_AUTO, MATCHER_PER_BATCH, MATCHER_STREAM_FED = 0, 1, 2

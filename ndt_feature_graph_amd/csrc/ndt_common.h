@@ -209,6 +209,7 @@ hipError_t ndt_launch_covariance(const NdtSetView &tset, const uint32_t *tidx_de
 // the stream-fed matcher of the registrar (csrc/ndt_match.hip): a queue of published batches in device memory
 size_t ndt_stream_queue_bytes();
 size_t ndt_stream_abort_offset();
+size_t ndt_stream_live_offset();
 unsigned ndt_stream_ring();
 hipError_t ndt_stream_publish(void *queue_dev, const NdtSetView &set, double *T16_dev, NdtMatchResultDev *res_dev,
                               const NdtMatchParamsDev &prm, unsigned n_pairs, unsigned seq, hipStream_t stream);

@@ -1509,6 +1509,7 @@ hipError_t ndt_stream_reset(void *queue_dev, unsigned submitted, unsigned ring)
     return hipMemcpy((char *)queue_dev + offsetof(NdtStreamQueue, done_seq), done_seq, sizeof done_seq, hipMemcpyHostToDevice);
 }
 // the two stamps of batch `seq` (valid while fewer than NDT_STREAM_STAMPS batches have been published since)
+size_t ndt_stream_live_offset() { return offsetof(NdtStreamQueue, live); }
 hipError_t ndt_stream_read_stamps(const void *queue_dev, unsigned seq, unsigned long long out[2])
 {
     return hipMemcpy(out, (const char *)queue_dev + offsetof(NdtStreamQueue, stamp) + (size_t)(seq % NDT_STREAM_STAMPS) * 16u, 16u,
@@ -1580,14 +1581,24 @@ __global__ void ndt_stream_wait_kernel(NdtStreamQueue *q, unsigned entry, unsign
         for (unsigned k = 0; k < (1u << 22) && sys_load(&q->live) != 0u; k++) __builtin_amdgcn_s_sleep(64);
 }
 
-// R registrations in flight per workgroup: two with hit lists of 1024 entries per share, or THREE with 512 -- enough for maps of up
-// to ~450 cells (62 cells x 5 neighbours per share), whose registrations spend 40 % of their time in one-lane solver steps that
-// a third registration covers (round 6, bench: 666 -> 722 k registrations/s; the cluttered scene, 1 085 hits per share in three
-// passes: 90-97 against 99 k -- the registrar picks by the cells per map it measured).  Same shares, same sums: the same bits.
+// R registrations in flight per workgroup: two with hit lists of 1024 entries per share, or THREE with 640 (what 160 KB of LDS
+// hold) -- enough for maps of up to ~450 cells (62 cells x 5 neighbours per share), whose registrations spend 40 % of their time
+// in one-lane solver steps that a third registration covers (round 6, bench: 666 -> 722-738 k registrations/s; the cluttered scene,
+// 1 085 hits per share in two passes: 88-92 against 99 k -- the registrar picks by the cells per map it measured; four with lists
+// of 384: 660 k).  Same shares, same sums: the same bits.
 template <int NN, int R>
 __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ndt_match_stream_kernel(NdtStreamQueue *q)
 {
-    constexpr int QL = R >= 3 ? 512 : 1024;
+#ifndef NDT_STREAM_RETRY
+#define NDT_STREAM_RETRY 4096
+#endif
+#ifndef NDT_STREAM_QLX
+#define NDT_STREAM_QLX 640
+#endif
+#ifndef NDT_STREAM_RX
+#define NDT_STREAM_RX 3
+#endif
+    constexpr int QL = R >= 3 ? NDT_STREAM_QLX : 1024;
     typedef MatchSlot<QL> Slot;
     __shared__ Slot slots[R];
     __shared__ StreamSlotExt ext[R];
@@ -1780,7 +1791,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
                     lds_store(&S.state, SLOT_RUN);
                     lds_store(&S.next, 0u);
                 } else {
-                    if (new_state == SLOT_FREE) lds_store(&S.retry, clock_lo() + 4096u);
+                    if (new_state == SLOT_FREE) lds_store(&S.retry, clock_lo() + (unsigned)NDT_STREAM_RETRY);
                     else atomicAdd(&s_closed, 1u);
                     lds_store(&S.state, new_state);
                 }
@@ -1891,7 +1902,7 @@ hipError_t ndt_launch_match_stream(void *queue_dev, int n_neighbours, int slots,
     NdtStreamQueue *q = (NdtStreamQueue *)queue_dev;
 #define NDT_LAUNCH_STREAM(NN_)                                                                                                   \
     do {                                                                                                                         \
-        if (slots >= 3) hipLaunchKernelGGL((ndt_match_stream_kernel<NN_, 3>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); \
+        if (slots >= 3) hipLaunchKernelGGL((ndt_match_stream_kernel<NN_, NDT_STREAM_RX>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q); \
         else hipLaunchKernelGGL((ndt_match_stream_kernel<NN_, 2>), dim3(n_groups), dim3(NDT_MATCH_THREADS), 0, stream, q);         \
     } while (0)
     switch (n_neighbours) {

@@ -1430,7 +1430,12 @@ ndtgpu_status ndtgpu_registrar_get_info(const ndtgpu_registrar *r, ndtgpu_regist
     info->submitted = (uint64_t)r->submitted;
     info->cells_per_map = r->calib_cells;
     info->matcher_slots = r->queue ? r->stream_slots : 2;
-    info->pad_ = 0;
+    info->resident_groups = 0;
+    if (r->queue) {                                         // (a 4-byte read on the null stream; the registrar's streams do not block it)
+        unsigned live = 0u;
+        HIP_TRY(hipMemcpy(&live, (const char *)r->queue + ndt_stream_live_offset(), sizeof live, hipMemcpyDeviceToHost));
+        info->resident_groups = (int32_t)live;
+    }
     return NDTGPU_OK;
 }
 
@@ -1786,6 +1791,19 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
         HIP_TRY(hipStreamSynchronize(r->pst));
         HIP_TRY(hipStreamSynchronize(r->mst));
         if (r->hst) HIP_TRY(hipStreamSynchronize(r->hst));
+        if (getenv("NDTGPU_REG_TRACE") && r->submitted) {
+            // (experiments: when the last batches were published -- their maps built -- and when their last registration finished,
+            //  in microseconds after the first of them)
+            const size_t nb = std::min<size_t>(r->submitted, ndt_stream_stamps());
+            unsigned long long t0 = 0;
+            for (size_t k = r->submitted - nb; k < r->submitted; k++) {
+                unsigned long long st[2] = {0, 0};
+                HIP_TRY(ndt_stream_read_stamps(r->queue, (unsigned)k, st));
+                if (!t0) t0 = st[0];
+                fprintf(stderr, "[ndtgpu trace] batch %zu published %+.1f us, done %+.1f us\n", k, ((double)st[0] - (double)t0) * 0.01,
+                        ((double)st[1] - (double)t0) * 0.01);
+            }
+        }
         unsigned aborted = 0;
         HIP_TRY(hipMemcpy(&aborted, (char *)r->queue + ndt_stream_abort_offset(), sizeof aborted, hipMemcpyDeviceToHost));
         if (aborted) {
