@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) __attribute__((amdgpu_waves_per_
     const double *__restrict__ feat_cells /* 18 doubles per correspondence */,
     unsigned n_pairs, int park_iters, unsigned double_thresh, char *__restrict__ work_mem)
 {
-    constexpr int QL = R >= 3 ? 512 : 1024;     // (three slots: half the hit list per share; longer lists take two passes)
+    constexpr int QL = R >= 3 ? 640 : 1024;     // (three slots: 5/8 of the hit list per share -- what fits; longer lists take two passes)
     typedef MatchSlot<QL> Slot;
     __shared__ Slot slots[R];
     __shared__ double w_src[NDT_MATCH_WAVES * 9 * 64];   // per wave: the transformed source tile, one column per lane
@@ -2101,7 +2101,7 @@ struct NdtCoopCtrl {
     alignas(64) unsigned grp[16 * 16];   // arrival counter of workgroup group i at grp[16 * i] (one 64-byte line each)
 };
 static_assert(sizeof(NdtCoopCtrl) % 64 == 0, "control block keeps the partials aligned");
-size_t ndt_match_coop_work_bytes(size_t n_chunks) { return sizeof(NdtCoopCtrl) + n_chunks * 32 * sizeof(double); }   // multiple of 64
+size_t ndt_match_coop_work_bytes(size_t n_chunks) { return sizeof(NdtCoopCtrl) + 2 * n_chunks * 32 * sizeof(double); }   // multiple of 64; two sets of rows (ndt_match_coop_kernel)
 size_t ndt_match_coop_ctrl_bytes() { return sizeof(NdtCoopCtrl); }   // what a launch sequence must find zeroed
 
 // Grid barrier number `epoch` (1, 2, ...).  Arrivals on ONE counter serialise at the L2 (~50-100 ns each: 30 us for
@@ -2157,11 +2157,9 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     unsigned pair_begin)
 {
     __shared__ EvalShared<NDT_MATCH_WAVES> sh;
-    __shared__ MatchState st;       // workgroup 0 only
+    __shared__ MatchState st;       // every workgroup its own copy, all alike (see below)
     __shared__ NewtonWs s_ws;
     __shared__ NdtMatchParamsDev s_prm;     // the solver takes the parameters by reference: LDS, not a private copy
-    __shared__ rigid s_T;
-    __shared__ int s_with_h, s_done;
     __shared__ long long s_cnt[5];          // clocks: evaluations, solver, barriers; pair terms: gradient-only, with Hessian
     __shared__ double s_rows[4 * NDT_VW * 32];      // eval_chunks: up to 4 chunks x 8 shares x 32 sums
     __shared__ double s_out[4 * 32];                // ... and their sums over the shares
@@ -2169,22 +2167,12 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     // blockIdx.y = registration: its gridDim.x workgroups have their own control block and barrier.  The caller sizes
     // the grid by the occupancy query and lets one such launch run at a time: every workgroup that stays is resident,
     // so no barrier can wait for a workgroup that has not started.
-    // What the workgroups of a registration hand to each other (the request, the rows of partial sums) is stored
+    // What the workgroups of a registration hand to each other (the rows of partial sums) is stored
     // write-through and LOADED with system-scope accesses (past the L1 and the XCD's L2); a writer's stores are complete
     // (vmcnt 0) before its workgroup arrives at the barrier.  The barrier itself is agent-scope atomics.  No
     // cache-maintenance fence (1.7 - 3.5 us each, two or three per barrier before): the maps stay in L1 / L2.
-    auto ld64 = [](const void *q) { return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     auto st64 = [](void *q, unsigned long long v) { __hip_atomic_store(reinterpret_cast<unsigned long long *>(q), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
-    auto ldd = [&](const double *q) { return __builtin_bit_cast(double, ld64(q)); };
     auto std_ = [&](double *q, double v) { st64(q, __builtin_bit_cast(unsigned long long, v)); };
-    auto publish = [&](NdtCoopCtrl *c) {                    // workgroup 0, after a barrier of its threads: the next request,
-        unsigned t = threadIdx.x;                           // one store per lane (thirteen from one lane cost 2 us more)
-        asm volatile("" : "+v"(t));                         // (opaque: the addresses are not worth registers across the loop)
-        if (t < 9) std_(&c->Teval.r[t], st.Teval.r[t]);
-        else if (t < 12) std_(&c->Teval.t[t - 9], st.Teval.t[t - 9]);
-        else if (t == 12) st64(&c->with_h, (unsigned long long)(unsigned)st.with_h | ((unsigned long long)(unsigned)st.done << 32));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
     const unsigned pair = pair_begin + blockIdx.y;
     char *work_mem = work_all + (size_t)pair * work_stride;
     double *T16 = T16_all + (size_t)pair * 16;
@@ -2234,11 +2222,15 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
 
     if (threadIdx.x == 0) s_prm = prm;
     __syncthreads();
-    if (g == 0) {
-        if (threadIdx.x == 0) match_state_init(st, T16, s_prm, Q36);
-        __syncthreads();
-        publish(ctrl);
-    }
+    // EVERY workgroup keeps the solver state and steps it itself (round 6).  The rows of partial sums are what the workgroups
+    // hand to each other; the sums of the rows, in chunk order, are the same doubles in every workgroup, the solver step is the
+    // same code on the same inputs, so the states never differ -- and nobody has to publish the next pose: ONE grid barrier per
+    // evaluation instead of two, and no request to fetch across the fabric (a 2D pair of 100 k points: 0.32 -> see DESIGN 7).
+    // The rows of consecutive evaluations go to alternating halves of the row buffer: a workgroup that is already writing the
+    // rows of evaluation e + 1 cannot disturb one that still reads those of e, and nobody writes the rows of e + 2 before
+    // everybody has arrived at the barrier of e + 1, i.e. has read the rows of e.
+    if (threadIdx.x == 0) match_state_init(st, T16, s_prm, Q36);
+    __syncthreads();
     // a barrier that gave up (a foreign process holding CUs: bounded spin): the registration reports exit code -4 and
     // leaves the pose as it came in; the host-pointer entries run it again on the persistent kernel
     auto gave_up = [&]() {
@@ -2250,26 +2242,12 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
             *res = o;
         }
     };
+    unsigned parity = 0u;
     for (;;) {
-        long long b0 = __builtin_readcyclecounter();
-        if (!coop_barrier(ctrl, target, G)) { gave_up(); return; }   // the request is published
-        if (threadIdx.x == 0) s_cnt[2] += (long long)__builtin_readcyclecounter() - b0;
-        {
-            // the request, one word per lane: ONE round trip across the fabric (a single lane reading the thirteen words
-            // pays one per word -- system-scope loads are issued in program order and each is waited for before its value
-            // goes to LDS)
-            unsigned t = threadIdx.x;
-            asm volatile("" : "+v"(t));
-            if (t < 9) s_T.r[t] = ldd(&ctrl->Teval.r[t]);
-            else if (t < 12) s_T.t[t - 9] = ldd(&ctrl->Teval.t[t - 9]);
-            else if (t == 12) {
-                const unsigned long long hd = ld64(&ctrl->with_h);
-                s_with_h = (int)(unsigned)hd; s_done = (int)(unsigned)(hd >> 32);
-            }
-        }
-        __syncthreads();
-        if (s_done) break;
-        const rigid &Te = s_T;            // (read from LDS where the transform needs it, see ndt_match_pool_kernel)
+        if (st.done) break;               // (LDS, written before the last barrier of the workgroup's threads: the same everywhere)
+        const rigid &Te = st.Teval;       // (read from LDS where the transform needs it, see ndt_match_pool_kernel)
+        const int with_h = st.with_h;
+        double *rows = partials + (size_t)parity * NC * 32;
         long long c0 = __builtin_readcyclecounter();
 #pragma unroll 1
         for (unsigned q = g; q < NQ; q += G) {
@@ -2277,46 +2255,44 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
             const int begin = min(sv.n_cells, (int)c * per), count = min(sv.n_cells - begin, (int)CH * per);
             if (packed) {
                 const unsigned n_out = min(CH, NC - c);
-                if (s_with_h) eval_chunks<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, s_out, n_out);
+                if (with_h) eval_chunks<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, s_out, n_out);
                 else eval_chunks<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh, seg_lanes, s_rows, s_out, n_out);
-                if (threadIdx.x < n_out * 32u) std_(partials + c * 32 + threadIdx.x, s_out[threadIdx.x]);
+                if (threadIdx.x < n_out * 32u) std_(rows + c * 32 + threadIdx.x, s_out[threadIdx.x]);
             } else {
-                if (s_with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
+                if (with_h) eval_derivs<NN, true>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
                 else eval_derivs<NN, false>(tg, sv.cells + begin, count, Te, prm.lfd1, prm.lfd2, sh);
-                if (threadIdx.x < 32) std_(partials + c * 32 + threadIdx.x, sh.sums[threadIdx.x]);
+                if (threadIdx.x < 32) std_(rows + c * 32 + threadIdx.x, sh.sums[threadIdx.x]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the rows are in memory before the workgroup arrives
         long long c1 = __builtin_readcyclecounter();
         if (threadIdx.x == 0) s_cnt[0] += c1 - c0;
-        if (!coop_barrier(ctrl, target, G)) { gave_up(); return; }   // all partials are in memory
+        if (!coop_barrier(ctrl, target, G)) { gave_up(); return; }   // all rows of this evaluation are in memory
         if (threadIdx.x == 0) s_cnt[2] += (long long)__builtin_readcyclecounter() - c1;
-        if (g == 0) {
-            // 16 x 32 threads: thread (r, k) adds value k of chunks r, r + 16, ... (loads of different threads
-            // overlap: a single lane walking all NC rows pays NC dependent L2 round trips); the 16 rows are then
-            // added in order.  Fixed order: deterministic.
-            {
-                unsigned t = threadIdx.x;
-                asm volatile("" : "+v"(t));           // (recomputed here: hoisted out of the loop the shift is kept in a spilled register)
-                const unsigned k = t & 31u, r = t >> 5;
-                sh.src[r * 32 + k] = sum_rows_16x32(partials, NC, r, k);    // the source tile buffer is free between evaluations
-            }
-            __syncthreads();
-            if (threadIdx.x < 29) {
-                double a = 0;
-                for (unsigned r = 0; r < 16u; r++) a += sh.src[r * 32 + threadIdx.x];
-                sh.sums[threadIdx.x] = a;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                long long d0 = __builtin_readcyclecounter();
-                s_cnt[s_with_h ? 4 : 3] += (long long)sh.sums[28];
-                match_state_step(st, sh.sums, s_prm, s_ws);
-                s_cnt[1] += (long long)__builtin_readcyclecounter() - d0;
-            }
-            __syncthreads();
-            publish(ctrl);
+        // 16 x 32 threads: thread (r, k) adds value k of chunks r, r + 16, ... (loads of different threads
+        // overlap: a single lane walking all NC rows pays NC dependent L2 round trips); the 16 rows are then
+        // added in order.  Fixed order: deterministic, and the same in every workgroup.
+        {
+            unsigned t = threadIdx.x;
+            asm volatile("" : "+v"(t));           // (recomputed here: hoisted out of the loop the shift is kept in a spilled register)
+            const unsigned k = t & 31u, r = t >> 5;
+            sh.src[r * 32 + k] = sum_rows_16x32(rows, NC, r, k);    // the source tile buffer is free between evaluations
         }
+        __syncthreads();
+        if (threadIdx.x < 29) {
+            double a = 0;
+            for (unsigned r = 0; r < 16u; r++) a += sh.src[r * 32 + threadIdx.x];
+            sh.sums[threadIdx.x] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long d0 = __builtin_readcyclecounter();
+            s_cnt[with_h ? 4 : 3] += (long long)sh.sums[28];
+            match_state_step(st, sh.sums, s_prm, s_ws);
+            s_cnt[1] += (long long)__builtin_readcyclecounter() - d0;
+        }
+        __syncthreads();
+        parity ^= 1u;
     }
     // The barrier counters only grow while a registration runs and must be zero when the next one starts: the last
     // workgroup to leave (every other one has read the block for the last time) puts them back, so that the host does

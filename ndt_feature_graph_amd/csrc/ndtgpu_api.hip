@@ -1004,13 +1004,16 @@ static bool coop_plan(const ndtgpu_mapset *ss, size_t n_pairs, const NdtMatchPar
     const unsigned capacity = ndt_match_coop_capacity(p.n_neighbours);
     if (capacity == 0 || n_pairs == 0 || n_pairs > capacity) return false;
     // Source cells per chunk -- a property of the source SET (its cell capacity), so that a registration's rows, and with
-    // them its bits, do not depend on the batch it is in.  Sets of small maps (planar scans): 128 (16 per wave; fewer stop
-    // paying: barrier + solver latency dominate).  Sets that hold large maps (3D sweeps, >= 16 k cells): 256 -- every chunk
+    // them its bits, do not depend on the batch it is in.  Sets of small maps (planar scans): 96 (12 per wave; with ONE grid
+    // barrier per evaluation, round 6: 64 / 96 / 128 / 192 cells 0.295 / 0.282 / 0.297 / 0.288 ms for the 2D pair of 100 k
+    // points, build included).  Sets that hold large maps (3D sweeps, >= 16 k cells): 256 -- every chunk
     // costs its own pass over the pair terms (batches of 64 that end half empty) and its own wave sum, and every row a
     // hand-over: 12 k-cell maps, 4 / 8 / 16 / 32 pairs 1.41 / 2.33 / 3.57 / 4.75 ms with 128 against 1.34 / 2.20 / 3.29 /
     // 4.34 ms with 256 (384: 32 pairs 4.63, 512: 4.56); one pair alone 1.11 against 1.33 ms -- half as many workgroups.
+    // (Round 6, one barrier per evaluation: one pair alone 1.04 / 1.17 / 1.26 ms with 96 / 192 / 256, but the pool's 32 pairs
+    //  5.07 / 4.83 / 4.63 ms: the batch decides, 256 stays.)
     const char *cpg = getenv("NDTGPU_COOP_CELLS");
-    pl.per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : (ss->v.grid.max_cells >= 16384u ? 256u : 128u);
+    pl.per_group = (cpg && atoi(cpg) > 0) ? (unsigned)atoi(cpg) : (ss->v.grid.max_cells >= 16384u ? 256u : 96u);
     const unsigned n_chunks = std::max(1u, (ss->v.grid.max_cells + pl.per_group - 1u) / pl.per_group);
     // Up to 8 registrations: the grid-barrier kernel (static teams, the solver state stays in one workgroup's LDS: 12 k-cell
     // 3D maps, 1 / 4 / 8 pairs 1.63 / 2.30 / 3.01 ms against 1.94 / 2.57 / 3.14 ms).  More: the task pool (any workgroup
