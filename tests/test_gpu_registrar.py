@@ -185,6 +185,8 @@ def test_registrar_rejects_bad_arguments(N, scene):
         N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=1, matcher_form=2)
     with pytest.raises(N.NdtGpuError):
         N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=2, matcher_form=7)
+    with pytest.raises(N.NdtGpuError):                           # two or three registrations per matcher workgroup, or 0 = decide
+        N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=2, matcher_slots=4)
     reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=8, depth=1, max_cells=4096)
     assert reg.info()["matcher_form"] == 1 and reg.info()["calibrations"] == 0
     reg.sync()                                                   # nothing submitted: returns at once
@@ -222,8 +224,9 @@ def test_registrar_host_form(N, scene):
     reg.close()
 
 
-@pytest.mark.parametrize("mode,groups", [("stream", None), ("stream", 8), ("launch_per_batch", None)])
-def test_registrar_long_run_both_matcher_forms(N, scene, mode, groups):
+@pytest.mark.parametrize("mode,groups,slots", [("stream", None, 0), ("stream", 8, 0), ("stream", 8, 3), ("stream", None, 2),
+                                               ("launch_per_batch", None, 0)])
+def test_registrar_long_run_both_matcher_forms(N, scene, mode, groups, slots):
     """Twelve calls (36 sub-batches: many turns of the ring of four map sets) without a host wait, four output buffers in
     rotation guarded by tickets -- through the stream-fed matcher (one running instance serves batch after batch; its CU share
     measured on the first sub-batch, or forced to 8 workgroups) and through the form with one matcher launch per sub-batch
@@ -233,6 +236,8 @@ def test_registrar_long_run_both_matcher_forms(N, scene, mode, groups):
     fields = {"matcher_form": binding.MATCHER_STREAM_FED if mode == "stream" else binding.MATCHER_PER_BATCH}
     if groups:
         fields["matcher_groups"] = groups
+    if slots:
+        fields["matcher_slots"] = slots                          # (three: hit lists of 640 entries per share instead of 1024)
     B, both, dev = scene["B"], scene["both"], scene["dev"]
     T_ref, r_ref = two_call_reference(N, scene, 32)
     reg = N.Registrar(RES, [0, 0, 0], SIZE, pairs_per_batch=32, depth=4, max_cells=4096, **fields)
@@ -256,6 +261,8 @@ def test_registrar_long_run_both_matcher_forms(N, scene, mode, groups):
     assert len(kept) == 12
     for T16, res in kept:
         same_bits(binding, T16, res, T_ref, r_ref)
+    if mode == "stream":
+        assert reg.info()["matcher_slots"] == (slots if slots else (2 if groups else 3)), reg.info()
     reg.close()
 
 

@@ -117,6 +117,7 @@ def test_config3_through_the_registrar_full_size(N, O, halls):
     assert info["matcher_form"] == binding.MATCHER_STREAM_FED and info["build_streams"] == 2
     assert info["calibrations"] == 1 and 64 <= info["matcher_groups"] <= 224, info         # measured once, a plausible share
     assert info["submitted"] == 26 and 100 < info["cells_per_map"] < 2000
+    assert info["matcher_slots"] == 3, info        # maps of ~370 cells: three registrations in flight per matcher workgroup
     for k, (T16, res) in enumerate(kept):
         r = same_bits(binding, T16, res, T_ref, r_ref, "call %d" % k)
     assert r["converged"].mean() > 0.9 and np.all(r["exit_code"] >= 0)
@@ -146,10 +147,11 @@ def test_config3_through_the_registrar_full_size(N, O, halls):
 
 
 @pytest.mark.parametrize("fields", [{"matcher_groups": 96}, {"matcher_groups": 176, "build_streams": 1},
-                                    {"matcher_form": 1}])
+                                    {"matcher_form": 1}, {"matcher_slots": 2}, {"matcher_groups": 120, "matcher_slots": 3}])
 def test_full_size_bits_do_not_depend_on_the_split(N, halls, fields):
     """the same calls on registrars whose parameters are FORCED away from the measured defaults (ndtgpu_registrar_params): 96
-    or 176 matcher CUs, one build stream, one matcher launch per sub-batch -- the same bits"""
+    or 176 matcher CUs, one build stream, one matcher launch per sub-batch, two or three registrations in flight per matcher
+    workgroup -- the same bits"""
     import torch
     from ndt_feature_graph_amd import binding
     both, T0, T_ref, r_ref = halls["both"], halls["T0"], halls["T_ref"], halls["r_ref"]
@@ -160,6 +162,10 @@ def test_full_size_bits_do_not_depend_on_the_split(N, halls, fields):
         assert info["matcher_groups"] == fields["matcher_groups"] and info["calibrations"] == 0
     if fields.get("matcher_form") == 1:
         assert info["matcher_form"] == binding.MATCHER_PER_BATCH
+    if "matcher_slots" in fields:
+        assert info["matcher_slots"] == fields["matcher_slots"], info
+    elif "matcher_groups" in fields:
+        assert info["matcher_slots"] == 2, info       # a forced split is not measured: nothing is known about the maps
     for k, (T16, res) in enumerate(kept):
         same_bits(binding, T16, res, T_ref, r_ref, "call %d %r" % (k, fields))
     reg.close()
@@ -202,6 +208,7 @@ def test_one_registrar_halls_and_clutter_in_turn(N, O, halls):
             same_bits(binding, T16, res, Td_ref, rd_ref, "dense, call %d" % k)
     info = reg.info()
     assert 2 <= info["calibrations"] <= 4, info
+    assert info["matcher_slots"] in (2, 3) and info["resident_groups"] == 0, info      # (everything is done: no instance is left)
     # one dense pair against the oracle through this path (the scene has its own full test in tests/test_gpu_dense.py)
     T = outs[1][0].cpu().numpy().reshape(Bd, 4, 4).transpose(0, 2, 1)
     r = outs[1][1].cpu().numpy().view(binding.RESULT_DTYPE).reshape(Bd)
