@@ -215,7 +215,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.6.4 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.6.5 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1209,6 +1209,20 @@ struct ndtgpu_registrar {
     std::vector<hipEvent_t> pub_ev;
     unsigned stream_groups = 0;        // workgroups (= CUs) of a matcher instance; 0: to be measured on the next sub-batch
     int stream_slots = 2;              // registrations in flight per workgroup of an instance (2, or 3 with half the hit list each)
+    int device = 0;
+    hipEvent_t probe_ev[2] = {nullptr, nullptr};
+    std::vector<std::pair<unsigned, hipStream_t>> masked;      // streams that own the first F CUs of the mask (the split's build probes)
+    ndtgpu_status masked_stream(unsigned n_cus, hipStream_t *out)
+    {
+        for (auto &m : masked) if (m.first == n_cus) { *out = m.second; return NDTGPU_OK; }
+        std::vector<uint32_t> mask(((size_t)n_cu + 31) / 32, 0u);
+        for (unsigned i = 0; i < n_cus && i < (unsigned)n_cu; i++) mask[i / 32] |= 1u << (i % 32);
+        hipStream_t st = nullptr;
+        HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+        masked.emplace_back(n_cus, st);
+        *out = st;
+        return NDTGPU_OK;
+    }
     int stream_nn = -1;
     int n_cu = 256;
     // the split of the chip is measured on a sub-batch and re-measured when the maps change: per slot the map counters of
@@ -1266,6 +1280,8 @@ ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
     if (r->bst2) (void)hipStreamDestroy(r->bst2);
     for (hipEvent_t e : r->pub_ev) if (e) (void)hipEventDestroy(e);
     if (r->stat_host) (void)hipHostFree(r->stat_host);
+    for (auto &m : r->masked) if (m.second) { (void)hipStreamSynchronize(m.second); (void)hipStreamDestroy(m.second); }
+    for (hipEvent_t e : r->probe_ev) if (e) (void)hipEventDestroy(e);
     if (r->queue) (void)hipFree(r->queue);
     for (void *q : r->hstage) if (q) (void)hipFree(q);
     if (r->hio) (void)hipFree(r->hio);
@@ -1329,6 +1345,7 @@ ndtgpu_status ndtgpu_registrar_create_ex(const ndtgpu_grid_params *grid, const n
     r->per = pairs_per_batch;
     r->depth = depth;
     r->n_cu = device_cus();
+    (void)hipGetDevice(&r->device);
     r->sets.assign(depth, nullptr);
     r->streams.assign(depth, nullptr);
     r->built.assign(depth, nullptr);
@@ -1633,6 +1650,7 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
                     }
                 }
                 if (m_bad < res.size()) M *= (double)res.size() / (double)(res.size() - m_bad);
+                const double M_raw = M;                           // CU-clocks of the sub-batch's registrations
                 M *= 1.125;                                       // (measured optimum on the bench scene: 144 of 256 CUs where the raw clocks say 138)
                 const int n_cu = r->n_cu;
                 double share = (M + B) > 0 ? M / (M + B) : 0.5;
@@ -1655,6 +1673,88 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
                         if (best_t == 0 || t < 0.99 * best_t || (t <= 1.01 * best_t && closer && t <= best_t)) { best_t = t; best_g = (unsigned)g8; }
                     }
                     r->stream_groups = best_g;
+                }
+                // ... and, since 0.6.5, MEASURED on the build side (round 6).  The clocks above are those of workgroups that had the
+                // whole chip: beside a matcher instance the builds of the bench halls run 20 % faster than that (half as many
+                // workgroups pull on the HBM), those of a cluttered scene 30 % slower (four workgroups to a CU where the lone launch
+                // had three), and a quarter more or less decides between two splits (halls 120 instead of 128 CUs on one box in
+                // three: -5 %; clutter 184 instead of 160: 103 against 127 k registrations/s).  A build launch takes whole rounds,
+                // so the only splits worth having are those that leave the builds just enough CUs for k rounds, k = 1, 2, ...:
+                // the sub-batch is built again on a stream that owns exactly those CUs (hipExtStreamCreateWithCUMask: mask bits
+                // are dealt to the XCDs in turn, like the CUs a matcher instance leaves), timed with events, and the split whose
+                // slower side -- that time, or the registrations' CU-clocks over the matcher's CUs -- is fastest wins.  A few
+                // build launches, once per measurement; NDTGPU_REG_PROBE=0 keeps the model above.
+                if (B > 0 && M_raw > 0 && env_int("NDTGPU_REG_PROBE", 1) != 0) {
+                    int khz = 0;
+                    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, r->device) != hipSuccess || khz <= 0) khz = 2400000;
+                    const double clk_per_ms = 0.85 * (double)khz;              // (the clock under these kernels: 1.93-2.1 of 2.4 GHz)
+                    const size_t maps = 2 * p;
+                    struct Cand { unsigned g; double build_ms, t_ms; };
+                    std::vector<Cand> cand;
+                    auto groups_of = [&](unsigned k) -> unsigned {             // the most matcher CUs that leave the builds k rounds
+                        const unsigned F = (unsigned)((maps + 4u * k - 1u) / (4u * k));
+                        const unsigned F8 = (F + 7u) / 8u * 8u;
+                        return ((unsigned)n_cu > F8 + 15u) ? (unsigned)n_cu - F8 : 0u;
+                    };
+                    auto probe = [&](unsigned g, double *ms) -> ndtgpu_status {
+                        hipStream_t ms_st = nullptr;
+                        ndtgpu_status prc = r->masked_stream((unsigned)n_cu - g, &ms_st);
+                        if (prc != NDTGPU_OK) return prc;
+                        if (!r->probe_ev[0]) { HIP_TRY(hipEventCreate(&r->probe_ev[0])); HIP_TRY(hipEventCreate(&r->probe_ev[1])); }
+                        float best = 0.f;
+                        for (int rep = 0; rep < 2; rep++) {                    // (the first launch on a new stream pays for the stream)
+                            HIP_TRY(hipEventRecord(r->probe_ev[0], ms_st));
+                            prc = build_pairs(set, off, p, ms_st);
+                            if (prc != NDTGPU_OK) return prc;
+                            HIP_TRY(hipEventRecord(r->probe_ev[1], ms_st));
+                            HIP_TRY(hipEventSynchronize(r->probe_ev[1]));
+                            float e = 0.f;
+                            HIP_TRY(hipEventElapsedTime(&e, r->probe_ev[0], r->probe_ev[1]));
+                            if (rep == 0 || e < best) best = e;
+                        }
+                        *ms = (double)best;
+                        return NDTGPU_OK;
+                    };
+                    // the round count the model's split stands for, and its neighbours; further out while the edge keeps winning
+                    unsigned k0 = 1;
+                    for (unsigned k = 1; k <= 16; k++) { k0 = k; if (groups_of(k) >= r->stream_groups) break; }
+                    bool ok = true;
+                    auto have = [&](unsigned g) { for (const Cand &c : cand) if (c.g == g) return true; return false; };
+                    auto add = [&](unsigned k) {
+                        const unsigned g = k >= 1 && k <= 16 ? groups_of(k) : 0u;
+                        if (!ok || g < 16u || have(g)) return;
+                        Cand c{g, 0.0, 0.0};
+                        if (probe(g, &c.build_ms) != NDTGPU_OK) { ok = false; return; }
+                        c.t_ms = std::max(c.build_ms, M_raw / (double)g / clk_per_ms);
+                        cand.push_back(c);
+                    };
+                    auto best_of = [&]() { size_t b = 0; for (size_t i = 1; i < cand.size(); i++) if (cand[i].t_ms < cand[b].t_ms) b = i; return b; };
+                    add(k0); add(k0 > 1 ? k0 - 1 : k0 + 2); add(k0 + 1);
+                    for (int more = 0; ok && more < 3 && !cand.empty(); more++) {
+                        const Cand &b = cand[best_of()];
+                        unsigned kb = 0;
+                        for (unsigned k = 1; k <= 16; k++) if (groups_of(k) == b.g) { kb = k; break; }
+                        const size_t n_before = cand.size();
+                        if (kb > 1 && !have(groups_of(kb - 1))) add(kb - 1);
+                        if (kb && kb < 16 && !have(groups_of(kb + 1))) add(kb + 1);
+                        if (cand.size() == n_before) break;
+                    }
+                    if (ok && !cand.empty()) {
+                        const Cand &b = cand[best_of()];
+                        if (getenv("NDTGPU_REG_VERBOSE"))
+                            for (const Cand &c : cand)
+                                fprintf(stderr, "ndtgpu registrar: %u matcher CUs: builds %.3f ms on the other %u, registrations %.3f ms -> %.3f ms per sub-batch%s\n",
+                                        c.g, c.build_ms, (unsigned)n_cu - c.g, M_raw / (double)c.g / clk_per_ms, c.t_ms, c.g == b.g ? "  <-" : "");
+                        r->stream_groups = b.g;
+                    } else if (!ok) {
+                        (void)hipGetLastError();                               // (no masked streams on this device / runtime: the model's split stands)
+                        g_err.clear();
+                    }
+                    // (the probe streams go at once: each is a hardware queue of its own and of no use until the next measurement;
+                    //  creating them is most of what a measurement costs, ~50 ms with three or four candidates)
+                    for (auto &m : r->masked) if (m.second) { (void)hipStreamSynchronize(m.second); (void)hipStreamDestroy(m.second); }
+                    r->masked.clear();
+                    HIP_TRY(hipEventRecord(r->built[slot], st));               // (the maps were rebuilt: same contents)
                 }
                 r->calibrations++;
                 // three registrations per workgroup where the hit lists of a share fit 512 entries (maps of up to ~450 cells: 64 cells
