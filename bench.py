@@ -470,7 +470,7 @@ def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_c
     D = max(1, min(8, int(args.buffers)))
     reg = N.Registrar(res, [0, 0, 0], size_m, pairs_per_batch=B, depth=D, max_cells=4096)
     outs = [(T_init_cm.clone(), torch.zeros((B, 64), dtype=torch.uint8, device=dev), [0]) for _ in range(D)]
-    n_pipe = 12
+    n_pipe = 32            # (12 until round 6: fill and drain of the eight-deep ring were a fifth of that region)
 
     def pstep(k):
         T_k, r_k, tk = outs[k % D]
@@ -487,13 +487,14 @@ def dense_scene_leg(args, torch, N, binding, synth, dev, size_m, rng_lim, with_c
     reg.sync(); torch.cuda.synchronize()
     elapsed_pipe = time.perf_counter() - t0
     same = bool(torch.equal(outs[(n_pipe - 1) % D][0], T16) and torch.equal(outs[(n_pipe - 1) % D][1][:, :32], results[:, :32]))
+    reg_info = reg.info()
     reg.close()
-    out = {"value": B * n_pipe / elapsed_pipe, "unit": "registrations/s", "pairs": B, "steps": n_pipe,
+    out = {"value": B * n_pipe / elapsed_pipe, "unit": "registrations/s", "pairs": B, "steps": n_pipe, "registrar": reg_info,
            "ms_per_step": 1e3 * elapsed_pipe / n_pipe, "value_serial": B * n_steps / elapsed,
            "ms_per_step_serial": 1e3 * elapsed / n_steps, "pipelined_equals_serial_bits": same,
            "workload": "%d pairs x %d pts, %.2f m cells, synth scene 'dense' (the hall of the headline scene + 3000 posts of 2-4 cm), "
-                       "fuser preset; value: ONE ndtgpu_register_batch_device call per step (one build launch + one matcher launch, three "
-                       "internal map sets / streams); *_serial and kernel_ms: the two launches alone on one stream" % (B, NP, res),
+                       "fuser preset; value: ONE ndtgpu_register_batch_device call per step through a default registrar (eight map sets, "
+                       "the split of the chip measured on the first sub-batch: `registrar`); *_serial and kernel_ms: the two launches alone on one stream" % (B, NP, res),
            "mean_cells_per_map": cells / (2 * B), "kernel_ms": {"ndt_build_kernel": build_ms, "ndt_match_kernel": match_ms},
            "build_hbm_frac": build_bytes / build_ms / 1e6 / HBM_PEAK_GBS, "match_fp64_frac": gflop / match_ms / 78.6,
            "pair_terms_per_registration": float((r["pair_terms_g"].sum() + r["pair_terms_h"].sum()) / B),
