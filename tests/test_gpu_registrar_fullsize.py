@@ -118,6 +118,10 @@ def test_config3_through_the_registrar_full_size(N, O, halls):
     assert info["calibrations"] == 1 and 64 <= info["matcher_groups"] <= 224, info         # measured once, a plausible share
     assert info["submitted"] == 26 and 100 < info["cells_per_map"] < 2000
     assert info["matcher_slots"] == 3, info        # maps of ~370 cells: three registrations in flight per matcher workgroup
+    # the split leaves the builds just enough CUs for a whole number of rounds (one workgroup per map, four to a CU)
+    n_cu = torch.cuda.get_device_properties(halls["dev"]).multi_processor_count
+    whole = {n_cu - (-(-(-(-2 * B // (4 * k))) // 8) * 8) for k in range(1, 17)}
+    assert info["matcher_groups"] in whole, (info, sorted(whole))
     for k, (T16, res) in enumerate(kept):
         r = same_bits(binding, T16, res, T_ref, r_ref, "call %d" % k)
     assert r["converged"].mean() > 0.9 and np.all(r["exit_code"] >= 0)
