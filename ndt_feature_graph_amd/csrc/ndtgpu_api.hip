@@ -1757,8 +1757,9 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
                     HIP_TRY(hipEventRecord(r->built[slot], st));               // (the maps were rebuilt: same contents)
                 }
                 r->calibrations++;
-                // three registrations per workgroup where the hit lists of a share fit 512 entries (maps of up to ~450 cells: 64 cells
-                // x 5-6 neighbours, with room), two with lists of 1024 entries otherwise
+                // three registrations per workgroup (hit lists of 640 entries per share) where the maps are small -- up to 448 cells: the
+                // one-lane solver steps are a third of a registration there --, two with lists of 1024 entries otherwise (measured
+                // on the cluttered scene: three are slower)
                 if (r->prm.matcher_slots == 0) r->stream_slots = (cells / (double)(2 * p) <= 448.0) ? 3 : 2;
                 r->calib_cells = r->recal_ref > 0 ? r->recal_ref : cells / (double)(2 * p);
                 r->recal_ref = 0.0;
