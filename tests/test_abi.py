@@ -50,6 +50,26 @@ def test_struct_layouts_match_header(N):
     assert p.delta_score == 1e-6 and p.lfd1 == 1.0 and p.lfd2 == 0.05
 
 
+def test_struct_sizes_against_the_compiled_header(N, tmp_path):
+    """sizeof of every struct that crosses the boundary, as gcc sees include/ndtgpu.h, against the ctypes mirrors"""
+    import subprocess
+    from ndt_feature_graph_amd import binding
+    names = {"ndtgpu_match_result": binding.MatchResult, "ndtgpu_match_params": binding.MatchParams,
+             "ndtgpu_grid_params": binding.GridParams, "ndtgpu_cell_params": binding.CellParams,
+             "ndtgpu_registrar_params": binding.RegistrarParams, "ndtgpu_registrar_info": binding.RegistrarInfo,
+             "ndtgpu_fuser_params": binding.FuserParams, "ndtgpu_fuser_prepared": binding.FuserPrepared}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "ndtgpu.h"\nint main(void) {\n' +
+                   "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in names) +
+                   '  printf("ndtgpu_fuser_result %zu\\n", sizeof(ndtgpu_fuser_result));\n  return 0;\n}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for n, c in names.items():
+        assert int(out[n]) == ctypes.sizeof(c), (n, out[n], ctypes.sizeof(c))
+    assert int(out["ndtgpu_fuser_result"]) == binding.FUSER_RESULT_DTYPE.itemsize == 560
+
+
 def test_no_device_fails_loudly_no_cpu_fallback(N):
     if N.device_count() > 0:
         pytest.skip("a GPU is present")
