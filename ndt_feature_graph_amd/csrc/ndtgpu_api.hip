@@ -1206,6 +1206,8 @@ struct ndtgpu_registrar {
     int mst_prio = 0;                  // the matcher stream's priority: a stream of the caller's at this priority may share its hardware queue
     hipStream_t hst = nullptr;         // the drain helper of ndtgpu_registrar_sync
     size_t helped = 0;                 // sub-batches submitted when the last helper was launched
+    std::vector<hipEvent_t> trace_ev;  // NDTGPU_REG_TRACE: start / end of the build of the last 64 sub-batches
+    size_t trace_first = (size_t)-1;   // ... the first sub-batch that has them
     std::vector<hipEvent_t> pub_ev;
     unsigned stream_groups = 0;        // workgroups (= CUs) of a matcher instance; 0: to be measured on the next sub-batch
     int stream_slots = 2;              // registrations in flight per workgroup of an instance (2, or 3 with half the hit list each)
@@ -1282,6 +1284,7 @@ ndtgpu_status ndtgpu_registrar_destroy(ndtgpu_registrar *r)
     if (r->stat_host) (void)hipHostFree(r->stat_host);
     for (auto &m : r->masked) if (m.second) { (void)hipStreamSynchronize(m.second); (void)hipStreamDestroy(m.second); }
     for (hipEvent_t e : r->probe_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->trace_ev) if (e) (void)hipEventDestroy(e);
     if (r->queue) (void)hipFree(r->queue);
     for (void *q : r->hstage) if (q) (void)hipFree(q);
     if (r->hio) (void)hipFree(r->hio);
@@ -1780,8 +1783,15 @@ ndtgpu_status ndtgpu_register_batch_device(ndtgpu_registrar *r, const void *targ
             }
             ndtgpu_registrar::ProfMark *mk = nullptr;
             if (r->profiling) { ndtgpu_status mrc = new_mark((long long)j, &mk); if (mrc != NDTGPU_OK) return mrc; HIP_TRY(hipEventRecord(mk->e[0], st)); }
+            const bool tracing = getenv("NDTGPU_REG_TRACE") != nullptr;
+            if (tracing) {
+                if (r->trace_ev.empty()) { r->trace_ev.assign(128, nullptr); for (hipEvent_t &e : r->trace_ev) HIP_TRY(hipEventCreate(&e)); }
+                HIP_TRY(hipEventRecord(r->trace_ev[2 * (j % 64)], st));
+                if (r->trace_first == (size_t)-1) r->trace_first = j;
+            }
             ndtgpu_status rc = build_pairs(set, off, p, st);
             if (rc != NDTGPU_OK) return rc;
+            if (tracing) HIP_TRY(hipEventRecord(r->trace_ev[2 * (j % 64) + 1], st));
             if (mk) HIP_TRY(hipEventRecord(mk->e[1], st));
             if (r->stat_host && r->stat_seq[slot] < 0 && j % 3u == 0u) {
                 // (how many Gaussian cells the maps of this build hold: one small kernel behind it writes the sum to the host.
@@ -1904,8 +1914,16 @@ ndtgpu_status ndtgpu_registrar_sync(ndtgpu_registrar *r)
                 unsigned long long st[2] = {0, 0};
                 HIP_TRY(ndt_stream_read_stamps(r->queue, (unsigned)k, st));
                 if (!t0) t0 = st[0];
-                fprintf(stderr, "[ndtgpu trace] batch %zu published %+.1f us, done %+.1f us\n", k, ((double)st[0] - (double)t0) * 0.01,
-                        ((double)st[1] - (double)t0) * 0.01);
+                float b0 = 0.f, b1 = 0.f;          // the build's start and end, against the end of the first listed build (~ its publication)
+                const size_t kref = std::max(r->submitted - nb, r->trace_first);
+                if (!r->trace_ev.empty() && k >= kref) {
+                    (void)hipEventElapsedTime(&b0, r->trace_ev[2 * (kref % 64) + 1], r->trace_ev[2 * (k % 64)]);
+                    (void)hipEventElapsedTime(&b1, r->trace_ev[2 * (kref % 64) + 1], r->trace_ev[2 * (k % 64) + 1]);
+                    (void)hipGetLastError();
+                }
+                if (k == kref) t0 = st[0];
+                fprintf(stderr, "[ndtgpu trace] batch %zu build %+.1f .. %+.1f us, published %+.1f us, done %+.1f us\n", k, 1e3 * b0, 1e3 * b1,
+                        ((double)st[0] - (double)t0) * 0.01, ((double)st[1] - (double)t0) * 0.01);
             }
         }
         unsigned aborted = 0;
