@@ -928,6 +928,23 @@ def main():
     else:
         k_build = [m[0].elapsed_time(m[1]) for m in marks]
         k_match = [m[4].elapsed_time(m[3]) for m in marks]
+    # ---- labelled extra, outside the timed region: the same steps over a region long enough for the ring's fill and drain not to
+    # matter (a burst pays one pipeline latency, ~3.6 ms, whatever its length: a tenth of 20 steps, a fortieth of 100)
+    steady = None
+    if reg is not None and args.steps < 100 and not args.no_pipeline:
+        barrier()
+        ts0 = time.perf_counter()
+        for _ in range(100):
+            step()
+        reg.sync()
+        barrier()
+        steady_s = time.perf_counter() - ts0
+        if use_dist:
+            tm2 = torch.tensor([steady_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+            steady_s = float(tm2.item())
+        steady = {"value": world * B * 100 / steady_s, "unit": "registrations/s", "steps": 100, "ms_per_step": 1e3 * steady_s / 100,
+                  "note": "the same call, 100 steps between the same barriers, after the timed region: not the headline value"}
     last = bufs[(state["k"] - 1) % n_buf]
     T16, results = last.T16, last.results
     if use_dist:
@@ -1048,6 +1065,7 @@ def main():
         # SURVEY.md 8d (config 4): node maps and edges are separate units when node maps are reused across edges
         # north_star: scans/s and achieved HBM-bandwidth fraction (algorithmic bytes / time / 8 TB/s), per kernel
         "scans_per_s": 2 * value,
+        "steady_state": steady,
         "hbm_fraction": {k: {"timed_region": kern[k]["GBps"] / HBM_PEAK_GBS,
                              "kernel_alone": kern[k]["algorithmic_bytes"] / kern[k]["ms_isolated"] / 1e6 / HBM_PEAK_GBS}
                          for k in kern},
