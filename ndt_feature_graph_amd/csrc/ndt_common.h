@@ -197,7 +197,7 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_de
                                  const uint32_t *sidx_dev, double *T16_dev, size_t pair_begin, size_t pair_count,
                                  const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
                                  unsigned n_groups, unsigned cells_per_group, void *work_dev, size_t work_stride, int checked,
-                                 hipStream_t stream);
+                                 hipStream_t stream, unsigned *done_host = nullptr);
 hipError_t ndt_launch_match(const NdtSetView &tset, const uint32_t *tidx_dev, const NdtSetView &sset,
                             const uint32_t *sidx_dev, double *T16_dev, size_t n_pairs, const NdtMatchParamsDev &prm,
                             NdtMatchResultDev *res_dev, const double *Q36_dev, const unsigned *feat_off_dev,

@@ -2115,7 +2115,10 @@ NDT_D bool coop_barrier(NdtCoopCtrl *c, unsigned &epoch, unsigned G)
         epoch += 1u;
         const unsigned NG = G < 16u ? G : 16u, gi = blockIdx.x % NG;
         const unsigned gsize = (G - gi + NG - 1u) / NG;            // workgroups w with w % NG == gi
-        if (atomicAdd(&c->grp[16u * gi], 1u) + 1u == gsize * epoch) atomicAdd(&c->top, 1u);
+        // (up to 16 workgroups: every group is one workgroup, and its arrival goes straight to the top counter -- one atomic
+        //  round trip less per barrier, 18 barriers in the registration of a planar pair)
+        if (G <= 16u) atomicAdd(&c->top, 1u);
+        else if (atomicAdd(&c->grp[16u * gi], 1u) + 1u == gsize * epoch) atomicAdd(&c->top, 1u);
         unsigned spins = 0;
         while (__hip_atomic_load(&c->top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NG * epoch) {
             __builtin_amdgcn_s_sleep(2);
@@ -2154,7 +2157,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
     NdtSetView tset, const uint32_t *__restrict__ tidx, NdtSetView sset, const uint32_t *__restrict__ sidx,
     double *__restrict__ T16_all, NdtMatchParamsDev prm, NdtMatchResultDev *__restrict__ res_all,
     const double *__restrict__ Q36_all, char *__restrict__ work_all, size_t work_stride, unsigned cells_per_group,
-    unsigned pair_begin)
+    unsigned pair_begin, unsigned *__restrict__ done_host /* NULL, or one word per pair in host memory: set when pose and result are written */)
 {
     __shared__ EvalShared<NDT_MATCH_WAVES> sh;
     __shared__ MatchState st;       // every workgroup its own copy, all alike (see below)
@@ -2192,6 +2195,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
             o.score = 0.0; o.n_source = 0; o.n_target = 0;
             o.cycles_eval = 0; o.cycles_solver = 0; o.pair_terms_g = 0; o.pair_terms_h = 0;
             *res = o;
+            if (done_host) { __threadfence_system(); __hip_atomic_store(&done_host[pair], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
         return;
     }
@@ -2240,6 +2244,7 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
             o.score = 0.0; o.n_source = sv.n_cells; o.n_target = tg.n_cells;
             o.cycles_eval = 0; o.cycles_solver = 0; o.pair_terms_g = 0; o.pair_terms_h = 0;
             *res = o;
+            if (done_host) { __threadfence_system(); __hip_atomic_store(&done_host[pair], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     };
     unsigned parity = 0u;
@@ -2318,6 +2323,8 @@ __global__ __launch_bounds__(NDT_MATCH_THREADS) void ndt_match_coop_kernel(
         o.pair_terms_g = s_cnt[3];
         o.pair_terms_h = s_cnt[4];
         *res = o;
+        // (a host that polls this word instead of waiting for the stream: pose and result are visible before it is)
+        if (done_host) { __threadfence_system(); __hip_atomic_store(&done_host[pair], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
 }
 
@@ -2355,19 +2362,19 @@ hipError_t ndt_launch_match_coop(const NdtSetView &tset, const uint32_t *tidx_de
                                  const uint32_t *sidx_dev, double *T16_dev, size_t pair_begin, size_t pair_count,
                                  const NdtMatchParamsDev &prm, NdtMatchResultDev *res_dev, const double *Q36_dev,
                                  unsigned n_groups, unsigned cells_per_group, void *work_dev, size_t work_stride, int checked,
-                                 hipStream_t stream)
+                                 hipStream_t stream, unsigned *done_host)
 {
     size_t stride = work_stride;        // per registration: a control block + one row of partial sums per chunk
     NdtSetView ts = tset, ss = sset;
     NdtMatchParamsDev p = prm;
     char *work = (char *)work_dev;
     unsigned pb = (unsigned)pair_begin;
-    void *args[] = {&ts, &tidx_dev, &ss, &sidx_dev, &T16_dev, &p, &res_dev, &Q36_dev, &work, &stride, &cells_per_group, &pb};
+    void *args[] = {&ts, &tidx_dev, &ss, &sidx_dev, &T16_dev, &p, &res_dev, &Q36_dev, &work, &stride, &cells_per_group, &pb, &done_host};
     const dim3 grid(n_groups, (unsigned)pair_count), block(NDT_MATCH_THREADS);
     if (!checked) {
 #define NDT_LAUNCH_COOP(NN)                                                                                            \
     hipLaunchKernelGGL(ndt_match_coop_kernel<NN>, grid, block, 0, stream, ts, tidx_dev, ss, sidx_dev, T16_dev, p, res_dev, \
-                       Q36_dev, work, stride, cells_per_group, pb)
+                       Q36_dev, work, stride, cells_per_group, pb, done_host)
         switch (prm.n_neighbours) {
         case 0: NDT_LAUNCH_COOP(0); break;
         case 1: NDT_LAUNCH_COOP(1); break;

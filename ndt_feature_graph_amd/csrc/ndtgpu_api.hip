@@ -15,6 +15,7 @@
 #include <atomic>
 #include <functional>
 #include <mutex>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -78,6 +79,14 @@ struct ndtgpu_mapset {
         HIP_TRY(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(m.ev, st));
         marks.push_back(m);
+        return NDTGPU_OK;
+    }
+    // ... for work that is about to be enqueued on `st`: what was recorded on `st` itself is ordered by the stream
+    ndtgpu_status wait_all_on(hipStream_t st)
+    {
+        if (null_stream_used && st != nullptr) { HIP_TRY(hipStreamSynchronize(nullptr)); null_stream_used = false; }
+        for (StreamMark &m : marks)
+            if (m.st != st) HIP_TRY(hipEventSynchronize(m.ev));
         return NDTGPU_OK;
     }
     ndtgpu_status wait_all()
@@ -215,7 +224,7 @@ struct ndtgpu_mapset {
 extern "C" {
 
 // (bumped whenever a kernel changes: bench.py only quotes PMC figures taken with the same version)
-const char *ndtgpu_version(void) { return "ndtgpu 0.6.5 (gfx950)"; }
+const char *ndtgpu_version(void) { return "ndtgpu 0.6.6 (gfx950)"; }
 const char *ndtgpu_last_error(void) { return g_err.c_str(); }
 
 int ndtgpu_device_count(void)
@@ -1039,7 +1048,8 @@ static bool coop_plan(const ndtgpu_mapset *ss, size_t n_pairs, const NdtMatchPar
 // Enqueues ONE launch for the whole batch on `st` behind the previous grid-barrier launch of the process (g_coop_mutex held).
 static ndtgpu_status coop_enqueue(ndtgpu_mapset *ts, ndtgpu_mapset *ss, const uint32_t *tidx_dev, const uint32_t *sidx_dev,
                                   double *T16_dev, NdtMatchResultDev *res_dev, const double *Q36_dev, size_t n_pairs,
-                                  const NdtMatchParamsDev &p, const CoopPlan &pl, bool clear, bool record, hipStream_t st)
+                                  const NdtMatchParamsDev &p, const CoopPlan &pl, bool clear, bool record, hipStream_t st,
+                                  unsigned *done_host = nullptr)
 {
     if (g_coop_ev_valid) HIP_TRY(hipStreamWaitEvent(st, g_coop_ev, 0));
     // the control blocks must be zero (barrier counters only grow while a registration runs); the kernels leave them so
@@ -1054,7 +1064,7 @@ static ndtgpu_status coop_enqueue(ndtgpu_mapset *ts, ndtgpu_mapset *ss, const ui
     } else {
         if (clear) HIP_TRY(hipMemset2DAsync(ts->coop_work, pl.stride, 0, ndt_match_coop_ctrl_bytes(), n_pairs, st));
         e = ndt_launch_match_coop(ts->v, tidx_dev, ss->v, sidx_dev, T16_dev, 0, n_pairs, p, res_dev, Q36_dev, pl.groups,
-                                  pl.per_group, ts->coop_work, pl.stride, pl.checked, st);
+                                  pl.per_group, ts->coop_work, pl.stride, pl.checked, st, done_host);
     }
     if (e != hipSuccess) return fail(NDTGPU_ERR_HIP, "match: grid-barrier launch", e);
     if (record) {     // (a caller that waits for its launch under the mutex leaves nothing for later launches to wait for)
@@ -2213,7 +2223,7 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
     const size_t off_ctrl = (total + 255) & ~(size_t)255;
     ndtgpu_status rc = ts->ensure_stage(total);
     if (rc != NDTGPU_OK) return rc;
-    rc = ts->ensure_pin(off_ctrl + n_pairs * 16);
+    rc = ts->ensure_pin(off_ctrl + n_pairs * 16 + n_pairs * sizeof(unsigned));
     if (rc != NDTGPU_OK) return rc;
     char *base = (char *)ts->stage, *hp = (char *)ts->pin;
     memcpy(hp, T16, bT);
@@ -2226,7 +2236,18 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
         std::lock_guard<std::mutex> coop_lock(g_coop_mutex);
         rc = ts->ensure_coop(n_pairs * pl.stride + (pl.pool ? ndt_match_pool_ctrl_bytes() : 0));
         if (rc != NDTGPU_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(base, hp, total, hipMemcpyHostToDevice, st));
+        // The grid-barrier kernel (up to eight registrations) reads poses, indices and Tcov from the pinned block where it is and
+        // writes poses and results there: 16 doubles per workgroup over the link at the start, 192 bytes back at the end, instead of
+        // two copies on the stream (~6 us each) around a 0.2 ms launch.  The task pool keeps its staging copies.
+        const bool direct = !pl.pool && env_int("NDTGPU_COOP_DIRECT", 1) != 0;
+        // ... and the host then watches one word per registration in that block, which workgroup 0 sets behind pose and result,
+        // instead of waiting for the stream (the runtime's completion signal costs ~8 us more than the store takes to arrive); the
+        // next launch of this kind is ordered behind the kernel's end by its event, like any asynchronous one
+        const bool poll = direct && env_int("NDTGPU_COOP_POLL", 1) != 0;
+        unsigned *flags = reinterpret_cast<unsigned *>(hp + off_ctrl + n_pairs * 16);
+        if (poll) for (size_t k = 0; k < n_pairs; k++) __atomic_store_n(&flags[k], 0u, __ATOMIC_RELEASE);
+        if (direct) base = hp;
+        else HIP_TRY(hipMemcpyAsync(base, hp, total, hipMemcpyHostToDevice, st));
         // only blocks this set has not seen finish cleanly at this stride are cleared
         const bool clear = ts->coop_clean_stride != pl.stride || ts->coop_clean_upto < n_pairs;
         const size_t clean_before = clear ? n_pairs : ts->coop_clean_upto;
@@ -2234,13 +2255,25 @@ static ndtgpu_status match_coop(ndtgpu_mapset *ts, const uint32_t *tidx, ndtgpu_
         ts->coop_clean_upto = 0;                                // (until this call is known to have ended cleanly)
         rc = coop_enqueue(ts, ss, (const uint32_t *)(base + off_ti), (const uint32_t *)(base + off_si), (double *)base,
                           reinterpret_cast<NdtMatchResultDev *>(base + off_R), Q36 ? (const double *)(base + off_Q) : nullptr,
-                          n_pairs, p, pl, clear, false, st);
+                          n_pairs, p, pl, clear, poll, st, poll ? flags : nullptr);
         if (rc != NDTGPU_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(hp, base, off_R + bR, hipMemcpyDeviceToHost, st));                      // poses + results
-        if (!pl.pool) HIP_TRY(hipMemcpy2DAsync(hp + off_ctrl, 16, ts->coop_work, pl.stride, 16, n_pairs, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        g_coop_ev_valid = false;          // (this stream waited for the last asynchronous launch, and is drained now)
-        if (pl.pool) {                    // a registration the launch gave up on reports exit code -4 (the kernel's opening mark)
+        if (!direct) HIP_TRY(hipMemcpyAsync(hp, base, off_R + bR, hipMemcpyDeviceToHost, st));         // poses + results
+        bool seen = poll;
+        if (poll) {
+            const auto t_poll = std::chrono::steady_clock::now();
+            for (size_t k = 0; k < n_pairs && seen; k++) {
+                unsigned spins = 0;
+                while (__atomic_load_n(&flags[k], __ATOMIC_ACQUIRE) == 0u) {
+                    __builtin_ia32_pause();
+                    if ((++spins & 0xFFFFu) == 0u && std::chrono::steady_clock::now() - t_poll > std::chrono::seconds(2)) { seen = false; break; }
+                }
+            }
+        }
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(st));
+            g_coop_ev_valid = false;      // (this stream waited for the last asynchronous launch, and is drained now)
+        }
+        {                                 // a registration the launch gave up on reports exit code -4 (both kernels)
             const ndtgpu_match_result *hr = reinterpret_cast<const ndtgpu_match_result *>(hp + off_R);
             unsigned *cw = reinterpret_cast<unsigned *>(hp + off_ctrl);
             for (size_t k = 0; k < n_pairs; k++) { cw[4 * k] = 0u; cw[4 * k + 1] = hr[k].exit_code == -4 ? 1u : 0u; }
@@ -2391,9 +2424,10 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
     for (size_t k = 0; k < n_pairs; k++)
         if (tidx[k] >= ts->n_maps || sidx[k] >= ss->n_maps) return fail(NDTGPU_ERR_INVALID, "match_batch: map index");
     hipStream_t st = (hipStream_t)stream;
-    // builds on other streams must have finished before the maps are read
-    { ndtgpu_status wrc_ = ts->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
-    { ndtgpu_status wrc_ = ss->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
+    // builds on other streams must have finished before the maps are read (a build on THIS stream is ordered by the stream: the
+    // host stages the call while it runs -- a third of the build of a single pair, tools/latency_probe.py)
+    { ndtgpu_status wrc_ = ts->wait_all_on(st); if (wrc_ != NDTGPU_OK) return wrc_; }
+    { ndtgpu_status wrc_ = ss->wait_all_on(st); if (wrc_ != NDTGPU_OK) return wrc_; }
     {
         NdtMatchParamsDev p = to_dev(prm);
         p.fusion_flags = fusion_flags;
@@ -2407,6 +2441,8 @@ static ndtgpu_status match_batch_common(ndtgpu_mapset *ts, const uint32_t *tidx,
         ndtgpu_status crc = match_coop(ts, tidx, ss, sidx, T16, n_pairs, p, Q36, results, st, &done);
         if (crc != NDTGPU_OK || done) return crc;
     }
+    { ndtgpu_status wrc_ = ts->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
+    { ndtgpu_status wrc_ = ss->wait_all(); if (wrc_ != NDTGPU_OK) return wrc_; }
     NdtMatchParamsDev pp = to_dev(prm);
     pp.fusion_flags = fusion_flags;
     return match_persistent_host(ts, tidx, ss, sidx, T16, n_pairs, pp, Q36, results, st);
